@@ -1,0 +1,351 @@
+"""CPU restatement (eager PyTorch, fp32) of the NeuroViT hot path.  TEST INFRASTRUCTURE ONLY.
+
+Restates, op for op, what the reference executes on this path:
+  * ViT / Transformer / Attention / FeedForward      -> reference src/models/vit_3d.py:14-126
+  * ViT3DEncoder permute, NeuroEncoder 3D/4D forward  -> reference src/models/NeuroEncoder.py:49-68,197-205
+  * TemporalTransformer / ProjectionHead              -> reference src/models/NeuroEncoder.py:207-230
+    (torch ``nn.TransformerEncoderLayer`` defaults: post-norm, ReLU, ff=2048)
+
+Two modes
+---------
+``emulate_bf16=False``  exact fp32 restatement.  Pinned (<=1e-5 rel) against golden
+    vectors produced by importing the reference (tests/golden/make_golden.py).
+``emulate_bf16=True``   the same math with the HIP path's bf16 cast points
+    (bf16 MFMA operands, fp32 accumulate, fp32 residual stream / LN / softmax),
+    forward AND backward.  This is the checker the gfx950 kernels are gated
+    against (<=1e-3 rel, see tests/).
+
+Parameters are passed as a plain dict keyed exactly like the reference's
+``ViT.state_dict()`` (e.g. ``transformer.layers.0.0.to_qkv.weight``).
+
+Parity pin: the reference has no tests or golden vectors of its own
+ - the pin is the set of fixtures under tests/golden/.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LN_EPS = 1e-5  # nn.LayerNorm default (vit_3d.py:18,37,93,95,108)
+
+
+# --------------------------------------------------------------------------- config
+
+@dataclass
+class ViTCfg:
+    """Constructor arguments of the reference ViT (vit_3d.py:78)."""
+    image_size: int
+    image_patch_size: int
+    frames: int
+    frame_patch_size: int
+    num_classes: int
+    dim: int
+    depth: int
+    heads: int
+    mlp_dim: int
+    pool: str = "cls"
+    channels: int = 3
+    dim_head: int = 64
+
+    @property
+    def grid(self) -> Tuple[int, int, int]:
+        return (self.frames // self.frame_patch_size,
+                self.image_size // self.image_patch_size,
+                self.image_size // self.image_patch_size)
+
+    @property
+    def num_patches(self) -> int:
+        f, h, w = self.grid
+        return f * h * w
+
+    @property
+    def patch_dim(self) -> int:
+        return self.channels * self.image_patch_size ** 2 * self.frame_patch_size
+
+    @property
+    def inner(self) -> int:
+        return self.heads * self.dim_head
+
+
+def strip_prefix(sd: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Tensor]:
+    """NeuroEncoder.py:27-31 - keep only keys under `prefix`, drop the prefix."""
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+# --------------------------------------------------------------------------- bf16 emulation helpers
+
+def _r(x: torch.Tensor) -> torch.Tensor:
+    """Round-to-nearest-even to bf16, keep fp32 storage.  Autograd: identity."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundGrad(torch.autograd.Function):
+    """Identity forward; backward rounds the incoming gradient to bf16 (the HIP
+    path feeds gradients to MFMA as bf16 operands)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r(g)
+
+
+def _gelu_grad(u: torch.Tensor) -> torch.Tensor:
+    # d/du [ u * Phi(u) ] = Phi(u) + u * phi(u)   (exact-erf GELU, vit_3d.py:20)
+    cdf = 0.5 * (1.0 + torch.erf(u * (1.0 / math.sqrt(2.0))))
+    pdf = torch.exp(-0.5 * u * u) * (1.0 / math.sqrt(2.0 * math.pi))
+    return cdf + u * pdf
+
+
+class _GeluEmu(torch.autograd.Function):
+    """h = bf16(gelu(u_fp32)); backward dU = bf16(dH * gelu'(bf16(u)))."""
+
+    @staticmethod
+    def forward(ctx, u):
+        ctx.save_for_backward(_r(u))
+        return _r(F.gelu(u))
+
+    @staticmethod
+    def backward(ctx, dh):
+        (u16,) = ctx.saved_tensors
+        return _r(dh * _gelu_grad(u16))
+
+
+class _AttnEmu(torch.autograd.Function):
+    """Flash-style attention with the HIP kernel's cast points.
+
+    forward : S = q k^T (fp32 acc), p = exp(scale*S - m), l = sum p (fp32),
+              O = (bf16(p) @ v) / l, returns bf16(O) and LSE.
+    backward: delta = rowsum(dO*O); P = exp(scale*S - LSE); dV = bf16(P)^T dO;
+              dP = dO v^T; dS = bf16(P*(dP-delta)); dQ = scale*dS k; dK = scale*dS^T q;
+              all outputs rounded to bf16.
+    q, k, v : [B, h, n, dh] (bf16-representable values in fp32 storage).
+    """
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        s = torch.matmul(q, k.transpose(-1, -2)) * scale
+        m = s.amax(dim=-1, keepdim=True)
+        p = torch.exp(s - m)
+        l = p.sum(dim=-1, keepdim=True)
+        o = _r(torch.matmul(_r(p), v) / l)
+        lse = m + torch.log(l)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        scale = ctx.scale
+        do = _r(do)
+        delta = (do * o).sum(dim=-1, keepdim=True)
+        p = torch.exp(torch.matmul(q, k.transpose(-1, -2)) * scale - lse)
+        dv = torch.matmul(_r(p).transpose(-1, -2), do)
+        dp = torch.matmul(do, v.transpose(-1, -2))
+        ds = _r(p * (dp - delta))
+        dq = torch.matmul(ds, k) * scale
+        dk = torch.matmul(ds.transpose(-1, -2), q) * scale
+        return _r(dq), _r(dk), _r(dv), None
+
+
+# --------------------------------------------------------------------------- A1: patchify
+
+def patchify(video: torch.Tensor, p1: int, p2: int, pf: int) -> torch.Tensor:
+    """Rearrange('b c (f pf) (h p1) (w p2) -> b (f h w) (p1 p2 pf c)')  (vit_3d.py:92).
+
+    Pure index map, bit exact.  video: [B, C, F, H, W] (any strides)."""
+    B, C, Fr, H, W = video.shape
+    f, h, w = Fr // pf, H // p1, W // p2
+    v = video.reshape(B, C, f, pf, h, p1, w, p2)
+    #            b  f  h  w  p1 p2 pf c
+    v = v.permute(0, 2, 4, 6, 5, 7, 3, 1)
+    return v.reshape(B, f * h * w, p1 * p2 * pf * C)
+
+
+def fmri_to_video(fmri: torch.Tensor) -> torch.Tensor:
+    """ViT3DEncoder.forward (NeuroEncoder.py:200-202): [B,H,W,D] -> [B,1,D,H,W] (a view)."""
+    return fmri.permute(0, 3, 1, 2).unsqueeze(1)
+
+
+def patch_index_map(S: int, p: int) -> np.ndarray:
+    """Integer restatement of A1 for the NeuroEncoder layout.
+
+    For a cubic volume V[x, y, z] of side S (dataset layout [H, W, D], z contiguous)
+    returns idx[N, P] (int64) with tokens[n, k] == V.flat[idx[n, k]]:
+        n = (z//p) G^2 + (x//p) G + (y//p),   k = (x%p) p^2 + (y%p) p + (z%p).
+    """
+    G = S // p
+    x, y, z = np.meshgrid(np.arange(S), np.arange(S), np.arange(S), indexing="ij")
+    n = (z // p) * G * G + (x // p) * G + (y // p)
+    k = (x % p) * p * p + (y % p) * p + (z % p)
+    flat = (x * S + y) * S + z
+    idx = np.empty((G ** 3, p ** 3), dtype=np.int64)
+    idx[n.ravel(), k.ravel()] = flat.ravel()
+    return idx
+
+
+# --------------------------------------------------------------------------- blocks
+
+def _linear(x, w, b, emulate):
+    if emulate:
+        y = _RoundGrad.apply(F.linear(_r(x), _r(w)))
+        return y if b is None else y + b
+    return F.linear(x, w, b)
+
+
+def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None):
+    """Attention.forward (vit_3d.py:48-60).  `pre` = 'transformer.layers.{i}.0.'."""
+    B, n, d = x.shape
+    inner = heads * dim_head
+    xn = F.layer_norm(x, (d,), sd[pre + "norm.weight"], sd[pre + "norm.bias"], LN_EPS)
+    if taps is not None:
+        taps[pre + "norm.out"] = xn
+    if emulate:
+        xn = _r(xn)
+        qkv = _r(_linear(xn, sd[pre + "to_qkv.weight"], None, True))
+    else:
+        qkv = F.linear(xn, sd[pre + "to_qkv.weight"])
+    q, k, v = qkv.chunk(3, dim=-1)
+    # 'b n (h d) -> b h n d'
+    q, k, v = (t.reshape(B, n, heads, dim_head).permute(0, 2, 1, 3) for t in (q, k, v))
+    scale = dim_head ** -0.5
+    if emulate:
+        out = _AttnEmu.apply(q, k, v, scale)
+    else:
+        dots = torch.matmul(q, k.transpose(-1, -2)) * scale
+        attn = torch.softmax(dots, dim=-1)
+        out = torch.matmul(attn, v)
+        if taps is not None:
+            taps[pre + "attn.rowsum"] = attn.sum(-1)
+    # 'b h n d -> b n (h d)'
+    out = out.permute(0, 2, 1, 3).reshape(B, n, inner)
+    if taps is not None:
+        taps[pre + "q"], taps[pre + "k"], taps[pre + "v"] = q, k, v
+        taps[pre + "attn.out"] = out
+    if (pre + "to_out.0.weight") in sd:            # project_out (vit_3d.py:32,43-46)
+        out = _linear(out, sd[pre + "to_out.0.weight"], sd[pre + "to_out.0.bias"], emulate)
+    return out
+
+
+def feed_forward(sd, pre, x, emulate=False):
+    """FeedForward.forward (vit_3d.py:16-26).  `pre` = 'transformer.layers.{i}.1.'."""
+    d = x.shape[-1]
+    xn = F.layer_norm(x, (d,), sd[pre + "net.0.weight"], sd[pre + "net.0.bias"], LN_EPS)
+    if emulate:
+        u = _linear(_r(xn), sd[pre + "net.1.weight"], sd[pre + "net.1.bias"], True)
+        h = _GeluEmu.apply(u)
+        return _linear(h, sd[pre + "net.4.weight"], sd[pre + "net.4.bias"], True)
+    h = F.gelu(F.linear(xn, sd[pre + "net.1.weight"], sd[pre + "net.1.bias"]))
+    return F.linear(h, sd[pre + "net.4.weight"], sd[pre + "net.4.bias"])
+
+
+def patch_embed(sd, cfg: ViTCfg, video, emulate=False, taps=None):
+    """to_patch_embedding + cls/pos (vit_3d.py:91-96,113-119); dropout = identity (eval / p=0)."""
+    tok = patchify(video, cfg.image_patch_size, cfg.image_patch_size, cfg.frame_patch_size)
+    P, d = cfg.patch_dim, cfg.dim
+    a2 = F.layer_norm(tok, (P,), sd["to_patch_embedding.1.weight"], sd["to_patch_embedding.1.bias"], LN_EPS)
+    a3 = _linear(a2, sd["to_patch_embedding.2.weight"], sd["to_patch_embedding.2.bias"], emulate)
+    a4 = F.layer_norm(a3, (d,), sd["to_patch_embedding.3.weight"], sd["to_patch_embedding.3.bias"], LN_EPS)
+    B, n, _ = a4.shape
+    cls = sd["cls_token"].expand(B, 1, d)
+    x = torch.cat((cls, a4), dim=1)
+    x = x + sd["pos_embedding"][:, : n + 1]
+    if taps is not None:
+        taps["A1"], taps["A2"], taps["A3"], taps["A4"], taps["A5"] = tok, a2, a3, a4, x
+    return x
+
+
+def vit_forward(sd: Dict[str, torch.Tensor], cfg: ViTCfg, video: torch.Tensor,
+                emulate_bf16: bool = False, taps: Optional[dict] = None) -> torch.Tensor:
+    """ViT.forward (vit_3d.py:112-126), dropout inactive.  video: [B, C, F, H, W]."""
+    x = patch_embed(sd, cfg, video, emulate_bf16, taps)
+    for i in range(cfg.depth):
+        pa, pf = f"transformer.layers.{i}.0.", f"transformer.layers.{i}.1."
+        x = attention(sd, pa, x, cfg.heads, cfg.dim_head, emulate_bf16, taps) + x
+        x = feed_forward(sd, pf, x, emulate_bf16) + x
+        if taps is not None:
+            taps[f"block{i}"] = x
+    x = x.mean(dim=1) if cfg.pool == "mean" else x[:, 0]
+    x = F.layer_norm(x, (cfg.dim,), sd["mlp_head.0.weight"], sd["mlp_head.0.bias"], LN_EPS)
+    return F.linear(x, sd["mlp_head.1.weight"], sd["mlp_head.1.bias"])
+
+
+# --------------------------------------------------------------------------- NeuroEncoder level
+
+def neuro_cfg(config: dict) -> ViTCfg:
+    """ViT3DEncoder.__init__ (NeuroEncoder.py:171-195): config dict -> ViT ctor args.
+    Optional TRAINING_VIT_* size keys default to the reference's hard-coded constants."""
+    S, p = config["TRAINING_VIT_INPUT_SIZE"], config["TRAINING_VIT_PATCH_SIZE"]
+    ncls = (S // config["GRADCAM_CUBE_SIZE"]) ** 3 if config["DATASET_NAME"] == "gradcam" else 2
+    return ViTCfg(image_size=S, image_patch_size=p, frames=S, frame_patch_size=p, num_classes=ncls,
+                  dim=config.get("TRAINING_VIT_DIM", 1024), depth=config.get("TRAINING_VIT_DEPTH", 6),
+                  heads=config.get("TRAINING_VIT_HEADS", 8), mlp_dim=config.get("TRAINING_VIT_MLP_DIM", 2048),
+                  pool="cls", channels=1, dim_head=config.get("TRAINING_VIT_DIM_HEAD", 64))
+
+
+def temporal_transformer(sd, pre, x):
+    """nn.TransformerEncoder(TransformerEncoderLayer(d_model=2, nhead=2, batch_first=True), 1)
+    (NeuroEncoder.py:211-212) restated: post-norm, ReLU, eval mode (no dropout).
+    `pre` = 'temporal_transformer.transformer.layers.0.'."""
+    B, T, E = x.shape
+    H = 2
+    dh = E // H
+    qkv = F.linear(x, sd[pre + "self_attn.in_proj_weight"], sd[pre + "self_attn.in_proj_bias"])
+    q, k, v = qkv.chunk(3, dim=-1)
+    q, k, v = (t.reshape(B, T, H, dh).permute(0, 2, 1, 3) for t in (q, k, v))
+    a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+    o = torch.matmul(a, v).permute(0, 2, 1, 3).reshape(B, T, E)
+    o = F.linear(o, sd[pre + "self_attn.out_proj.weight"], sd[pre + "self_attn.out_proj.bias"])
+    x = F.layer_norm(x + o, (E,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], LN_EPS)
+    f = F.linear(F.relu(F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"])),
+                 sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
+    return F.layer_norm(x + f, (E,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], LN_EPS)
+
+
+def neuro_forward(sd: Dict[str, torch.Tensor], config: dict, fmri: torch.Tensor,
+                  emulate_bf16: bool = False, taps: Optional[dict] = None) -> torch.Tensor:
+    """NeuroEncoder.forward (NeuroEncoder.py:49-68).  `sd` keyed like NeuroEncoder.state_dict()."""
+    cfg = neuro_cfg(config)
+    vsd = strip_prefix(sd, "volume_encoder.vit3d.")
+    if config["TRAINING_DIM"] == 3:
+        return vit_forward(vsd, cfg, fmri_to_video(fmri), emulate_bf16, taps)
+    f = fmri.permute(0, 4, 1, 2, 3)
+    B, T, H, W, D = f.shape
+    vols = f.reshape(B * T, H, W, D)
+    enc = vit_forward(vsd, cfg, fmri_to_video(vols), emulate_bf16, taps).reshape(B, T, -1)
+    enc = temporal_transformer(sd, "temporal_transformer.transformer.layers.0.", enc)
+    enc = enc.mean(dim=1)
+    return F.linear(enc, sd["projection_head.projection_head.weight"], sd["projection_head.projection_head.bias"])
+
+
+# --------------------------------------------------------------------------- Grad-CAM (§8f F1)
+
+def grad_cam(activations: torch.Tensor, gradients: torch.Tensor, S: int, p: int, threshold: float):
+    """NeuroEncoder.get_attention_map steps 1-6 (NeuroEncoder.py:101-131) given the hooked
+    activation / gradient of the last block's attention LayerNorm output ([1, n, d])."""
+    weights = gradients.mean(dim=2, keepdim=True)
+    cam = (weights * activations).sum(dim=2)[:, 1:]
+    G = S // p
+    cam = F.relu(cam.reshape(1, G, G, G))
+    cam = (cam - cam.min()) / (cam.max() - cam.min() + 1e-8)
+    thr = np.percentile(cam.numpy(), 100 - threshold)
+    m = torch.from_numpy(np.where(cam.numpy() >= thr, cam.numpy(), 0)).unsqueeze(0)
+    return F.interpolate(m, size=(S, S, S), mode="trilinear", align_corners=False).squeeze()
+
+
+# --------------------------------------------------------------------------- algorithmic work
+
+def flops_forward(cfg: ViTCfg) -> float:
+    """Algorithmic FLOPs per volume, forward (2*MAC; LN/softmax/GELU/bias excluded)."""
+    N, n, P, d, inner, m, L, C = (cfg.num_patches, cfg.num_patches + 1, cfg.patch_dim, cfg.dim,
+                                  cfg.inner, cfg.mlp_dim, cfg.depth, cfg.num_classes)
+    per_layer = 2 * n * d * 3 * inner + 2 * n * n * inner + 2 * n * n * inner + 2 * n * inner * d + 4 * n * d * m
+    return 2.0 * N * P * d + L * per_layer + 2 * d * C

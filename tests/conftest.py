@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, GOLDEN):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` tests need a GPU: skip (not fail) them when collected on a box without one."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return load
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b|  (per-tensor normalised max error) on numpy/torch inputs."""
+    import torch
+    def cv(t):
+        if isinstance(t, torch.Tensor):
+            return t.detach().cpu().double()
+        return torch.as_tensor(np.asarray(t)).double()
+    a, b = cv(a), cv(b)
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
