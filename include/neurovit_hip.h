@@ -1,0 +1,125 @@
+/* neurovit_hip.h - C ABI of libneurovit_hip.so: the MI355X (gfx950) hot path of NeuroViT.
+ *
+ * The reference (gillet-thomas/NeuroViT) has NO native/FFI interface: its seam is the Python
+ * nn.Module contract.  This header is the C-ABI that sits beneath our drop-in
+ * nn.Modules; every entry point names the reference code it replaces (paths relative to the
+ * reference checkout).  The Python binding a maintainer adds is a ctypes.CDLL stub - see
+ * INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch types; `void*` buffers marked bf16 hold bfloat16;
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch owns all memory);
+ *   - `stream` is a hipStream_t; nothing here allocates, frees or synchronises;
+ *   - returns 0 on success, <0 on error (NV_ERR_*); nv_last_error() gives the message;
+ *   - row-major, `ld*` = leading dimension in ELEMENTS;
+ *   - arithmetic: bf16 MFMA operands, fp32 accumulate, fp32 residual stream / LayerNorm /
+ *     softmax / optimizer state ("dtype": "bf16" in bench.py).
+ */
+#ifndef NEUROVIT_HIP_H
+#define NEUROVIT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NV_OK 0
+#define NV_ERR_ARG (-1)
+#define NV_ERR_HIP (-2)
+#define NV_ERR_ARCH (-3)
+
+/* ---- housekeeping ------------------------------------------------------------------------- */
+int nv_version(void);
+int nv_arch_ok(void);                 /* 1 iff the current HIP device is gfx950 */
+const char* nv_last_error(void);
+
+/* ---- GEMM with fused epilogues (replaces every nn.Linear on the path: vit_3d.py:19,22,41,44,94)
+ * layout 0 (NT): C[M,N] = A[M,K] . B[N,K]^T      forward  y = x W^T
+ * layout 1 (NN): C[M,N] = A[M,K] . B[K,N]        dgrad    dx = dy W
+ * layout 2 (TN): C[M,N] = A[K,M]^T . B[K,N]      wgrad    dW = dy^T x
+ * epi 0 STORE_BF16, 1 STORE_F32 (+= if accumulate), 2 BIAS_F32, 3 BIAS_GELU (aux_out = pre-activation bf16,
+ * C = exact-erf GELU bf16; vit_3d.py:19-20), 4 BIAS_RESID (C f32 = aux_in f32 + acc + bias; vit_3d.py:73-74),
+ * 5 DGELU (C bf16 = acc * gelu'(aux_in bf16)).  A, B bf16. */
+int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C,
+                 long ldc, const float* bias, const void* aux_in, long ld_aux_in, void* aux_out, long ld_aux_out,
+                 int accumulate, float alpha, void* stream);
+
+/* ---- LayerNorm of the residual stream (vit_3d.py:18,37): x f32 [M,d] -> y bf16, saves mean / rstd */
+int nv_ln_fwd(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, void* y, long ldy,
+              float* mean, float* rstd, void* stream);
+long nv_ln_bwd_workspace_bytes(int M, int d);
+/* g_out = g_in + dLN(dy); g16 = bf16(g_out); dgamma / dbeta / dcolsum(= column sums of g_out) optional */
+int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd, const float* gamma,
+              int M, int d, const float* g_in, float* g_out, long ldg, void* g16, long ldg16, float* dgamma, float* dbeta,
+              float* dcolsum, int accumulate, void* workspace, long ws_bytes, void* stream);
+
+/* ---- patch embedding front end (vit_3d.py:92-93 + the permute of NeuroEncoder.py:200-202)
+ * video [B,C,F,H,W] f32 with arbitrary element strides (pass the strides of the permuted VIEW of the
+ * [B,H,W,D] dataset tensor - no copy); out bf16 [B*N, ldo] = LayerNorm(patch_dim)(patches). */
+int nv_patch_ln_fwd(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
+                    const float* gamma, const float* beta, float eps, void* out, long ldo, float* mean, float* rstd,
+                    void* stream);
+long nv_patch_ln_bwd_workspace_bytes(int tokens, int P);
+int nv_patch_ln_bwd(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
+                    const float* dxp, long ldd, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                    int accumulate, void* workspace, long ws_bytes, void* stream);
+
+/* ---- LayerNorm(dim) + cls token + positional embedding (vit_3d.py:95,116-118): t [B*N,d] -> x [B,N+1,d] */
+int nv_embed_finish_fwd(const float* t, long ldt, int B, int N, int d, const float* gamma, const float* beta, float eps,
+                        const float* pos, const float* cls, float* x, long ldx, float* mean, float* rstd, void* stream);
+long nv_embed_finish_bwd_workspace_bytes(int B, int N, int d);
+int nv_embed_finish_bwd(const float* g, long ldg, const float* t, long ldt, const float* mean, const float* rstd,
+                        const float* gamma, int B, int N, int d, float* dt, long lddt, void* dt16, long lddt16, float* dgamma,
+                        float* dbeta, float* dbias_pe, float* dpos, float* dcls, int accumulate, void* workspace, long ws_bytes,
+                        void* stream);
+
+/* ---- multi-head attention core (vit_3d.py:51-59): qkv bf16 [B,n,3*inner] -> out bf16 [B,n,inner], lse f32 [B,heads,n] */
+int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
+                float* lse, void* stream);
+int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const void* dout, long ld_out, const float* lse, int B, int n,
+                int heads, int dim_head, float scale, float* delta, void* dqkv, long ld_dqkv, void* stream);
+
+/* ---- classification head (vit_3d.py:107-110,123-126): cls row -> LayerNorm -> Linear(dim, C), fp32 */
+int nv_head_fwd(const float* x, long row_stride, int B, int d, const float* gamma, const float* beta, float eps,
+                const float* W, const float* bias, int C, float* xh, float* stats, float* logits, void* stream);
+long nv_head_bwd_workspace_bytes(int B, int d);
+int nv_head_bwd(const float* dlogits, int B, int C, const float* W, const float* x, long row_stride, const float* stats,
+                const float* xh, const float* gamma, int d, int n, float* g, long ldg, void* g16, long ldg16, float* dgamma,
+                float* dbeta, float* dW, float* dbias, float* dcolsum, int accumulate, void* workspace, long ws_bytes,
+                void* stream);
+
+/* ---- bias gradients: out[c] (+)= sum_r X[r,c], X bf16 */
+long nv_colsum_workspace_bytes(int M, int N);
+int nv_colsum_bf16(const void* X, long ld, int M, int N, float* out, int accumulate, void* workspace, long ws_bytes,
+                   void* stream);
+
+/* ---- loss / optimizer (Trainer.py:30-31,70,75): nn.CrossEntropyLoss (mean) and torch.optim.AdamW */
+int nv_ce_loss(const float* logits, const long* target, int B, int C, float grad_scale, float* loss, float* dlogits,
+               void* stream);
+int nv_adamw_step(float* p, const float* grad, float* m, float* v, void* p16, long count, int step, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+int nv_cast_bf16_2d(const float* src, long ld_src, int rows, int cols, void* dst, long ld_dst, void* stream);
+
+/* ---- whole-encoder engine: ViT.forward / its backward as ONE call each (vit_3d.py:112-126)
+ * Parameters live in one flat fp32 arena (+ a bf16 shadow with identical element offsets) laid out by
+ * nv_vit_param_table in the reference's state_dict order; gradients go to an arena of the same layout. */
+typedef struct nv_vit_config {
+  int image_size, image_patch_size, frames, frame_patch_size;
+  int channels, num_classes, dim, depth, heads, dim_head, mlp_dim;
+  float ln_eps;
+} nv_vit_config;
+
+long nv_vit_param_count(const nv_vit_config* cfg);
+int nv_vit_param_table(const nv_vit_config* cfg, long* offsets, long* numels, int max_entries);
+long nv_vit_workspace_bytes(const nv_vit_config* cfg, int B, int training);
+/* byte offset of a named activation inside the workspace (-1 if unknown); layer < 0 for global buffers */
+long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int training, const char* name, int layer);
+int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
+                   const void* params16, void* workspace, long ws_bytes, int training, float* logits, void* stream);
+int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
+                    const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
+                    int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUROVIT_HIP_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of libneurovit_hip.so (the gfx950 C-ABI, include/neurovit_hip.h).
+
+The prototypes are parsed from the header itself so the binding cannot drift from it.
+There is NO fallback: if the library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "neurovit_hip.h")
+LIB_PATH = os.path.join(_HERE, "lib", "libneurovit_hip.so")
+
+_SCALARS = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
+
+
+class VitConfig(ctypes.Structure):
+    """struct nv_vit_config (neurovit_hip.h) == ctor arguments of the reference ViT (vit_3d.py:78)."""
+    _fields_ = [("image_size", ctypes.c_int), ("image_patch_size", ctypes.c_int), ("frames", ctypes.c_int),
+                ("frame_patch_size", ctypes.c_int), ("channels", ctypes.c_int), ("num_classes", ctypes.c_int),
+                ("dim", ctypes.c_int), ("depth", ctypes.c_int), ("heads", ctypes.c_int), ("dim_head", ctypes.c_int),
+                ("mlp_dim", ctypes.c_int), ("ln_eps", ctypes.c_float)]
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
+    """{symbol: (restype, [argtypes])} for every `nv_*` prototype declared in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|long|const char\s*\*)\s+(nv_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        restype = ctypes.c_char_p if "char" in ret else _SCALARS[ret]
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_char_p if re.match(r"const char\s*\*", a) else ctypes.c_void_p)
+                else:
+                    argtypes.append(_SCALARS[a.split()[0]])
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+class _Lib:
+    def __init__(self):
+        self._dll = None
+        self.protos = parse_header()
+
+    def load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"neurovit_amd: {LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or `make -C neurovit_amd/csrc`). There is no CPU / PyTorch fallback for this path.")
+            dll = ctypes.CDLL(LIB_PATH)
+            for name, (restype, argtypes) in self.protos.items():
+                fn = getattr(dll, name)          # AttributeError if the .so lacks a declared symbol
+                fn.restype, fn.argtypes = restype, argtypes
+            self._dll = dll
+        return self._dll
+
+    def __getattr__(self, name):
+        return getattr(self.load(), name)
+
+
+lib = _Lib()
+
+
+def last_error() -> str:
+    return (lib.nv_last_error() or b"").decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError(f"neurovit_amd C-ABI call failed ({what}, rc={rc}): {last_error()}")
+
+
+def require_gpu() -> None:
+    """Fail loudly unless a gfx950 device and the HIP library are usable."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("neurovit_amd: no HIP device available - this path only runs on MI355X (gfx950); "
+                           "there is no CPU fallback.")
+    if lib.nv_arch_ok() != 1:
+        raise RuntimeError(f"neurovit_amd: current device is not gfx950: {last_error()}")

@@ -1,0 +1,354 @@
+// Flash-style multi-head attention for the ViT3D encoder (vit_3d.py:48-59), gfx950, dim_head = 64.
+//
+// Input is the packed projection qkv [B, n, 3*inner] bf16 ('b n (h d)' per chunk); output is
+// 'b n (h d)' bf16 - the rearranges of the reference are pure addressing here.  n = N+1 is never
+// tile aligned (513, 65, 1001): keys beyond n are zero-filled and masked to -inf, query rows
+// beyond n are computed on clamped loads and never stored.
+//
+// MFMA orientation (v_mfma_f32_16x16x32_bf16, one wave = 16 query rows):
+//   S^T = K . Q^T      -> accumulator lane (r,g) holds S[q = r][key = 16t + 4g + reg]: the softmax row index
+//                         is the LANE, so row max/sum need only two shuffles (xor 16, 32), and
+//   O^T = V^T . P^T    -> the P accumulators ARE the next MFMA's B operand (no LDS round trip); V^T comes
+//                         from the row-major V tile through ds_read_b64_tr_b16.
+// The k index of the second product is permuted (element j<4 <- key tile 2ks, j>=4 <- key tile 2ks+1) and the
+// transposed V reads use the same permutation (row groups 4g and 16+4g).
+// Backward = two deterministic kernels (no atomics): dQ per query tile, dK/dV per key tile, both
+// recomputing P from the saved log-sum-exp.
+#include "common.h"
+
+constexpr int DH = 64;            // dim_head (reference default, vit_3d.py:29)
+constexpr int TQ = 64;            // rows per workgroup (4 waves x 16)
+constexpr int TK = 64;            // keys per LDS tile
+constexpr int IMG = TK * DH * 2;  // 8 KiB image
+
+// stage one [64 rows][64 bf16] tile: rows row0.. of X (row stride ld), zero-fill rows >= nrows
+__device__ __forceinline__ void tile_gload(const bf16* X, long ld, int row0, int nrows, int tid, uint4 (&reg)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i, row = row0 + (c >> 3);
+    const bool ok = row < nrows;
+    const uint4 v = *reinterpret_cast<const uint4*>(X + (ok ? (long)row * ld + ((c & 7) << 3) : 0));
+    reg[i] = ok ? v : make_uint4(0, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void tile_swrite(char* img, int tid, const uint4 (&reg)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    *reinterpret_cast<uint4*>(img + img128_off(c >> 3, c & 7)) = reg[i];
+  }
+}
+// row-read fragment: lane (r,g) <- X[16t + r][32ks + 8g .. +7]
+__device__ __forceinline__ bf16x8 frag_row(const char* img, int t, int ks, int r, int g) {
+  return *reinterpret_cast<const bf16x8*>(img + img128_off(16 * t + r, 4 * ks + g));
+}
+// transposed fragment: lane (r,g) <- { X[32ks + 4g + j][16t + r] (j<4), X[32ks + 16 + 4g + j-4][16t + r] (j>=4) }
+__device__ __forceinline__ bf16x8 frag_tr(const char* img, int t, int ks, int r, int g) {
+  const int q = r >> 2, p = r & 3;
+  const int ch = 2 * t + (p >> 1), sub = (p & 1) << 3;
+  const bf16x4 lo = lds_read_tr(img + img128_off(32 * ks + 4 * g + q, ch) + sub);
+  const bf16x4 hi = lds_read_tr(img + img128_off(32 * ks + 16 + 4 * g + q, ch) + sub);
+  return cat4(lo, hi);
+}
+__device__ __forceinline__ float group_max(float v) {   // over the 4 lane groups sharing r
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
+                                                       bf16* __restrict__ out, long ldo, float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
+  char* sK = smem;
+  char* sV = smem + IMG;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const bf16* K = Q + inner;
+  const bf16* V = Q + 2 * inner;
+  const int q0 = blockIdx.x * TQ + 16 * wid;
+  const int qrow = min(q0 + r, n - 1);
+
+  bf16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+
+  f32x4 o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+
+  const int nkt = (n + TK - 1) / TK;
+  uint4 rk[2], rv[2];
+  tile_gload(K, ld, 0, n, tid, rk);
+  tile_gload(V, ld, 0, n, tid, rv);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    tile_swrite(sK, tid, rk);
+    tile_swrite(sV, tid, rv);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_gload(K, ld, (kt + 1) * TK, n, tid, rk);
+      tile_gload(V, ld, (kt + 1) * TK, n, tid, rv);
+    }
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t, ks, r, g), qf[ks], s[t], 0, 0, 0);
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kt * TK + 16 * t + 4 * g + j;
+        const float v = (key < n) ? s[t][j] * scale_log2e : -INFINITY;
+        s[t][j] = v;
+        mloc = fmaxf(mloc, v);
+      }
+    const float mnew = fmaxf(m, group_max(mloc));
+    const float alpha = exp2f(m - mnew);
+    m = mnew;
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p = exp2f(s[t][j] - mnew);
+        s[t][j] = p;
+        psum += p;
+      }
+    l = l * alpha + psum;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] *= alpha;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 pf = cvt8(s[2 * ks], s[2 * ks + 1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sV, t, ks, r, g), pf, o[t], 0, 0, 0);
+    }
+  }
+  const float ltot = group_sum(l);
+  const float inv = 1.0f / ltot;
+  const int q = q0 + r;
+  if (q < n) {
+    bf16* orow = out + ((long)b * n + q) * ldo + h * DH;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<bf16x4*>(orow + 16 * t + 4 * g) = cvt4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
+    if (g == 0 && lse) lse[((long)b * heads + h) * n + q] = (m + log2f(ltot)) * 0.69314718055994530942f;
+  }
+}
+
+extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
+                           float* lse, void* stream) {
+  NV_CHECK_ARG(dim_head == DH, "nv_attn_fwd: dim_head=%d unsupported (only 64)", dim_head);
+  NV_CHECK_ARG(B > 0 && n > 0 && heads > 0 && ld_qkv >= 3 * heads * DH && ld_out >= heads * DH && (ld_qkv % 8) == 0 && (ld_out % 4) == 0,
+               "nv_attn_fwd: bad dims");
+  NV_CHECK_ARG(nv_aligned16(qkv) && nv_aligned16(out), "nv_attn_fwd: alignment");
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((n + TQ - 1) / TQ, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
+                     heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse);
+  NV_CHECK_LAUNCH("nv_attn_fwd");
+  return NV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
+                                                          const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse, int n,
+                                                          int heads, float scale, float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                          long ldd) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
+  char* sK = smem;
+  char* sV = smem + IMG;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const bf16* K = Q + inner;
+  const bf16* V = Q + 2 * inner;
+  const int q0 = blockIdx.x * TQ + 16 * wid;
+  const int qrow = min(q0 + r, n - 1);
+  const float scale_log2e = scale * 1.44269504088896340736f;
+
+  bf16x8 qf[2], dof[2];
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+    const long off = ((long)b * n + qrow) * ldo + h * DH + 32 * ks + 8 * g;
+    dof[ks] = *reinterpret_cast<const bf16x8*>(dout + off);
+    const bf16x8 of = *reinterpret_cast<const bf16x8*>(out + off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[j];
+  }
+  dl = group_sum(dl);
+  const float lse2 = lse[((long)b * heads + h) * n + qrow] * 1.44269504088896340736f;
+  if (g == 0 && q0 + r < n) delta[((long)b * heads + h) * n + q0 + r] = dl;
+
+  f32x4 dq[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (n + TK - 1) / TK;
+  uint4 rk[2], rv[2];
+  tile_gload(K, ld, 0, n, tid, rk);
+  tile_gload(V, ld, 0, n, tid, rv);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    tile_swrite(sK, tid, rk);
+    tile_swrite(sV, tid, rv);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_gload(K, ld, (kt + 1) * TK, n, tid, rk);
+      tile_gload(V, ld, (kt + 1) * TK, n, tid, rv);
+    }
+    f32x4 ds[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t, ks, r, g), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sV, t, ks, r, g), dof[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kt * TK + 16 * t + 4 * g + j;
+        const float p = (key < n) ? exp2f(s[j] * scale_log2e - lse2) : 0.f;
+        ds[t][j] = p * (dp[j] - dl);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 dsf = cvt8(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sK, t, ks, r, g), dsf, dq[t], 0, 0, 0);
+    }
+  }
+  const int q = q0 + r;
+  if (q < n) {
+    bf16* drow = dqkv + ((long)b * n + q) * ldd + h * DH;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<bf16x4*>(drow + 16 * t + 4 * g) = cvt4(dq[t][0] * scale, dq[t][1] * scale, dq[t][2] * scale, dq[t][3] * scale);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout, long ldo,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta, int n,
+                                                           int heads, float scale, bf16* __restrict__ dqkv, long ldd) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * IMG + 2 * TQ * 4];
+  char* sQ = smem;
+  char* sD = smem + IMG;
+  float* sL = reinterpret_cast<float*>(smem + 2 * IMG);
+  float* sDl = sL + TQ;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const bf16* K = Q + inner;
+  const bf16* V = Q + 2 * inner;
+  const bf16* dO = dout + (long)b * n * ldo + h * DH;
+  const float* L = lse + ((long)b * heads + h) * n;
+  const float* Dl = delta + ((long)b * heads + h) * n;
+  const int key0 = blockIdx.x * TK + 16 * wid;
+  const int krow = min(key0 + r, n - 1);
+  const float scale_log2e = scale * 1.44269504088896340736f;
+
+  bf16x8 kf[2], vf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(K + (long)krow * ld + 32 * ks + 8 * g);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(V + (long)krow * ld + 32 * ks + 8 * g);
+  }
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nqt = (n + TQ - 1) / TQ;
+  uint4 rq[2], rd[2];
+  float rl = 0.f, rdl = 0.f;
+  auto stats_load = [&](int qt) {
+    if (tid < TQ) {
+      const int q = qt * TQ + tid;
+      rl = (q < n) ? L[q] * 1.44269504088896340736f : INFINITY;   // exp2(x - inf) = 0 masks padded query rows
+      rdl = (q < n) ? Dl[q] : 0.f;
+    }
+  };
+  tile_gload(Q, ld, 0, n, tid, rq);
+  tile_gload(dO, ldo, 0, n, tid, rd);
+  stats_load(0);
+  for (int qt = 0; qt < nqt; ++qt) {
+    __syncthreads();
+    tile_swrite(sQ, tid, rq);
+    tile_swrite(sD, tid, rd);
+    if (tid < TQ) { sL[tid] = rl; sDl[tid] = rdl; }
+    __syncthreads();
+    if (qt + 1 < nqt) {
+      tile_gload(Q, ld, (qt + 1) * TQ, n, tid, rq);
+      tile_gload(dO, ldo, (qt + 1) * TQ, n, tid, rd);
+      stats_load(qt + 1);
+    }
+    f32x4 p[4], ds[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sQ, t, ks, r, g), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sD, t, ks, r, g), vf[ks], dp, 0, 0, 0);
+      }
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 16 * t + 4 * g);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + 16 * t + 4 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float pv = exp2f(s[j] * scale_log2e - l4[j]);
+        p[t][j] = pv;
+        ds[t][j] = pv * (dp[j] - d4[j]);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 pf = cvt8(p[2 * ks], p[2 * ks + 1]);
+      const bf16x8 dsf = cvt8(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sD, t, ks, r, g), pf, dv[t], 0, 0, 0);
+        dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQ, t, ks, r, g), dsf, dk[t], 0, 0, 0);
+      }
+    }
+  }
+  const int key = key0 + r;
+  if (key < n) {
+    bf16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      *reinterpret_cast<bf16x4*>(drow + inner + 16 * t + 4 * g) = cvt4(dk[t][0] * scale, dk[t][1] * scale, dk[t][2] * scale, dk[t][3] * scale);
+      *reinterpret_cast<bf16x4*>(drow + 2 * inner + 16 * t + 4 * g) = cvt4(dv[t][0], dv[t][1], dv[t][2], dv[t][3]);
+    }
+  }
+}
+
+// delta: [B, heads, n] fp32 scratch (written by the dQ kernel, read by the dK/dV kernel).
+extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const void* dout, long ld_out, const float* lse, int B, int n,
+                           int heads, int dim_head, float scale, float* delta, void* dqkv, long ld_dqkv, void* stream) {
+  NV_CHECK_ARG(dim_head == DH, "nv_attn_bwd: dim_head=%d unsupported (only 64)", dim_head);
+  NV_CHECK_ARG(B > 0 && n > 0 && heads > 0 && ld_qkv >= 3 * heads * DH && ld_dqkv >= 3 * heads * DH && ld_out >= heads * DH &&
+                   (ld_qkv % 8) == 0 && (ld_out % 8) == 0 && (ld_dqkv % 4) == 0,
+               "nv_attn_bwd: bad dims");
+  NV_CHECK_ARG(nv_aligned16(qkv) && nv_aligned16(out) && nv_aligned16(dout) && nv_aligned16(dqkv), "nv_attn_bwd: alignment");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((n + TQ - 1) / TQ, B * heads);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out, lse, n,
+                     heads, scale, delta, (bf16*)dqkv, ld_dqkv);
+  NV_CHECK_LAUNCH("nv_attn_bwd/dq");
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)dout, ld_out, lse, delta, n, heads,
+                     scale, (bf16*)dqkv, ld_dqkv);
+  NV_CHECK_LAUNCH("nv_attn_bwd/dkv");
+  return NV_OK;
+}

@@ -1,0 +1,104 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of neurovit_amd.
+// Wave size is 64; MFMA shape used throughout is v_mfma_f32_16x16x32_bf16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+#define NV_OK 0
+#define NV_ERR_ARG (-1)        // bad shape / alignment / unsupported configuration
+#define NV_ERR_HIP (-2)        // HIP runtime error (see nv_last_error)
+#define NV_ERR_ARCH (-3)       // not a gfx950 device
+
+extern "C" void nv_set_error(const char* fmt, ...);
+
+#define NV_CHECK_ARG(cond, ...)                                                                   \
+  do {                                                                                            \
+    if (!(cond)) {                                                                                \
+      nv_set_error(__VA_ARGS__);                                                                  \
+      return NV_ERR_ARG;                                                                          \
+    }                                                                                             \
+  } while (0)
+
+#define NV_CHECK_LAUNCH(name)                                                                     \
+  do {                                                                                            \
+    hipError_t e__ = hipGetLastError();                                                           \
+    if (e__ != hipSuccess) {                                                                      \
+      nv_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));                        \
+      return NV_ERR_HIP;                                                                          \
+    }                                                                                             \
+  } while (0)
+
+static inline bool nv_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ------------------------------------------------------------------------------------------------
+// LDS images.  All byte offsets are relative to a 16-byte aligned tile base.
+//
+// IMG128: [rows][64 bf16] tile, 128-byte rows, 8 x 16-byte chunks per row, chunk index XOR (row & 7).
+//   * ds_read_b128 "row reads" (lane = row r, chunk 4*ks + g) are conflict free,
+//   * ds_read_b64_tr_b16 "transposed reads" whose 16-lane group g reads rows k0 + q with
+//     k0 = 4*g (+16) are conflict free too, so ONE image serves both MFMA operand orientations.
+__device__ __forceinline__ int img128_off(int row, int chunk) {
+  return row * 128 + ((chunk ^ (row & 7)) << 4);
+}
+// IMG256: [64 k-rows][128 bf16] tile, 256-byte rows, 16 chunks per row (transposed-read GEMM operands;
+// layout (b) of the CDNA4 guide: conflict free for tr reads whose group g reads rows 8g+q / 8g+4+q).
+__device__ __forceinline__ int img256_off(int row, int chunk) {
+  return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+__device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+}
+
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ bf16x4 cvt4(float a, float b, float c, float d) {
+  bf16x4 r = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+  return r;
+}
+
+__device__ __forceinline__ bf16x8 cvt8(f32x4 a, f32x4 b) {
+  bf16x8 r = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+  return r;
+}
+
+// exact-erf GELU (nn.GELU() default) and its derivative
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float u) {
+  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+  const float pdf = __expf(-0.5f * u * u) * 0.39894228040143267794f;
+  return cdf + u * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Counter-based dropout RNG: one 32-bit hash per element index (murmur3 finaliser over a
+// seed/offset mix).  keep(idx) is recomputable in backward, nothing is stored.
+__device__ __forceinline__ uint32_t nv_hash32(uint64_t seed, uint64_t idx) {
+  uint64_t x = (idx + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull ^ seed;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 16);
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks b, b+8, ... share an XCD (round-robin dispatch),
+// so give each XCD a contiguous range of logical tiles (L2 locality of shared operand panels).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}

@@ -1,0 +1,275 @@
+// Whole-encoder engine: sequences the gfx950 kernels for ViT.forward (vit_3d.py:112-126) and its
+// backward as ONE C-ABI call each, over a flat parameter arena and a caller-owned workspace.
+// Host-side only (no kernels here): a native "executor" so the Python layer issues 1 call per
+// forward / backward instead of ~100 per-op launches.  Never allocates, never synchronises.
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/neurovit_hip.h"
+#include "common.h"
+
+namespace {
+
+inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
+
+struct Dims {
+  int B, N, n, P, Ppad, d, inner, m, L, C, heads, dh, M, T;   // M = B*n rows of the stream, T = B*N tokens
+  int gf, gh, gw;
+};
+
+int make_dims(const nv_vit_config* c, int B, Dims& D) {
+  NV_CHECK_ARG(c && B > 0, "nv_vit: null config or B <= 0");
+  NV_CHECK_ARG(c->image_size > 0 && c->image_patch_size > 0 && c->frames > 0 && c->frame_patch_size > 0 &&
+                   c->image_size % c->image_patch_size == 0,
+               "Image dimensions must be divisible by the patch size.");
+  NV_CHECK_ARG(c->frames % c->frame_patch_size == 0, "Frames must be divisible by frame patch size");
+  NV_CHECK_ARG(c->dim_head == 64, "nv_vit: dim_head=%d unsupported by the gfx950 attention kernel (64 only)", c->dim_head);
+  NV_CHECK_ARG(c->dim % 8 == 0 && c->dim <= 2048 && c->mlp_dim % 8 == 0, "nv_vit: dim must be a multiple of 8 and <= 2048, mlp_dim a multiple of 8");
+  NV_CHECK_ARG(!(c->heads == 1 && c->dim_head == c->dim), "nv_vit: heads==1 && dim_head==dim (no output projection) is not supported");
+  NV_CHECK_ARG(c->depth >= 1 && c->num_classes >= 1 && c->channels >= 1, "nv_vit: bad depth/classes/channels");
+  D.B = B;
+  D.gf = c->frames / c->frame_patch_size;
+  D.gh = D.gw = c->image_size / c->image_patch_size;
+  D.N = D.gf * D.gh * D.gw;
+  D.n = D.N + 1;
+  D.P = c->channels * c->image_patch_size * c->image_patch_size * c->frame_patch_size;
+  D.Ppad = (int)align_up(D.P, 8);
+  D.d = c->dim; D.heads = c->heads; D.dh = c->dim_head; D.inner = c->heads * c->dim_head; D.m = c->mlp_dim;
+  D.L = c->depth; D.C = c->num_classes;
+  D.M = B * D.n; D.T = B * D.N;
+  return NV_OK;
+}
+
+// ---- parameter arena layout (reference ViT.state_dict() order, vit_3d.py:91-110) -------------------
+struct LayerP { long n1g, n1b, wqkv, wo, bo, n2g, n2b, w1, b1, w2, b2; };
+struct ParamTab {
+  long pos, cls, pe_g, pe_b, pe_w, pe_bias, pe_g2, pe_b2, hg, hb, hw, hbias, total;
+  std::vector<LayerP> layer;
+  std::vector<long> offsets, numels;
+};
+
+void make_params(const Dims& D, ParamTab& T) {
+  long cur = 0;
+  auto add = [&](long numel) { const long o = cur; T.offsets.push_back(o); T.numels.push_back(numel); cur = align_up(cur + numel, 8); return o; };
+  T.pos = add((long)D.n * D.d); T.cls = add(D.d);
+  T.pe_g = add(D.P); T.pe_b = add(D.P); T.pe_w = add((long)D.d * D.P); T.pe_bias = add(D.d); T.pe_g2 = add(D.d); T.pe_b2 = add(D.d);
+  T.layer.resize(D.L);
+  for (int l = 0; l < D.L; ++l) {
+    LayerP& p = T.layer[l];
+    p.n1g = add(D.d); p.n1b = add(D.d); p.wqkv = add(3L * D.inner * D.d); p.wo = add((long)D.d * D.inner); p.bo = add(D.d);
+    p.n2g = add(D.d); p.n2b = add(D.d); p.w1 = add((long)D.m * D.d); p.b1 = add(D.m); p.w2 = add((long)D.d * D.m); p.b2 = add(D.d);
+  }
+  T.hg = add(D.d); T.hb = add(D.d); T.hw = add((long)D.C * D.d); T.hbias = add(D.C);
+  T.total = cur;
+}
+
+// ---- workspace layout -------------------------------------------------------------------------------
+struct LayerW { long xn1, st1, qkv, lse, ao, x1, xn2, st2, u, h, x2; };
+struct WS {
+  long xp, pst, t, est, x0, xh, hst, wpe16;
+  std::vector<LayerW> layer;
+  // backward scratch
+  long g, g16, dxn, hookg, du, dao, dqkv, delta, dt, dt16, dxp, dwpe, red;
+  long red_bytes, total;
+};
+
+void make_ws(const Dims& D, int training, WS& W) {
+  long cur = 0;
+  auto add = [&](long bytes) { const long o = cur; cur = align_up(cur + bytes, 256); return o; };
+  const long M = D.M, T = D.T, d = D.d;
+  W.xp = add(T * D.Ppad * 2); W.pst = add(T * 2 * 4); W.t = add(T * d * 4); W.est = add(T * 2 * 4); W.x0 = add(M * d * 4);
+  W.xh = add((long)D.B * d * 4); W.hst = add((long)D.B * 2 * 4);
+  W.wpe16 = (D.P != D.Ppad) ? add(d * D.Ppad * 2) : -1;
+  const int nl = training ? D.L : 1;     // inference: every layer reuses one set of buffers (x ping-pongs x1 <-> x2/x0)
+  W.layer.resize(D.L);
+  for (int l = 0; l < nl; ++l) {
+    LayerW& w = W.layer[l];
+    w.xn1 = add(M * d * 2); w.st1 = add(M * 2 * 4); w.qkv = add(M * 3 * D.inner * 2); w.lse = add((long)D.B * D.heads * D.n * 4);
+    w.ao = add(M * D.inner * 2); w.x1 = add(M * d * 4); w.xn2 = add(M * d * 2); w.st2 = add(M * 2 * 4);
+    w.u = add(M * D.m * 2); w.h = add(M * D.m * 2); w.x2 = add(M * d * 4);
+  }
+  for (int l = nl; l < D.L; ++l) W.layer[l] = W.layer[0];
+  if (training) {
+    W.g = add(M * d * 4); W.g16 = add(M * d * 2); W.dxn = add(M * d * 4); W.hookg = add(M * d * 4); W.du = add(M * D.m * 2);
+    W.dao = add(M * D.inner * 2); W.dqkv = add(M * 3 * D.inner * 2); W.delta = add((long)D.B * D.heads * D.n * 4);
+    W.dt = add(T * d * 4); W.dt16 = add(T * d * 2); W.dxp = add(T * D.Ppad * 4);
+    W.dwpe = (D.P != D.Ppad) ? add(d * D.Ppad * 4) : -1;
+    long r = nv_ln_bwd_workspace_bytes(D.M, D.d);
+    const long r2 = nv_patch_ln_bwd_workspace_bytes(D.T, D.P), r3 = nv_head_bwd_workspace_bytes(D.B, D.d),
+               r4 = nv_colsum_workspace_bytes(D.M, D.m);
+    r = r > r2 ? r : r2; r = r > r3 ? r : r3; r = r > r4 ? r : r4;
+    W.red_bytes = r; W.red = add(r);
+  } else {
+    W.g = W.g16 = W.dxn = W.hookg = W.du = W.dao = W.dqkv = W.delta = W.dt = W.dt16 = W.dxp = W.dwpe = W.red = -1;
+    W.red_bytes = 0;
+  }
+  W.total = cur;
+}
+
+#define RUN(call)            \
+  do {                       \
+    const int rc__ = (call); \
+    if (rc__) return rc__;   \
+  } while (0)
+
+}  // namespace
+
+extern "C" long nv_vit_param_count(const nv_vit_config* cfg) {
+  Dims D; if (make_dims(cfg, 1, D)) return -1;
+  ParamTab T; make_params(D, T);
+  return T.total;
+}
+
+extern "C" int nv_vit_param_table(const nv_vit_config* cfg, long* offsets, long* numels, int max_entries) {
+  Dims D; if (make_dims(cfg, 1, D)) return NV_ERR_ARG;
+  ParamTab T; make_params(D, T);
+  const int cnt = (int)T.offsets.size();
+  for (int i = 0; i < cnt && i < max_entries; ++i) { offsets[i] = T.offsets[i]; numels[i] = T.numels[i]; }
+  return cnt;
+}
+
+extern "C" long nv_vit_workspace_bytes(const nv_vit_config* cfg, int B, int training) {
+  Dims D; if (make_dims(cfg, B, D)) return -1;
+  WS W; make_ws(D, training, W);
+  return W.total;
+}
+
+extern "C" long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int training, const char* name, int layer) {
+  Dims D; if (make_dims(cfg, B, D)) return -1;
+  WS W; make_ws(D, training, W);
+  if (layer >= 0) {
+    if (layer >= D.L) return -1;
+    const LayerW& w = W.layer[layer];
+    if (!strcmp(name, "xn1")) return w.xn1; if (!strcmp(name, "st1")) return w.st1; if (!strcmp(name, "qkv")) return w.qkv;
+    if (!strcmp(name, "lse")) return w.lse; if (!strcmp(name, "ao")) return w.ao; if (!strcmp(name, "x1")) return w.x1;
+    if (!strcmp(name, "xn2")) return w.xn2; if (!strcmp(name, "st2")) return w.st2; if (!strcmp(name, "u")) return w.u;
+    if (!strcmp(name, "h")) return w.h; if (!strcmp(name, "x2")) return w.x2;
+    return -1;
+  }
+  if (!strcmp(name, "xp")) return W.xp; if (!strcmp(name, "pst")) return W.pst; if (!strcmp(name, "t")) return W.t;
+  if (!strcmp(name, "est")) return W.est; if (!strcmp(name, "x0")) return W.x0; if (!strcmp(name, "xh")) return W.xh;
+  if (!strcmp(name, "g")) return W.g; if (!strcmp(name, "hookg")) return W.hookg; if (!strcmp(name, "dqkv")) return W.dqkv;
+  if (!strcmp(name, "dt")) return W.dt; if (!strcmp(name, "dxp")) return W.dxp;
+  return -1;
+}
+
+extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
+                              const void* params16, void* workspace, long ws_bytes, int training, float* logits, void* stream) {
+  Dims D; RUN(make_dims(cfg, B, D));
+  ParamTab T; make_params(D, T);
+  WS W; make_ws(D, training, W);
+  NV_CHECK_ARG(video && strides5 && params && params16 && workspace && logits, "nv_vit_forward: null pointer");
+  NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_forward: workspace too small (%ld < %ld)", ws_bytes, W.total);
+  NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params) && nv_aligned16(params16), "nv_vit_forward: alignment");
+  char* ws = (char*)workspace;
+  const float* p = params;
+  const bf16* p16 = (const bf16*)params16;
+  const float eps = cfg->ln_eps;
+  const int M = D.M, d = D.d;
+
+  // A1+A2: gather + LayerNorm(patch_dim) -> bf16
+  float* pst = (float*)(ws + W.pst);
+  RUN(nv_patch_ln_fwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
+                      cfg->image_patch_size, cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, ws + W.xp, D.Ppad, pst, pst + D.T, stream));
+  // A3: Linear(patch_dim, dim)
+  const void* wpe = p16 + T.pe_w;
+  if (D.P != D.Ppad) {
+    RUN(nv_cast_bf16_2d(p + T.pe_w, D.P, d, D.P, ws + W.wpe16, D.Ppad, stream));
+    wpe = ws + W.wpe16;
+  }
+  RUN(nv_gemm_bf16(0, 2, D.T, d, D.Ppad, ws + W.xp, D.Ppad, wpe, D.Ppad, ws + W.t, d, p + T.pe_bias, nullptr, 0, nullptr, 0, 0, 1.f, stream));
+  // A4+A5: LayerNorm(dim) + cls + pos
+  float* est = (float*)(ws + W.est);
+  RUN(nv_embed_finish_fwd((float*)(ws + W.t), d, B, D.N, d, p + T.pe_g2, p + T.pe_b2, eps, p + T.pos, p + T.cls, (float*)(ws + W.x0), d, est,
+                          est + D.T, stream));
+
+  const float scale = 1.0f / sqrtf((float)D.dh);
+  const float* xin = (float*)(ws + W.x0);
+  for (int l = 0; l < D.L; ++l) {
+    const LayerP& q = T.layer[l];
+    const LayerW& w = W.layer[l];
+    // inference ping-pong: layer output goes to x2, except that x2 would alias the next layer's output -> alternate x0/x2
+    float* x1 = (float*)(ws + w.x1);
+    float* x2 = (float*)(ws + ((!training && (l & 1)) ? W.x0 : w.x2));
+    float* st1 = (float*)(ws + w.st1);
+    float* st2 = (float*)(ws + w.st2);
+    RUN(nv_ln_fwd(xin, d, M, d, p + q.n1g, p + q.n1b, eps, ws + w.xn1, d, st1, st1 + M, stream));
+    RUN(nv_gemm_bf16(0, 0, M, 3 * D.inner, d, ws + w.xn1, d, p16 + q.wqkv, d, ws + w.qkv, 3 * D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, stream));
+    RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), stream));
+    RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, stream));
+    RUN(nv_ln_fwd(x1, d, M, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d, st2, st2 + M, stream));
+    RUN(nv_gemm_bf16(0, 3, M, D.m, d, ws + w.xn2, d, p16 + q.w1, d, ws + w.h, D.m, p + q.b1, nullptr, 0, ws + w.u, D.m, 0, 1.f, stream));
+    RUN(nv_gemm_bf16(0, 4, M, d, D.m, ws + w.h, D.m, p16 + q.w2, D.m, x2, d, p + q.b2, x1, d, nullptr, 0, 0, 1.f, stream));
+    xin = x2;
+  }
+  // A9: cls pooling + LayerNorm + Linear(dim, C)
+  RUN(nv_head_fwd(xin, (long)D.n * d, B, d, p + T.hg, p + T.hb, eps, p + T.hw, p + T.hbias, D.C, (float*)(ws + W.xh), (float*)(ws + W.hst),
+                  logits, stream));
+  return NV_OK;
+}
+
+extern "C" int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
+                               const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
+                               int accumulate, void* stream) {
+  Dims D; RUN(make_dims(cfg, B, D));
+  ParamTab T; make_params(D, T);
+  WS W; make_ws(D, 1, W);
+  NV_CHECK_ARG(video && strides5 && params && params16 && workspace && dlogits && grads, "nv_vit_backward: null pointer");
+  NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_backward: workspace too small (%ld < %ld) - forward must run with training=1", ws_bytes, W.total);
+  NV_CHECK_ARG(nv_aligned16(grads), "nv_vit_backward: grads must be 16-byte aligned");
+  NV_CHECK_ARG(D.P == D.Ppad, "nv_vit_backward: patch_dim=%d not a multiple of 8 is not supported yet", D.P);
+  char* ws = (char*)workspace;
+  const float* p = params;
+  const bf16* p16 = (const bf16*)params16;
+  float* gr = grads;
+  const int M = D.M, d = D.d, acc = accumulate;
+  float* g = (float*)(ws + W.g);
+  void* g16 = ws + W.g16;
+  void* red = ws + W.red;
+  const float scale = 1.0f / sqrtf((float)D.dh);
+
+  // head: writes g (zeros + cls rows) and the last layer's FC2 bias gradient (colsum of g)
+  const float* xlast = (float*)(ws + W.layer[D.L - 1].x2);
+  RUN(nv_head_bwd(dlogits, B, D.C, p + T.hw, xlast, (long)D.n * d, (float*)(ws + W.hst), (float*)(ws + W.xh), p + T.hg, d, D.n, g, d, g16, d,
+                  gr + T.hg, gr + T.hb, gr + T.hw, gr + T.hbias, gr + T.layer[D.L - 1].b2, acc, red, W.red_bytes, stream));
+
+  for (int l = D.L - 1; l >= 0; --l) {
+    const LayerP& q = T.layer[l];
+    const LayerW& w = W.layer[l];
+    const float* xin = (l == 0) ? (float*)(ws + W.x0) : (float*)(ws + W.layer[l - 1].x2);
+    float* st1 = (float*)(ws + w.st1);
+    float* st2 = (float*)(ws + w.st2);
+    float* dxn = (float*)(ws + W.dxn);
+    // ---- FeedForward backward (vit_3d.py:16-26)
+    RUN(nv_gemm_bf16(1, 5, M, D.m, d, g16, d, p16 + q.w2, D.m, ws + W.du, D.m, nullptr, ws + w.u, D.m, nullptr, 0, 0, 1.f, stream));           // dU = (g W2) * gelu'(u)
+    RUN(nv_gemm_bf16(2, 1, d, D.m, M, g16, d, ws + w.h, D.m, gr + q.w2, D.m, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, stream));              // dW2 = g^T h
+    RUN(nv_colsum_bf16(ws + W.du, D.m, M, D.m, gr + q.b1, acc, red, W.red_bytes, stream));                                                       // db1
+    RUN(nv_gemm_bf16(1, 1, M, d, D.m, ws + W.du, D.m, p16 + q.w1, d, dxn, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, stream));                 // dxn2 = dU W1
+    RUN(nv_gemm_bf16(2, 1, D.m, d, M, ws + W.du, D.m, ws + w.xn2, d, gr + q.w1, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, stream));         // dW1 = dU^T xn2
+    RUN(nv_ln_bwd(dxn, d, (float*)(ws + w.x1), d, st2, st2 + M, p + q.n2g, M, d, g, g, d, g16, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, red,
+                  W.red_bytes, stream));                                                                                                       // g += dLN2; dbo = colsum(g)
+    // ---- Attention backward (vit_3d.py:48-60)
+    RUN(nv_gemm_bf16(1, 0, M, D.inner, d, g16, d, p16 + q.wo, D.inner, ws + W.dao, D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, stream));   // dAO = g Wo
+    RUN(nv_gemm_bf16(2, 1, d, D.inner, M, g16, d, ws + w.ao, D.inner, gr + q.wo, D.inner, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, stream));   // dWo = g^T ao
+    RUN(nv_attn_bwd(ws + w.qkv, 3 * D.inner, ws + w.ao, ws + W.dao, D.inner, (float*)(ws + w.lse), B, D.n, D.heads, D.dh, scale,
+                    (float*)(ws + W.delta), ws + W.dqkv, 3 * D.inner, stream));
+    float* dxn1 = (l == D.L - 1) ? (float*)(ws + W.hookg) : dxn;    // gradient of the last block's attention-LN output is kept (Grad-CAM hook)
+    RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, ws + W.dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, stream));
+    RUN(nv_gemm_bf16(2, 1, 3 * D.inner, d, M, ws + W.dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, stream));
+    RUN(nv_ln_bwd(dxn1, d, xin, d, st1, st1 + M, p + q.n1g, M, d, g, g, d, g16, d, gr + q.n1g, gr + q.n1b, (l > 0) ? gr + T.layer[l - 1].b2 : nullptr,
+                  acc, red, W.red_bytes, stream));
+  }
+
+  // ---- patch embedding backward (vit_3d.py:91-96,116-118)
+  float* est = (float*)(ws + W.est);
+  float* pst = (float*)(ws + W.pst);
+  RUN(nv_embed_finish_bwd(g, d, (float*)(ws + W.t), d, est, est + D.T, p + T.pe_g2, B, D.N, d, (float*)(ws + W.dt), d, ws + W.dt16, d, gr + T.pe_g2,
+                          gr + T.pe_b2, gr + T.pe_bias, gr + T.pos, gr + T.cls, acc, red, W.red_bytes, stream));
+  RUN(nv_gemm_bf16(2, 1, d, D.P, D.T, ws + W.dt16, d, ws + W.xp, D.Ppad, gr + T.pe_w, D.P, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, stream));   // dWpe = dt^T xp
+  RUN(nv_gemm_bf16(1, 1, D.T, D.P, d, ws + W.dt16, d, p16 + T.pe_w, D.P, ws + W.dxp, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, stream)); // dxp = dt Wpe
+  RUN(nv_patch_ln_bwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
+                      cfg->image_patch_size, cfg->frame_patch_size, (float*)(ws + W.dxp), D.Ppad, pst, pst + D.T, gr + T.pe_g, gr + T.pe_b, acc, red,
+                      W.red_bytes, stream));
+  return NV_OK;
+}

@@ -1,0 +1,605 @@
+// Row-wise (LayerNorm-family) kernels of the ViT3D hot path, gfx950.  All HBM-bound, one 64-lane
+// wave per row, rows cached in registers, 16-byte accesses, two-pass (mean, then centred variance)
+// statistics in fp32 exactly as nn.LayerNorm (eps inside the sqrt, biased variance).
+//
+//   patch_ln_fwd      A1+A2  gather p^3 voxels of a token straight from the [B,H,W,D] volume (any strides),
+//                            LayerNorm(patch_dim), write bf16 GEMM operand            (vit_3d.py:92-93, NeuroEncoder.py:200-202)
+//   embed_finish_fwd  A4+A5  LayerNorm(dim) + pos-embedding add + cls row             (vit_3d.py:95,116-118)
+//   ln_fwd            LN of the residual stream -> bf16 GEMM operand                  (vit_3d.py:18,37)
+//   head_fwd          A9     cls-row LayerNorm + Linear(dim, C)                       (vit_3d.py:107-110,123-126)
+//   *_bwd             the matching backward passes; parameter gradients are produced as deterministic
+//                     per-workgroup partial sums + reduce_partials (no float atomics).
+#include "common.h"
+
+#define WAVES_PER_BLOCK 4
+
+// --------------------------------------------------------------------------------------- helpers
+// Row of d floats (d % 4 == 0, d <= 256*NV) spread over a wave: lane holds float4 #(lane + 64 v).
+template <int NV>
+__device__ __forceinline__ void row_load(const float* row, int d, int lane, f32x4 (&x)[NV]) {
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (lane + 64 * v) * 4;
+    x[v] = (c < d) ? *reinterpret_cast<const f32x4*>(row + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+template <int NV>
+__device__ __forceinline__ void row_stats(const f32x4 (&x)[NV], int d, int lane, float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) s += (x[v][0] + x[v][1]) + (x[v][2] + x[v][3]);
+  mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (lane + 64 * v) * 4;
+    if (c < d) {
+      const f32x4 t = x[v] - mean;
+      q += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
+    }
+  }
+  rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+}
+
+// --------------------------------------------------------------------------------------- ln_fwd
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx, int M, int d, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, bf16* __restrict__ y, long ldy,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  f32x4 xv[NV];
+  row_load<NV>(x + (long)row * ldx, d, lane, xv);
+  float mean, rstd;
+  row_stats<NV>(xv, d, lane, eps, mean, rstd);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (lane + 64 * v) * 4;
+    if (c < d) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+      const f32x4 o = (xv[v] - mean) * rstd * gm + bt;
+      *reinterpret_cast<bf16x4*>(y + (long)row * ldy + c) = cvt4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  if (lane == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+extern "C" int nv_ln_fwd(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, void* y,
+                         long ldy, float* mean, float* rstd, void* stream) {
+  NV_CHECK_ARG(M > 0 && d > 0 && (d % 4) == 0 && d <= 2048, "nv_ln_fwd: d=%d must be a multiple of 4 and <= 2048", d);
+  NV_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0 && nv_aligned16(x) && nv_aligned16(y) && nv_aligned16(gamma) && nv_aligned16(beta),
+               "nv_ln_fwd: alignment");
+  const dim3 grid((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (d <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, x, ldx, M, d, gamma, beta, eps, (bf16*)y, ldy, mean, rstd);
+  else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, s, x, ldx, M, d, gamma, beta, eps, (bf16*)y, ldy, mean, rstd);
+  NV_CHECK_LAUNCH("nv_ln_fwd");
+  return NV_OK;
+}
+
+// --------------------------------------------------------------------------------------- ln_bwd
+// g_out = g_in + LN'(dy);  g16 = bf16(g_out);  partials[blk][0] = sum dy*xhat, [1] = sum dy, [2] = sum g_out.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ gamma, int M, int d, const float* g_in, float* g_out,
+                                                     long ldg, bf16* __restrict__ g16, long ldg16, float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][3][d]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nw = gridDim.x * WAVES_PER_BLOCK;
+  f32x4 gm[NV], a_g[NV], a_b[NV], a_c[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (lane + 64 * v) * 4;
+    gm[v] = (c < d) ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    a_g[v] = a_b[v] = a_c[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * WAVES_PER_BLOCK + wid; row < M; row += nw) {
+    f32x4 xv[NV], dv[NV];
+    row_load<NV>(x + (long)row * ldx, d, lane, xv);
+    row_load<NV>(dy + (long)row * lddy, d, lane, dv);
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      xv[v] = (xv[v] - mean) * rstd;           // xhat (zero-padded lanes hold -mean*rstd but dv = 0 there)
+      const f32x4 dyh = dv[v] * gm[v];
+      s1 += (dyh[0] + dyh[1]) + (dyh[2] + dyh[3]);
+      const f32x4 t = dyh * xv[v];
+      s2 += (t[0] + t[1]) + (t[2] + t[3]);
+      a_g[v] += dv[v] * xv[v];
+      a_b[v] += dv[v];
+    }
+    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = (lane + 64 * v) * 4;
+      if (c < d) {
+        f32x4 o = (dv[v] * gm[v] - c1 - xv[v] * c2) * rstd;
+        if (g_in) o += *reinterpret_cast<const f32x4*>(g_in + (long)row * ldg + c);
+        *reinterpret_cast<f32x4*>(g_out + (long)row * ldg + c) = o;
+        if (g16) *reinterpret_cast<bf16x4*>(g16 + (long)row * ldg16 + c) = cvt4(o[0], o[1], o[2], o[3]);
+        a_c[v] += o;
+      }
+    }
+  }
+  // deterministic in-block reduction of the three column accumulators
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (lane + 64 * v) * 4;
+    if (c < d) {
+      *reinterpret_cast<f32x4*>(red + (wid * 3 + 0) * d + c) = a_g[v];
+      *reinterpret_cast<f32x4*>(red + (wid * 3 + 1) * d + c) = a_b[v];
+      *reinterpret_cast<f32x4*>(red + (wid * 3 + 2) * d + c) = a_c[v];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * d; i += 256) {
+    const float t = (red[i] + red[3 * d + i]) + (red[6 * d + i] + red[9 * d + i]);
+    partials[(long)blockIdx.x * 3 * d + i] = t;
+  }
+}
+
+// out[c] (=|+=) sum_r part[r][c] for up to three concatenated segments of width d each.
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int R, int d, int nseg, float* o0, float* o1, float* o2,
+                                       int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg * d) return;
+  const long stride = (long)nseg * d;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < R; r += 4) {
+    s0 += part[(long)r * stride + i];
+    s1 += part[(long)(r + 1) * stride + i];
+    s2 += part[(long)(r + 2) * stride + i];
+    s3 += part[(long)(r + 3) * stride + i];
+  }
+  for (; r < R; ++r) s0 += part[(long)r * stride + i];
+  const float s = (s0 + s1) + (s2 + s3);
+  const int seg = i / d, c = i - seg * d;
+  float* o = seg == 0 ? o0 : (seg == 1 ? o1 : o2);
+  if (o) o[c] = accumulate ? o[c] + s : s;
+}
+
+static int ln_bwd_blocks(int M) {
+  int b = (M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  return b < 256 ? b : 256;
+}
+
+extern "C" long nv_ln_bwd_workspace_bytes(int M, int d) { return (long)ln_bwd_blocks(M) * 3 * d * sizeof(float); }
+
+// dgamma/dbeta/dcolsum may be null (skipped).  g_in may be null (g_out = dx) or equal g_out (in place).
+extern "C" int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
+                         const float* gamma, int M, int d, const float* g_in, float* g_out, long ldg, void* g16, long ldg16,
+                         float* dgamma, float* dbeta, float* dcolsum, int accumulate, void* workspace, long ws_bytes,
+                         void* stream) {
+  NV_CHECK_ARG(M > 0 && d > 0 && (d % 4) == 0 && d <= 2048, "nv_ln_bwd: d=%d must be a multiple of 4 and <= 2048", d);
+  NV_CHECK_ARG(ws_bytes >= nv_ln_bwd_workspace_bytes(M, d), "nv_ln_bwd: workspace too small");
+  NV_CHECK_ARG((lddy % 4) == 0 && (ldx % 4) == 0 && (ldg % 4) == 0 && (ldg16 % 4) == 0, "nv_ln_bwd: leading dims must be multiples of 4");
+  const int nb = ln_bwd_blocks(M);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)WAVES_PER_BLOCK * 3 * d * sizeof(float);
+  if (d <= 1024)
+    hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
+                       (bf16*)g16, ldg16, (float*)workspace);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
+                       (bf16*)g16, ldg16, (float*)workspace);
+  NV_CHECK_LAUNCH("nv_ln_bwd");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, d, 3, dgamma,
+                     dbeta, dcolsum, accumulate);
+  NV_CHECK_LAUNCH("nv_ln_bwd/reduce");
+  return NV_OK;
+}
+
+// --------------------------------------------------------------------------------------- patch gather + LN(patch_dim)
+struct PatchGeom {
+  long sb, sc, sf, sh, sw;     // element strides of video[B,C,F,H,W]
+  int B, C, F, H, W, p1, p2, pf;
+  int gf, gh, gw;              // patch grid
+  int P, N;                    // patch_dim, patches per volume
+};
+
+// feature k = ((i1*p2 + i2)*pf + ifr)*C + c  ('p1 p2 pf c');  token n = (ft*gh + ht)*gw + wt  ('f h w')
+__device__ __forceinline__ long patch_elem_offset(const PatchGeom& g, int b, int n, int k) {
+  const int c = k % g.C; int t = k / g.C;
+  const int ifr = t % g.pf; t /= g.pf;
+  const int i2 = t % g.p2, i1 = t / g.p2;
+  const int wt = n % g.gw; int u = n / g.gw;
+  const int ht = u % g.gh, ft = u / g.gh;
+  return (long)b * g.sb + (long)c * g.sc + (long)(ft * g.pf + ifr) * g.sf + (long)(ht * g.p1 + i1) * g.sh + (long)(wt * g.p2 + i2) * g.sw;
+}
+
+// VEC: C == 1, sf == 1, pf % 4 == 0, 16-byte aligned runs, P <= 4096: float4 gathers, row cached in registers.
+template <bool VEC>
+__global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const float* __restrict__ video, PatchGeom g, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, bf16* __restrict__ out, long ldo,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (tok >= g.B * g.N) return;
+  const int b = tok / g.N, n = tok - b * g.N;
+  bf16* orow = out + (long)tok * ldo;
+  float mean, rstd;
+  if constexpr (VEC) {
+    constexpr int NV = 16;
+    f32x4 xv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int k = (lane + 64 * v) * 4;
+      xv[v] = (k < g.P) ? *reinterpret_cast<const f32x4*>(video + patch_elem_offset(g, b, n, k)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    row_stats<NV>(xv, g.P, lane, eps, mean, rstd);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int k = (lane + 64 * v) * 4;
+      if (k < g.P) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + k), bt = *reinterpret_cast<const f32x4*>(beta + k);
+        const f32x4 o = (xv[v] - mean) * rstd * gm + bt;
+        *reinterpret_cast<bf16x4*>(orow + k) = cvt4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  } else {
+    float s = 0.f;
+    for (int k = lane; k < g.P; k += 64) s += video[patch_elem_offset(g, b, n, k)];
+    mean = wave_sum(s) / (float)g.P;
+    float q = 0.f;
+    for (int k = lane; k < g.P; k += 64) {
+      const float t = video[patch_elem_offset(g, b, n, k)] - mean;
+      q += t * t;
+    }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)g.P + eps);
+    for (int k = lane; k < ldo; k += 64)
+      orow[k] = (k < g.P) ? (bf16)((video[patch_elem_offset(g, b, n, k)] - mean) * rstd * gamma[k] + beta[k]) : (bf16)0.f;
+  }
+  if (lane == 0) {
+    mean_out[tok] = mean;
+    rstd_out[tok] = rstd;
+  }
+}
+
+static bool patch_vec_ok(const float* video, const PatchGeom& g, long ldo) {
+  return g.C == 1 && g.sf == 1 && (g.pf % 4) == 0 && g.P <= 4096 && nv_aligned16(video) && (g.sb % 4) == 0 && (g.sh % 4) == 0 &&
+         (g.sw % 4) == 0 && ldo == g.P;
+}
+
+static int make_geom(PatchGeom& g, const long* strides, int B, int C, int F, int H, int W, int p1, int p2, int pf) {
+  NV_CHECK_ARG(B > 0 && C > 0 && p1 > 0 && p2 > 0 && pf > 0 && H % p1 == 0 && W % p2 == 0 && F % pf == 0,
+               "patch geometry: image dims must be divisible by the patch size");
+  g.sb = strides[0]; g.sc = strides[1]; g.sf = strides[2]; g.sh = strides[3]; g.sw = strides[4];
+  g.B = B; g.C = C; g.F = F; g.H = H; g.W = W; g.p1 = p1; g.p2 = p2; g.pf = pf;
+  g.gf = F / pf; g.gh = H / p1; g.gw = W / p2;
+  g.P = C * p1 * p2 * pf; g.N = g.gf * g.gh * g.gw;
+  return NV_OK;
+}
+
+// out: [B*N, ldo] bf16 with ldo >= P (columns P..ldo-1 are written as zero), mean/rstd: [B*N].
+extern "C" int nv_patch_ln_fwd(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
+                               const float* gamma, const float* beta, float eps, void* out, long ldo, float* mean, float* rstd,
+                               void* stream) {
+  PatchGeom g;
+  int rc = make_geom(g, strides5, B, C, F, H, W, p1, p2, pf);
+  if (rc) return rc;
+  NV_CHECK_ARG(ldo >= g.P && (ldo % 8) == 0, "nv_patch_ln_fwd: ldo=%ld must be >= patch_dim=%d and a multiple of 8", ldo, g.P);
+  const dim3 grid((g.B * g.N + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (patch_vec_ok(video, g, ldo) && nv_aligned16(gamma) && nv_aligned16(beta) && nv_aligned16(out))
+    hipLaunchKernelGGL(patch_ln_fwd_kernel<true>, grid, block, 0, s, video, g, gamma, beta, eps, (bf16*)out, ldo, mean, rstd);
+  else
+    hipLaunchKernelGGL(patch_ln_fwd_kernel<false>, grid, block, 0, s, video, g, gamma, beta, eps, (bf16*)out, ldo, mean, rstd);
+  NV_CHECK_LAUNCH("nv_patch_ln_fwd");
+  return NV_OK;
+}
+
+// Backward of LayerNorm(patch_dim) w.r.t. its affine parameters only (the volume needs no gradient):
+// dgamma[k] = sum_tok dxp[tok,k] * xhat[tok,k], dbeta[k] = sum_tok dxp[tok,k]; xhat is re-gathered.
+__global__ __launch_bounds__(256) void patch_ln_bwd_kernel(const float* __restrict__ video, PatchGeom g, const float* __restrict__ dxp,
+                                                           long ldd, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                           int tok_per_block, float* __restrict__ partials) {
+  const int T = g.B * g.N;
+  const int t0 = blockIdx.x * tok_per_block, t1 = min(T, t0 + tok_per_block);
+  for (int k = threadIdx.x; k < g.P; k += 256) {
+    float ag = 0.f, ab = 0.f;
+    for (int tok = t0; tok < t1; ++tok) {
+      const int b = tok / g.N, n = tok - b * g.N;
+      const float xh = (video[patch_elem_offset(g, b, n, k)] - mean_in[tok]) * rstd_in[tok];
+      const float dv = dxp[(long)tok * ldd + k];
+      ag += dv * xh;
+      ab += dv;
+    }
+    partials[(long)blockIdx.x * 2 * g.P + k] = ag;
+    partials[(long)blockIdx.x * 2 * g.P + g.P + k] = ab;
+  }
+}
+
+static int patch_bwd_blocks(int T, int* tpb) {
+  int t = (T + 511) / 512;
+  if (t < 1) t = 1;
+  *tpb = t;
+  return (T + t - 1) / t;
+}
+
+extern "C" long nv_patch_ln_bwd_workspace_bytes(int tokens, int P) {
+  int tpb;
+  return (long)patch_bwd_blocks(tokens, &tpb) * 2 * P * sizeof(float);
+}
+
+extern "C" int nv_patch_ln_bwd(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
+                               const float* dxp, long ldd, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                               int accumulate, void* workspace, long ws_bytes, void* stream) {
+  PatchGeom g;
+  int rc = make_geom(g, strides5, B, C, F, H, W, p1, p2, pf);
+  if (rc) return rc;
+  const int T = g.B * g.N;
+  int tpb;
+  const int nb = patch_bwd_blocks(T, &tpb);
+  NV_CHECK_ARG(ws_bytes >= (long)nb * 2 * g.P * (long)sizeof(float), "nv_patch_ln_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(patch_ln_bwd_kernel, dim3(nb), dim3(256), 0, s, video, g, dxp, ldd, mean, rstd, tpb, (float*)workspace);
+  NV_CHECK_LAUNCH("nv_patch_ln_bwd");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * g.P + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, g.P, 2, dgamma,
+                     dbeta, (float*)nullptr, accumulate);
+  NV_CHECK_LAUNCH("nv_patch_ln_bwd/reduce");
+  return NV_OK;
+}
+
+// --------------------------------------------------------------------------------------- embed finish (A4 + A5)
+// x[b, 0, :] = cls + pos[0];  x[b, 1+i, :] = LN(t[b*N+i]) * gamma + beta + pos[1+i]
+template <int NV>
+__global__ __launch_bounds__(256) void embed_finish_fwd_kernel(const float* __restrict__ t, long ldt, int B, int N, int d,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                               const float* __restrict__ pos, const float* __restrict__ cls,
+                                                               float* __restrict__ x, long ldx, float* __restrict__ mean_out,
+                                                               float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int n = N + 1;
+  if (r >= B * n) return;
+  const int b = r / n, i = r - b * n;
+  float* xrow = x + (long)r * ldx;
+  if (i == 0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = (lane + 64 * v) * 4;
+      if (c < d) *reinterpret_cast<f32x4*>(xrow + c) = *reinterpret_cast<const f32x4*>(cls + c) + *reinterpret_cast<const f32x4*>(pos + c);
+    }
+    return;
+  }
+  const int tok = b * N + (i - 1);
+  f32x4 xv[NV];
+  row_load<NV>(t + (long)tok * ldt, d, lane, xv);
+  float mean, rstd;
+  row_stats<NV>(xv, d, lane, eps, mean, rstd);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (lane + 64 * v) * 4;
+    if (c < d) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+      const f32x4 pe = *reinterpret_cast<const f32x4*>(pos + (long)i * d + c);
+      // same association as the reference: (LN output) + pos   (vit_3d.py:118 `x += pos_embedding`)
+      *reinterpret_cast<f32x4*>(xrow + c) = ((xv[v] - mean) * rstd * gm + bt) + pe;
+    }
+  }
+  if (lane == 0) {
+    mean_out[tok] = mean;
+    rstd_out[tok] = rstd;
+  }
+}
+
+extern "C" int nv_embed_finish_fwd(const float* t, long ldt, int B, int N, int d, const float* gamma, const float* beta, float eps,
+                                   const float* pos, const float* cls, float* x, long ldx, float* mean, float* rstd, void* stream) {
+  NV_CHECK_ARG(B > 0 && N > 0 && (d % 4) == 0 && d <= 2048, "nv_embed_finish_fwd: d=%d must be a multiple of 4 and <= 2048", d);
+  NV_CHECK_ARG((ldt % 4) == 0 && (ldx % 4) == 0, "nv_embed_finish_fwd: leading dims must be multiples of 4");
+  const int rows = B * (N + 1);
+  const dim3 grid((rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (d <= 1024) hipLaunchKernelGGL(embed_finish_fwd_kernel<4>, grid, block, 0, s, t, ldt, B, N, d, gamma, beta, eps, pos, cls, x, ldx, mean, rstd);
+  else hipLaunchKernelGGL(embed_finish_fwd_kernel<8>, grid, block, 0, s, t, ldt, B, N, d, gamma, beta, eps, pos, cls, x, ldx, mean, rstd);
+  NV_CHECK_LAUNCH("nv_embed_finish_fwd");
+  return NV_OK;
+}
+
+// dpos[i, :] = sum_b g[b, i, :];  dcls = dpos[0]
+__global__ void batch_sum_kernel(const float* __restrict__ g, long ldg, int B, int n, int d, float* dpos, float* dcls, int accumulate) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * d) return;
+  const int i = (int)(idx / d), c = (int)(idx - (long)i * d);
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += g[((long)b * n + i) * ldg + c];
+  if (dpos) dpos[idx] = accumulate ? dpos[idx] + s : s;
+  if (i == 0 && dcls) dcls[c] = accumulate ? dcls[c] + s : s;
+}
+
+// Backward of A4/A5: g [B, n, d] -> dt [B*N, d] (fp32 + bf16 copy), dgamma3/dbeta3, dbias_pe = colsum(dt), dpos, dcls.
+extern "C" long nv_embed_finish_bwd_workspace_bytes(int B, int N, int d) { return nv_ln_bwd_workspace_bytes(B * N, d); }
+
+extern "C" int nv_embed_finish_bwd(const float* g, long ldg, const float* t, long ldt, const float* mean, const float* rstd,
+                                   const float* gamma, int B, int N, int d, float* dt, long lddt, void* dt16, long lddt16,
+                                   float* dgamma, float* dbeta, float* dbias_pe, float* dpos, float* dcls, int accumulate,
+                                   void* workspace, long ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  // token rows of volume b are rows b*n+1 .. b*n+N of g: one strided LN backward per volume keeps the kernel generic.
+  // (B launches of a memory-bound kernel; B is the per-GPU batch.)  Partials of all volumes are reduced together.
+  NV_CHECK_ARG(B > 0 && N > 0 && (d % 4) == 0 && d <= 2048, "nv_embed_finish_bwd: bad dims");
+  const int n = N + 1;
+  const long need = nv_embed_finish_bwd_workspace_bytes(B, N, d);
+  NV_CHECK_ARG(ws_bytes >= need, "nv_embed_finish_bwd: workspace too small");
+  // Treat g's token rows as one [B*N] row set by launching over a virtual row map: row r -> g row (r/N)*n + 1 + r%N.
+  // Implemented by B calls writing disjoint partial blocks; the first call overwrites / later calls accumulate.
+  for (int b = 0; b < B; ++b) {
+    const int rc = nv_ln_bwd(g + ((long)b * n + 1) * ldg, ldg, t + (long)b * N * ldt, ldt, mean + (long)b * N, rstd + (long)b * N, gamma, N,
+                             d, nullptr, dt + (long)b * N * lddt, lddt, dt16 ? (char*)dt16 + (long)b * N * lddt16 * 2 : nullptr, lddt16, dgamma,
+                             dbeta, dbias_pe, (accumulate || b > 0) ? 1 : 0, workspace, ws_bytes, stream);
+    if (rc) return rc;
+  }
+  const long tot = (long)n * d;
+  hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, g, ldg, B, n, d, dpos, dcls, accumulate);
+  NV_CHECK_LAUNCH("nv_embed_finish_bwd/batch_sum");
+  return NV_OK;
+}
+
+// --------------------------------------------------------------------------------------- classification head (A9)
+// One workgroup per volume: xh = LN(x[b, 0, :]); logits[b, c] = xh . W[c, :] + bias[c].  All fp32 (VALU).
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, long row_stride, int d, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, const float* __restrict__ Wt,
+                                                       const float* __restrict__ bias, int C, float* __restrict__ xh_out,
+                                                       float* __restrict__ stats_out, float* __restrict__ logits) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];   // d floats + 8 scratch
+  float* xs = sh;
+  float* scratch = sh + d;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* row = x + (long)b * row_stride;
+  float s = 0.f;
+  for (int c = tid; c < d; c += 256) { xs[c] = row[c]; s += xs[c]; }
+  s = wave_sum(s);
+  if (lane == 0) scratch[wid] = s;
+  __syncthreads();
+  const float mean = ((scratch[0] + scratch[1]) + (scratch[2] + scratch[3])) / (float)d;
+  float q = 0.f;
+  for (int c = tid; c < d; c += 256) { const float t = xs[c] - mean; q += t * t; }
+  q = wave_sum(q);
+  if (lane == 0) scratch[4 + wid] = q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((scratch[4] + scratch[5]) + (scratch[6] + scratch[7])) / (float)d + eps);
+  for (int c = tid; c < d; c += 256) {
+    const float v = (xs[c] - mean) * rstd * gamma[c] + beta[c];
+    xs[c] = v;
+    if (xh_out) xh_out[(long)b * d + c] = v;
+  }
+  if (tid == 0 && stats_out) { stats_out[2 * b] = mean; stats_out[2 * b + 1] = rstd; }
+  __syncthreads();
+  for (int c = wid; c < C; c += WAVES_PER_BLOCK) {
+    float a = 0.f;
+    for (int k = lane; k < d; k += 64) a += xs[k] * Wt[(long)c * d + k];
+    a = wave_sum(a);
+    if (lane == 0) logits[(long)b * C + c] = a + bias[c];
+  }
+}
+
+extern "C" int nv_head_fwd(const float* x, long row_stride, int B, int d, const float* gamma, const float* beta, float eps,
+                           const float* W, const float* bias, int C, float* xh, float* stats, float* logits, void* stream) {
+  NV_CHECK_ARG(B > 0 && d > 0 && C > 0, "nv_head_fwd: bad dims");
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (d + 8) * sizeof(float), (hipStream_t)stream, x, row_stride, d, gamma, beta,
+                     eps, W, bias, C, xh, stats, logits);
+  NV_CHECK_LAUNCH("nv_head_fwd");
+  return NV_OK;
+}
+
+// Backward of the head for volume b (one workgroup): dxh = dlogits[b] . W; LN backward on the cls row;
+// writes g[b, 0, :] = dx and g[b, 1.., :] = 0 (fp32 + bf16), and per-volume partials [b][3][d] =
+// (dgamma, dbeta, dx) reduced afterwards.
+__global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict__ dlogits, int C, const float* __restrict__ Wt,
+                                                         const float* __restrict__ x, long row_stride, const float* __restrict__ stats,
+                                                         const float* __restrict__ gamma, int d, int n, float* __restrict__ g, long ldg,
+                                                         bf16* __restrict__ g16, long ldg16, float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];   // dyh[d] + 8 scratch
+  float* dys = sh;
+  float* scratch = sh + d;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+  const float* row = x + (long)b * row_stride;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = tid; c < d; c += 256) {
+    float dy = 0.f;
+    for (int k = 0; k < C; ++k) dy += dlogits[(long)b * C + k] * Wt[(long)k * d + c];
+    const float xh = (row[c] - mean) * rstd;
+    partials[((long)b * 3 + 0) * d + c] = dy * xh;
+    partials[((long)b * 3 + 1) * d + c] = dy;
+    const float dyh = dy * gamma[c];
+    dys[c] = dyh;
+    s1 += dyh;
+    s2 += dyh * xh;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) { scratch[wid] = s1; scratch[4 + wid] = s2; }
+  __syncthreads();
+  const float c1 = ((scratch[0] + scratch[1]) + (scratch[2] + scratch[3])) / (float)d;
+  const float c2 = ((scratch[4] + scratch[5]) + (scratch[6] + scratch[7])) / (float)d;
+  for (int c = tid; c < d; c += 256) {
+    const float xh = (row[c] - mean) * rstd;
+    const float dx = (dys[c] - c1 - xh * c2) * rstd;
+    g[(long)b * n * ldg + c] = dx;
+    if (g16) g16[(long)b * n * ldg16 + c] = (bf16)dx;
+    partials[((long)b * 3 + 2) * d + c] = dx;
+  }
+  // zero the non-cls rows of this volume's residual gradient
+  for (long idx = tid; idx < (long)(n - 1) * d; idx += 256) {
+    const long r = 1 + idx / d, c = idx % d;
+    g[((long)b * n + r) * ldg + c] = 0.f;
+    if (g16) g16[((long)b * n + r) * ldg16 + c] = (bf16)0.f;
+  }
+}
+
+// dW[c, k] = sum_b dlogits[b, c] * xh[b, k];  dbias[c] = sum_b dlogits[b, c]
+__global__ void head_bwd_w_kernel(const float* __restrict__ dlogits, const float* __restrict__ xh, int B, int C, int d, float* dW,
+                                  float* dbias, int accumulate) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < (long)C * d) {
+    const int c = (int)(idx / d), k = (int)(idx - (long)c * d);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogits[(long)b * C + c] * xh[(long)b * d + k];
+    dW[idx] = accumulate ? dW[idx] + s : s;
+  }
+  if (idx < C) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogits[(long)b * C + idx];
+    dbias[idx] = accumulate ? dbias[idx] + s : s;
+  }
+}
+
+extern "C" long nv_head_bwd_workspace_bytes(int B, int d) { return (long)B * 3 * d * sizeof(float); }
+
+extern "C" int nv_head_bwd(const float* dlogits, int B, int C, const float* W, const float* x, long row_stride, const float* stats,
+                           const float* xh, const float* gamma, int d, int n, float* g, long ldg, void* g16, long ldg16,
+                           float* dgamma, float* dbeta, float* dW, float* dbias, float* dcolsum, int accumulate, void* workspace,
+                           long ws_bytes, void* stream) {
+  NV_CHECK_ARG(ws_bytes >= nv_head_bwd_workspace_bytes(B, d), "nv_head_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(head_bwd_x_kernel, dim3(B), dim3(256), (d + 8) * sizeof(float), s, dlogits, C, W, x, row_stride, stats, gamma, d, n,
+                     g, ldg, (bf16*)g16, ldg16, (float*)workspace);
+  NV_CHECK_LAUNCH("nv_head_bwd/x");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 255) / 256), dim3(256), 0, s, (const float*)workspace, B, d, 3, dgamma, dbeta,
+                     dcolsum, accumulate);
+  NV_CHECK_LAUNCH("nv_head_bwd/reduce");
+  const long tot = (long)C * d;
+  hipLaunchKernelGGL(head_bwd_w_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, dlogits, xh, B, C, d, dW, dbias, accumulate);
+  NV_CHECK_LAUNCH("nv_head_bwd/w");
+  return NV_OK;
+}
+
+// --------------------------------------------------------------------------------------- column sum of a bf16 matrix (bias grads)
+// partial[chunk][c] = sum over the chunk's rows of X[r, c]; 8 columns per lane (16-byte loads).
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ X, long ld, int M, int N, int rows_per_chunk,
+                                                          float* __restrict__ partials) {
+  const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (col >= N) return;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = r0; r < r1; ++r) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (long)r * ld + col);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
+  }
+  float* p = partials + (long)blockIdx.y * N + col;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = a[j];
+}
+
+static int colsum_chunks(int M) { int c = (M + 31) / 32; return c > 128 ? 128 : c; }
+extern "C" long nv_colsum_workspace_bytes(int M, int N) { return (long)colsum_chunks(M) * N * sizeof(float); }
+
+extern "C" int nv_colsum_bf16(const void* X, long ld, int M, int N, float* out, int accumulate, void* workspace, long ws_bytes,
+                              void* stream) {
+  NV_CHECK_ARG(M > 0 && N > 0 && (N % 8) == 0 && (ld % 8) == 0 && nv_aligned16(X), "nv_colsum_bf16: N, ld must be multiples of 8");
+  NV_CHECK_ARG(ws_bytes >= nv_colsum_workspace_bytes(M, N), "nv_colsum_bf16: workspace too small");
+  const int chunks = colsum_chunks(M), rpc = (M + chunks - 1) / chunks;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N / 8 + 255) / 256, chunks), dim3(256), 0, s, (const bf16*)X, ld, M, N, rpc, (float*)workspace);
+  NV_CHECK_LAUNCH("nv_colsum_bf16");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)workspace, chunks, N, 1, out,
+                     (float*)nullptr, (float*)nullptr, accumulate);
+  NV_CHECK_LAUNCH("nv_colsum_bf16/reduce");
+  return NV_OK;
+}

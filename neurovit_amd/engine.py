@@ -1,0 +1,95 @@
+"""Python side of the native encoder engine (csrc/engine.hip): flat parameter arenas + workspace.
+
+Memory design (MI355X-first, 288 GB HBM per GPU): all parameters of a ViT live in ONE contiguous fp32
+arena (master weights), mirrored by a bf16 shadow arena of identical element offsets that the MFMA
+kernels read, plus one gradient arena and (optimizer) m / v arenas.  nn.Parameters are VIEWS into the
+arena, so the fused AdamW kernel, the bf16 refresh and the data-parallel gradient all-reduce all work
+on a few large contiguous ranges instead of ~150 small tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._cabi import VitConfig, check, lib
+
+_BYTES = {torch.float32: 4, torch.bfloat16: 2}
+
+
+def make_config(*, image_size, image_patch_size, frames, frame_patch_size, num_classes, dim, depth, heads, mlp_dim,
+                channels=3, dim_head=64, ln_eps=1e-5, **_) -> VitConfig:
+    return VitConfig(image_size, image_patch_size, frames, frame_patch_size, channels, num_classes, dim, depth, heads,
+                     dim_head, mlp_dim, ln_eps)
+
+
+def param_layout(cfg: VitConfig) -> Tuple[List[int], List[int], int]:
+    """(offsets, numels, total) of the arena, in the reference's ViT.state_dict() order."""
+    total = lib.nv_vit_param_count(ctypes.byref(cfg))
+    if total < 0:
+        check(-1, "nv_vit_param_count")
+    cap = 8 + 11 * cfg.depth + 4 + 8
+    off = (ctypes.c_long * cap)()
+    num = (ctypes.c_long * cap)()
+    cnt = lib.nv_vit_param_table(ctypes.byref(cfg), off, num, cap)
+    if cnt < 0:
+        check(cnt, "nv_vit_param_table")
+    return list(off[:cnt]), list(num[:cnt]), int(total)
+
+
+class VitRuntime:
+    """Executes ViT forward / backward through the native engine on caller-provided arenas."""
+
+    def __init__(self, cfg: VitConfig):
+        self.cfg = cfg
+        self._ws: Dict[Tuple[int, int, str], torch.Tensor] = {}
+        self._last = None   # (B, training, workspace, video) of the most recent forward
+
+    def workspace(self, B: int, training: bool, device) -> torch.Tensor:
+        key = (B, int(training), str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = lib.nv_vit_workspace_bytes(ctypes.byref(self.cfg), B, int(training))
+            if nbytes < 0:
+                check(-1, "nv_vit_workspace_bytes")
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+            pad = (-ws.data_ptr()) % 256
+            ws = ws[pad:pad + nbytes]
+            self._ws[key] = ws
+        return ws
+
+    def forward(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, training: bool) -> torch.Tensor:
+        """video: [B, C, F, H, W] fp32 view (any strides).  Returns logits [B, num_classes] fp32."""
+        if not video.is_cuda:
+            raise RuntimeError("neurovit_amd: ViT forward needs a CUDA/HIP tensor on MI355X - there is no CPU fallback")
+        assert video.dtype == torch.float32 and video.dim() == 5
+        B = video.shape[0]
+        ws = self.workspace(B, training, video.device)
+        logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
+        check(lib.nv_vit_forward(ctypes.byref(self.cfg), B, video.data_ptr(), ops.strides5(video), params.data_ptr(),
+                                 params16.data_ptr(), ws.data_ptr(), ws.numel(), int(training), logits.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream), "nv_vit_forward")
+        self._last = (B, training, ws, video)
+        return logits
+
+    def backward(self, dlogits: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, grads: torch.Tensor,
+                 accumulate: bool) -> None:
+        assert self._last is not None and self._last[1], "backward needs a preceding forward(training=True)"
+        B, _, ws, video = self._last
+        dlogits = dlogits.contiguous().float()
+        check(lib.nv_vit_backward(ctypes.byref(self.cfg), B, video.data_ptr(), ops.strides5(video), params.data_ptr(),
+                                  params16.data_ptr(), ws.data_ptr(), ws.numel(), dlogits.data_ptr(), grads.data_ptr(),
+                                  int(accumulate), torch.cuda.current_stream().cuda_stream), "nv_vit_backward")
+
+    def tap(self, name: str, layer: int, shape, dtype) -> torch.Tensor:
+        """View of a named activation inside the last forward's workspace (tests, Grad-CAM hooks)."""
+        B, training, ws, _ = self._last
+        off = lib.nv_vit_workspace_offset(ctypes.byref(self.cfg), B, int(training), name.encode(), layer)
+        if off < 0:
+            raise KeyError(f"no workspace buffer {name!r} (layer {layer})")
+        n = 1
+        for s in shape:
+            n *= s
+        return ws[off:off + n * _BYTES[dtype]].view(dtype).view(*shape)

@@ -1,0 +1,203 @@
+"""Thin functional wrappers over the C-ABI (one Python function per kernel entry point).
+
+PyTorch is plumbing only: it owns the device buffers and the stream; every FLOP below runs in
+libneurovit_hip.so.  No fallbacks: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from ._cabi import check, lib
+
+NT, NN, TN = 0, 1, 2
+EPI_STORE_BF16, EPI_STORE_F32, EPI_BIAS_F32, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_DGELU = 0, 1, 2, 3, 4, 5
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("neurovit_amd ops run on MI355X only (got a CPU tensor); there is no CPU fallback")
+
+
+def strides5(video: torch.Tensor):
+    assert video.dim() == 5
+    return (ctypes.c_long * 5)(*video.stride())
+
+
+def gemm(layout: int, epi: int, A: torch.Tensor, B: torch.Tensor, *, out: Optional[torch.Tensor] = None, bias=None,
+         aux_in=None, aux_out=None, accumulate: bool = False, alpha: float = 1.0) -> torch.Tensor:
+    """C = op(A) op(B) with a fused epilogue; A, B bf16 2-D row-major (last stride 1)."""
+    _need_cuda(A, B)
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.stride(1) == 1 and B.stride(1) == 1
+    if layout == NT:
+        M, K = A.shape; N = B.shape[0]; assert B.shape[1] == K
+    elif layout == NN:
+        M, K = A.shape; N = B.shape[1]; assert B.shape[0] == K
+    else:
+        K, M = A.shape; N = B.shape[1]; assert B.shape[0] == K
+    odt = torch.bfloat16 if epi in (EPI_STORE_BF16, EPI_BIAS_GELU, EPI_DGELU) else torch.float32
+    if out is None:
+        out = torch.empty((M, N), dtype=odt, device=A.device)
+    assert out.dtype == odt and out.shape == (M, N) and out.stride(1) == 1
+    check(lib.nv_gemm_bf16(layout, epi, M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _p(bias),
+                           _p(aux_in), 0 if aux_in is None else aux_in.stride(0), _p(aux_out),
+                           0 if aux_out is None else aux_out.stride(0), int(accumulate), float(alpha), _stream()), "nv_gemm_bf16")
+    return out
+
+
+def ln_fwd(x: torch.Tensor, gamma, beta, eps: float = 1e-5):
+    _need_cuda(x)
+    M, d = x.shape
+    y = torch.empty((M, d), dtype=torch.bfloat16, device=x.device)
+    st = torch.empty((2, M), dtype=torch.float32, device=x.device)
+    check(lib.nv_ln_fwd(_p(x), x.stride(0), M, d, _p(gamma), _p(beta), eps, _p(y), d, _p(st[0]), _p(st[1]), _stream()), "nv_ln_fwd")
+    return y, st
+
+
+def ln_bwd(dy, x, st, gamma, g_in=None, want_g16=True, accumulate=False, dgamma=None, dbeta=None, dcolsum=None):
+    _need_cuda(dy, x)
+    M, d = x.shape
+    g_out = torch.empty((M, d), dtype=torch.float32, device=x.device) if g_in is None else g_in
+    g16 = torch.empty((M, d), dtype=torch.bfloat16, device=x.device) if want_g16 else None
+    dgamma = torch.empty(d, device=x.device) if dgamma is None else dgamma
+    dbeta = torch.empty(d, device=x.device) if dbeta is None else dbeta
+    dcolsum = torch.empty(d, device=x.device) if dcolsum is None else dcolsum
+    nb = lib.nv_ln_bwd_workspace_bytes(M, d)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    check(lib.nv_ln_bwd(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(st[0]), _p(st[1]), _p(gamma), M, d, _p(g_in), _p(g_out), d, _p(g16), d,
+                        _p(dgamma), _p(dbeta), _p(dcolsum), int(accumulate), _p(ws), nb, _stream()), "nv_ln_bwd")
+    return g_out, g16, dgamma, dbeta, dcolsum
+
+
+def patch_ln_fwd(video: torch.Tensor, p1: int, p2: int, pf: int, gamma, beta, eps: float = 1e-5, ldo: Optional[int] = None):
+    """video [B,C,F,H,W] (any strides, e.g. the permuted view of a [B,H,W,D] volume)."""
+    _need_cuda(video)
+    B, C, F, H, W = video.shape
+    P = C * p1 * p2 * pf
+    N = (F // pf) * (H // p1) * (W // p2)
+    ldo = (P + 7) // 8 * 8 if ldo is None else ldo
+    out = torch.empty((B * N, ldo), dtype=torch.bfloat16, device=video.device)
+    st = torch.empty((2, B * N), dtype=torch.float32, device=video.device)
+    check(lib.nv_patch_ln_fwd(_p(video), strides5(video), B, C, F, H, W, p1, p2, pf, _p(gamma), _p(beta), eps, _p(out), ldo, _p(st[0]),
+                              _p(st[1]), _stream()), "nv_patch_ln_fwd")
+    return out, st
+
+
+def patch_ln_bwd(video, p1, p2, pf, dxp, st, accumulate=False):
+    B, C, F, H, W = video.shape
+    P = C * p1 * p2 * pf
+    T = dxp.shape[0]
+    dg = torch.empty(P, device=video.device); db = torch.empty(P, device=video.device)
+    nb = lib.nv_patch_ln_bwd_workspace_bytes(T, P)
+    ws = torch.empty(nb, dtype=torch.uint8, device=video.device)
+    check(lib.nv_patch_ln_bwd(_p(video), strides5(video), B, C, F, H, W, p1, p2, pf, _p(dxp), dxp.stride(0), _p(st[0]), _p(st[1]), _p(dg),
+                              _p(db), int(accumulate), _p(ws), nb, _stream()), "nv_patch_ln_bwd")
+    return dg, db
+
+
+def embed_finish_fwd(t, B, N, gamma, beta, pos, cls, eps=1e-5):
+    d = t.shape[1]
+    x = torch.empty((B, N + 1, d), dtype=torch.float32, device=t.device)
+    st = torch.empty((2, B * N), dtype=torch.float32, device=t.device)
+    check(lib.nv_embed_finish_fwd(_p(t), t.stride(0), B, N, d, _p(gamma), _p(beta), eps, _p(pos), _p(cls), _p(x), d, _p(st[0]), _p(st[1]),
+                                  _stream()), "nv_embed_finish_fwd")
+    return x, st
+
+
+def embed_finish_bwd(g, t, st, gamma, B, N):
+    d = t.shape[1]
+    dev = t.device
+    dt = torch.empty((B * N, d), device=dev); dt16 = torch.empty((B * N, d), dtype=torch.bfloat16, device=dev)
+    dgamma, dbeta, dbias = (torch.empty(d, device=dev) for _ in range(3))
+    dpos = torch.empty((N + 1, d), device=dev); dcls = torch.empty(d, device=dev)
+    nb = lib.nv_embed_finish_bwd_workspace_bytes(B, N, d)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    g2 = g.reshape(B * (N + 1), d)
+    check(lib.nv_embed_finish_bwd(_p(g2), d, _p(t), t.stride(0), _p(st[0]), _p(st[1]), _p(gamma), B, N, d, _p(dt), d, _p(dt16), d, _p(dgamma),
+                                  _p(dbeta), _p(dbias), _p(dpos), _p(dcls), 0, _p(ws), nb, _stream()), "nv_embed_finish_bwd")
+    return dt, dt16, dgamma, dbeta, dbias, dpos, dcls
+
+
+def attn_fwd(qkv: torch.Tensor, B: int, n: int, heads: int, dim_head: int = 64):
+    """qkv bf16 [B*n, 3*inner] -> (out bf16 [B*n, inner], lse f32 [B, heads, n])."""
+    _need_cuda(qkv)
+    inner = heads * dim_head
+    out = torch.empty((B * n, inner), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, heads, n), dtype=torch.float32, device=qkv.device)
+    check(lib.nv_attn_fwd(_p(qkv), qkv.stride(0), B, n, heads, dim_head, dim_head ** -0.5, _p(out), inner, _p(lse), _stream()), "nv_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, B, n, heads, dim_head=64):
+    inner = heads * dim_head
+    dqkv = torch.empty((B * n, 3 * inner), dtype=torch.bfloat16, device=qkv.device)
+    delta = torch.empty((B, heads, n), dtype=torch.float32, device=qkv.device)
+    check(lib.nv_attn_bwd(_p(qkv), qkv.stride(0), _p(out), _p(dout), inner, _p(lse), B, n, heads, dim_head, dim_head ** -0.5, _p(delta),
+                          _p(dqkv), 3 * inner, _stream()), "nv_attn_bwd")
+    return dqkv, delta
+
+
+def head_fwd(x: torch.Tensor, gamma, beta, W, bias, eps=1e-5):
+    """x f32 [B, n, d] -> logits [B, C] from the cls row (pool='cls')."""
+    B, n, d = x.shape
+    C = W.shape[0]
+    xh = torch.empty((B, d), device=x.device); st = torch.empty((B, 2), device=x.device)
+    logits = torch.empty((B, C), device=x.device)
+    check(lib.nv_head_fwd(_p(x), n * d, B, d, _p(gamma), _p(beta), eps, _p(W), _p(bias), C, _p(xh), _p(st), _p(logits), _stream()), "nv_head_fwd")
+    return logits, xh, st
+
+
+def head_bwd(dlogits, W, x, st, xh, gamma):
+    B, n, d = x.shape
+    C = W.shape[0]
+    dev = x.device
+    g = torch.empty((B, n, d), device=dev); g16 = torch.empty((B, n, d), dtype=torch.bfloat16, device=dev)
+    dgamma, dbeta, dcol = (torch.empty(d, device=dev) for _ in range(3))
+    dW = torch.empty((C, d), device=dev); db = torch.empty(C, device=dev)
+    nb = lib.nv_head_bwd_workspace_bytes(B, d)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    check(lib.nv_head_bwd(_p(dlogits), B, C, _p(W), _p(x), n * d, _p(st), _p(xh), _p(gamma), d, n, _p(g), d, _p(g16), d, _p(dgamma), _p(dbeta),
+                          _p(dW), _p(db), _p(dcol), 0, _p(ws), nb, _stream()), "nv_head_bwd")
+    return g, g16, dgamma, dbeta, dW, db, dcol
+
+
+def colsum_bf16(X: torch.Tensor, accumulate=False, out=None):
+    M, N = X.shape
+    out = torch.empty(N, device=X.device) if out is None else out
+    nb = lib.nv_colsum_workspace_bytes(M, N)
+    ws = torch.empty(nb, dtype=torch.uint8, device=X.device)
+    check(lib.nv_colsum_bf16(_p(X), X.stride(0), M, N, _p(out), int(accumulate), _p(ws), nb, _stream()), "nv_colsum_bf16")
+    return out
+
+
+def ce_loss(logits: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0, want_grad=True):
+    B, C = logits.shape
+    loss = torch.empty(1, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    check(lib.nv_ce_loss(_p(logits), _p(target), B, C, grad_scale, _p(loss), _p(dl), _stream()), "nv_ce_loss")
+    return loss, dl
+
+
+def adamw_step(p, grad, m, v, p16, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+    check(lib.nv_adamw_step(_p(p), _p(grad), _p(m), _p(v), _p(p16), p.numel(), step, lr, betas[0], betas[1], eps, weight_decay, grad_scale,
+                            _stream()), "nv_adamw_step")
+
+
+def cast_bf16(src: torch.Tensor, ld_dst: Optional[int] = None) -> torch.Tensor:
+    """fp32 [rows, cols] -> bf16 [rows, ld_dst] (zero padded columns)."""
+    rows, cols = src.shape
+    ld_dst = (cols + 3) // 4 * 4 if ld_dst is None else ld_dst
+    dst = torch.empty((rows, ld_dst), dtype=torch.bfloat16, device=src.device)
+    check(lib.nv_cast_bf16_2d(_p(src), src.stride(0), rows, cols, _p(dst), ld_dst, _stream()), "nv_cast_bf16_2d")
+    return dst

@@ -1,0 +1,315 @@
+"""Per-kernel parity on a real MI355X, through the C-ABI (neurovit_amd.ops -> libneurovit_hip.so).
+
+Checker = the CPU oracle (oracle/ref_cpu.py) or a plain fp32/fp64 restatement of the single op.
+Tolerances (north_star: "within 1e-3 rel bf16; bit-exact for patch indexing / cls-token scatter"):
+  * fp32 outputs : max|a-b| <= 1e-3 * max|b|                       (REL)
+  * bf16 outputs : |a-b| <= 1e-3 * max|b| + 1 bf16 ulp of |b|      (a value on a rounding boundary may
+                   round the other way when the fp32 accumulation order differs)
+  * integer / index work: bit exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import weights as W
+from conftest import rel_err
+from oracle import ref_cpu, train_step
+
+pytestmark = pytest.mark.gpu
+REL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from neurovit_amd import ops as _ops
+    from neurovit_amd._cabi import require_gpu
+    require_gpu()
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def assert_close_bf16(a, b, what=""):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    ulp = 2.0 ** (torch.floor(torch.log2(b.abs().clamp_min(1e-30))) - 7)
+    tol = REL * b.abs().max() + ulp
+    bad = ((a - b).abs() > tol)
+    assert not bad.any(), f"{what}: {int(bad.sum())} / {bad.numel()} outside tol, max diff {(a - b).abs().max():.3e}, max ref {b.abs().max():.3e}"
+
+
+def assert_close_f32(a, b, what="", rel=REL):
+    e = rel_err(a, b)
+    assert e <= rel, f"{what}: rel err {e:.3e} > {rel}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+SHAPES = [(130, 136, 72), (128, 128, 64), (257, 264, 200), (65, 192, 4096), (2052, 768, 768), (16, 8, 8)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_nt_epilogues(ops, M, N, K):
+    A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias, resid = rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = A.double() @ B.double().T
+    Ad, Bd = dev(A), dev(B)
+    assert_close_bf16(ops.gemm(ops.NT, ops.EPI_STORE_BF16, Ad, Bd), ref, "store_bf16")
+    assert_close_f32(ops.gemm(ops.NT, ops.EPI_STORE_F32, Ad, Bd), ref, "store_f32", 1e-5)
+    assert_close_f32(ops.gemm(ops.NT, ops.EPI_BIAS_F32, Ad, Bd, bias=dev(bias)), ref + bias.double(), "bias_f32", 1e-5)
+    out = ops.gemm(ops.NT, ops.EPI_BIAS_RESID, Ad, Bd, bias=dev(bias), aux_in=dev(resid))
+    assert_close_f32(out, ref + bias.double() + resid.double(), "bias_resid", 1e-5)
+    u = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    h = ops.gemm(ops.NT, ops.EPI_BIAS_GELU, Ad, Bd, bias=dev(bias), aux_out=u)
+    uref = ref + bias.double()
+    assert_close_bf16(u, uref, "gelu.u")
+    assert_close_bf16(h, F.gelu(uref), "gelu.h")
+    # accumulate: C += A B^T
+    c0 = rnd(M, N, seed=5)
+    c = dev(c0.clone())
+    ops.gemm(ops.NT, ops.EPI_STORE_F32, Ad, Bd, out=c, accumulate=True)
+    assert_close_f32(c, ref + c0.double(), "accumulate", 1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_nn_tn(ops, M, N, K):
+    A, Bt = bf(rnd(M, K, seed=6)), bf(rnd(K, N, seed=7, scale=K ** -0.5))
+    ref = A.double() @ Bt.double()
+    assert_close_f32(ops.gemm(ops.NN, ops.EPI_STORE_F32, dev(A), dev(Bt)), ref, "nn_f32", 1e-5)
+    assert_close_bf16(ops.gemm(ops.NN, ops.EPI_STORE_BF16, dev(A), dev(Bt)), ref, "nn_bf16")
+    u = bf(rnd(M, N, seed=8))
+    dg = ops.gemm(ops.NN, ops.EPI_DGELU, dev(A), dev(Bt), aux_in=dev(u))
+    assert_close_bf16(dg, ref * ref_cpu._gelu_grad(u.double()), "dgelu")
+    # TN: C[Mo, N] = A[K, Mo]^T B[K, N]   (K plays the token dimension; ragged K is the 2052-row case)
+    Mo = (M + 7) // 8 * 8
+    At, B2 = bf(rnd(K, Mo, seed=9)), bf(rnd(K, N, seed=10, scale=K ** -0.5))
+    assert_close_f32(ops.gemm(ops.TN, ops.EPI_STORE_F32, dev(At), dev(B2)), At.double().T @ B2.double(), "tn_f32", 1e-5)
+
+
+def test_gemm_tn_ragged_tokens(ops):
+    K, Mo, N = 2052, 768, 264          # reduction over 2052 token rows (not a multiple of the 64-deep K tile)
+    At, B2 = bf(rnd(K, Mo, seed=11)), bf(rnd(K, N, seed=12, scale=K ** -0.5))
+    assert_close_f32(ops.gemm(ops.TN, ops.EPI_STORE_F32, dev(At), dev(B2)), At.double().T @ B2.double(), "tn_ragged", 1e-5)
+
+
+def test_gemm_rejects_bad_args(ops):
+    A, B = dev(bf(rnd(16, 12))), dev(bf(rnd(8, 12)))
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.gemm(ops.NT, ops.EPI_STORE_BF16, A, B)          # K = 12 not a multiple of 8
+    with pytest.raises(RuntimeError):
+        ops.gemm(ops.NT, ops.EPI_STORE_BF16, A.cpu(), B.cpu())
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M,d", [(65, 192), (130, 128), (2052, 768), (9, 1024), (33, 2048)])
+def test_ln_fwd_bwd(ops, M, d):
+    x, gamma, beta = rnd(M, d, seed=1) * 2 + 0.3, 1 + 0.1 * rnd(d, seed=2), 0.1 * rnd(d, seed=3)
+    y, st = ops.ln_fwd(dev(x), dev(gamma), dev(beta))
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = F.layer_norm(xd, (d,), gd, bd, 1e-5)
+    assert_close_bf16(y, ref, "ln_fwd")
+    assert_close_f32(st[0], x.double().mean(1), "mean", 1e-5)
+    assert_close_f32(st[1], 1 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-5), "rstd", 1e-5)
+    dy, g_in = rnd(M, d, seed=4), rnd(M, d, seed=5)
+    ref.backward(dy.double())
+    g_out, g16, dg, db, dc = ops.ln_bwd(dev(dy), dev(x), st, dev(gamma), g_in=dev(g_in.clone()))
+    assert_close_f32(g_out, xd.grad + g_in.double(), "ln_bwd.dx", 1e-5)
+    assert_close_bf16(g16, xd.grad + g_in.double(), "ln_bwd.g16")
+    assert_close_f32(dg, gd.grad, "ln_bwd.dgamma", 1e-5)
+    assert_close_f32(db, bd.grad, "ln_bwd.dbeta", 1e-5)
+    assert_close_f32(dc, (xd.grad + g_in.double()).sum(0), "ln_bwd.colsum", 1e-5)
+
+
+# ------------------------------------------------------------------------------------------ patch gather (G1 bit exact) + LN(P)
+def _balanced_pm1(B, S, p, seed):
+    """Volume of +-1 whose every p^3 patch has exactly as many +1 as -1: LN(eps=0) maps it onto itself
+    exactly, so the kernel's bf16 output IS the gathered voxel -> bit-exact test of the index map."""
+    idx = torch.from_numpy(ref_cpu.patch_index_map(S, p))            # [N, P]
+    g = torch.Generator().manual_seed(seed)
+    vol = torch.empty(B, S ** 3)
+    half = torch.cat([torch.ones(p ** 3 // 2), -torch.ones(p ** 3 - p ** 3 // 2)])
+    for b in range(B):
+        for n in range(idx.shape[0]):
+            vol[b, idx[n]] = half[torch.randperm(p ** 3, generator=g)]
+    return vol.reshape(B, S, S, S)
+
+
+@pytest.mark.parametrize("S,p", [(32, 8), (64, 16), (16, 4)])
+def test_patch_gather_bit_exact(ops, S, p):
+    B = 2
+    vol = _balanced_pm1(B, S, p, seed=S + p)
+    P = p ** 3
+    out, st = ops.patch_ln_fwd(ref_cpu.fmri_to_video(dev(vol)), p, p, p, dev(torch.ones(P)), dev(torch.zeros(P)), eps=0.0)
+    tok = ref_cpu.patchify(ref_cpu.fmri_to_video(vol), p, p, p).reshape(-1, P)
+    assert torch.equal(out.float().cpu(), tok), "patch index map is not bit exact"
+    assert torch.equal(st[0].cpu(), torch.zeros_like(st[0].cpu())) and torch.equal(st[1].cpu(), torch.ones_like(st[1].cpu()))
+
+
+def test_patch_gather_matches_golden_index_map(ops, golden):
+    """Same check against the fixture produced by the reference's own Rearrange (S=32, p=8)."""
+    S, p = 32, 8
+    idx = torch.from_numpy(golden("patchify.npz")[f"tok_S{S}_p{p}"].astype(np.int64))
+    vol = _balanced_pm1(1, S, p, seed=5)
+    out, _ = ops.patch_ln_fwd(ref_cpu.fmri_to_video(dev(vol)), p, p, p, dev(torch.ones(p ** 3)), dev(torch.zeros(p ** 3)), eps=0.0)
+    assert torch.equal(out.float().cpu(), vol.reshape(-1)[idx])
+
+
+@pytest.mark.parametrize("S,p,C", [(32, 8, 1), (18, 9, 1), (16, 8, 3)])
+def test_patch_ln_fwd_bwd_general(ops, S, p, C):
+    """Scalar path: odd patch size (p=9, P=729 -> padded to 736) and multi-channel video."""
+    B = 2
+    g = torch.Generator().manual_seed(3)
+    video = torch.randn(B, C, S, S, S, generator=g)
+    P = C * p ** 3
+    gamma, beta = 1 + 0.1 * rnd(P, seed=1), 0.1 * rnd(P, seed=2)
+    out, st = ops.patch_ln_fwd(dev(video), p, p, p, dev(gamma), dev(beta))
+    tok = ref_cpu.patchify(video, p, p, p).reshape(-1, P).double()
+    ref = F.layer_norm(tok, (P,), gamma.double(), beta.double(), 1e-5)
+    assert out.shape[1] == (P + 7) // 8 * 8
+    assert_close_bf16(out[:, :P], ref, "patch_ln")
+    assert torch.count_nonzero(out[:, P:]) == 0
+    dxp = rnd(tok.shape[0], out.shape[1], seed=4)
+    dg, db = ops.patch_ln_bwd(dev(video), p, p, p, dev(dxp), st)
+    xh = (tok - tok.mean(1, keepdim=True)) / torch.sqrt(tok.var(1, unbiased=False, keepdim=True) + 1e-5)
+    assert_close_f32(dg, (dxp[:, :P].double() * xh).sum(0), "patch_ln.dgamma", 1e-4)
+    assert_close_f32(db, dxp[:, :P].double().sum(0), "patch_ln.dbeta", 1e-4)
+
+
+# ------------------------------------------------------------------------------------------ embed finish (A4+A5)
+def test_embed_finish_scatter_bit_exact(ops):
+    """cls/pos scatter (G1): with eps=0 and balanced +-1 rows LN is the identity, so every output row must
+    equal (+-1 + pos[i]) / (cls + pos[0]) bit for bit."""
+    B, N, d = 3, 27, 64
+    g = torch.Generator().manual_seed(0)
+    t = torch.stack([torch.cat([torch.ones(d // 2), -torch.ones(d // 2)])[torch.randperm(d, generator=g)] for _ in range(B * N)])
+    pos, cls = rnd(N + 1, d, seed=1), rnd(d, seed=2)
+    x, st = ops.embed_finish_fwd(dev(t), B, N, dev(torch.ones(d)), dev(torch.zeros(d)), dev(pos), dev(cls), eps=0.0)
+    x = x.cpu()
+    assert torch.equal(x[:, 0], (cls + pos[0]).expand(B, -1))
+    assert torch.equal(x[:, 1:], t.reshape(B, N, d) + pos[1:])
+
+
+def test_embed_finish_fwd_bwd(ops):
+    B, N, d = 2, 64, 192
+    t, gamma, beta = rnd(B * N, d, seed=1), 1 + 0.1 * rnd(d, seed=2), 0.1 * rnd(d, seed=3)
+    pos, cls = rnd(N + 1, d, seed=4), rnd(d, seed=5)
+    x, st = ops.embed_finish_fwd(dev(t), B, N, dev(gamma), dev(beta), dev(pos), dev(cls))
+    td = t.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    pd, cd = pos.double().requires_grad_(True), cls.double().requires_grad_(True)
+    a4 = F.layer_norm(td, (d,), gd, bd, 1e-5).reshape(B, N, d)
+    ref = torch.cat((cd.expand(B, 1, d), a4), dim=1) + pd
+    assert_close_f32(x, ref, "embed_finish", 1e-5)
+    g = rnd(B, N + 1, d, seed=6)
+    ref.backward(g.double())
+    dt, dt16, dg, db, dbias, dpos, dcls = ops.embed_finish_bwd(dev(g), dev(t), st, dev(gamma), B, N)
+    assert_close_f32(dt, td.grad, "dt", 1e-5)
+    assert_close_bf16(dt16, td.grad, "dt16")
+    assert_close_f32(dg, gd.grad, "dgamma", 1e-5)
+    assert_close_f32(db, bd.grad, "dbeta", 1e-5)
+    assert_close_f32(dbias, td.grad.sum(0), "dbias", 1e-5)
+    assert_close_f32(dpos, pd.grad, "dpos", 1e-5)
+    assert_close_f32(dcls, cd.grad, "dcls", 1e-5)
+
+
+# ------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,n,heads", [(2, 65, 3), (1, 513, 2), (2, 9, 1), (1, 130, 2), (1, 64, 1)])
+def test_attention_fwd_bwd(ops, B, n, heads):
+    dh, inner = 64, heads * 64
+    qkv = bf(rnd(B * n, 3 * inner, seed=n)).float()
+    q, k, v = (t.reshape(B, n, heads, dh).permute(0, 2, 1, 3).clone().requires_grad_(True) for t in qkv.chunk(3, dim=-1))
+    ref = ref_cpu._AttnEmu.apply(q, k, v, dh ** -0.5)
+    out, lse = ops.attn_fwd(dev(bf(qkv)), B, n, heads)
+    ref2 = ref.permute(0, 2, 1, 3).reshape(B * n, inner)
+    assert_close_bf16(out, ref2, "attn.out")
+    s = torch.matmul(q.double(), k.double().transpose(-1, -2)) * dh ** -0.5
+    assert_close_f32(lse, torch.logsumexp(s, dim=-1), "attn.lse", 1e-4)
+    do = bf(rnd(B * n, inner, seed=7)).float()
+    ref.backward(do.reshape(B, n, heads, dh).permute(0, 2, 1, 3))
+    # feed the kernel the oracle's own bf16 forward output so both sides use the same delta = rowsum(dO * O)
+    dqkv, delta = ops.attn_bwd(dev(bf(qkv)), dev(bf(ref2.detach())), dev(bf(do)), lse, B, n, heads)
+    dref = torch.cat([t.grad.permute(0, 2, 1, 3).reshape(B * n, inner) for t in (q, k, v)], dim=-1)
+    assert_close_bf16(dqkv, dref, "attn.dqkv")
+
+
+def test_attention_rescale_branch(ops):
+    """Force the online-softmax rescale: one key in the LAST tile dominates one query row."""
+    B, n, heads, dh = 1, 200, 1, 64
+    qkv = bf(rnd(B * n, 3 * dh, seed=1) * 0.5).float()
+    qkv[5, :dh] = 4.0
+    qkv[190, dh:2 * dh] = 4.0                      # q5 . k190 = 64*16 -> scaled 128, far above everything else
+    q, k, v = (t.reshape(B, n, heads, dh).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
+    ref = ref_cpu._AttnEmu.apply(q, k, v, dh ** -0.5).permute(0, 2, 1, 3).reshape(B * n, dh)
+    out, _ = ops.attn_fwd(dev(bf(qkv)), B, n, heads)
+    assert_close_bf16(out, ref, "attn.rescale")
+    assert torch.isfinite(out.float()).all()
+
+
+# ------------------------------------------------------------------------------------------ head, colsum, CE, AdamW, cast
+def test_head_fwd_bwd(ops):
+    B, n, d, C = 3, 9, 192, 5
+    x, gamma, beta = rnd(B, n, d, seed=1), 1 + 0.1 * rnd(d, seed=2), 0.1 * rnd(d, seed=3)
+    Wt, bias = rnd(C, d, seed=4, scale=d ** -0.5), 0.1 * rnd(C, seed=5)
+    logits, xh, st = ops.head_fwd(dev(x), dev(gamma), dev(beta), dev(Wt), dev(bias))
+    xd = x.double().requires_grad_(True)
+    gd, bd, wd, cd = (t.double().requires_grad_(True) for t in (gamma, beta, Wt, bias))
+    ref = F.linear(F.layer_norm(xd[:, 0], (d,), gd, bd, 1e-5), wd, cd)
+    assert_close_f32(logits, ref, "head.logits", 1e-5)
+    dl = rnd(B, C, seed=6)
+    ref.backward(dl.double())
+    g, g16, dgm, dbt, dW, db, dcol = ops.head_bwd(dev(dl), dev(Wt), dev(x), st, xh, dev(gamma))
+    assert_close_f32(g, xd.grad, "head.g", 1e-5)
+    assert torch.count_nonzero(g[:, 1:]) == 0
+    assert_close_f32(dgm, gd.grad, "head.dgamma", 1e-5)
+    assert_close_f32(dbt, bd.grad, "head.dbeta", 1e-5)
+    assert_close_f32(dW, wd.grad, "head.dW", 1e-5)
+    assert_close_f32(db, cd.grad, "head.db", 1e-5)
+    assert_close_f32(dcol, xd.grad.sum((0, 1)), "head.colsum", 1e-5)
+
+
+def test_colsum_and_cast(ops):
+    X = bf(rnd(2052, 384, seed=1))
+    assert_close_f32(ops.colsum_bf16(dev(X)), X.double().sum(0), "colsum", 1e-5)
+    src = rnd(37, 729, seed=2)
+    dst = ops.cast_bf16(dev(src), 736).cpu()
+    assert torch.equal(dst[:, :729], bf(src)) and torch.count_nonzero(dst[:, 729:]) == 0
+
+
+def test_ce_loss(ops):
+    logits, target = rnd(4, 7, seed=1) * 3, torch.tensor([0, 6, 3, 3])
+    ld = logits.double().requires_grad_(True)
+    ref = F.cross_entropy(ld, target)
+    ref.backward()
+    loss, dl = ops.ce_loss(dev(logits), dev(target))
+    assert abs(loss.item() - ref.item()) < 1e-6 * max(1, abs(ref.item()))
+    assert_close_f32(dl, ld.grad, "ce.grad", 1e-5)
+    assert abs(loss.item() - train_step.cross_entropy(logits, target).item()) < 1e-5
+
+
+def test_adamw_matches_oracle(ops):
+    n = 4096 + 8
+    p0, g1, g2 = rnd(n, seed=1), rnd(n, seed=2) * 0.1, rnd(n, seed=3) * 0.1
+    params = {"w": p0.clone()}
+    opt = train_step.AdamW(params, lr=1e-3, weight_decay=1e-2)
+    p, m, v = dev(p0.clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    p16 = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for step, g in enumerate((g1, g2), start=1):
+        opt.step({"w": g})
+        ops.adamw_step(p, dev(g), m, v, p16, step, 1e-3, weight_decay=1e-2)
+        assert_close_f32(p, params["w"], f"adamw.p step{step}", 1e-6)
+        assert_close_f32(m, opt.m["w"], "adamw.m", 1e-6)
+        assert_close_f32(v, opt.v["w"], "adamw.v", 1e-6)
+        assert torch.equal(p16.cpu(), bf(p.cpu()))
