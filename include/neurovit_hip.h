@@ -95,8 +95,8 @@ int nv_colsum_bf16(const void* X, long ld, int M, int N, float* out, int accumul
 /* ---- loss / optimizer (Trainer.py:30-31,70,75): nn.CrossEntropyLoss (mean) and torch.optim.AdamW */
 int nv_ce_loss(const float* logits, const long* target, int B, int C, float grad_scale, float* loss, float* dlogits,
                void* stream);
-int nv_adamw_step(float* p, const float* grad, float* m, float* v, void* p16, long count, int step, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+int nv_adamw_step(float* p, const float* grad, float* m, float* v, void* p16, long count, int step, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, float grad_scale, void* stream);
 int nv_cast_bf16_2d(const float* src, long ld_src, int rows, int cols, void* dst, long ld_dst, void* stream);
 
 /* ---- whole-encoder engine: ViT.forward / its backward as ONE call each (vit_3d.py:112-126)

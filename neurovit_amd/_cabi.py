@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "neurovit_hip.h")
 LIB_PATH = os.path.join(_HERE, "lib", "libneurovit_hip.so")
 
-_SCALARS = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
+_SCALARS = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
 
 
 class VitConfig(ctypes.Structure):

