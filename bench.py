@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py - fMRI volumes/sec (fwd+bwd+AdamW) of ViT3D-base on MI355X, BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = the reference's train step (src/Trainer.py:65-79: forward, CrossEntropyLoss, backward, AdamW)
+on one per-GPU batch of synthetic ADNI-shaped volumes already resident in HBM.  Workload = BASELINE.json
+configs[1]: ViT3D-base (128^3, patch 16, dim 768, depth 12, heads 12, mlp 3072), bf16 MFMA operands with
+fp32 accumulate / master weights, batch 4 per GPU (weak scaling: configs[2] = 32 over 8 GPUs).
+
+Prints ONE JSON line on rank 0 (fields documented in DESIGN.md "Measurement").
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+KIND_NAMES = {0: "gemm_bf16_kernel<NT> (forward linears)", 1: "gemm_bf16_kernel<NN> (data grads)",
+              2: "gemm_bf16_kernel<TN> (weight grads)", 3: "attn_fwd_kernel", 4: "attn_bwd_dq+dkv kernels"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="volumes per GPU (BASELINE.json configs[1]: 4)")
+    ap.add_argument("--preset", default="base", choices=["tiny", "base", "large"])
+    ap.add_argument("--buckets", type=int, default=4, help="gradient all-reduce buckets")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def make_batch(B, S, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(B, S, S, S, generator=g)
+    flat = x.reshape(B, -1)
+    x = ((flat - flat.mean(1, keepdim=True)) / (flat.std(1, keepdim=True) + 1e-8)).reshape(B, S, S, S)   # DatasetADNI.py:213
+    y = torch.randint(0, 2, (B,), generator=g)
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(model, vcfg, B, S, steps):
+    """The oracle's restatement of the same train step (eager PyTorch CPU fp32 = the reference's own CPU path,
+    SURVEY.md 8d), timed on this host's cores on a bounded sample: `steps` steps of the same workload."""
+    from oracle import ref_cpu, train_step
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    sd = {k[len("volume_encoder.vit3d."):]: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    cfg = ref_cpu.ViTCfg(**vcfg)
+    opt = train_step.AdamW(sd, lr=1e-4, weight_decay=1e-2)
+    x, y = make_batch(B, S, "cpu", 4242)
+    video = ref_cpu.fmri_to_video(x)
+    train_step.train_step(sd, cfg, opt, video, y)            # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        train_step.train_step(sd, cfg, opt, video, y)
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} train steps (fwd+bwd+AdamW, fp32 eager PyTorch CPU) of the same workload, batch {B}, after 1 warm-up step"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from neurovit_amd import config as nvcfg
+    from neurovit_amd._cabi import lib, require_gpu
+    from neurovit_amd.NeuroEncoder import NeuroEncoder
+    from neurovit_amd.trainer import TrainStep
+    require_gpu()
+
+    size = nvcfg.preset(a.preset)
+    S, p = size["TRAINING_VIT_INPUT_SIZE"], size["TRAINING_VIT_PATCH_SIZE"]
+    config = dict(DEVICE=str(device), TRAINING_DIM=3, TRAINING_DROPOUT=0.0, GRADCAM_CUBE_SIZE=8, DATASET_NAME="adni",
+                  TRAINING_LEARNING_RATE=1e-4, TRAINING_WEIGHT_DECAY=1e-2, **size)
+    torch.manual_seed(42)                                   # main.py:86-88
+    model = NeuroEncoder(config)
+    model.train()
+    step = TrainStep(model, process_group=None, n_buckets=a.buckets)
+    B = a.batch
+    x, y = make_batch(B, S, device, 42 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(x, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step(x, y)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms = elapsed / a.steps * 1e3
+    value = B * world * a.steps / elapsed
+
+    # ---- roofline leg: per-launch hipEvent durations of the dominant kernel family, same steps, same stream
+    lib.nv_prof_enable(1)
+    prof_steps = 3
+    for _ in range(prof_steps):
+        step(x, y)
+    torch.cuda.synchronize()
+    kinds = {}
+    for k in KIND_NAMES:
+        msk, wk, ck = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+        lib.nv_prof_summary(k, ctypes.byref(msk), ctypes.byref(wk), ctypes.byref(ck))
+        if ck.value:
+            kinds[k] = dict(ms=msk.value, flops=wk.value, launches=ck.value)
+    lib.nv_prof_enable(0)
+    gemm = [kinds[k] for k in (0, 1, 2) if k in kinds]
+    g_ms, g_fl, g_n = sum(k["ms"] for k in gemm), sum(k["flops"] for k in gemm), sum(k["launches"] for k in gemm)
+    achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel (NT/NN/TN instantiations, all fused epilogues)",
+                "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                "traffic": None, "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches_per_step": g_n // prof_steps,
+                "gemm_share_of_step": round(g_ms / prof_steps / ms, 3),
+                "by_kernel": {KIND_NAMES[k]: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "avg_us": round(v["ms"] * 1e3 / v["launches"], 2),
+                                              "launches_per_step": v["launches"] // prof_steps} for k, v in kinds.items()}}
+
+    from oracle.ref_cpu import ViTCfg, flops_forward
+    vcfg = dict(image_size=S, image_patch_size=p, frames=S, frame_patch_size=p, num_classes=2, dim=size["TRAINING_VIT_DIM"],
+                depth=size["TRAINING_VIT_DEPTH"], heads=size["TRAINING_VIT_HEADS"], mlp_dim=size["TRAINING_VIT_MLP_DIM"], channels=1, dim_head=64)
+    f_step = 3.0 * flops_forward(ViTCfg(**vcfg))           # fwd + bwd = 3 x fwd algorithmic FLOPs
+
+    out = {"metric": "fMRI volumes/sec (fwd+bwd+AdamW) ViT3D 128^3 p16 d768 L12", "value": round(value, 2), "unit": "volumes/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"ViT3D-{a.preset} {S}^3 patch {p}, train step (fwd+bwd+AdamW), batch {B}/GPU, dropout 0",
+                      "global_batch": B * world, "parallelism": f"dp{world}", "grad_buckets": a.buckets},
+           "mfma_frac_step": round(value / world * f_step / (PEAK_BF16_TFLOPS * 1e12), 4),
+           "loss": round(float(loss), 5), "roofline": roofline}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, vcfg, B, S, a.cpu_steps)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

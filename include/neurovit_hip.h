@@ -32,6 +32,11 @@ int nv_version(void);
 int nv_arch_ok(void);                 /* 1 iff the current HIP device is gfx950 */
 const char* nv_last_error(void);
 
+/* ---- optional per-launch hipEvent profiler (bench.py roofline leg).  kind: 0 gemm NT, 1 gemm NN, 2 gemm TN,
+ * 3 attention fwd, 4 attention bwd.  nv_prof_summary synchronises; call it outside timed regions. */
+int nv_prof_enable(int on);
+int nv_prof_summary(int kind, double* ms, double* work, long* count);
+
 /* ---- GEMM with fused epilogues (replaces every nn.Linear on the path: vit_3d.py:19,22,41,44,94)
  * layout 0 (NT): C[M,N] = A[M,K] . B[N,K]^T      forward  y = x W^T
  * layout 1 (NN): C[M,N] = A[M,K] . B[K,N]        dgrad    dx = dy W
@@ -118,6 +123,13 @@ int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const lo
 int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                     const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
                     int accumulate, void* stream);
+
+/* Backward split into stages (0 = head, 1+k = layer depth-1-k, depth+1 = patch embedding) so the caller can start the
+ * data-parallel all-reduce of a stage's gradient range (nv_vit_stage_param_range) while later stages still run. */
+int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
+                           const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
+                           int accumulate, int first_stage, int last_stage, void* stream);
+int nv_vit_stage_param_range(const nv_vit_config* cfg, int stage, long* begin, long* end);
 
 #ifdef __cplusplus
 }

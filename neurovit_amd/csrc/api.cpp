@@ -25,3 +25,54 @@ extern "C" int nv_arch_ok(void) {
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { nv_set_error("nv_arch_ok: hipGetDeviceProperties failed"); return -2; }
   return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
+
+// ---- optional per-launch event profiler (bench.py's roofline leg) -------------------------------------
+// When enabled, kernel launchers bracket each launch of a profiled kind with hipEvents on the launch stream.
+// Kinds: 0 gemm NT, 1 gemm NN, 2 gemm TN, 3 attention fwd, 4 attention bwd (dQ + dK/dV).
+#include <vector>
+namespace {
+struct Rec { hipEvent_t a, b; int kind; double work; };
+std::vector<Rec> g_pool;
+size_t g_used = 0;
+bool g_on = false;
+}  // namespace
+
+extern "C" int nv_prof_enable(int on) {
+  g_on = on != 0;
+  g_used = 0;
+  return 0;
+}
+
+extern "C" int nv_prof_begin(int kind, double work, void* stream) {
+  if (!g_on) return -1;
+  if (g_used == g_pool.size()) {
+    if (g_pool.size() >= 65536) return -1;
+    Rec r; r.kind = kind; r.work = work;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+    g_pool.push_back(r);
+  }
+  Rec& r = g_pool[g_used];
+  r.kind = kind; r.work = work;
+  (void)hipEventRecord(r.a, (hipStream_t)stream);
+  return (int)g_used++;
+}
+
+extern "C" void nv_prof_end(int slot, void* stream) {
+  if (slot >= 0 && (size_t)slot < g_pool.size()) (void)hipEventRecord(g_pool[slot].b, (hipStream_t)stream);
+}
+
+// Sums over the records of `kind` since nv_prof_enable(1): total milliseconds, total work (flops), launch count.
+// Synchronises with the recorded events (call it outside any timed region).
+extern "C" int nv_prof_summary(int kind, double* ms, double* work, long* count) {
+  double tms = 0, tw = 0; long c = 0;
+  for (size_t i = 0; i < g_used; ++i) {
+    Rec& r = g_pool[i];
+    if (r.kind != kind) continue;
+    if (hipEventSynchronize(r.b) != hipSuccess) { nv_set_error("nv_prof_summary: event sync failed"); return -2; }
+    float e = 0.f;
+    if (hipEventElapsedTime(&e, r.a, r.b) != hipSuccess) { nv_set_error("nv_prof_summary: elapsed failed"); return -2; }
+    tms += e; tw += r.work; ++c;
+  }
+  if (ms) *ms = tms; if (work) *work = tw; if (count) *count = c;
+  return 0;
+}

@@ -152,8 +152,10 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
   NV_CHECK_ARG(B > 0 && n > 0 && heads > 0 && ld_qkv >= 3 * heads * DH && ld_out >= heads * DH && (ld_qkv % 8) == 0 && (ld_out % 4) == 0,
                "nv_attn_fwd: bad dims");
   NV_CHECK_ARG(nv_aligned16(qkv) && nv_aligned16(out), "nv_attn_fwd: alignment");
+  const int slot = nv_prof_begin(3, 4.0 * B * heads * (double)n * n * DH, stream);
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((n + TQ - 1) / TQ, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
                      heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse);
+  nv_prof_end(slot, stream);
   NV_CHECK_LAUNCH("nv_attn_fwd");
   return NV_OK;
 }
@@ -344,11 +346,13 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
   NV_CHECK_ARG(nv_aligned16(qkv) && nv_aligned16(out) && nv_aligned16(dout) && nv_aligned16(dqkv), "nv_attn_bwd: alignment");
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((n + TQ - 1) / TQ, B * heads);
+  const int slot = nv_prof_begin(4, 10.0 * B * heads * (double)n * n * DH, stream);   // algorithmic: 5 products
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out, lse, n,
                      heads, scale, delta, (bf16*)dqkv, ld_dqkv);
   NV_CHECK_LAUNCH("nv_attn_bwd/dq");
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)dout, ld_out, lse, delta, n, heads,
                      scale, (bf16*)dqkv, ld_dqkv);
+  nv_prof_end(slot, stream);
   NV_CHECK_LAUNCH("nv_attn_bwd/dkv");
   return NV_OK;
 }

@@ -17,6 +17,8 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 #define NV_ERR_ARCH (-3)       // not a gfx950 device
 
 extern "C" void nv_set_error(const char* fmt, ...);
+extern "C" int nv_prof_begin(int kind, double work, void* stream);   // -1 when profiling is off
+extern "C" void nv_prof_end(int slot, void* stream);
 
 #define NV_CHECK_ARG(cond, ...)                                                                   \
   do {                                                                                            \

@@ -209,9 +209,13 @@ extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* vide
   return NV_OK;
 }
 
-extern "C" int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
-                               const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
-                               int accumulate, void* stream) {
+// Backward in stages so the caller can overlap the data-parallel gradient all-reduce with it:
+//   stage 0 = classification head, stage 1+k = transformer layer (depth-1-k), stage depth+1 = patch embedding.
+// Stages must be run in increasing order over [0, depth+1]; the running residual gradient lives in the workspace.
+// When stage s has run, the gradient-arena range of its parameters is final (see nv_vit_stage_param_range).
+extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
+                                      const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
+                                      int accumulate, int first_stage, int last_stage, void* stream) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 1, W);
@@ -229,12 +233,16 @@ extern "C" int nv_vit_backward(const nv_vit_config* cfg, int B, const float* vid
   void* red = ws + W.red;
   const float scale = 1.0f / sqrtf((float)D.dh);
 
+  NV_CHECK_ARG(first_stage >= 0 && last_stage <= D.L + 1 && first_stage <= last_stage, "nv_vit_backward_stages: bad stage range [%d, %d]", first_stage, last_stage);
   // head: writes g (zeros + cls rows) and the last layer's FC2 bias gradient (colsum of g)
   const float* xlast = (float*)(ws + W.layer[D.L - 1].x2);
+  if (first_stage == 0)
   RUN(nv_head_bwd(dlogits, B, D.C, p + T.hw, xlast, (long)D.n * d, (float*)(ws + W.hst), (float*)(ws + W.xh), p + T.hg, d, D.n, g, d, g16, d,
                   gr + T.hg, gr + T.hb, gr + T.hw, gr + T.hbias, gr + T.layer[D.L - 1].b2, acc, red, W.red_bytes, stream));
 
   for (int l = D.L - 1; l >= 0; --l) {
+    const int stage = D.L - l;
+    if (stage < first_stage || stage > last_stage) continue;
     const LayerP& q = T.layer[l];
     const LayerW& w = W.layer[l];
     const float* xin = (l == 0) ? (float*)(ws + W.x0) : (float*)(ws + W.layer[l - 1].x2);
@@ -261,6 +269,7 @@ extern "C" int nv_vit_backward(const nv_vit_config* cfg, int B, const float* vid
                   acc, red, W.red_bytes, stream));
   }
 
+  if (last_stage < D.L + 1) return NV_OK;
   // ---- patch embedding backward (vit_3d.py:91-96,116-118)
   float* est = (float*)(ws + W.est);
   float* pst = (float*)(ws + W.pst);
@@ -271,5 +280,26 @@ extern "C" int nv_vit_backward(const nv_vit_config* cfg, int B, const float* vid
   RUN(nv_patch_ln_bwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
                       cfg->image_patch_size, cfg->frame_patch_size, (float*)(ws + W.dxp), D.Ppad, pst, pst + D.T, gr + T.pe_g, gr + T.pe_b, acc, red,
                       W.red_bytes, stream));
+  return NV_OK;
+}
+
+extern "C" int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
+                               const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
+                               int accumulate, void* stream) {
+  return nv_vit_backward_stages(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, accumulate, 0,
+                                cfg ? cfg->depth + 1 : 0, stream);
+}
+
+// Element range [begin, end) of the parameter / gradient arena that is FINAL once backward stage `stage` has run.
+// (stage 0: head; stage 1+k: layer depth-1-k - its FC2 bias was already written by the stage before; last stage: embedding.)
+extern "C" int nv_vit_stage_param_range(const nv_vit_config* cfg, int stage, long* begin, long* end) {
+  Dims D; RUN(make_dims(cfg, 1, D));
+  ParamTab T; make_params(D, T);
+  NV_CHECK_ARG(stage >= 0 && stage <= D.L + 1 && begin && end, "nv_vit_stage_param_range: bad stage %d", stage);
+  if (stage == 0) { *begin = T.hg; *end = T.total; return NV_OK; }
+  if (stage == D.L + 1) { *begin = 0; *end = T.layer[0].n1g; return NV_OK; }
+  const int l = D.L - stage;
+  *begin = T.layer[l].n1g;
+  *end = (l + 1 < D.L) ? T.layer[l + 1].n1g : T.hg;
   return NV_OK;
 }

@@ -206,10 +206,12 @@ static int launch(const GemmArgs& a, hipStream_t s) {
   auto kern = gemm_bf16_kernel<A_T, B_T, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     attr_set = true;
   }
+  const int slot = nv_prof_begin((A_T ? 2 : (B_T ? 1 : 0)), 2.0 * a.M * a.N * a.K, s);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), 4 * TILE_BYTES, s, a);
+  nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_bf16");
   return NV_OK;
 }

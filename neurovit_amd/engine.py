@@ -75,13 +75,27 @@ class VitRuntime:
         return logits
 
     def backward(self, dlogits: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, grads: torch.Tensor,
-                 accumulate: bool) -> None:
+                 accumulate: bool, stages: Optional[Tuple[int, int]] = None) -> None:
+        """Whole backward, or only stages [first, last] (0 = head, 1+k = layer depth-1-k, depth+1 = embedding)."""
         assert self._last is not None and self._last[1], "backward needs a preceding forward(training=True)"
         B, _, ws, video = self._last
-        dlogits = dlogits.contiguous().float()
-        check(lib.nv_vit_backward(ctypes.byref(self.cfg), B, video.data_ptr(), ops.strides5(video), params.data_ptr(),
-                                  params16.data_ptr(), ws.data_ptr(), ws.numel(), dlogits.data_ptr(), grads.data_ptr(),
-                                  int(accumulate), torch.cuda.current_stream().cuda_stream), "nv_vit_backward")
+        first, last = (0, self.cfg.depth + 1) if stages is None else stages
+        if first == 0:
+            self._dlogits = dlogits.contiguous().float()
+        check(lib.nv_vit_backward_stages(ctypes.byref(self.cfg), B, video.data_ptr(), ops.strides5(video), params.data_ptr(),
+                                         params16.data_ptr(), ws.data_ptr(), ws.numel(), self._dlogits.data_ptr(),
+                                         grads.data_ptr(), int(accumulate), first, last,
+                                         torch.cuda.current_stream().cuda_stream), "nv_vit_backward_stages")
+
+    def stage_range(self, first: int, last: int) -> Tuple[int, int]:
+        """Arena element range [begin, end) that is final after backward stages first..last have run."""
+        lo, hi = None, None
+        b, e = ctypes.c_long(), ctypes.c_long()
+        for s in range(first, last + 1):
+            check(lib.nv_vit_stage_param_range(ctypes.byref(self.cfg), s, ctypes.byref(b), ctypes.byref(e)), "nv_vit_stage_param_range")
+            lo = b.value if lo is None else min(lo, b.value)
+            hi = e.value if hi is None else max(hi, e.value)
+        return lo, hi
 
     def tap(self, name: str, layer: int, shape, dtype) -> torch.Tensor:
         """View of a named activation inside the last forward's workspace (tests, Grad-CAM hooks)."""

@@ -194,10 +194,13 @@ def adamw_step(p, grad, m, v, p16, step, lr, betas=(0.9, 0.999), eps=1e-8, weigh
                             _stream()), "nv_adamw_step")
 
 
-def cast_bf16(src: torch.Tensor, ld_dst: Optional[int] = None) -> torch.Tensor:
+def cast_bf16(src: torch.Tensor, ld_dst: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 [rows, cols] -> bf16 [rows, ld_dst] (zero padded columns)."""
+    _need_cuda(src)
     rows, cols = src.shape
+    if out is not None:
+        ld_dst = out.stride(0) if rows > 1 else out.shape[1]
     ld_dst = (cols + 3) // 4 * 4 if ld_dst is None else ld_dst
-    dst = torch.empty((rows, ld_dst), dtype=torch.bfloat16, device=src.device)
+    dst = torch.empty((rows, ld_dst), dtype=torch.bfloat16, device=src.device) if out is None else out
     check(lib.nv_cast_bf16_2d(_p(src), src.stride(0), rows, cols, _p(dst), ld_dst, _stream()), "nv_cast_bf16_2d")
     return dst

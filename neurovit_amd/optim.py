@@ -1,0 +1,90 @@
+"""Fused AdamW for the flat parameter arenas (Trainer.py:31,75).
+
+`FusedAdamW(model.parameters(), lr=..., weight_decay=...)` has the constructor of torch.optim.AdamW
+(defaults betas (0.9, 0.999), eps 1e-8, decoupled weight decay on every parameter).  Parameters that
+are views of a ViT arena are updated by ONE nv_adamw_step launch per arena (which also refreshes the
+bf16 shadow the MFMA kernels read); any other parameter (the 10 k-parameter temporal head of the 4D
+model) is delegated to torch.optim.AdamW.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+
+from . import ops
+from .vit_3d import ViT
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, *, model: torch.nn.Module = None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._model = model
+        self._arenas: List[ViT] = []
+        self._state_mv: Dict[int, tuple] = {}
+        self._rest = None
+        self._bound = False
+        self._steps = 0
+
+    def bind(self, model: torch.nn.Module):
+        """Tell the optimizer which module tree owns the parameters (needed to find the arenas)."""
+        self._model = model
+        self._bound = False
+        return self
+
+    def _bind(self):
+        mine = {id(p) for g in self.param_groups for p in g["params"]}
+        claimed = set()
+        self._arenas = []
+        if self._model is not None:
+            for m in self._model.modules():
+                if isinstance(m, ViT):
+                    m.flat_parameters()
+                    ids = [id(p) for p in m._plist]
+                    if all(i in mine for i in ids) and all(p.requires_grad for p in m._plist):
+                        self._arenas.append(m)
+                        claimed.update(ids)
+        rest = [p for g in self.param_groups for p in g["params"] if id(p) not in claimed and p.requires_grad]
+        g0 = self.param_groups[0]
+        self._rest = torch.optim.AdamW(rest, lr=g0["lr"], betas=g0["betas"], eps=g0["eps"], weight_decay=g0["weight_decay"]) if rest else None
+        self._bound = True
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        if not self._bound:
+            self._bind()
+        self._steps += 1
+        g0 = self.param_groups[0]
+        for vit in self._arenas:
+            arena, shadow = vit.flat_parameters()
+            grads = vit.flat_gradients()
+            key = id(vit)
+            if key not in self._state_mv or self._state_mv[key][0].data_ptr() == 0 or self._state_mv[key][0].device != arena.device:
+                self._state_mv[key] = (torch.zeros_like(arena), torch.zeros_like(arena))
+            m, v = self._state_mv[key]
+            ops.adamw_step(arena, grads, m, v, shadow, self._steps, g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"], grad_scale)
+            vit.mark_shadow_fresh()
+        if self._rest is not None:
+            for g in self._rest.param_groups:
+                g["lr"] = g0["lr"]
+            self._rest.step()
+        return None
+
+    def step_range(self, vit: ViT, begin: int, end: int, grad_scale: float = 1.0):
+        """AdamW on arena elements [begin, end) only (DP: run per gradient bucket behind its all-reduce).
+        The caller advances the step counter once per optimizer step with `begin_step()`."""
+        arena, shadow = vit.flat_parameters()
+        grads = vit.flat_gradients()
+        key = id(vit)
+        if key not in self._state_mv:
+            self._state_mv[key] = (torch.zeros_like(arena), torch.zeros_like(arena))
+        m, v = self._state_mv[key]
+        g0 = self.param_groups[0]
+        ops.adamw_step(arena[begin:end], grads[begin:end], m[begin:end], v[begin:end], shadow[begin:end], self._steps, g0["lr"],
+                       g0["betas"], g0["eps"], g0["weight_decay"], grad_scale)
+
+    def begin_step(self):
+        if not self._bound:
+            self._bind()
+        self._steps += 1

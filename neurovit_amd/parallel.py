@@ -1,0 +1,78 @@
+"""Data-parallel gradient synchronisation: one process per GPU, RCCL (torch.distributed "nccl") over xGMI.
+
+The reference is single-device (main.py:41-46); DP is additive.  fMRI volumes are independent, so
+the batch is sharded across ranks and the only collective is one SUM all-reduce of the gradients per optimizer
+step - issued per BUCKET (a contiguous range of the flat gradient arena that becomes final when a group of
+backward stages has run) on a side stream, so it overlaps the rest of the backward pass.  The 1/world_size
+averaging is folded into the fused AdamW (grad_scale), not a separate pass.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def bucket_stages(n_stages: int, n_buckets: int) -> List[Tuple[int, int]]:
+    """Split backward stages 0..n_stages-1 (head, layers last->first, embedding) into <= n_buckets contiguous
+    groups of near-equal stage count.  Returns [(first_stage, last_stage)] in execution order."""
+    n_buckets = max(1, min(n_buckets, n_stages))
+    base, extra = divmod(n_stages, n_buckets)
+    out, s = [], 0
+    for b in range(n_buckets):
+        cnt = base + (1 if b < extra else 0)
+        out.append((s, s + cnt - 1))
+        s += cnt
+    return out
+
+
+class GradSync:
+    """All-reduce (SUM) of gradient-arena ranges as they become final.  Device agnostic: with CUDA tensors the
+    collectives run on a dedicated stream behind an event; with CPU tensors (gloo, tests) they run inline."""
+
+    def __init__(self, process_group=None, n_buckets: int = 4):
+        self.pg = process_group
+        self.n_buckets = n_buckets
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._comm_stream: Optional[torch.cuda.Stream] = None
+        self._works = []
+        self.bytes_reduced = 0
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def begin(self):
+        self._works = []
+
+    def bucket_ready(self, flat_grads: torch.Tensor, begin: int, end: int):
+        if self.world == 1 or end <= begin:
+            return
+        chunk = flat_grads[begin:end]
+        self.bytes_reduced += chunk.numel() * chunk.element_size()
+        if chunk.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=chunk.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._comm_stream.wait_event(ev)
+            with torch.cuda.stream(self._comm_stream):
+                self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def finish(self):
+        """Make the current stream wait for every outstanding bucket."""
+        if self._comm_stream is not None:
+            with torch.cuda.stream(self._comm_stream):
+                for w in self._works:
+                    w.wait()
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._works = []
+
+
+def broadcast_parameters(flat_params: torch.Tensor, process_group=None, src: int = 0):
+    """Identical replicas at start: one broadcast of the flat parameter arena."""
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.broadcast(flat_params, src=src, group=process_group)

@@ -1,0 +1,293 @@
+"""Drop-in for the reference's src/models/vit_3d.py on MI355X.
+
+Same classes, constructor signatures, attribute paths and state_dict keys as the reference
+(vit_3d.py:14-126): FeedForward, Attention, Transformer, ViT.  The module tree is built from the same
+torch building blocks in the same order, so `torch.manual_seed(s)` yields bit-identical initial
+weights to the reference; the compute, however, never goes through those blocks:
+
+  ViT.forward runs the whole encoder through the native gfx950 engine (csrc/engine.hip) in ONE
+  C-ABI call, and its backward in one more.  Parameters are views into a flat fp32 arena with a
+  bf16 shadow (see engine.py), gradients are written straight into a flat gradient arena that
+  `param.grad` views.
+
+There is no CPU / eager fallback: a CPU input raises.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import engine, ops
+
+
+def pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+class FeedForward(nn.Module):
+    """vit_3d.py:14-26 - parameter container (net.0 LayerNorm, net.1 Linear, net.4 Linear)."""
+
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(
+            nn.LayerNorm(dim),
+            nn.Linear(dim, hidden_dim),
+            nn.GELU(),
+            nn.Dropout(dropout),
+            nn.Linear(hidden_dim, dim),
+            nn.Dropout(dropout)
+        )
+
+    def forward(self, x):
+        raise NotImplementedError("neurovit_amd: FeedForward runs fused inside ViT.forward (native engine); "
+                                  "standalone use is not provided on this path")
+
+
+class Attention(nn.Module):
+    """vit_3d.py:28-60 - parameter container (norm, to_qkv without bias, to_out.0)."""
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        project_out = not (heads == 1 and dim_head == dim)
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.norm = nn.LayerNorm(dim)
+        self.attend = nn.Softmax(dim=-1)
+        self.dropout = nn.Dropout(dropout)
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        self.to_out = nn.Sequential(
+            nn.Linear(inner_dim, dim),
+            nn.Dropout(dropout)
+        ) if project_out else nn.Identity()
+
+    def forward(self, x):
+        raise NotImplementedError("neurovit_amd: Attention runs fused inside ViT.forward (native engine); "
+                                  "standalone use is not provided on this path")
+
+
+class Transformer(nn.Module):
+    """vit_3d.py:62-75."""
+
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout),
+                FeedForward(dim, mlp_dim, dropout=dropout)
+            ]))
+
+    def forward(self, x):
+        raise NotImplementedError("neurovit_amd: Transformer runs fused inside ViT.forward (native engine)")
+
+
+class PatchRearrange(nn.Module):
+    """Placeholder for einops `Rearrange('b c (f pf) (h p1) (w p2) -> b (f h w) (p1 p2 pf c)')`
+    (vit_3d.py:92): keeps `to_patch_embedding.{1,2,3}` state_dict indices.  The index map itself is
+    executed inside the patch-gather kernel (csrc/norm.hip::patch_ln_fwd_kernel)."""
+
+    def __init__(self, p1, p2, pf):
+        super().__init__()
+        self.p1, self.p2, self.pf = p1, p2, pf
+
+    def extra_repr(self):
+        return f"'b c (f pf) (h p1) (w p2) -> b (f h w) (p1 p2 pf c)', p1={self.p1}, p2={self.p2}, pf={self.pf}"
+
+
+class _ViTFunction(torch.autograd.Function):
+    """Whole-encoder autograd node.  Parameters are passed as inputs only so autograd knows the output
+    depends on them; their gradients are written by the engine directly into the module's gradient
+    arena (which `param.grad` views), so backward returns None for them (no per-tensor accumulate copies)."""
+
+    @staticmethod
+    def forward(ctx, module, video, *params):
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        ctx.module = module
+        return module._run_forward(video, need_grad)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.module._run_backward(dlogits)
+        return (None, None) + (None,) * len(ctx.module._plist)
+
+
+class ViT(nn.Module):
+    """vit_3d.py:77-126, MI355X-native.  forward(video[B, C, F, H, W]) -> [B, num_classes] (fp32)."""
+
+    def __init__(self, *, image_size, image_patch_size, frames, frame_patch_size, num_classes, dim, depth, heads, mlp_dim,
+                 pool='cls', channels=3, dim_head=64, dropout=0., emb_dropout=0.):
+        super().__init__()
+        image_height, image_width = pair(image_size)
+        patch_height, patch_width = pair(image_patch_size)
+
+        assert image_height % patch_height == 0 and image_width % patch_width == 0, 'Image dimensions must be divisible by the patch size.'
+        assert frames % frame_patch_size == 0, 'Frames must be divisible by frame patch size'
+
+        num_patches = (image_height // patch_height) * (image_width // patch_width) * (frames // frame_patch_size)
+        patch_dim = channels * patch_height * patch_width * frame_patch_size
+
+        assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
+
+        self.to_patch_embedding = nn.Sequential(
+            PatchRearrange(patch_height, patch_width, frame_patch_size),
+            nn.LayerNorm(patch_dim),
+            nn.Linear(patch_dim, dim),
+            nn.LayerNorm(dim),
+        )
+
+        self.pos_embedding = nn.Parameter(torch.randn(1, num_patches + 1, dim))
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.dropout = nn.Dropout(emb_dropout)
+
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
+
+        self.pool = pool
+        self.to_latent = nn.Identity()
+
+        self.mlp_head = nn.Sequential(
+            nn.LayerNorm(dim),
+            nn.Linear(dim, num_classes)
+        )
+
+        # ---- native engine state (not part of the reference surface) ----
+        if image_height != image_width or patch_height != patch_width:
+            raise NotImplementedError("neurovit_amd: the gfx950 engine supports square images / patches (the NeuroEncoder "
+                                      "path is cubic: NeuroEncoder.py:183-186)")
+        if pool != 'cls':
+            raise NotImplementedError("neurovit_amd: pool='mean' is not on the hot path (NeuroEncoder.py:194 uses 'cls')")
+        self._dropout_p = (float(dropout), float(emb_dropout))
+        self._cfg = engine.make_config(image_size=image_height, image_patch_size=patch_height, frames=frames,
+                                       frame_patch_size=frame_patch_size, num_classes=num_classes, dim=dim, depth=depth,
+                                       heads=heads, mlp_dim=mlp_dim, channels=channels, dim_head=dim_head)
+        self._rt = engine.VitRuntime(self._cfg)
+        self._arena: Optional[torch.Tensor] = None      # flat fp32 master parameters
+        self._shadow: Optional[torch.Tensor] = None     # flat bf16 copy read by the MFMA kernels
+        self._grads: Optional[torch.Tensor] = None      # flat fp32 gradients (param.grad are views)
+        self._layout = None
+        self._plist: List[nn.Parameter] = []
+        self._shadow_key = None
+        self._grad_sync = None     # parallel.GradSync: all-reduce gradient buckets while backward still runs
+
+    # ------------------------------------------------------------------ arena management
+    def _build_arena(self):
+        """(Re)pack all parameters into one contiguous fp32 arena on their current device and make every
+        nn.Parameter a view of it.  Called lazily: after construction, after .to(device), after foreign code
+        replaced a parameter's storage."""
+        plist = [p for _, p in self.named_parameters()]
+        if self._layout is None:
+            off, num, total = engine.param_layout(self._cfg)
+            assert len(off) == len(plist) and all(p.numel() == n for p, n in zip(plist, num)), \
+                "parameter table of the native engine does not match the module tree"
+            self._layout = (off, num, total)
+        off, num, total = self._layout
+        dev = plist[0].device
+        arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        grads_alive = self._grads is not None and self._grads.device == dev
+        with torch.no_grad():
+            for p, o, n in zip(plist, off, num):
+                arena[o:o + n].copy_(p.detach().reshape(-1).float())
+                p.data = arena[o:o + n].view(p.shape)
+        self._arena, self._plist = arena, plist
+        self._shadow = torch.empty(total, dtype=torch.bfloat16, device=dev)
+        self._shadow_key = None
+        if not grads_alive:
+            self._grads = None
+
+    def _arena_ok(self) -> bool:
+        if self._arena is None:
+            return False
+        off, num, _ = self._layout
+        base = self._arena.data_ptr()
+        for p, o in zip(self._plist, off):
+            if p.data_ptr() != base + 4 * o:
+                return False
+        return True
+
+    def flat_parameters(self):
+        """(arena fp32, shadow bf16) - used by the fused optimizer and the DP gradient all-reduce."""
+        if not self._arena_ok():
+            self._build_arena()
+        return self._arena, self._shadow
+
+    def flat_gradients(self) -> torch.Tensor:
+        self.flat_parameters()
+        if self._grads is None:
+            self._grads = torch.zeros_like(self._arena)
+        return self._grads
+
+    def _grad_view(self, i: int) -> torch.Tensor:
+        off, num, _ = self._layout
+        return self._grads[off[i]:off[i] + num[i]].view(self._plist[i].shape)
+
+    def mark_shadow_fresh(self):
+        """Called by the fused AdamW, which writes the bf16 shadow itself."""
+        self._shadow_key = tuple(p._version for p in self._plist)
+
+    def _refresh_shadow(self):
+        key = tuple(p._version for p in self._plist)
+        if key != self._shadow_key:
+            ops.cast_bf16(self._arena.view(1, -1), out=self._shadow.view(1, -1))
+            self._shadow_key = key
+
+    # ------------------------------------------------------------------ execution
+    def _run_forward(self, video, need_grad):
+        if self.training and (self._dropout_p[0] > 0 or self._dropout_p[1] > 0):
+            raise NotImplementedError("neurovit_amd: dropout > 0 in training mode is not implemented in the native engine yet "
+                                      "(set TRAINING_DROPOUT: 0 or call .eval())")
+        self._refresh_shadow()
+        return self._rt.forward(video, self._arena, self._shadow, training=need_grad)
+
+    def _run_backward(self, dlogits):
+        grads = self.flat_gradients()
+        trainable = [i for i, p in enumerate(self._plist) if p.requires_grad]
+        state = [self._plist[i].grad for i in trainable]
+        if all(g is None for g in state):
+            self._backward_into(dlogits, grads, accumulate=False)
+            for i in trainable:
+                self._plist[i].grad = self._grad_view(i)
+        elif all(g is not None and g.data_ptr() == self._grad_view(i).data_ptr() for g, i in zip(state, trainable)):
+            self._backward_into(dlogits, grads, accumulate=True)
+        else:   # foreign .grad tensors: compute into a scratch arena and add
+            scratch = torch.empty_like(grads)
+            self._rt.backward(dlogits, self._arena, self._shadow, scratch, accumulate=False)
+            off, num, _ = self._layout
+            for i in trainable:
+                g = scratch[off[i]:off[i] + num[i]].view(self._plist[i].shape)
+                p = self._plist[i]
+                p.grad = g.clone() if p.grad is None else p.grad.add_(g)
+
+    def _backward_into(self, dlogits, grads, accumulate):
+        sync = self._grad_sync
+        if sync is None:
+            self._rt.backward(dlogits, self._arena, self._shadow, grads, accumulate=accumulate)
+            return
+        from .parallel import bucket_stages
+        sync.begin()
+        for first, last in bucket_stages(self._cfg.depth + 2, sync.n_buckets):
+            self._rt.backward(dlogits, self._arena, self._shadow, grads, accumulate=accumulate, stages=(first, last))
+            begin, end = self._rt.stage_range(first, last)
+            sync.bucket_ready(grads, begin, end)
+        sync.finish()
+
+    def forward(self, video):
+        if not video.is_cuda:
+            raise RuntimeError("neurovit_amd.ViT: input must live on the MI355X (cuda) device - there is no CPU fallback")
+        if not self._arena_ok():
+            self._build_arena()
+        if self._arena.device != video.device:
+            raise RuntimeError(f"neurovit_amd.ViT: parameters on {self._arena.device}, input on {video.device}")
+        return _ViTFunction.apply(self, video.float(), *self._plist)
+
+    # activations / gradients of the last block's attention LayerNorm output (Grad-CAM contract, NeuroEncoder.py:70-82)
+    def last_attn_norm_output(self) -> torch.Tensor:
+        B = self._rt._last[0]
+        n, d = self.pos_embedding.shape[1], self.pos_embedding.shape[2]
+        return self._rt.tap("xn1", self._cfg.depth - 1, (B, n, d), torch.bfloat16).float()
+
+    def last_attn_norm_grad(self) -> torch.Tensor:
+        B = self._rt._last[0]
+        n, d = self.pos_embedding.shape[1], self.pos_embedding.shape[2]
+        return self._rt.tap("hookg", -1, (B, n, d), torch.float32).clone()
