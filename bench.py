@@ -54,7 +54,11 @@ def cpu_baseline(model, vcfg, B, S, steps):
     """The oracle's restatement of the same train step (eager PyTorch CPU fp32 = the reference's own CPU path,
     SURVEY.md 8d), timed on this host's cores on a bounded sample: `steps` steps of the same workload."""
     from oracle import ref_cpu, train_step
-    nthreads = os.cpu_count() or 1
+    try:
+        nthreads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nthreads = os.cpu_count() or 1
+    nthreads = max(1, min(nthreads, 16))       # the GPU box grants a 16-core share per GPU
     torch.set_num_threads(nthreads)
     sd = {k[len("volume_encoder.vit3d."):]: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
     cfg = ref_cpu.ViTCfg(**vcfg)
@@ -68,6 +72,10 @@ def cpu_baseline(model, vcfg, B, S, steps):
     dt = time.perf_counter() - t0
     return {"value": B * steps / dt, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} train steps (fwd+bwd+AdamW, fp32 eager PyTorch CPU) of the same workload, batch {B}, after 1 warm-up step"}
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -105,9 +113,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"model built on {device}, warm-up {a.warmup} steps")
     for _ in range(a.warmup):
         step(x, y)
     barrier()
+    log("timed region")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step(x, y)
@@ -120,6 +130,7 @@ def main():
     ms = elapsed / a.steps * 1e3
     value = B * world * a.steps / elapsed
 
+    log(f"{ms:.3f} ms/step, {value:.1f} volumes/s; roofline leg")
     # ---- roofline leg: per-launch hipEvent durations of the dominant kernel family, same steps, same stream
     lib.nv_prof_enable(1)
     prof_steps = 3
@@ -156,6 +167,7 @@ def main():
            "mfma_frac_step": round(value / world * f_step / (PEAK_BF16_TFLOPS * 1e12), 4),
            "loss": round(float(loss), 5), "roofline": roofline}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        log("cpu baseline leg")
         out["cpu_baseline"] = cpu_baseline(model, vcfg, B, S, a.cpu_steps)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -48,6 +48,9 @@ int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void* A, long l
                  long ldc, const float* bias, const void* aux_in, long ld_aux_in, void* aux_out, long ld_aux_out,
                  int accumulate, float alpha, void* stream);
 
+/* tuning aid: force the workgroup tile (bm, bn in {64, 128}); bm = 0 restores the built-in heuristic */
+int nv_gemm_set_tile(int bm, int bn);
+
 /* ---- LayerNorm of the residual stream (vit_3d.py:18,37): x f32 [M,d] -> y bf16, saves mean / rstd */
 int nv_ln_fwd(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, void* y, long ldy,
               float* mean, float* rstd, void* stream);

@@ -104,7 +104,8 @@ class _ViTFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, video, *params):
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        # grad mode is always off inside Function.forward: needs_input_grad tells whether a graph is being built
+        need_grad = any(ctx.needs_input_grad[2:])
         ctx.module = module
         return module._run_forward(video, need_grad)
 

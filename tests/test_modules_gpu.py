@@ -126,8 +126,10 @@ def test_train_step_tracks_reference_golden(nv, golden):
                 ref = torch.from_numpy(g[key])
                 upd_ref = ref - p0[name].cpu()
                 upd = sd[name] - p0[name].cpu()
-                # compare the UPDATE (what the step computed), relative to its own size
-                assert rel_l2(upd, upd_ref) < 0.1, (key, rel_l2(upd, upd_ref))
+                # compare the UPDATE (what the step computed), relative to its own size.  The first AdamW update is
+                # lr * sign(grad): gradient elements at the bf16 noise level flip sign (measured ~1 % of elements,
+                # each contributing 2*lr), which bounds this at ~0.2 after one step.
+                assert rel_l2(upd, upd_ref) < 0.3, (key, rel_l2(upd, upd_ref))
                 assert (sd[name] - ref).abs().max().item() <= 2.5 * stepno * lr, key
     # the bf16 shadow the kernels read equals the fp32 master rounded once
     arena, shadow = vit.flat_parameters()
@@ -153,7 +155,14 @@ def test_drop_in_with_stock_torch_optimizer_and_accumulation(nv):
     assert rel_err(vit.flat_gradients(), 2 * g1) < 1e-5
     opt.step()
     l1 = crit(model(x), y)
-    assert l1.item() < l0.item()
+    # the same step restated by the fp32 CPU oracle (AdamW is scale invariant: the doubled gradient changes nothing)
+    sd = {k: v.clone() for k, v in W.make_tensors(W.vit_param_spec(**W.MICRO), 1).items()}
+    oopt = train_step.AdamW(sd, lr=1e-3, weight_decay=1e-2)
+    ocfg, video = ref_cpu.ViTCfg(**W.MICRO), ref_cpu.fmri_to_video(x.cpu())
+    ol0, _, _ = train_step.train_step(sd, ocfg, oopt, video, y.cpu())
+    with torch.no_grad():
+        ol1 = train_step.cross_entropy(ref_cpu.vit_forward(sd, ocfg, video), y.cpu())
+    assert abs(l0.item() - ol0.item()) < 5e-3 and abs(l1.item() - ol1.item()) < 2e-2, (l0.item(), ol0.item(), l1.item(), ol1.item())
     arena, shadow = vit.flat_parameters()
     assert torch.equal(shadow, arena.to(torch.bfloat16))
     # our criterion and torch's agree
