@@ -38,11 +38,13 @@ struct GemmArgs {
   long lda, ldb, ldc, ld_aux_in, ld_aux_out;
   int M, N, K;
   int accumulate;
+  int col_order;   // 1: consecutive workgroups walk DOWN a tile column (keeps the B panel in the XCD's L2), 0: along a tile row
   float alpha;
 };
 
 constexpr int BK = 64;
 constexpr int NTHREADS = 256;
+typedef __attribute__((address_space(3))) void lds_void_t;
 
 // [64 k-rows][64 cols] transposed-read image with 128-byte rows: chunk XOR so that the four same-parity rows a
 // 32-lane half touches in one ds_read_b64_tr_b16 ({0,2,8,10} + multiples) land on four different chunk pairs.
@@ -109,7 +111,6 @@ __device__ __forceinline__ void swrite_kmajor(char* img, int tid, const uint4 (&
 }
 
 // ---- staging: global -> LDS directly (LDS-DMA) ----------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 __device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
@@ -169,6 +170,48 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int rc0, int ks, in
   }
 }
 
+// ---- epilogue: lane holds C[m = mb + 16i + (lane&15)][n = nb + 16j + 4*(lane>>4) + 0..3] ---------------------
+template <int EPI, int MI, int NI>
+__device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmArgs& g, int mb, int nb, int lane) {
+  const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mb + 16 * i + lr;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = nb + 16 * j + 4 * lg;
+      if (n >= g.N) continue;
+      f32x4 v = acc[i][j];
+      if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+        v += bv;
+      }
+      if constexpr (EPI == EPI_STORE_BF16) {
+        *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) = cvt4(v[0], v[1], v[2], v[3]);
+      } else if constexpr (EPI == EPI_STORE_F32) {
+        float* c = (float*)g.C + (long)m * g.ldc + n;
+        if (g.accumulate) v += *reinterpret_cast<const f32x4*>(c);
+        *reinterpret_cast<f32x4*>(c) = v;
+      } else if constexpr (EPI == EPI_BIAS_F32) {
+        *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
+      } else if constexpr (EPI == EPI_BIAS_GELU) {
+        *reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n) = cvt4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
+            cvt4(gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3]));
+      } else if constexpr (EPI == EPI_BIAS_RESID) {
+        v += *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
+        *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
+      } else if constexpr (EPI == EPI_DGELU) {
+        const bf16x4 u = *reinterpret_cast<const bf16x4*>((const bf16*)g.aux_in + (long)m * g.ld_aux_in + n);
+        *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
+            cvt4(v[0] * gelu_grad_f((float)u[0]), v[1] * gelu_grad_f((float)u[1]),
+                 v[2] * gelu_grad_f((float)u[2]), v[3] * gelu_grad_f((float)u[3]));
+      }
+    }
+  }
+}
+
 template <int BM, int BN, bool A_T, bool B_T, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -177,9 +220,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmArgs g) {
   constexpr int MI = TM / 16, NI = TN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  const int m0 = (g.col_order ? bid % tiles_m : bid / tiles_n) * BM, n0 = (g.col_order ? bid / tiles_m : bid % tiles_n) * BN;
   const int nk = (g.K + BK - 1) / BK;
 
   char* sA0 = smem;
@@ -254,50 +297,155 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3] ---------------------
-  const int lr = lane & 15, lg = lane >> 4;
+  epilogue<EPI, MI, NI>(acc, g, m0 + wm * TM, n0 + wn * TN, lane);
+}
+
+// =====================================================================================================
+// Warp-specialised BM x BN x 64 kernel (512 threads): waves 0-3 are CONSUMERS (2x2, MFMA + ds_read only), waves
+// 4-7 are LOADERS (LDS-DMA only).  Measured on MI355X: waves that do nothing but issue buffer_load...lds stream
+// L2 -> LDS at 122-134 GB/s per CU (tools/l2_stream_bench.hip), three times what a wave that also issues MFMAs
+// sustains, because every DMA issue stalls the in-order instruction stream behind it.  A 128x128x64 step moves
+// 32 KiB (~550 cycles at that rate) for 512 cycles of MFMA per SIMD: with the two roles on different waves of
+// each SIMD both pipes run concurrently.
+//   * three LDS stages; loaders run two K tiles ahead (counted vmcnt), one raw s_barrier per K tile joins all
+//     eight waves: after barrier kt tile kt+1 is complete in LDS and the stage of tile kt-1 is free;
+//   * consumers double-buffer the MFMA operand fragments so the ds_reads of one 32-deep half step overlap the
+//     MFMAs of the other;
+//   * buffer descriptors return zeros for out-of-range rows (ragged M / N, ragged token count K of the
+//     weight-gradient GEMMs): no masks, no clamps.  Requires K % 64 == 0 for K-contiguous operands.
+// =====================================================================================================
+constexpr int WS_THREADS = 512;
+
+template <bool T, int BX>
+__device__ __forceinline__ void ws_offsets(long ld, int rc0, int lw, int lane, int (&voff)[BX / 32]) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * TM + 16 * i + lr;
-    if (m >= g.M) continue;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wn * TN + 16 * j + 4 * lg;
-      if (n >= g.N) continue;
-      f32x4 v = acc[i][j];
-      if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
-        v += bv;
-      }
-      if constexpr (EPI == EPI_STORE_BF16) {
-        *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) = cvt4(v[0], v[1], v[2], v[3]);
-      } else if constexpr (EPI == EPI_STORE_F32) {
-        float* c = (float*)g.C + (long)m * g.ldc + n;
-        if (g.accumulate) v += *reinterpret_cast<const f32x4*>(c);
-        *reinterpret_cast<f32x4*>(c) = v;
-      } else if constexpr (EPI == EPI_BIAS_F32) {
-        *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
-      } else if constexpr (EPI == EPI_BIAS_GELU) {
-        *reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n) = cvt4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
-            cvt4(gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3]));
-      } else if constexpr (EPI == EPI_BIAS_RESID) {
-        v += *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
-        *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
-      } else if constexpr (EPI == EPI_DGELU) {
-        const bf16x4 u = *reinterpret_cast<const bf16x4*>((const bf16*)g.aux_in + (long)m * g.ld_aux_in + n);
-        *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
-            cvt4(v[0] * gelu_grad_f((float)u[0]), v[1] * gelu_grad_f((float)u[1]),
-                 v[2] * gelu_grad_f((float)u[2]), v[3] * gelu_grad_f((float)u[3]));
-      }
+  for (int i = 0; i < BX / 32; ++i) {
+    const int I = lw + 4 * i;
+    if constexpr (!T) {
+      const int row = I * 8 + (lane >> 3), ch = (lane & 7) ^ ((lane >> 3) & 7);           // img128_off inverse
+      voff[i] = (int)((((long)(rc0 + row)) * ld + (ch << 3)) * 2);
+    } else if constexpr (BX == 128) {
+      const int krow = I * 4 + (lane >> 4);
+      const int ch = (lane & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3));               // img256_off inverse
+      voff[i] = (int)(((long)krow * ld + rc0 + (ch << 3)) * 2);
+    } else {
+      const int krow = I * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1);  // img128t_off inverse
+      voff[i] = (int)(((long)krow * ld + rc0 + (ch << 3)) * 2);
     }
   }
 }
+template <int N>
+__device__ __forceinline__ void ws_issue(__amdgpu_buffer_rsrc_t rsrc, const int* voff, int soff, char* img, int lw) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(img + (lw + 4 * i) * 1024), 16, voff[i], soff, 0, 0);
+}
+template <int N> __device__ __forceinline__ void ws_wait_one_tile_in_flight();
+template <> __device__ __forceinline__ void ws_wait_one_tile_in_flight<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+template <> __device__ __forceinline__ void ws_wait_one_tile_in_flight<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <> __device__ __forceinline__ void ws_wait_one_tile_in_flight<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+
+template <int BM, int BN, bool A_T, bool B_T, int EPI>
+__global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
+  constexpr int TM = BM / 2, TN = BN / 2, MI = TM / 16, NI = TN / 16;
+  constexpr int PIECES = BM / 32 + BN / 32;      // DMA instructions per loader wave per K tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (g.col_order ? bid % tiles_m : bid / tiles_n) * BM, n0 = (g.col_order ? bid / tiles_m : bid % tiles_n) * BN;
+  const int nk = (g.K + BK - 1) / BK;
+  char* s0 = smem;
+  char* s1 = smem + STAGE;
+  char* s2 = smem + 2 * STAGE;
+
+  if (wid >= 4) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = wid - 4;
+    const unsigned bytesA = (unsigned)((((long)(A_T ? g.K : g.M) - 1) * g.lda + (A_T ? g.M : g.K)) * 2);
+    const unsigned bytesB = (unsigned)((((long)(B_T ? g.K : g.N) - 1) * g.ldb + (B_T ? g.N : g.K)) * 2);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, bytesB, 0x00020000);
+    int voA[BM / 32], voB[BN / 32];
+    ws_offsets<A_T, BM>(g.lda, m0, lw, lane, voA);
+    ws_offsets<B_T, BN>(g.ldb, n0, lw, lane, voB);
+    const int stepA = (int)((A_T ? (long)BK * g.lda : BK) * 2), stepB = (int)((B_T ? (long)BK * g.ldb : BK) * 2);
+    ws_issue<BM / 32>(rA, voA, 0, s0, lw);
+    ws_issue<BN / 32>(rB, voB, 0, s0 + A_BYTES, lw);
+    if (nk > 1) {
+      ws_issue<BM / 32>(rA, voA, stepA, s1, lw);
+      ws_issue<BN / 32>(rB, voB, stepB, s1 + A_BYTES, lw);
+      ws_wait_one_tile_in_flight<PIECES>();
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                       // barrier -1: tile 0 is in LDS
+    char* fill = s2;
+    char* f1 = s0;
+    char* f2 = s1;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 2 < nk) {                                // stage of tile kt-1: every consumer read retired at barrier kt-1
+        ws_issue<BM / 32>(rA, voA, (kt + 2) * stepA, fill, lw);
+        ws_issue<BN / 32>(rB, voB, (kt + 2) * stepB, fill + A_BYTES, lw);
+        ws_wait_one_tile_in_flight<PIECES>();           // tile kt+1 landed (this wave's share)
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                     // barrier kt
+      char* t = fill; fill = f1; f1 = f2; f2 = t;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer waves
+  const int wm = wid >> 1, wn = wid & 1;
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+  char* cur = s0;
+  char* nxt = s1;
+  char* aft = s2;
+
+#define WS_READ(FA, FB, BUF, KS)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) FA[i] = read_frag<A_T, BM>(BUF, wm * TM + 16 * i, KS, lane); \
+  _Pragma("unroll") for (int j = 0; j < NI; ++j) FB[j] = read_frag<B_T, BN>(BUF + A_BYTES, wn * TN + 16 * j, KS, lane);
+#define WS_MFMA(FA, FB)                                                       \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i)                             \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j)                           \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[i][j], 0, 0, 0);
+#define SB __builtin_amdgcn_sched_barrier(0);   // pin the phase order: [reads][MFMAs][barrier][reads][MFMAs]
+
+  __builtin_amdgcn_s_barrier();                         // barrier -1
+  WS_READ(fa0, fb0, cur, 0)
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    WS_READ(fa1, fb1, cur, 1)
+    SB WS_MFMA(fa0, fb0) SB
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // all reads of `cur` have returned before it can be refilled
+    __builtin_amdgcn_s_barrier();                       // barrier kt: tile kt+1 complete
+    SB WS_READ(fa0, fb0, nxt, 0)
+    SB WS_MFMA(fa1, fb1) SB
+    char* t = cur; cur = nxt; nxt = aft; aft = t;
+  }
+  WS_READ(fa1, fb1, cur, 1)                             // last tile
+  SB WS_MFMA(fa0, fb0)
+  __builtin_amdgcn_s_barrier();                         // barrier nk-1 (pairs with the loaders' last one)
+  WS_MFMA(fa1, fb1)
+#undef WS_READ
+#undef WS_MFMA
+#undef SB
+  epilogue<EPI, MI, NI>(acc, g, m0 + wm * TM, n0 + wn * TN, lane);
+}
 
 // ---- host side ---------------------------------------------------------------------------------------
-static int g_tile_override = 0;   // 0 = heuristic; else BM*1000 + BN (tuning aid, tools/gemm_bench.py)
-extern "C" int nv_gemm_set_tile(int bm, int bn) {
-  g_tile_override = (bm == 0) ? 0 : bm * 1000 + bn;
+static int g_tile_override = 0;   // 0 = heuristic; 1..3 = warp-specialised 128x128 / 128x64 / 64x128; else BM*1000 + BN (small-tile kernel)
+extern "C" int nv_gemm_set_tile(int bm, int bn) {   // tuning aid (tools/gemm_bench.py)
+  g_tile_override = (bm == 0) ? 0 : (bm <= 3 ? bm : bm * 1000 + bn);
   return 0;
 }
 
@@ -318,9 +466,41 @@ static int launch_tile(const GemmArgs& a, hipStream_t s) {
   return NV_OK;
 }
 
+template <int BM, int BN, bool A_T, bool B_T, int EPI>
+static int launch_ws(const GemmArgs& a, hipStream_t s) {
+  constexpr int LDS = 3 * (BM + BN) * BK * 2;
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  auto kern = gemm_ws_kernel<BM, BN, A_T, B_T, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int slot = nv_prof_begin((A_T ? 2 : (B_T ? 1 : 0)), 2.0 * a.M * a.N * a.K, s);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(WS_THREADS), LDS, s, a);
+  nv_prof_end(slot, s);
+  NV_CHECK_LAUNCH("nv_gemm_bf16/ws");
+  return NV_OK;
+}
+
 template <bool A_T, bool B_T, int EPI>
 static int launch(const GemmArgs& a, hipStream_t s) {
-  int sel = g_tile_override;
+  // warp-specialised kernel: needs whole K tiles for K-contiguous operands (buffer bounds zero-fill a ragged K only
+  // when K is the row index, i.e. for "T" operands) and 31-bit byte offsets; tiny problems keep the small-tile kernel.
+  const bool k_ok = (a.K % BK == 0) || (A_T && B_T);
+  const long rowsA = A_T ? a.K : a.M, rowsB = B_T ? a.K : a.N;
+  const bool fits = rowsA * a.lda < (1L << 30) && rowsB * a.ldb < (1L << 30);
+  const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  if (k_ok && fits && g_tile_override < 1000) {
+    int ws = g_tile_override;                 // 1: 128x128, 2: 128x64, 3: 64x128 (forced); 0: heuristic
+    // measured on the ViT3D-base shapes (M = 2052): the 64x128 tile wins or ties everywhere (two workgroups per CU, so
+    // one block's epilogue overlaps the other's MFMA phase); very large problems prefer 128x128 (less LDS / L2 traffic)
+    if (ws == 0 && t128 >= 32) ws = (t128 >= 1024) ? 1 : 3;
+    if (ws == 1) return launch_ws<128, 128, A_T, B_T, EPI>(a, s);
+    if (ws == 2) return launch_ws<128, 64, A_T, B_T, EPI>(a, s);
+    if (ws == 3) return launch_ws<64, 128, A_T, B_T, EPI>(a, s);
+  }
+  int sel = g_tile_override >= 1000 ? g_tile_override : 0;
   if (!sel) {
     // enough workgroups to give every one of the 256 CUs several co-resident blocks; prefer the larger tile
     // (less LDS traffic per MFMA) when the problem is big enough.
@@ -352,6 +532,9 @@ extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C; a.bias = bias; a.aux_in = aux_in; a.aux_out = aux_out;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ld_aux_in = ld_aux_in; a.ld_aux_out = ld_aux_out;
   a.M = M; a.N = N; a.K = K; a.accumulate = accumulate; a.alpha = alpha;
+  // each XCD (private 4 MiB L2) gets a contiguous run of tiles: run along the dimension of the SMALLER operand so the
+  // larger operand's panel is the one that stays resident
+  a.col_order = (N > M) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   const bool need_bias = (epi == EPI_BIAS_F32 || epi == EPI_BIAS_GELU || epi == EPI_BIAS_RESID);
   NV_CHECK_ARG(!need_bias || (bias && nv_aligned16(bias)), "nv_gemm_bf16: epilogue %d needs a 16-byte aligned bias", epi);

@@ -144,24 +144,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // out[c] (=|+=) sum_r part[r][c] for up to three concatenated segments of width d each.
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int R, int d, int nseg, float* o0, float* o1, float* o2,
-                                       int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nseg * d) return;
+// Block = 32 columns x 8 row groups: every thread streams R/8 independent loads (all in flight), the 8 row groups
+// are combined through LDS in a fixed order -> deterministic, and wide enough (nseg*d/32 blocks) to be latency-free.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int R, int d, int nseg, float* o0, float* o1,
+                                                              float* o2, int accumulate) {
+  __shared__ float sh[8][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl;
   const long stride = (long)nseg * d;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int r = 0;
-  for (; r + 3 < R; r += 4) {
-    s0 += part[(long)r * stride + i];
-    s1 += part[(long)(r + 1) * stride + i];
-    s2 += part[(long)(r + 2) * stride + i];
-    s3 += part[(long)(r + 3) * stride + i];
+  if (i < nseg * d) {
+    int r = rg;
+    for (; r + 24 < R; r += 32) {
+      s0 += part[(long)r * stride + i];
+      s1 += part[(long)(r + 8) * stride + i];
+      s2 += part[(long)(r + 16) * stride + i];
+      s3 += part[(long)(r + 24) * stride + i];
+    }
+    for (; r < R; r += 8) s0 += part[(long)r * stride + i];
   }
-  for (; r < R; ++r) s0 += part[(long)r * stride + i];
-  const float s = (s0 + s1) + (s2 + s3);
-  const int seg = i / d, c = i - seg * d;
-  float* o = seg == 0 ? o0 : (seg == 1 ? o1 : o2);
-  if (o) o[c] = accumulate ? o[c] + s : s;
+  sh[rg][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && i < nseg * d) {
+    const float s = ((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl])) + ((sh[4][cl] + sh[5][cl]) + (sh[6][cl] + sh[7][cl]));
+    const int seg = i / d, c = i - seg * d;
+    float* o = seg == 0 ? o0 : (seg == 1 ? o1 : o2);
+    if (o) o[c] = accumulate ? o[c] + s : s;
+  }
 }
 
 static int ln_bwd_blocks(int M) {
@@ -189,7 +198,7 @@ extern "C" int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, c
     hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
                        (bf16*)g16, ldg16, (float*)workspace);
   NV_CHECK_LAUNCH("nv_ln_bwd");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, d, 3, dgamma,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 31) / 32), dim3(256), 0, s, (const float*)workspace, nb, d, 3, dgamma,
                      dbeta, dcolsum, accumulate);
   NV_CHECK_LAUNCH("nv_ln_bwd/reduce");
   return NV_OK;
@@ -340,7 +349,7 @@ extern "C" int nv_patch_ln_bwd(const float* video, const long* strides5, int B, 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(patch_ln_bwd_kernel, dim3(nb), dim3(256), 0, s, video, g, dxp, ldd, mean, rstd, tpb, (float*)workspace);
   NV_CHECK_LAUNCH("nv_patch_ln_bwd");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * g.P + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, g.P, 2, dgamma,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * g.P + 31) / 32), dim3(256), 0, s, (const float*)workspace, nb, g.P, 2, dgamma,
                      dbeta, (float*)nullptr, accumulate);
   NV_CHECK_LAUNCH("nv_patch_ln_bwd/reduce");
   return NV_OK;
@@ -488,8 +497,8 @@ extern "C" int nv_head_fwd(const float* x, long row_stride, int B, int d, const 
 }
 
 // Backward of the head for volume b (one workgroup): dxh = dlogits[b] . W; LN backward on the cls row;
-// writes g[b, 0, :] = dx and g[b, 1.., :] = 0 (fp32 + bf16), and per-volume partials [b][3][d] =
-// (dgamma, dbeta, dx) reduced afterwards.
+// writes g[b, 0, :] = dx (fp32 + bf16; the other rows were zeroed by a memset node in front) and per-volume
+// partials [b][3][d] = (dgamma, dbeta, dx) reduced afterwards.
 __global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict__ dlogits, int C, const float* __restrict__ Wt,
                                                          const float* __restrict__ x, long row_stride, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, int d, int n, float* __restrict__ g, long ldg,
@@ -524,12 +533,6 @@ __global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict
     if (g16) g16[(long)b * n * ldg16 + c] = (bf16)dx;
     partials[((long)b * 3 + 2) * d + c] = dx;
   }
-  // zero the non-cls rows of this volume's residual gradient
-  for (long idx = tid; idx < (long)(n - 1) * d; idx += 256) {
-    const long r = 1 + idx / d, c = idx % d;
-    g[((long)b * n + r) * ldg + c] = 0.f;
-    if (g16) g16[((long)b * n + r) * ldg16 + c] = (bf16)0.f;
-  }
 }
 
 // dW[c, k] = sum_b dlogits[b, c] * xh[b, k];  dbias[c] = sum_b dlogits[b, c]
@@ -557,10 +560,17 @@ extern "C" int nv_head_bwd(const float* dlogits, int B, int C, const float* W, c
                            long ws_bytes, void* stream) {
   NV_CHECK_ARG(ws_bytes >= nv_head_bwd_workspace_bytes(B, d), "nv_head_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
+  NV_CHECK_ARG(ldg == d && (!g16 || ldg16 == d), "nv_head_bwd: g / g16 must be dense [B*n, d]");
+  // the residual gradient is zero except for the cls rows (pool = 'cls'): wide memsets, then the cls rows
+  if (hipMemsetAsync(g, 0, (size_t)B * n * d * sizeof(float), s) != hipSuccess ||
+      (g16 && hipMemsetAsync(g16, 0, (size_t)B * n * d * 2, s) != hipSuccess)) {
+    nv_set_error("nv_head_bwd: hipMemsetAsync failed");
+    return NV_ERR_HIP;
+  }
   hipLaunchKernelGGL(head_bwd_x_kernel, dim3(B), dim3(256), (d + 8) * sizeof(float), s, dlogits, C, W, x, row_stride, stats, gamma, d, n,
                      g, ldg, (bf16*)g16, ldg16, (float*)workspace);
   NV_CHECK_LAUNCH("nv_head_bwd/x");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 255) / 256), dim3(256), 0, s, (const float*)workspace, B, d, 3, dgamma, dbeta,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 31) / 32), dim3(256), 0, s, (const float*)workspace, B, d, 3, dgamma, dbeta,
                      dcolsum, accumulate);
   NV_CHECK_LAUNCH("nv_head_bwd/reduce");
   const long tot = (long)C * d;
@@ -598,7 +608,7 @@ extern "C" int nv_colsum_bf16(const void* X, long ld, int M, int N, float* out, 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N / 8 + 255) / 256, chunks), dim3(256), 0, s, (const bf16*)X, ld, M, N, rpc, (float*)workspace);
   NV_CHECK_LAUNCH("nv_colsum_bf16");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)workspace, chunks, N, 1, out,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 31) / 32), dim3(256), 0, s, (const float*)workspace, chunks, N, 1, out,
                      (float*)nullptr, (float*)nullptr, accumulate);
   NV_CHECK_LAUNCH("nv_colsum_bf16/reduce");
   return NV_OK;

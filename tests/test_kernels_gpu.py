@@ -112,6 +112,31 @@ def test_gemm_tn_ragged_tokens(ops):
     assert_close_f32(ops.gemm(ops.TN, ops.EPI_STORE_F32, dev(At), dev(B2)), At.double().T @ B2.double(), "tn_ragged", 1e-5)
 
 
+@pytest.mark.parametrize("ws", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 264, 192), (130, 136, 128), (2052, 768, 768), (300, 8, 64)])
+def test_gemm_warp_specialised_kernel_forced(ops, M, N, K, ws):
+    """The warp-specialised LDS-DMA kernels (128x128, 128x64, 64x128) on ragged M / N (hardware bounds give
+    zeros) and on a ragged token count."""
+    from neurovit_amd._cabi import lib
+    lib.nv_gemm_set_tile(ws, 0)
+    try:
+        A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+        bias, resid = rnd(N, seed=3), rnd(M, N, seed=4)
+        ref = A.double() @ B.double().T
+        assert_close_f32(ops.gemm(ops.NT, ops.EPI_BIAS_RESID, dev(A), dev(B), bias=dev(bias), aux_in=dev(resid)),
+                         ref + bias.double() + resid.double(), "pipe.nt", 1e-5)
+        Bt = bf(rnd(K, N, seed=7, scale=K ** -0.5))
+        assert_close_f32(ops.gemm(ops.NN, ops.EPI_STORE_F32, dev(A), dev(Bt)), A.double() @ Bt.double(), "pipe.nn", 1e-5)
+        Kt, Mo = M, (K + 7) // 8 * 8                      # TN: reduction over a ragged token count
+        At, B2 = bf(rnd(Kt, Mo, seed=9)), bf(rnd(Kt, N, seed=10, scale=Kt ** -0.5))
+        c0 = rnd(Mo, N, seed=11)
+        c = dev(c0.clone())
+        ops.gemm(ops.TN, ops.EPI_STORE_F32, dev(At), dev(B2), out=c, accumulate=True)
+        assert_close_f32(c, At.double().T @ B2.double() + c0.double(), "pipe.tn", 1e-5)
+    finally:
+        lib.nv_gemm_set_tile(0, 0)
+
+
 def test_gemm_rejects_bad_args(ops):
     A, B = dev(bf(rnd(16, 12))), dev(bf(rnd(8, 12)))
     with pytest.raises((RuntimeError, AssertionError)):

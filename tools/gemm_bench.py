@@ -25,6 +25,8 @@ SHAPES = [  # name, layout, epi, M, N, K
     ("dWo      TN f32  ", ops.TN, ops.EPI_STORE_F32, d, inner, M),
     ("dWqkv    TN f32  ", ops.TN, ops.EPI_STORE_F32, 3 * inner, d, M),
     ("big      NT bf16 ", ops.NT, ops.EPI_STORE_BF16, 8192, 8192, 4096),
+    ("xfc1shp  NT bf16 ", ops.NT, ops.EPI_STORE_BF16, M, m, d),
+    ("xfc1shp  NT f32  ", ops.NT, ops.EPI_STORE_F32, M, m, d),
 ]
 
 
@@ -36,7 +38,7 @@ def main():
     a = ap.parse_args()
     if a.tile:
         from neurovit_amd._cabi import lib
-        bm, bn = (int(v) for v in a.tile.split("x"))
+        bm, bn = {"ws128x128": (1, 0), "ws128x64": (2, 0), "ws64x128": (3, 0)}.get(a.tile) or tuple(int(v) for v in a.tile.split("x"))
         lib.nv_gemm_set_tile(bm, bn)
         print(f"--- tile {bm}x{bn}")
     dev = "cuda"
@@ -76,7 +78,7 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.iters
         fl = 2.0 * Mo * N * K
-        if "big" not in name:
+        if "big" not in name and not name.startswith("x"):
             tot_t += us; tot_f += fl
         print(f"{name}  M={Mo:5d} N={N:5d} K={K:5d}  {us:8.2f} us  {fl / us / 1e6:8.1f} TFLOP/s", flush=True)
     if tot_t:
