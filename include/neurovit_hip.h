@@ -43,10 +43,13 @@ int nv_prof_summary(int kind, double* ms, double* work, long* count);
  * layout 2 (TN): C[M,N] = A[K,M]^T . B[K,N]      wgrad    dW = dy^T x
  * epi 0 STORE_BF16, 1 STORE_F32 (+= if accumulate), 2 BIAS_F32, 3 BIAS_GELU (aux_out = pre-activation bf16,
  * C = exact-erf GELU bf16; vit_3d.py:19-20), 4 BIAS_RESID (C f32 = aux_in f32 + acc + bias; vit_3d.py:73-74),
- * 5 DGELU (C bf16 = acc * gelu'(aux_in bf16)).  A, B bf16. */
+ * 5 DGELU (C bf16 = acc * gelu'(aux_in bf16)).  A, B bf16.
+ * Dropout (nn.Dropout of vit_3d.py:21,23,45; drop_p = 0 disables): applied by epilogue 3 to the GELU output, by 4 to
+ * (acc + bias) before the residual add, by 5 to acc; element (m, n) is kept iff hash(drop_seed, m*N + n) >= p*2^32 and
+ * scaled by 1/(1-p) - the same mask is recomputed wherever the backward pass needs it. */
 int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C,
                  long ldc, const float* bias, const void* aux_in, long ld_aux_in, void* aux_out, long ld_aux_out,
-                 int accumulate, float alpha, void* stream);
+                 int accumulate, float alpha, unsigned long drop_seed, float drop_p, void* stream);
 
 /* tuning aid: force the workgroup tile (bm, bn in {64, 128}); bm = 0 restores the built-in heuristic */
 int nv_gemm_set_tile(int bm, int bn);
@@ -55,10 +58,12 @@ int nv_gemm_set_tile(int bm, int bn);
 int nv_ln_fwd(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, void* y, long ldy,
               float* mean, float* rstd, void* stream);
 long nv_ln_bwd_workspace_bytes(int M, int d);
-/* g_out = g_in + dLN(dy); g16 = bf16(g_out); dgamma / dbeta / dcolsum(= column sums of g_out) optional */
+/* g_out = g_in + dLN(dy); g16 = bf16(g_out * mask); dgamma / dbeta / dcolsum(= column sums of g_out * mask) optional.
+ * mask = the dropout mask (drop_seed, drop_p) of the Linear output that was added to this residual stream (1 if p = 0). */
 int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd, const float* gamma,
               int M, int d, const float* g_in, float* g_out, long ldg, void* g16, long ldg16, float* dgamma, float* dbeta,
-              float* dcolsum, int accumulate, void* workspace, long ws_bytes, void* stream);
+              float* dcolsum, int accumulate, void* workspace, long ws_bytes, unsigned long drop_seed, float drop_p,
+              void* stream);
 
 /* ---- patch embedding front end (vit_3d.py:92-93 + the permute of NeuroEncoder.py:200-202)
  * video [B,C,F,H,W] f32 with arbitrary element strides (pass the strides of the permuted VIEW of the
@@ -73,18 +78,20 @@ int nv_patch_ln_bwd(const float* video, const long* strides5, int B, int C, int 
 
 /* ---- LayerNorm(dim) + cls token + positional embedding (vit_3d.py:95,116-118): t [B*N,d] -> x [B,N+1,d] */
 int nv_embed_finish_fwd(const float* t, long ldt, int B, int N, int d, const float* gamma, const float* beta, float eps,
-                        const float* pos, const float* cls, float* x, long ldx, float* mean, float* rstd, void* stream);
+                        const float* pos, const float* cls, float* x, long ldx, float* mean, float* rstd,
+                        unsigned long drop_seed, float drop_p, void* stream);
 long nv_embed_finish_bwd_workspace_bytes(int B, int N, int d);
 int nv_embed_finish_bwd(const float* g, long ldg, const float* t, long ldt, const float* mean, const float* rstd,
                         const float* gamma, int B, int N, int d, float* dt, long lddt, void* dt16, long lddt16, float* dgamma,
                         float* dbeta, float* dbias_pe, float* dpos, float* dcls, int accumulate, void* workspace, long ws_bytes,
-                        void* stream);
+                        unsigned long drop_seed, float drop_p, void* stream);
 
 /* ---- multi-head attention core (vit_3d.py:51-59): qkv bf16 [B,n,3*inner] -> out bf16 [B,n,inner], lse f32 [B,heads,n] */
 int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
-                float* lse, void* stream);
+                float* lse, unsigned long drop_seed, float drop_p, void* stream);
 int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const void* dout, long ld_out, const float* lse, int B, int n,
-                int heads, int dim_head, float scale, float* delta, void* dqkv, long ld_dqkv, void* stream);
+                int heads, int dim_head, float scale, float* delta, void* dqkv, long ld_dqkv, unsigned long drop_seed,
+                float drop_p, void* stream);
 
 /* ---- classification head (vit_3d.py:107-110,123-126): cls row -> LayerNorm -> Linear(dim, C), fp32 */
 int nv_head_fwd(const float* x, long row_stride, int B, int d, const float* gamma, const float* beta, float eps,
@@ -93,7 +100,7 @@ long nv_head_bwd_workspace_bytes(int B, int d);
 int nv_head_bwd(const float* dlogits, int B, int C, const float* W, const float* x, long row_stride, const float* stats,
                 const float* xh, const float* gamma, int d, int n, float* g, long ldg, void* g16, long ldg16, float* dgamma,
                 float* dbeta, float* dW, float* dbias, float* dcolsum, int accumulate, void* workspace, long ws_bytes,
-                void* stream);
+                unsigned long drop_seed, float drop_p, void* stream);
 
 /* ---- bias gradients: out[c] (+)= sum_r X[r,c], X bf16 */
 long nv_colsum_workspace_bytes(int M, int N);
@@ -121,17 +128,21 @@ int nv_vit_param_table(const nv_vit_config* cfg, long* offsets, long* numels, in
 long nv_vit_workspace_bytes(const nv_vit_config* cfg, int B, int training);
 /* byte offset of a named activation inside the workspace (-1 if unknown); layer < 0 for global buffers */
 long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int training, const char* name, int layer);
+/* drop_p / emb_drop_p / drop_seed: nn.Dropout of the blocks (vit_3d.py:21,23,39,45) and of the embedding (:100); both 0
+ * in eval mode.  backward must be given the forward's values. */
 int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
-                   const void* params16, void* workspace, long ws_bytes, int training, float* logits, void* stream);
+                   const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
+                   unsigned long drop_seed, float* logits, void* stream);
 int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                     const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
-                    int accumulate, void* stream);
+                    int accumulate, float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream);
 
 /* Backward split into stages (0 = head, 1+k = layer depth-1-k, depth+1 = patch embedding) so the caller can start the
  * data-parallel all-reduce of a stage's gradient range (nv_vit_stage_param_range) while later stages still run. */
 int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                            const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
-                           int accumulate, int first_stage, int last_stage, void* stream);
+                           int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
+                           unsigned long drop_seed, void* stream);
 int nv_vit_stage_param_range(const nv_vit_config* cfg, int stage, long* begin, long* end);
 
 #ifdef __cplusplus

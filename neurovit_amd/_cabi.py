@@ -39,6 +39,8 @@ def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
                 a = a.strip()
                 if "*" in a:
                     argtypes.append(ctypes.c_char_p if re.match(r"const char\s*\*", a) else ctypes.c_void_p)
+                elif a.startswith("unsigned long"):
+                    argtypes.append(ctypes.c_ulong)
                 else:
                     argtypes.append(_SCALARS[a.split()[0]])
         protos[name] = (restype, argtypes)

@@ -61,7 +61,7 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // ------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
-                                                       bf16* __restrict__ out, long ldo, float* __restrict__ lse) {
+                                                       bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
   char* sK = smem;
   char* sV = smem + IMG;
@@ -125,6 +125,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         psum += p;
       }
     l = l * alpha + psum;
+    if (drop.thresh) {      // attention dropout (vit_3d.py:56): mask the probabilities that enter P.V, not the normaliser
+      const unsigned long long base = (((unsigned long long)blockIdx.y * n + (q0 + r)) * n) + (unsigned long long)kt * TK;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[t][j] *= drop_factor(drop, base + 16 * t + 4 * g + j);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) o[t] *= alpha;
 #pragma unroll
@@ -147,14 +154,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 }
 
 extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
-                           float* lse, void* stream) {
+                           float* lse, unsigned long drop_seed, float drop_p, void* stream) {
   NV_CHECK_ARG(dim_head == DH, "nv_attn_fwd: dim_head=%d unsupported (only 64)", dim_head);
   NV_CHECK_ARG(B > 0 && n > 0 && heads > 0 && ld_qkv >= 3 * heads * DH && ld_out >= heads * DH && (ld_qkv % 8) == 0 && (ld_out % 4) == 0,
                "nv_attn_fwd: bad dims");
   NV_CHECK_ARG(nv_aligned16(qkv) && nv_aligned16(out), "nv_attn_fwd: alignment");
   const int slot = nv_prof_begin(3, 4.0 * B * heads * (double)n * n * DH, stream);
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((n + TQ - 1) / TQ, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
-                     heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse);
+                     heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
   nv_prof_end(slot, stream);
   NV_CHECK_LAUNCH("nv_attn_fwd");
   return NV_OK;
@@ -164,7 +171,7 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
                                                           const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse, int n,
                                                           int heads, float scale, float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                          long ldd) {
+                                                          long ldd, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
   char* sK = smem;
   char* sV = smem + IMG;
@@ -222,7 +229,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       for (int j = 0; j < 4; ++j) {
         const int key = kt * TK + 16 * t + 4 * g + j;
         const float p = (key < n) ? exp2f(s[j] * scale_log2e - lse2) : 0.f;
-        ds[t][j] = p * (dp[j] - dl);
+        const float f = drop.thresh ? drop_factor(drop, (((unsigned long long)blockIdx.y * n + (q0 + r)) * n) + key) : 1.f;
+        ds[t][j] = p * (dp[j] * f - dl);
       }
     }
 #pragma unroll
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout, long ldo,
                                                            const float* __restrict__ lse, const float* __restrict__ delta, int n,
-                                                           int heads, float scale, bf16* __restrict__ dqkv, long ldd) {
+                                                           int heads, float scale, bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG + 2 * TQ * 4];
   char* sQ = smem;
   char* sD = smem + IMG;
@@ -310,8 +318,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float pv = exp2f(s[j] * scale_log2e - l4[j]);
-        p[t][j] = pv;
-        ds[t][j] = pv * (dp[j] - d4[j]);
+        const float f = drop.thresh ? drop_factor(drop, (((unsigned long long)blockIdx.y * n + (qt * TQ + 16 * t + 4 * g + j)) * n) + (key0 + r)) : 1.f;
+        p[t][j] = pv * f;
+        ds[t][j] = pv * (dp[j] * f - d4[j]);
       }
     }
 #pragma unroll
@@ -338,7 +347,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 
 // delta: [B, heads, n] fp32 scratch (written by the dQ kernel, read by the dK/dV kernel).
 extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const void* dout, long ld_out, const float* lse, int B, int n,
-                           int heads, int dim_head, float scale, float* delta, void* dqkv, long ld_dqkv, void* stream) {
+                           int heads, int dim_head, float scale, float* delta, void* dqkv, long ld_dqkv, unsigned long drop_seed, float drop_p,
+                           void* stream) {
   NV_CHECK_ARG(dim_head == DH, "nv_attn_bwd: dim_head=%d unsupported (only 64)", dim_head);
   NV_CHECK_ARG(B > 0 && n > 0 && heads > 0 && ld_qkv >= 3 * heads * DH && ld_dqkv >= 3 * heads * DH && ld_out >= heads * DH &&
                    (ld_qkv % 8) == 0 && (ld_out % 8) == 0 && (ld_dqkv % 4) == 0,
@@ -348,10 +358,10 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
   const dim3 grid((n + TQ - 1) / TQ, B * heads);
   const int slot = nv_prof_begin(4, 10.0 * B * heads * (double)n * n * DH, stream);   // algorithmic: 5 products
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out, lse, n,
-                     heads, scale, delta, (bf16*)dqkv, ld_dqkv);
+                     heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
   NV_CHECK_LAUNCH("nv_attn_bwd/dq");
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)dout, ld_out, lse, delta, n, heads,
-                     scale, (bf16*)dqkv, ld_dqkv);
+                     scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
   nv_prof_end(slot, stream);
   NV_CHECK_LAUNCH("nv_attn_bwd/dkv");
   return NV_OK;

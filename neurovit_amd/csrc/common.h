@@ -11,10 +11,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-#define NV_OK 0
-#define NV_ERR_ARG (-1)        // bad shape / alignment / unsupported configuration
-#define NV_ERR_HIP (-2)        // HIP runtime error (see nv_last_error)
-#define NV_ERR_ARCH (-3)       // not a gfx950 device
+#include "../../include/neurovit_hip.h"   // every definition is checked against the published C-ABI declarations
 
 extern "C" void nv_set_error(const char* fmt, ...);
 extern "C" int nv_prof_begin(int kind, double work, void* stream);   // -1 when profiling is off
@@ -109,6 +106,25 @@ __device__ __forceinline__ uint32_t nv_hash32(uint64_t seed, uint64_t idx) {
   x ^= x >> 27; x *= 0x94D049BB133111EBull;
   x ^= x >> 31;
   return (uint32_t)(x >> 16);
+}
+
+// Dropout configuration of one site: keep element idx iff hash(seed, idx) >= thresh; kept values are scaled by 1/(1-p).
+// thresh == 0 means "no dropout" (kernels skip the hash).  The mask is recomputed in backward from (seed, idx).
+struct DropCfg {
+  unsigned long long seed;
+  unsigned thresh;
+  float scale;
+};
+static inline DropCfg make_drop(unsigned long long seed, float p) {
+  DropCfg d;
+  d.seed = seed;
+  if (p <= 0.f) { d.thresh = 0; d.scale = 1.f; }
+  else if (p >= 1.f) { d.thresh = 0xFFFFFFFFu; d.scale = 0.f; }
+  else { d.thresh = (unsigned)((double)p * 4294967296.0); d.scale = 1.0f / (1.0f - p); }
+  return d;
+}
+__device__ __forceinline__ float drop_factor(const DropCfg& d, unsigned long long idx) {
+  return (nv_hash32(d.seed, idx) >= d.thresh) ? d.scale : 0.f;
 }
 
 // XCD-aware bijective remap of a 1-D block id: blocks b, b+8, ... share an XCD (round-robin dispatch),

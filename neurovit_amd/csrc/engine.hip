@@ -107,6 +107,9 @@ void make_ws(const Dims& D, int training, WS& W) {
   W.total = cur;
 }
 
+// per-site dropout seeds: site = 4*layer + {0 attention probs, 1 to_out, 2 FF hidden, 3 FF out}; 4*depth = embedding
+inline unsigned long site_seed(unsigned long seed, int site) { return seed ^ (0x9E3779B97F4A7C15ul * (unsigned long)(site + 1)); }
+
 #define RUN(call)            \
   do {                       \
     const int rc__ = (call); \
@@ -155,7 +158,8 @@ extern "C" long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int tra
 }
 
 extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
-                              const void* params16, void* workspace, long ws_bytes, int training, float* logits, void* stream) {
+                              const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
+                              unsigned long drop_seed, float* logits, void* stream) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, training, W);
@@ -178,11 +182,11 @@ extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* vide
     RUN(nv_cast_bf16_2d(p + T.pe_w, D.P, d, D.P, ws + W.wpe16, D.Ppad, stream));
     wpe = ws + W.wpe16;
   }
-  RUN(nv_gemm_bf16(0, 2, D.T, d, D.Ppad, ws + W.xp, D.Ppad, wpe, D.Ppad, ws + W.t, d, p + T.pe_bias, nullptr, 0, nullptr, 0, 0, 1.f, stream));
+  RUN(nv_gemm_bf16(0, 2, D.T, d, D.Ppad, ws + W.xp, D.Ppad, wpe, D.Ppad, ws + W.t, d, p + T.pe_bias, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
   // A4+A5: LayerNorm(dim) + cls + pos
   float* est = (float*)(ws + W.est);
   RUN(nv_embed_finish_fwd((float*)(ws + W.t), d, B, D.N, d, p + T.pe_g2, p + T.pe_b2, eps, p + T.pos, p + T.cls, (float*)(ws + W.x0), d, est,
-                          est + D.T, stream));
+                          est + D.T, site_seed(drop_seed, 4 * D.L), emb_drop_p, stream));
 
   const float scale = 1.0f / sqrtf((float)D.dh);
   const float* xin = (float*)(ws + W.x0);
@@ -195,12 +199,12 @@ extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* vide
     float* st1 = (float*)(ws + w.st1);
     float* st2 = (float*)(ws + w.st2);
     RUN(nv_ln_fwd(xin, d, M, d, p + q.n1g, p + q.n1b, eps, ws + w.xn1, d, st1, st1 + M, stream));
-    RUN(nv_gemm_bf16(0, 0, M, 3 * D.inner, d, ws + w.xn1, d, p16 + q.wqkv, d, ws + w.qkv, 3 * D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, stream));
-    RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), stream));
-    RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, stream));
+    RUN(nv_gemm_bf16(0, 0, M, 3 * D.inner, d, ws + w.xn1, d, p16 + q.wqkv, d, ws + w.qkv, 3 * D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+    RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), site_seed(drop_seed, 4 * l + 0), drop_p, stream));
+    RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 1), drop_p, stream));
     RUN(nv_ln_fwd(x1, d, M, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d, st2, st2 + M, stream));
-    RUN(nv_gemm_bf16(0, 3, M, D.m, d, ws + w.xn2, d, p16 + q.w1, d, ws + w.h, D.m, p + q.b1, nullptr, 0, ws + w.u, D.m, 0, 1.f, stream));
-    RUN(nv_gemm_bf16(0, 4, M, d, D.m, ws + w.h, D.m, p16 + q.w2, D.m, x2, d, p + q.b2, x1, d, nullptr, 0, 0, 1.f, stream));
+    RUN(nv_gemm_bf16(0, 3, M, D.m, d, ws + w.xn2, d, p16 + q.w1, d, ws + w.h, D.m, p + q.b1, nullptr, 0, ws + w.u, D.m, 0, 1.f, site_seed(drop_seed, 4 * l + 2), drop_p, stream));
+    RUN(nv_gemm_bf16(0, 4, M, d, D.m, ws + w.h, D.m, p16 + q.w2, D.m, x2, d, p + q.b2, x1, d, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 3), drop_p, stream));
     xin = x2;
   }
   // A9: cls pooling + LayerNorm + Linear(dim, C)
@@ -215,7 +219,8 @@ extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* vide
 // When stage s has run, the gradient-arena range of its parameters is final (see nv_vit_stage_param_range).
 extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                                       const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
-                                      int accumulate, int first_stage, int last_stage, void* stream) {
+                                      int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
+                                      unsigned long drop_seed, void* stream) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 1, W);
@@ -238,7 +243,8 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   const float* xlast = (float*)(ws + W.layer[D.L - 1].x2);
   if (first_stage == 0)
   RUN(nv_head_bwd(dlogits, B, D.C, p + T.hw, xlast, (long)D.n * d, (float*)(ws + W.hst), (float*)(ws + W.xh), p + T.hg, d, D.n, g, d, g16, d,
-                  gr + T.hg, gr + T.hb, gr + T.hw, gr + T.hbias, gr + T.layer[D.L - 1].b2, acc, red, W.red_bytes, stream));
+                  gr + T.hg, gr + T.hb, gr + T.hw, gr + T.hbias, gr + T.layer[D.L - 1].b2, acc, red, W.red_bytes,
+                  site_seed(drop_seed, 4 * (D.L - 1) + 3), drop_p, stream));
 
   for (int l = D.L - 1; l >= 0; --l) {
     const int stage = D.L - l;
@@ -250,23 +256,23 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     float* st2 = (float*)(ws + w.st2);
     float* dxn = (float*)(ws + W.dxn);
     // ---- FeedForward backward (vit_3d.py:16-26)
-    RUN(nv_gemm_bf16(1, 5, M, D.m, d, g16, d, p16 + q.w2, D.m, ws + W.du, D.m, nullptr, ws + w.u, D.m, nullptr, 0, 0, 1.f, stream));           // dU = (g W2) * gelu'(u)
-    RUN(nv_gemm_bf16(2, 1, d, D.m, M, g16, d, ws + w.h, D.m, gr + q.w2, D.m, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, stream));              // dW2 = g^T h
+    RUN(nv_gemm_bf16(1, 5, M, D.m, d, g16, d, p16 + q.w2, D.m, ws + W.du, D.m, nullptr, ws + w.u, D.m, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 2), drop_p, stream));   // dU = (g W2 * mask) * gelu'(u)
+    RUN(nv_gemm_bf16(2, 1, d, D.m, M, g16, d, ws + w.h, D.m, gr + q.w2, D.m, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));              // dW2 = g^T h
     RUN(nv_colsum_bf16(ws + W.du, D.m, M, D.m, gr + q.b1, acc, red, W.red_bytes, stream));                                                       // db1
-    RUN(nv_gemm_bf16(1, 1, M, d, D.m, ws + W.du, D.m, p16 + q.w1, d, dxn, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, stream));                 // dxn2 = dU W1
-    RUN(nv_gemm_bf16(2, 1, D.m, d, M, ws + W.du, D.m, ws + w.xn2, d, gr + q.w1, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, stream));         // dW1 = dU^T xn2
+    RUN(nv_gemm_bf16(1, 1, M, d, D.m, ws + W.du, D.m, p16 + q.w1, d, dxn, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));                 // dxn2 = dU W1
+    RUN(nv_gemm_bf16(2, 1, D.m, d, M, ws + W.du, D.m, ws + w.xn2, d, gr + q.w1, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));         // dW1 = dU^T xn2
     RUN(nv_ln_bwd(dxn, d, (float*)(ws + w.x1), d, st2, st2 + M, p + q.n2g, M, d, g, g, d, g16, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, red,
-                  W.red_bytes, stream));                                                                                                       // g += dLN2; dbo = colsum(g)
+                  W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream));                                                                                                       // g += dLN2; dbo = colsum(g)
     // ---- Attention backward (vit_3d.py:48-60)
-    RUN(nv_gemm_bf16(1, 0, M, D.inner, d, g16, d, p16 + q.wo, D.inner, ws + W.dao, D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, stream));   // dAO = g Wo
-    RUN(nv_gemm_bf16(2, 1, d, D.inner, M, g16, d, ws + w.ao, D.inner, gr + q.wo, D.inner, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, stream));   // dWo = g^T ao
+    RUN(nv_gemm_bf16(1, 0, M, D.inner, d, g16, d, p16 + q.wo, D.inner, ws + W.dao, D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));   // dAO = g Wo
+    RUN(nv_gemm_bf16(2, 1, d, D.inner, M, g16, d, ws + w.ao, D.inner, gr + q.wo, D.inner, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));   // dWo = g^T ao
     RUN(nv_attn_bwd(ws + w.qkv, 3 * D.inner, ws + w.ao, ws + W.dao, D.inner, (float*)(ws + w.lse), B, D.n, D.heads, D.dh, scale,
-                    (float*)(ws + W.delta), ws + W.dqkv, 3 * D.inner, stream));
+                    (float*)(ws + W.delta), ws + W.dqkv, 3 * D.inner, site_seed(drop_seed, 4 * l + 0), drop_p, stream));
     float* dxn1 = (l == D.L - 1) ? (float*)(ws + W.hookg) : dxn;    // gradient of the last block's attention-LN output is kept (Grad-CAM hook)
-    RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, ws + W.dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, stream));
-    RUN(nv_gemm_bf16(2, 1, 3 * D.inner, d, M, ws + W.dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, stream));
+    RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, ws + W.dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+    RUN(nv_gemm_bf16(2, 1, 3 * D.inner, d, M, ws + W.dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));
     RUN(nv_ln_bwd(dxn1, d, xin, d, st1, st1 + M, p + q.n1g, M, d, g, g, d, g16, d, gr + q.n1g, gr + q.n1b, (l > 0) ? gr + T.layer[l - 1].b2 : nullptr,
-                  acc, red, W.red_bytes, stream));
+                  acc, red, W.red_bytes, site_seed(drop_seed, 4 * (l - 1) + 3), (l > 0) ? drop_p : 0.f, stream));
   }
 
   if (last_stage < D.L + 1) return NV_OK;
@@ -274,9 +280,9 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   float* est = (float*)(ws + W.est);
   float* pst = (float*)(ws + W.pst);
   RUN(nv_embed_finish_bwd(g, d, (float*)(ws + W.t), d, est, est + D.T, p + T.pe_g2, B, D.N, d, (float*)(ws + W.dt), d, ws + W.dt16, d, gr + T.pe_g2,
-                          gr + T.pe_b2, gr + T.pe_bias, gr + T.pos, gr + T.cls, acc, red, W.red_bytes, stream));
-  RUN(nv_gemm_bf16(2, 1, d, D.P, D.T, ws + W.dt16, d, ws + W.xp, D.Ppad, gr + T.pe_w, D.P, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, stream));   // dWpe = dt^T xp
-  RUN(nv_gemm_bf16(1, 1, D.T, D.P, d, ws + W.dt16, d, p16 + T.pe_w, D.P, ws + W.dxp, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, stream)); // dxp = dt Wpe
+                          gr + T.pe_b2, gr + T.pe_bias, gr + T.pos, gr + T.cls, acc, red, W.red_bytes, site_seed(drop_seed, 4 * D.L), emb_drop_p, stream));
+  RUN(nv_gemm_bf16(2, 1, d, D.P, D.T, ws + W.dt16, d, ws + W.xp, D.Ppad, gr + T.pe_w, D.P, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));   // dWpe = dt^T xp
+  RUN(nv_gemm_bf16(1, 1, D.T, D.P, d, ws + W.dt16, d, p16 + T.pe_w, D.P, ws + W.dxp, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream)); // dxp = dt Wpe
   RUN(nv_patch_ln_bwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
                       cfg->image_patch_size, cfg->frame_patch_size, (float*)(ws + W.dxp), D.Ppad, pst, pst + D.T, gr + T.pe_g, gr + T.pe_b, acc, red,
                       W.red_bytes, stream));
@@ -285,9 +291,9 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
 
 extern "C" int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                                const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
-                               int accumulate, void* stream) {
+                               int accumulate, float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream) {
   return nv_vit_backward_stages(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, accumulate, 0,
-                                cfg ? cfg->depth + 1 : 0, stream);
+                                cfg ? cfg->depth + 1 : 0, drop_p, emb_drop_p, drop_seed, stream);
 }
 
 // Element range [begin, end) of the parameter / gradient arena that is FINAL once backward stage `stage` has run.

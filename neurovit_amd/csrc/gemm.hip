@@ -38,6 +38,7 @@ struct GemmArgs {
   long lda, ldb, ldc, ld_aux_in, ld_aux_out;
   int M, N, K;
   int accumulate;
+  DropCfg drop;    // EPI_BIAS_RESID: on (acc + bias); EPI_BIAS_GELU: on gelu(u); EPI_DGELU: on acc (the incoming dH)
   int col_order;   // 1: consecutive workgroups walk DOWN a tile column (keeps the B panel in the XCD's L2), 0: along a tile row
   float alpha;
 };
@@ -187,6 +188,14 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmA
         const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
         v += bv;
       }
+      f32x4 keep = f32x4{1.f, 1.f, 1.f, 1.f};
+      if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_DGELU) {
+        if (g.drop.thresh) {
+          const unsigned long long idx = (unsigned long long)m * g.N + n;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) keep[q] = drop_factor(g.drop, idx + q);
+        }
+      }
       if constexpr (EPI == EPI_STORE_BF16) {
         *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) = cvt4(v[0], v[1], v[2], v[3]);
       } else if constexpr (EPI == EPI_STORE_F32) {
@@ -198,15 +207,15 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmA
       } else if constexpr (EPI == EPI_BIAS_GELU) {
         *reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n) = cvt4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
-            cvt4(gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3]));
+            cvt4(gelu_f(v[0]) * keep[0], gelu_f(v[1]) * keep[1], gelu_f(v[2]) * keep[2], gelu_f(v[3]) * keep[3]);
       } else if constexpr (EPI == EPI_BIAS_RESID) {
-        v += *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
+        v = v * keep + *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
         *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
       } else if constexpr (EPI == EPI_DGELU) {
         const bf16x4 u = *reinterpret_cast<const bf16x4*>((const bf16*)g.aux_in + (long)m * g.ld_aux_in + n);
         *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
-            cvt4(v[0] * gelu_grad_f((float)u[0]), v[1] * gelu_grad_f((float)u[1]),
-                 v[2] * gelu_grad_f((float)u[2]), v[3] * gelu_grad_f((float)u[3]));
+            cvt4(v[0] * keep[0] * gelu_grad_f((float)u[0]), v[1] * keep[1] * gelu_grad_f((float)u[1]),
+                 v[2] * keep[2] * gelu_grad_f((float)u[2]), v[3] * keep[3] * gelu_grad_f((float)u[3]));
       }
     }
   }
@@ -518,7 +527,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 
 extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                             void* C, long ldc, const float* bias, const void* aux_in, long ld_aux_in, void* aux_out,
-                            long ld_aux_out, int accumulate, float alpha, void* stream) {
+                            long ld_aux_out, int accumulate, float alpha, unsigned long drop_seed, float drop_p, void* stream) {
   NV_CHECK_ARG(M > 0 && N > 0 && K > 0, "nv_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
   NV_CHECK_ARG(A && B && C, "nv_gemm_bf16: null operand");
   NV_CHECK_ARG(nv_aligned16(A) && nv_aligned16(B) && nv_aligned16(C), "nv_gemm_bf16: operands must be 16-byte aligned");
@@ -532,6 +541,7 @@ extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C; a.bias = bias; a.aux_in = aux_in; a.aux_out = aux_out;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ld_aux_in = ld_aux_in; a.ld_aux_out = ld_aux_out;
   a.M = M; a.N = N; a.K = K; a.accumulate = accumulate; a.alpha = alpha;
+  a.drop = make_drop(drop_seed, drop_p);
   // each XCD (private 4 MiB L2) gets a contiguous run of tiles: run along the dimension of the SMALLER operand so the
   // larger operand's panel is the one that stays resident
   a.col_order = (N > M) ? 1 : 0;

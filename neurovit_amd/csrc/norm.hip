@@ -81,12 +81,13 @@ extern "C" int nv_ln_fwd(const float* x, long ldx, int M, int d, const float* ga
 }
 
 // --------------------------------------------------------------------------------------- ln_bwd
-// g_out = g_in + LN'(dy);  g16 = bf16(g_out);  partials[blk][0] = sum dy*xhat, [1] = sum dy, [2] = sum g_out.
+// g_out = g_in + LN'(dy);  g16 = bf16(g_out * dropmask);  partials[blk][0] = sum dy*xhat, [1] = sum dy, [2] = sum g_out * dropmask.
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, int M, int d, const float* g_in, float* g_out,
-                                                     long ldg, bf16* __restrict__ g16, long ldg16, float* __restrict__ partials) {
+                                                     long ldg, bf16* __restrict__ g16, long ldg16, float* __restrict__ partials,
+                                                     DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][3][d]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nw = gridDim.x * WAVES_PER_BLOCK;
@@ -121,6 +122,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         f32x4 o = (dv[v] * gm[v] - c1 - xv[v] * c2) * rstd;
         if (g_in) o += *reinterpret_cast<const f32x4*>(g_in + (long)row * ldg + c);
         *reinterpret_cast<f32x4*>(g_out + (long)row * ldg + c) = o;
+        // g16 / colsum feed the backward of the Linear whose (dropped-out) output was added to this residual stream
+        if (drop.thresh) {
+          const unsigned long long idx = (unsigned long long)row * d + c;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] *= drop_factor(drop, idx + q);
+        }
         if (g16) *reinterpret_cast<bf16x4*>(g16 + (long)row * ldg16 + c) = cvt4(o[0], o[1], o[2], o[3]);
         a_c[v] += o;
       }
@@ -184,8 +191,9 @@ extern "C" long nv_ln_bwd_workspace_bytes(int M, int d) { return (long)ln_bwd_bl
 extern "C" int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
                          const float* gamma, int M, int d, const float* g_in, float* g_out, long ldg, void* g16, long ldg16,
                          float* dgamma, float* dbeta, float* dcolsum, int accumulate, void* workspace, long ws_bytes,
-                         void* stream) {
+                         unsigned long drop_seed, float drop_p, void* stream) {
   NV_CHECK_ARG(M > 0 && d > 0 && (d % 4) == 0 && d <= 2048, "nv_ln_bwd: d=%d must be a multiple of 4 and <= 2048", d);
+  const DropCfg drop = make_drop(drop_seed, drop_p);
   NV_CHECK_ARG(ws_bytes >= nv_ln_bwd_workspace_bytes(M, d), "nv_ln_bwd: workspace too small");
   NV_CHECK_ARG((lddy % 4) == 0 && (ldx % 4) == 0 && (ldg % 4) == 0 && (ldg16 % 4) == 0, "nv_ln_bwd: leading dims must be multiples of 4");
   const int nb = ln_bwd_blocks(M);
@@ -193,10 +201,10 @@ extern "C" int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, c
   const size_t lds = (size_t)WAVES_PER_BLOCK * 3 * d * sizeof(float);
   if (d <= 1024)
     hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
-                       (bf16*)g16, ldg16, (float*)workspace);
+                       (bf16*)g16, ldg16, (float*)workspace, drop);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
-                       (bf16*)g16, ldg16, (float*)workspace);
+                       (bf16*)g16, ldg16, (float*)workspace, drop);
   NV_CHECK_LAUNCH("nv_ln_bwd");
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 31) / 32), dim3(256), 0, s, (const float*)workspace, nb, d, 3, dgamma,
                      dbeta, dcolsum, accumulate);
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(256) void embed_finish_fwd_kernel(const float* __re
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                const float* __restrict__ pos, const float* __restrict__ cls,
                                                                float* __restrict__ x, long ldx, float* __restrict__ mean_out,
-                                                               float* __restrict__ rstd_out) {
+                                                               float* __restrict__ rstd_out, DropCfg drop) {
   const int lane = threadIdx.x & 63, r = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   const int n = N + 1;
   if (r >= B * n) return;
@@ -372,7 +380,14 @@ __global__ __launch_bounds__(256) void embed_finish_fwd_kernel(const float* __re
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int c = (lane + 64 * v) * 4;
-      if (c < d) *reinterpret_cast<f32x4*>(xrow + c) = *reinterpret_cast<const f32x4*>(cls + c) + *reinterpret_cast<const f32x4*>(pos + c);
+      if (c < d) {
+        f32x4 o = *reinterpret_cast<const f32x4*>(cls + c) + *reinterpret_cast<const f32x4*>(pos + c);
+        if (drop.thresh) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] *= drop_factor(drop, (unsigned long long)r * d + c + q);
+        }
+        *reinterpret_cast<f32x4*>(xrow + c) = o;
+      }
     }
     return;
   }
@@ -387,8 +402,13 @@ __global__ __launch_bounds__(256) void embed_finish_fwd_kernel(const float* __re
     if (c < d) {
       const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
       const f32x4 pe = *reinterpret_cast<const f32x4*>(pos + (long)i * d + c);
-      // same association as the reference: (LN output) + pos   (vit_3d.py:118 `x += pos_embedding`)
-      *reinterpret_cast<f32x4*>(xrow + c) = ((xv[v] - mean) * rstd * gm + bt) + pe;
+      // same association as the reference: (LN output) + pos   (vit_3d.py:118 `x += pos_embedding`), then emb dropout (:119)
+      f32x4 o = ((xv[v] - mean) * rstd * gm + bt) + pe;
+      if (drop.thresh) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] *= drop_factor(drop, (unsigned long long)r * d + c + q);
+      }
+      *reinterpret_cast<f32x4*>(xrow + c) = o;
     }
   }
   if (lane == 0) {
@@ -398,14 +418,16 @@ __global__ __launch_bounds__(256) void embed_finish_fwd_kernel(const float* __re
 }
 
 extern "C" int nv_embed_finish_fwd(const float* t, long ldt, int B, int N, int d, const float* gamma, const float* beta, float eps,
-                                   const float* pos, const float* cls, float* x, long ldx, float* mean, float* rstd, void* stream) {
+                                   const float* pos, const float* cls, float* x, long ldx, float* mean, float* rstd,
+                                   unsigned long drop_seed, float drop_p, void* stream) {
+  const DropCfg drop = make_drop(drop_seed, drop_p);
   NV_CHECK_ARG(B > 0 && N > 0 && (d % 4) == 0 && d <= 2048, "nv_embed_finish_fwd: d=%d must be a multiple of 4 and <= 2048", d);
   NV_CHECK_ARG((ldt % 4) == 0 && (ldx % 4) == 0, "nv_embed_finish_fwd: leading dims must be multiples of 4");
   const int rows = B * (N + 1);
   const dim3 grid((rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (d <= 1024) hipLaunchKernelGGL(embed_finish_fwd_kernel<4>, grid, block, 0, s, t, ldt, B, N, d, gamma, beta, eps, pos, cls, x, ldx, mean, rstd);
-  else hipLaunchKernelGGL(embed_finish_fwd_kernel<8>, grid, block, 0, s, t, ldt, B, N, d, gamma, beta, eps, pos, cls, x, ldx, mean, rstd);
+  if (d <= 1024) hipLaunchKernelGGL(embed_finish_fwd_kernel<4>, grid, block, 0, s, t, ldt, B, N, d, gamma, beta, eps, pos, cls, x, ldx, mean, rstd, drop);
+  else hipLaunchKernelGGL(embed_finish_fwd_kernel<8>, grid, block, 0, s, t, ldt, B, N, d, gamma, beta, eps, pos, cls, x, ldx, mean, rstd, drop);
   NV_CHECK_LAUNCH("nv_embed_finish_fwd");
   return NV_OK;
 }
@@ -421,14 +443,31 @@ __global__ void batch_sum_kernel(const float* __restrict__ g, long ldg, int B, i
   if (i == 0 && dcls) dcls[c] = accumulate ? dcls[c] + s : s;
 }
 
+__global__ void apply_drop_kernel(float* __restrict__ g, long count, DropCfg drop) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= count) return;
+  f32x4 v = *reinterpret_cast<f32x4*>(g + i);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] *= drop_factor(drop, (unsigned long long)(i + q));
+  *reinterpret_cast<f32x4*>(g + i) = v;
+}
+
 // Backward of A4/A5: g [B, n, d] -> dt [B*N, d] (fp32 + bf16 copy), dgamma3/dbeta3, dbias_pe = colsum(dt), dpos, dcls.
+// With embedding dropout the incoming g is first multiplied by the forward mask IN PLACE (g is dead afterwards).
 extern "C" long nv_embed_finish_bwd_workspace_bytes(int B, int N, int d) { return nv_ln_bwd_workspace_bytes(B * N, d); }
 
 extern "C" int nv_embed_finish_bwd(const float* g, long ldg, const float* t, long ldt, const float* mean, const float* rstd,
                                    const float* gamma, int B, int N, int d, float* dt, long lddt, void* dt16, long lddt16,
                                    float* dgamma, float* dbeta, float* dbias_pe, float* dpos, float* dcls, int accumulate,
-                                   void* workspace, long ws_bytes, void* stream) {
+                                   void* workspace, long ws_bytes, unsigned long drop_seed, float drop_p, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  const DropCfg drop = make_drop(drop_seed, drop_p);
+  if (drop.thresh) {
+    NV_CHECK_ARG(ldg == d, "nv_embed_finish_bwd: dropout needs a dense g");
+    const long count = (long)B * (N + 1) * d;
+    hipLaunchKernelGGL(apply_drop_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, (float*)g, count, drop);
+    NV_CHECK_LAUNCH("nv_embed_finish_bwd/drop");
+  }
   // token rows of volume b are rows b*n+1 .. b*n+N of g: one strided LN backward per volume keeps the kernel generic.
   // (B launches of a memory-bound kernel; B is the per-GPU batch.)  Partials of all volumes are reduced together.
   NV_CHECK_ARG(B > 0 && N > 0 && (d % 4) == 0 && d <= 2048, "nv_embed_finish_bwd: bad dims");
@@ -440,7 +479,7 @@ extern "C" int nv_embed_finish_bwd(const float* g, long ldg, const float* t, lon
   for (int b = 0; b < B; ++b) {
     const int rc = nv_ln_bwd(g + ((long)b * n + 1) * ldg, ldg, t + (long)b * N * ldt, ldt, mean + (long)b * N, rstd + (long)b * N, gamma, N,
                              d, nullptr, dt + (long)b * N * lddt, lddt, dt16 ? (char*)dt16 + (long)b * N * lddt16 * 2 : nullptr, lddt16, dgamma,
-                             dbeta, dbias_pe, (accumulate || b > 0) ? 1 : 0, workspace, ws_bytes, stream);
+                             dbeta, dbias_pe, (accumulate || b > 0) ? 1 : 0, workspace, ws_bytes, 0, 0.f, stream);
     if (rc) return rc;
   }
   const long tot = (long)n * d;
@@ -502,7 +541,7 @@ extern "C" int nv_head_fwd(const float* x, long row_stride, int B, int d, const 
 __global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict__ dlogits, int C, const float* __restrict__ Wt,
                                                          const float* __restrict__ x, long row_stride, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, int d, int n, float* __restrict__ g, long ldg,
-                                                         bf16* __restrict__ g16, long ldg16, float* __restrict__ partials) {
+                                                         bf16* __restrict__ g16, long ldg16, float* __restrict__ partials, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) float sh[];   // dyh[d] + 8 scratch
   float* dys = sh;
   float* scratch = sh + d;
@@ -530,8 +569,9 @@ __global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict
     const float xh = (row[c] - mean) * rstd;
     const float dx = (dys[c] - c1 - xh * c2) * rstd;
     g[(long)b * n * ldg + c] = dx;
-    if (g16) g16[(long)b * n * ldg16 + c] = (bf16)dx;
-    partials[((long)b * 3 + 2) * d + c] = dx;
+    const float dxm = drop.thresh ? dx * drop_factor(drop, (unsigned long long)b * n * d + c) : dx;   // last block's FF output dropout
+    if (g16) g16[(long)b * n * ldg16 + c] = (bf16)dxm;
+    partials[((long)b * 3 + 2) * d + c] = dxm;
   }
 }
 
@@ -557,7 +597,7 @@ extern "C" long nv_head_bwd_workspace_bytes(int B, int d) { return (long)B * 3 *
 extern "C" int nv_head_bwd(const float* dlogits, int B, int C, const float* W, const float* x, long row_stride, const float* stats,
                            const float* xh, const float* gamma, int d, int n, float* g, long ldg, void* g16, long ldg16,
                            float* dgamma, float* dbeta, float* dW, float* dbias, float* dcolsum, int accumulate, void* workspace,
-                           long ws_bytes, void* stream) {
+                           long ws_bytes, unsigned long drop_seed, float drop_p, void* stream) {
   NV_CHECK_ARG(ws_bytes >= nv_head_bwd_workspace_bytes(B, d), "nv_head_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   NV_CHECK_ARG(ldg == d && (!g16 || ldg16 == d), "nv_head_bwd: g / g16 must be dense [B*n, d]");
@@ -568,7 +608,7 @@ extern "C" int nv_head_bwd(const float* dlogits, int B, int C, const float* W, c
     return NV_ERR_HIP;
   }
   hipLaunchKernelGGL(head_bwd_x_kernel, dim3(B), dim3(256), (d + 8) * sizeof(float), s, dlogits, C, W, x, row_stride, stats, gamma, d, n,
-                     g, ldg, (bf16*)g16, ldg16, (float*)workspace);
+                     g, ldg, (bf16*)g16, ldg16, (float*)workspace, make_drop(drop_seed, drop_p));
   NV_CHECK_LAUNCH("nv_head_bwd/x");
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 31) / 32), dim3(256), 0, s, (const float*)workspace, B, d, 3, dgamma, dbeta,
                      dcolsum, accumulate);

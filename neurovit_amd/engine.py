@@ -60,8 +60,10 @@ class VitRuntime:
             self._ws[key] = ws
         return ws
 
-    def forward(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, training: bool) -> torch.Tensor:
-        """video: [B, C, F, H, W] fp32 view (any strides).  Returns logits [B, num_classes] fp32."""
+    def forward(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, training: bool,
+                dropout: Tuple[float, float, int] = (0.0, 0.0, 0)) -> torch.Tensor:
+        """video: [B, C, F, H, W] fp32 view (any strides).  Returns logits [B, num_classes] fp32.
+        dropout = (p of the blocks, p of the embedding, seed) - (0, 0, *) in eval mode."""
         if not video.is_cuda:
             raise RuntimeError("neurovit_amd: ViT forward needs a CUDA/HIP tensor on MI355X - there is no CPU fallback")
         assert video.dtype == torch.float32 and video.dim() == 5
@@ -69,9 +71,11 @@ class VitRuntime:
         ws = self.workspace(B, training, video.device)
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
         check(lib.nv_vit_forward(ctypes.byref(self.cfg), B, video.data_ptr(), ops.strides5(video), params.data_ptr(),
-                                 params16.data_ptr(), ws.data_ptr(), ws.numel(), int(training), logits.data_ptr(),
+                                 params16.data_ptr(), ws.data_ptr(), ws.numel(), int(training), float(dropout[0]),
+                                 float(dropout[1]), int(dropout[2]), logits.data_ptr(),
                                  torch.cuda.current_stream().cuda_stream), "nv_vit_forward")
         self._last = (B, training, ws, video)
+        self._dropout = dropout
         return logits
 
     def backward(self, dlogits: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, grads: torch.Tensor,
@@ -84,7 +88,8 @@ class VitRuntime:
             self._dlogits = dlogits.contiguous().float()
         check(lib.nv_vit_backward_stages(ctypes.byref(self.cfg), B, video.data_ptr(), ops.strides5(video), params.data_ptr(),
                                          params16.data_ptr(), ws.data_ptr(), ws.numel(), self._dlogits.data_ptr(),
-                                         grads.data_ptr(), int(accumulate), first, last,
+                                         grads.data_ptr(), int(accumulate), first, last, float(self._dropout[0]),
+                                         float(self._dropout[1]), int(self._dropout[2]),
                                          torch.cuda.current_stream().cuda_stream), "nv_vit_backward_stages")
 
     def stage_range(self, first: int, last: int) -> Tuple[int, int]:

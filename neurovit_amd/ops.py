@@ -36,7 +36,7 @@ def strides5(video: torch.Tensor):
 
 
 def gemm(layout: int, epi: int, A: torch.Tensor, B: torch.Tensor, *, out: Optional[torch.Tensor] = None, bias=None,
-         aux_in=None, aux_out=None, accumulate: bool = False, alpha: float = 1.0) -> torch.Tensor:
+         aux_in=None, aux_out=None, accumulate: bool = False, alpha: float = 1.0, drop_seed: int = 0, drop_p: float = 0.0) -> torch.Tensor:
     """C = op(A) op(B) with a fused epilogue; A, B bf16 2-D row-major (last stride 1)."""
     _need_cuda(A, B)
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.stride(1) == 1 and B.stride(1) == 1
@@ -52,7 +52,7 @@ def gemm(layout: int, epi: int, A: torch.Tensor, B: torch.Tensor, *, out: Option
     assert out.dtype == odt and out.shape == (M, N) and out.stride(1) == 1
     check(lib.nv_gemm_bf16(layout, epi, M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _p(bias),
                            _p(aux_in), 0 if aux_in is None else aux_in.stride(0), _p(aux_out),
-                           0 if aux_out is None else aux_out.stride(0), int(accumulate), float(alpha), _stream()), "nv_gemm_bf16")
+                           0 if aux_out is None else aux_out.stride(0), int(accumulate), float(alpha), drop_seed, drop_p, _stream()), "nv_gemm_bf16")
     return out
 
 
@@ -65,7 +65,7 @@ def ln_fwd(x: torch.Tensor, gamma, beta, eps: float = 1e-5):
     return y, st
 
 
-def ln_bwd(dy, x, st, gamma, g_in=None, want_g16=True, accumulate=False, dgamma=None, dbeta=None, dcolsum=None):
+def ln_bwd(dy, x, st, gamma, g_in=None, want_g16=True, accumulate=False, dgamma=None, dbeta=None, dcolsum=None, drop_seed=0, drop_p=0.0):
     _need_cuda(dy, x)
     M, d = x.shape
     g_out = torch.empty((M, d), dtype=torch.float32, device=x.device) if g_in is None else g_in
@@ -76,7 +76,7 @@ def ln_bwd(dy, x, st, gamma, g_in=None, want_g16=True, accumulate=False, dgamma=
     nb = lib.nv_ln_bwd_workspace_bytes(M, d)
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
     check(lib.nv_ln_bwd(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(st[0]), _p(st[1]), _p(gamma), M, d, _p(g_in), _p(g_out), d, _p(g16), d,
-                        _p(dgamma), _p(dbeta), _p(dcolsum), int(accumulate), _p(ws), nb, _stream()), "nv_ln_bwd")
+                        _p(dgamma), _p(dbeta), _p(dcolsum), int(accumulate), _p(ws), nb, drop_seed, drop_p, _stream()), "nv_ln_bwd")
     return g_out, g16, dgamma, dbeta, dcolsum
 
 
@@ -106,16 +106,16 @@ def patch_ln_bwd(video, p1, p2, pf, dxp, st, accumulate=False):
     return dg, db
 
 
-def embed_finish_fwd(t, B, N, gamma, beta, pos, cls, eps=1e-5):
+def embed_finish_fwd(t, B, N, gamma, beta, pos, cls, eps=1e-5, drop_seed=0, drop_p=0.0):
     d = t.shape[1]
     x = torch.empty((B, N + 1, d), dtype=torch.float32, device=t.device)
     st = torch.empty((2, B * N), dtype=torch.float32, device=t.device)
     check(lib.nv_embed_finish_fwd(_p(t), t.stride(0), B, N, d, _p(gamma), _p(beta), eps, _p(pos), _p(cls), _p(x), d, _p(st[0]), _p(st[1]),
-                                  _stream()), "nv_embed_finish_fwd")
+                                  drop_seed, drop_p, _stream()), "nv_embed_finish_fwd")
     return x, st
 
 
-def embed_finish_bwd(g, t, st, gamma, B, N):
+def embed_finish_bwd(g, t, st, gamma, B, N, drop_seed=0, drop_p=0.0):
     d = t.shape[1]
     dev = t.device
     dt = torch.empty((B * N, d), device=dev); dt16 = torch.empty((B * N, d), dtype=torch.bfloat16, device=dev)
@@ -125,26 +125,26 @@ def embed_finish_bwd(g, t, st, gamma, B, N):
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     g2 = g.reshape(B * (N + 1), d)
     check(lib.nv_embed_finish_bwd(_p(g2), d, _p(t), t.stride(0), _p(st[0]), _p(st[1]), _p(gamma), B, N, d, _p(dt), d, _p(dt16), d, _p(dgamma),
-                                  _p(dbeta), _p(dbias), _p(dpos), _p(dcls), 0, _p(ws), nb, _stream()), "nv_embed_finish_bwd")
+                                  _p(dbeta), _p(dbias), _p(dpos), _p(dcls), 0, _p(ws), nb, drop_seed, drop_p, _stream()), "nv_embed_finish_bwd")
     return dt, dt16, dgamma, dbeta, dbias, dpos, dcls
 
 
-def attn_fwd(qkv: torch.Tensor, B: int, n: int, heads: int, dim_head: int = 64):
+def attn_fwd(qkv: torch.Tensor, B: int, n: int, heads: int, dim_head: int = 64, drop_seed=0, drop_p=0.0):
     """qkv bf16 [B*n, 3*inner] -> (out bf16 [B*n, inner], lse f32 [B, heads, n])."""
     _need_cuda(qkv)
     inner = heads * dim_head
     out = torch.empty((B * n, inner), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((B, heads, n), dtype=torch.float32, device=qkv.device)
-    check(lib.nv_attn_fwd(_p(qkv), qkv.stride(0), B, n, heads, dim_head, dim_head ** -0.5, _p(out), inner, _p(lse), _stream()), "nv_attn_fwd")
+    check(lib.nv_attn_fwd(_p(qkv), qkv.stride(0), B, n, heads, dim_head, dim_head ** -0.5, _p(out), inner, _p(lse), drop_seed, drop_p, _stream()), "nv_attn_fwd")
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, B, n, heads, dim_head=64):
+def attn_bwd(qkv, out, dout, lse, B, n, heads, dim_head=64, drop_seed=0, drop_p=0.0):
     inner = heads * dim_head
     dqkv = torch.empty((B * n, 3 * inner), dtype=torch.bfloat16, device=qkv.device)
     delta = torch.empty((B, heads, n), dtype=torch.float32, device=qkv.device)
     check(lib.nv_attn_bwd(_p(qkv), qkv.stride(0), _p(out), _p(dout), inner, _p(lse), B, n, heads, dim_head, dim_head ** -0.5, _p(delta),
-                          _p(dqkv), 3 * inner, _stream()), "nv_attn_bwd")
+                          _p(dqkv), 3 * inner, drop_seed, drop_p, _stream()), "nv_attn_bwd")
     return dqkv, delta
 
 
@@ -158,7 +158,7 @@ def head_fwd(x: torch.Tensor, gamma, beta, W, bias, eps=1e-5):
     return logits, xh, st
 
 
-def head_bwd(dlogits, W, x, st, xh, gamma):
+def head_bwd(dlogits, W, x, st, xh, gamma, drop_seed=0, drop_p=0.0):
     B, n, d = x.shape
     C = W.shape[0]
     dev = x.device
@@ -168,7 +168,7 @@ def head_bwd(dlogits, W, x, st, xh, gamma):
     nb = lib.nv_head_bwd_workspace_bytes(B, d)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     check(lib.nv_head_bwd(_p(dlogits), B, C, _p(W), _p(x), n * d, _p(st), _p(xh), _p(gamma), d, n, _p(g), d, _p(g16), d, _p(dgamma), _p(dbeta),
-                          _p(dW), _p(db), _p(dcol), 0, _p(ws), nb, _stream()), "nv_head_bwd")
+                          _p(dW), _p(db), _p(dcol), 0, _p(ws), nb, drop_seed, drop_p, _stream()), "nv_head_bwd")
     return g, g16, dgamma, dbeta, dW, db, dcol
 
 

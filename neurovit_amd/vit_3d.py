@@ -235,11 +235,14 @@ class ViT(nn.Module):
 
     # ------------------------------------------------------------------ execution
     def _run_forward(self, video, need_grad):
+        drop = (0.0, 0.0, 0)
         if self.training and (self._dropout_p[0] > 0 or self._dropout_p[1] > 0):
-            raise NotImplementedError("neurovit_amd: dropout > 0 in training mode is not implemented in the native engine yet "
-                                      "(set TRAINING_DROPOUT: 0 or call .eval())")
+            # nn.Dropout semantics (vit_3d.py:21,23,39,45,100) with a counter-based mask: a fresh seed per forward from
+            # torch's CPU generator (so torch.manual_seed reproduces runs); backward recomputes the same masks.
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            drop = (self._dropout_p[0], self._dropout_p[1], seed)
         self._refresh_shadow()
-        return self._rt.forward(video, self._arena, self._shadow, training=need_grad)
+        return self._rt.forward(video, self._arena, self._shadow, training=need_grad, dropout=drop)
 
     def _run_backward(self, dlogits):
         grads = self.flat_gradients()

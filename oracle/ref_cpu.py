@@ -105,17 +105,17 @@ def _gelu_grad(u: torch.Tensor) -> torch.Tensor:
 
 
 class _GeluEmu(torch.autograd.Function):
-    """h = bf16(gelu(u_fp32)); backward dU = bf16(dH * gelu'(bf16(u)))."""
+    """h = bf16(gelu(u_fp32) * mask); backward dU = bf16(dH * mask * gelu'(bf16(u))).  mask = dropout mask (or 1)."""
 
     @staticmethod
-    def forward(ctx, u):
-        ctx.save_for_backward(_r(u))
-        return _r(F.gelu(u))
+    def forward(ctx, u, mask):
+        ctx.save_for_backward(_r(u), mask)
+        return _r(F.gelu(u) * mask)
 
     @staticmethod
     def backward(ctx, dh):
-        (u16,) = ctx.saved_tensors
-        return _r(dh * _gelu_grad(u16))
+        u16, mask = ctx.saved_tensors
+        return _r(dh * mask * _gelu_grad(u16)), None
 
 
 class _AttnEmu(torch.autograd.Function):
@@ -133,7 +133,7 @@ class _AttnEmu(torch.autograd.Function):
     TK = 64   # key tile of the kernel's online softmax (csrc/attention.hip)
 
     @staticmethod
-    def forward(ctx, q, k, v, scale):
+    def forward(ctx, q, k, v, scale, mask=None):
         # Online softmax over 64-key tiles, exactly the kernel's schedule: P is rounded to bf16 relative to
         # the RUNNING row max of its tile (r(c*x) != c*r(x), so the rounding point matters at the 1e-3 level).
         n = k.shape[-2]
@@ -146,12 +146,14 @@ class _AttnEmu(torch.autograd.Function):
             alpha = torch.exp(m - mnew)
             p = torch.exp(s - mnew)
             l = l * alpha + p.sum(dim=-1, keepdim=True)
-            o = o * alpha + torch.matmul(_r(p), v[..., k0:k0 + _AttnEmu.TK, :])
+            pm = p if mask is None else p * mask[..., k0:k0 + _AttnEmu.TK]      # dropout hits P.V, not the normaliser
+            o = o * alpha + torch.matmul(_r(pm), v[..., k0:k0 + _AttnEmu.TK, :])
             m = mnew
         o = _r(o / l)
         lse = m + torch.log(l)
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.scale = scale
+        ctx.mask = mask
         return o
 
     @staticmethod
@@ -161,12 +163,42 @@ class _AttnEmu(torch.autograd.Function):
         do = _r(do)
         delta = (do * o).sum(dim=-1, keepdim=True)
         p = torch.exp(torch.matmul(q, k.transpose(-1, -2)) * scale - lse)
-        dv = torch.matmul(_r(p).transpose(-1, -2), do)
-        dp = torch.matmul(do, v.transpose(-1, -2))
+        mk = 1.0 if ctx.mask is None else ctx.mask
+        dv = torch.matmul(_r(p * mk).transpose(-1, -2), do)
+        dp = torch.matmul(do, v.transpose(-1, -2)) * mk
         ds = _r(p * (dp - delta))
         dq = torch.matmul(ds, k) * scale
         dk = torch.matmul(ds.transpose(-1, -2), q) * scale
-        return _r(dq), _r(dk), _r(dv), None
+        return _r(dq), _r(dk), _r(dv), None, None
+
+
+# --------------------------------------------------------------------------- dropout masks of the HIP path
+# The product uses a counter-based mask (csrc/common.h nv_hash32 / DropCfg): element idx of a site is kept iff
+# hash(site_seed, idx) >= p * 2^32 and scaled by 1/(1-p).  Restated here bit for bit so that dropout runs can be
+# checked against the oracle with IDENTICAL masks (torch's Philox stream cannot be matched - SURVEY.md 5 "RNG").
+_M64 = (1 << 64) - 1
+
+
+def site_seed(seed: int, site: int) -> int:
+    """csrc/engine.hip::site_seed - site = 4*layer + {0 attn probs, 1 to_out, 2 FF hidden, 3 FF out}; 4*depth = embedding."""
+    return (seed ^ ((0x9E3779B97F4A7C15 * (site + 1)) & _M64)) & _M64
+
+
+def drop_mask(seed: int, p: float, shape) -> torch.Tensor:
+    """fp32 tensor of `shape` holding 0 or 1/(1-p); element index = row-major position."""
+    if p <= 0:
+        return torch.ones(shape)
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64)
+        x = ((idx + np.uint64(0x9E3779B97F4A7C15)) * np.uint64(0xBF58476D1CE4E5B9)) ^ np.uint64(seed)
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+        h = (x >> np.uint64(16)) & np.uint64(0xFFFFFFFF)
+    thresh = np.uint64(0xFFFFFFFF) if p >= 1 else np.uint64(int(np.float32(p).astype(np.float64) * 4294967296.0))
+    scale = 0.0 if p >= 1 else float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+    return torch.from_numpy(np.where(h >= thresh, np.float32(scale), np.float32(0)).astype(np.float32).reshape(shape))
 
 
 # --------------------------------------------------------------------------- A1: patchify
@@ -214,8 +246,9 @@ def _linear(x, w, b, emulate):
     return F.linear(x, w, b)
 
 
-def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None):
-    """Attention.forward (vit_3d.py:48-60).  `pre` = 'transformer.layers.{i}.0.'."""
+def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None, drop=None):
+    """Attention.forward (vit_3d.py:48-60).  `pre` = 'transformer.layers.{i}.0.'.
+    drop = (p, seed_attn, seed_out) applies the HIP path's dropout masks (train mode, p > 0)."""
     B, n, d = x.shape
     inner = heads * dim_head
     xn = F.layer_norm(x, (d,), sd[pre + "norm.weight"], sd[pre + "norm.bias"], LN_EPS)
@@ -230,12 +263,13 @@ def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None):
     # 'b n (h d) -> b h n d'
     q, k, v = (t.reshape(B, n, heads, dim_head).permute(0, 2, 1, 3) for t in (q, k, v))
     scale = dim_head ** -0.5
+    amask = drop_mask(drop[1], drop[0], (B, heads, n, n)) if drop else None
     if emulate:
-        out = _AttnEmu.apply(q, k, v, scale)
+        out = _AttnEmu.apply(q, k, v, scale, amask)
     else:
         dots = torch.matmul(q, k.transpose(-1, -2)) * scale
         attn = torch.softmax(dots, dim=-1)
-        out = torch.matmul(attn, v)
+        out = torch.matmul(attn if amask is None else attn * amask, v)
         if taps is not None:
             taps[pre + "attn.rowsum"] = attn.sum(-1)
     # 'b h n d -> b n (h d)'
@@ -245,23 +279,32 @@ def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None):
         taps[pre + "attn.out"] = out
     if (pre + "to_out.0.weight") in sd:            # project_out (vit_3d.py:32,43-46)
         out = _linear(out, sd[pre + "to_out.0.weight"], sd[pre + "to_out.0.bias"], emulate)
+        if drop:
+            out = out * drop_mask(drop[2], drop[0], (B * n, out.shape[-1])).reshape(out.shape)
     return out
 
 
-def feed_forward(sd, pre, x, emulate=False):
-    """FeedForward.forward (vit_3d.py:16-26).  `pre` = 'transformer.layers.{i}.1.'."""
+def feed_forward(sd, pre, x, emulate=False, drop=None):
+    """FeedForward.forward (vit_3d.py:16-26).  `pre` = 'transformer.layers.{i}.1.'.  drop = (p, seed_hidden, seed_out)."""
     d = x.shape[-1]
+    rows = x.shape[0] * x.shape[1]
+    hmask = drop_mask(drop[1], drop[0], (rows, sd[pre + "net.1.weight"].shape[0])).reshape(x.shape[0], x.shape[1], -1) if drop else None
+    omask = drop_mask(drop[2], drop[0], (rows, d)).reshape(x.shape) if drop else None
     xn = F.layer_norm(x, (d,), sd[pre + "net.0.weight"], sd[pre + "net.0.bias"], LN_EPS)
     if emulate:
         u = _linear(_r(xn), sd[pre + "net.1.weight"], sd[pre + "net.1.bias"], True)
-        h = _GeluEmu.apply(u)
-        return _linear(h, sd[pre + "net.4.weight"], sd[pre + "net.4.bias"], True)
+        h = _GeluEmu.apply(u, torch.ones(()) if hmask is None else hmask)
+        y = _linear(h, sd[pre + "net.4.weight"], sd[pre + "net.4.bias"], True)
+        return y if omask is None else y * omask
     h = F.gelu(F.linear(xn, sd[pre + "net.1.weight"], sd[pre + "net.1.bias"]))
-    return F.linear(h, sd[pre + "net.4.weight"], sd[pre + "net.4.bias"])
+    if hmask is not None:
+        h = h * hmask
+    y = F.linear(h, sd[pre + "net.4.weight"], sd[pre + "net.4.bias"])
+    return y if omask is None else y * omask
 
 
-def patch_embed(sd, cfg: ViTCfg, video, emulate=False, taps=None):
-    """to_patch_embedding + cls/pos (vit_3d.py:91-96,113-119); dropout = identity (eval / p=0)."""
+def patch_embed(sd, cfg: ViTCfg, video, emulate=False, taps=None, drop=None):
+    """to_patch_embedding + cls/pos + emb dropout (vit_3d.py:91-96,113-119).  drop = (p_emb, seed) or None."""
     tok = patchify(video, cfg.image_patch_size, cfg.image_patch_size, cfg.frame_patch_size)
     P, d = cfg.patch_dim, cfg.dim
     a2 = F.layer_norm(tok, (P,), sd["to_patch_embedding.1.weight"], sd["to_patch_embedding.1.bias"], LN_EPS)
@@ -271,19 +314,26 @@ def patch_embed(sd, cfg: ViTCfg, video, emulate=False, taps=None):
     cls = sd["cls_token"].expand(B, 1, d)
     x = torch.cat((cls, a4), dim=1)
     x = x + sd["pos_embedding"][:, : n + 1]
+    if drop:
+        x = x * drop_mask(drop[1], drop[0], (B * (n + 1), d)).reshape(x.shape)
     if taps is not None:
         taps["A1"], taps["A2"], taps["A3"], taps["A4"], taps["A5"] = tok, a2, a3, a4, x
     return x
 
 
 def vit_forward(sd: Dict[str, torch.Tensor], cfg: ViTCfg, video: torch.Tensor,
-                emulate_bf16: bool = False, taps: Optional[dict] = None) -> torch.Tensor:
-    """ViT.forward (vit_3d.py:112-126), dropout inactive.  video: [B, C, F, H, W]."""
-    x = patch_embed(sd, cfg, video, emulate_bf16, taps)
+                emulate_bf16: bool = False, taps: Optional[dict] = None,
+                dropout: Optional[Tuple[float, float, int]] = None) -> torch.Tensor:
+    """ViT.forward (vit_3d.py:112-126).  video: [B, C, F, H, W].
+    dropout = None (eval / p = 0) or (p_blocks, p_embedding, seed): train-mode dropout with the HIP path's masks."""
+    dp = dropout if dropout and (dropout[0] > 0 or dropout[1] > 0) else None
+    x = patch_embed(sd, cfg, video, emulate_bf16, taps, (dp[1], site_seed(dp[2], 4 * cfg.depth)) if dp and dp[1] > 0 else None)
     for i in range(cfg.depth):
         pa, pf = f"transformer.layers.{i}.0.", f"transformer.layers.{i}.1."
-        x = attention(sd, pa, x, cfg.heads, cfg.dim_head, emulate_bf16, taps) + x
-        x = feed_forward(sd, pf, x, emulate_bf16) + x
+        da = (dp[0], site_seed(dp[2], 4 * i + 0), site_seed(dp[2], 4 * i + 1)) if dp and dp[0] > 0 else None
+        df = (dp[0], site_seed(dp[2], 4 * i + 2), site_seed(dp[2], 4 * i + 3)) if dp and dp[0] > 0 else None
+        x = attention(sd, pa, x, cfg.heads, cfg.dim_head, emulate_bf16, taps, da) + x
+        x = feed_forward(sd, pf, x, emulate_bf16, df) + x
         if taps is not None:
             taps[f"block{i}"] = x
     x = x.mean(dim=1) if cfg.pool == "mean" else x[:, 0]

@@ -56,7 +56,7 @@ def load_arena(engine, cfgdict, sd):
     return cfg, off, num, arena
 
 
-def run_case(engine, tag, cfgdict, seeds, B=2):
+def run_case(engine, tag, cfgdict, seeds, B=2, dropout=(0.0, 0.0, 0)):
     sd = W.make_tensors(W.vit_param_spec(**cfgdict), seeds[0])
     S = cfgdict["image_size"]
     fmri = W.make_volume((B, S, S, S), seeds[1])
@@ -66,13 +66,13 @@ def run_case(engine, tag, cfgdict, seeds, B=2):
     params16 = params.to(torch.bfloat16)
     rt = engine.VitRuntime(cfg)
     video = ref_cpu.fmri_to_video(fmri.cuda())
-    logits = rt.forward(video, params, params16, training=True)
+    logits = rt.forward(video, params, params16, training=True, dropout=dropout)
 
     # ---- oracles: bf16-emulating (same cast points) and exact fp32, both with autograd for the gradients
     def oracle(emulate):
         leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
         taps = {}
-        lg = ref_cpu.vit_forward(leaves, ocfg, ref_cpu.fmri_to_video(fmri), emulate_bf16=emulate, taps=taps)
+        lg = ref_cpu.vit_forward(leaves, ocfg, ref_cpu.fmri_to_video(fmri), emulate_bf16=emulate, taps=taps, dropout=dropout)
         return leaves, taps, lg
 
     leaves, taps, ref_logits = oracle(True)
@@ -127,6 +127,12 @@ def test_tiny_vs_emulating_oracle(eng, golden):
     """BASELINE.json configs[0]: ViT3D tiny (64^3, p16, d192, L4, h3), batch 2."""
     logits, _, _ = run_case(eng, "tiny", dict(W.TINY), (3, 4))
     check_g4("tiny", logits, golden("tiny_vit.npz")["logits"])
+
+
+def test_micro_train_mode_dropout_same_masks(eng):
+    """Train-mode dropout (vit_3d.py:21,23,39,45,100; config default 0.1): the oracle regenerates the product's
+    counter-based masks bit for bit, so forward stages, logits and every gradient are gated exactly as without dropout."""
+    run_case(eng, "micro+dropout", dict(W.MICRO), (1, 2), dropout=(0.1, 0.2, 123456789))
 
 
 def test_inference_mode_matches_training_forward(eng):

@@ -192,3 +192,34 @@ def test_fused_step_equals_stock_optimizer_step(nv):
     pa, _ = a.volume_encoder.vit3d.flat_parameters()
     pb, _ = b.volume_encoder.vit3d.flat_parameters()
     assert rel_err(pa, pb) < 1e-6
+
+
+def test_dropout_train_eval_semantics(nv):
+    """TRAINING_DROPOUT > 0: stochastic in train mode (fresh mask per forward, reproducible under torch.manual_seed),
+    deterministic in eval mode, and trainable end to end."""
+    size = dict(TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
+    cfg = W.neuro_config(32, 8, DEVICE="cuda", TRAINING_DROPOUT=0.1, TRAINING_LEARNING_RATE=1e-3, **size)
+    model = nv.NeuroEncoder(cfg)
+    model.load_state_dict(W.make_tensors(W.vit_param_spec(**W.MICRO), 1, prefix="volume_encoder.vit3d."), strict=True)
+    x = W.make_volume((2, 32, 32, 32), 2).cuda()
+    model.train()
+    torch.manual_seed(7)
+    a = model(x).detach().clone()
+    b = model(x).detach().clone()
+    torch.manual_seed(7)
+    c = model(x).detach().clone()
+    assert not torch.equal(a, b) and torch.equal(a, c)
+    model.eval()
+    with torch.no_grad():
+        e1, e2 = model(x).clone(), model(x).clone()
+    assert torch.equal(e1, e2)
+    # expectation over masks is close to the eval output (dropout is unbiased up to the nonlinearity)
+    model.train()
+    with torch.no_grad():
+        mean = torch.stack([model(x) for _ in range(64)]).mean(0)
+    assert rel_err(mean, e1) < 0.25
+    from neurovit_amd.trainer import TrainStep
+    step = TrainStep(model)
+    y = torch.tensor([0, 1], device="cuda")
+    losses = [step(x, y).item() for _ in range(8)]
+    assert all(np.isfinite(losses)) and min(losses[4:]) < losses[0]
