@@ -113,6 +113,7 @@ int nv_ce_loss(const float* logits, const long* target, int B, int C, float grad
 int nv_adamw_step(float* p, const float* grad, float* m, float* v, void* p16, long count, int step, double lr, double beta1,
                   double beta2, double eps, double weight_decay, float grad_scale, void* stream);
 int nv_cast_bf16_2d(const float* src, long ld_src, int rows, int cols, void* dst, long ld_dst, void* stream);
+int nv_copy_2d_f32(const float* src, long ld_src, int rows, int cols, float* dst, long ld_dst, int accumulate, void* stream);
 
 /* ---- whole-encoder engine: ViT.forward / its backward as ONE call each (vit_3d.py:112-126)
  * Parameters live in one flat fp32 arena (+ a bf16 shadow with identical element offsets) laid out by

@@ -227,7 +227,6 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   NV_CHECK_ARG(video && strides5 && params && params16 && workspace && dlogits && grads, "nv_vit_backward: null pointer");
   NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_backward: workspace too small (%ld < %ld) - forward must run with training=1", ws_bytes, W.total);
   NV_CHECK_ARG(nv_aligned16(grads), "nv_vit_backward: grads must be 16-byte aligned");
-  NV_CHECK_ARG(D.P == D.Ppad, "nv_vit_backward: patch_dim=%d not a multiple of 8 is not supported yet", D.P);
   char* ws = (char*)workspace;
   const float* p = params;
   const bf16* p16 = (const bf16*)params16;
@@ -281,8 +280,16 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   float* pst = (float*)(ws + W.pst);
   RUN(nv_embed_finish_bwd(g, d, (float*)(ws + W.t), d, est, est + D.T, p + T.pe_g2, B, D.N, d, (float*)(ws + W.dt), d, ws + W.dt16, d, gr + T.pe_g2,
                           gr + T.pe_b2, gr + T.pe_bias, gr + T.pos, gr + T.cls, acc, red, W.red_bytes, site_seed(drop_seed, 4 * D.L), emb_drop_p, stream));
-  RUN(nv_gemm_bf16(2, 1, d, D.P, D.T, ws + W.dt16, d, ws + W.xp, D.Ppad, gr + T.pe_w, D.P, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));   // dWpe = dt^T xp
-  RUN(nv_gemm_bf16(1, 1, D.T, D.P, d, ws + W.dt16, d, p16 + T.pe_w, D.P, ws + W.dxp, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream)); // dxp = dt Wpe
+  // patch_dim not a multiple of 8 (reference default 90^3 / p 9 -> P = 729): operands are zero padded to Ppad columns;
+  // the weight gradient is produced in a padded scratch matrix and its valid columns copied / added into the arena.
+  const void* wpe = (D.P != D.Ppad) ? (const void*)(ws + W.wpe16) : (const void*)(p16 + T.pe_w);
+  if (D.P != D.Ppad) {
+    RUN(nv_gemm_bf16(2, 1, d, D.Ppad, D.T, ws + W.dt16, d, ws + W.xp, D.Ppad, ws + W.dwpe, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+    RUN(nv_copy_2d_f32((float*)(ws + W.dwpe), D.Ppad, d, D.P, gr + T.pe_w, D.P, acc, stream));
+  } else {
+    RUN(nv_gemm_bf16(2, 1, d, D.P, D.T, ws + W.dt16, d, ws + W.xp, D.Ppad, gr + T.pe_w, D.P, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));   // dWpe = dt^T xp
+  }
+  RUN(nv_gemm_bf16(1, 1, D.T, D.Ppad, d, ws + W.dt16, d, wpe, D.Ppad, ws + W.dxp, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));           // dxp = dt Wpe
   RUN(nv_patch_ln_bwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
                       cfg->image_patch_size, cfg->frame_patch_size, (float*)(ws + W.dxp), D.Ppad, pst, pst + D.T, gr + T.pe_g, gr + T.pe_b, acc, red,
                       W.red_bytes, stream));

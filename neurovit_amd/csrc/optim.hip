@@ -112,3 +112,24 @@ extern "C" int nv_ce_loss(const float* logits, const long* target, int B, int C,
   NV_CHECK_LAUNCH("nv_ce_loss");
   return NV_OK;
 }
+
+// dst[r, c] (=|+=) src[r, c] for c < cols: strips the column padding of a [rows, ld_src] fp32 scratch matrix
+// (weight gradient of the patch embedding when patch_dim is not a multiple of 8, e.g. the reference default p = 9).
+__global__ __launch_bounds__(256) void copy_2d_f32_kernel(const float* __restrict__ src, long ld_src, int rows, int cols, float* __restrict__ dst,
+                                                          long ld_dst, int accumulate) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * cols) return;
+  const long r = idx / cols, c = idx - r * cols;
+  const float v = src[r * ld_src + c];
+  float* o = dst + r * ld_dst + c;
+  *o = accumulate ? *o + v : v;
+}
+
+extern "C" int nv_copy_2d_f32(const float* src, long ld_src, int rows, int cols, float* dst, long ld_dst, int accumulate, void* stream) {
+  NV_CHECK_ARG(rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols && src && dst, "nv_copy_2d_f32: bad dims");
+  const long tot = (long)rows * cols;
+  hipLaunchKernelGGL(copy_2d_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, cols, dst,
+                     ld_dst, accumulate);
+  NV_CHECK_LAUNCH("nv_copy_2d_f32");
+  return NV_OK;
+}

@@ -135,6 +135,13 @@ def test_micro_train_mode_dropout_same_masks(eng):
     run_case(eng, "micro+dropout", dict(W.MICRO), (1, 2), dropout=(0.1, 0.2, 123456789))
 
 
+def test_odd_patch_size_like_reference_default(eng):
+    """The reference's default geometry is 90^3 / patch 9 (configs/config.yaml:39-40): patch_dim = 729 is not a multiple
+    of 8 (scalar gather path, zero-padded GEMM operands, padded weight-gradient scratch) and n = N+1 is odd."""
+    cfgdict = dict(W.MICRO, image_size=27, image_patch_size=9, frames=27, frame_patch_size=9)
+    run_case(eng, "p9", cfgdict, (5, 6))
+
+
 def test_inference_mode_matches_training_forward(eng):
     cfgdict = dict(W.MICRO)
     sd = W.make_tensors(W.vit_param_spec(**cfgdict), 1)
