@@ -350,12 +350,21 @@ __device__ __forceinline__ void ws_issue(__amdgpu_buffer_rsrc_t rsrc, const int*
   for (int i = 0; i < N; ++i)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(img + (lw + 4 * i) * 1024), 16, voff[i], soff, 0, 0);
 }
-template <int N> __device__ __forceinline__ void ws_wait_one_tile_in_flight();
-template <> __device__ __forceinline__ void ws_wait_one_tile_in_flight<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-template <> __device__ __forceinline__ void ws_wait_one_tile_in_flight<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-template <> __device__ __forceinline__ void ws_wait_one_tile_in_flight<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+// wait until at most `tiles` K tiles (PIECES DMA instructions each) of this wave are still in flight
+#define WS_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+template <int PIECES>
+__device__ __forceinline__ void ws_wait_tiles_in_flight(int tiles) {
+  if constexpr (PIECES == 8) {
+    switch (tiles) { case 0: WS_VM(0); break; case 1: WS_VM(8); break; case 2: WS_VM(16); break; case 3: WS_VM(24); break; case 4: WS_VM(32); break; default: WS_VM(40); }
+  } else if constexpr (PIECES == 6) {
+    switch (tiles) { case 0: WS_VM(0); break; case 1: WS_VM(6); break; case 2: WS_VM(12); break; case 3: WS_VM(18); break; case 4: WS_VM(24); break; default: WS_VM(30); }
+  } else {
+    switch (tiles) { case 0: WS_VM(0); break; case 1: WS_VM(4); break; case 2: WS_VM(8); break; case 3: WS_VM(12); break; case 4: WS_VM(16); break; default: WS_VM(20); }
+  }
+}
+#undef WS_VM
 
-template <int BM, int BN, bool A_T, bool B_T, int EPI>
+template <int BM, int BN, int S, bool A_T, bool B_T, int EPI>     // S = LDS ring stages (loaders run S-1 K tiles ahead)
 __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
@@ -367,9 +376,8 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (g.col_order ? bid % tiles_m : bid / tiles_n) * BM, n0 = (g.col_order ? bid / tiles_m : bid % tiles_n) * BN;
   const int nk = (g.K + BK - 1) / BK;
-  char* s0 = smem;
-  char* s1 = smem + STAGE;
-  char* s2 = smem + 2 * STAGE;
+  constexpr int D = S - 1;
+  static_assert(S >= 3 && S <= 7, "ring depth");
 
   if (wid >= 4) {
     // ------------------------------------------------------------------ loader waves
@@ -382,29 +390,23 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
     ws_offsets<A_T, BM>(g.lda, m0, lw, lane, voA);
     ws_offsets<B_T, BN>(g.ldb, n0, lw, lane, voB);
     const int stepA = (int)((A_T ? (long)BK * g.lda : BK) * 2), stepB = (int)((B_T ? (long)BK * g.ldb : BK) * 2);
-    ws_issue<BM / 32>(rA, voA, 0, s0, lw);
-    ws_issue<BN / 32>(rB, voB, 0, s0 + A_BYTES, lw);
-    if (nk > 1) {
-      ws_issue<BM / 32>(rA, voA, stepA, s1, lw);
-      ws_issue<BN / 32>(rB, voB, stepB, s1 + A_BYTES, lw);
-      ws_wait_one_tile_in_flight<PIECES>();
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int pre = nk < D ? nk : D;
+    for (int t = 0; t < pre; ++t) {
+      ws_issue<BM / 32>(rA, voA, t * stepA, smem + t * STAGE, lw);
+      ws_issue<BN / 32>(rB, voB, t * stepB, smem + t * STAGE + A_BYTES, lw);
     }
+    ws_wait_tiles_in_flight<PIECES>(pre - 1);
     __builtin_amdgcn_s_barrier();                       // barrier -1: tile 0 is in LDS
-    char* fill = s2;
-    char* f1 = s0;
-    char* f2 = s1;
+    int fs = D % S;                                     // ring slot of tile kt + D
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 2 < nk) {                                // stage of tile kt-1: every consumer read retired at barrier kt-1
-        ws_issue<BM / 32>(rA, voA, (kt + 2) * stepA, fill, lw);
-        ws_issue<BN / 32>(rB, voB, (kt + 2) * stepB, fill + A_BYTES, lw);
-        ws_wait_one_tile_in_flight<PIECES>();           // tile kt+1 landed (this wave's share)
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (kt + D < nk) {                // slot of tile kt-1: every consumer read retired at barrier kt-1
+        ws_issue<BM / 32>(rA, voA, (kt + D) * stepA, smem + fs * STAGE, lw);
+        ws_issue<BN / 32>(rB, voB, (kt + D) * stepB, smem + fs * STAGE + A_BYTES, lw);
       }
+      const int last = (kt + D < nk) ? kt + D : nk - 1; // newest tile issued so far
+      ws_wait_tiles_in_flight<PIECES>(last - (kt + 1) > 0 ? last - (kt + 1) : 0);   // tile kt+1 landed (this wave's share)
       __builtin_amdgcn_s_barrier();                     // barrier kt
-      char* t = fill; fill = f1; f1 = f2; f2 = t;
+      fs = (fs + 1 == S) ? 0 : fs + 1;
     }
     return;
   }
@@ -417,9 +419,9 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
-  char* cur = s0;
-  char* nxt = s1;
-  char* aft = s2;
+  int ci = 0;                                           // ring slot of the current tile
+  char* cur = smem;
+  char* nxt = smem + STAGE;
 
 #define WS_READ(FA, FB, BUF, KS)                                                                        \
   _Pragma("unroll") for (int i = 0; i < MI; ++i) FA[i] = read_frag<A_T, BM>(BUF, wm * TM + 16 * i, KS, lane); \
@@ -439,7 +441,9 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
     __builtin_amdgcn_s_barrier();                       // barrier kt: tile kt+1 complete
     SB WS_READ(fa0, fb0, nxt, 0)
     SB WS_MFMA(fa1, fb1) SB
-    char* t = cur; cur = nxt; nxt = aft; aft = t;
+    ci = (ci + 1 == S) ? 0 : ci + 1;
+    cur = nxt;
+    nxt = smem + ((ci + 1 == S) ? 0 : ci + 1) * STAGE;
   }
   WS_READ(fa1, fb1, cur, 1)                             // last tile
   SB WS_MFMA(fa0, fb0)
@@ -452,9 +456,11 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
+static int g_ring_override = 0;   // 0 heuristic, 1 shallow (3 stages), 2 deep
 static int g_tile_override = 0;   // 0 = heuristic; 1..3 = warp-specialised 128x128 / 128x64 / 64x128; else BM*1000 + BN (small-tile kernel)
 extern "C" int nv_gemm_set_tile(int bm, int bn) {   // tuning aid (tools/gemm_bench.py)
   g_tile_override = (bm == 0) ? 0 : (bm <= 3 ? bm : bm * 1000 + bn);
+  g_ring_override = (bm >= 1 && bm <= 3) ? bn : 0;      // for the warp-specialised tiles bn selects the ring: 1 shallow, 2 deep
   return 0;
 }
 
@@ -475,11 +481,11 @@ static int launch_tile(const GemmArgs& a, hipStream_t s) {
   return NV_OK;
 }
 
-template <int BM, int BN, bool A_T, bool B_T, int EPI>
+template <int BM, int BN, int S, bool A_T, bool B_T, int EPI>
 static int launch_ws(const GemmArgs& a, hipStream_t s) {
-  constexpr int LDS = 3 * (BM + BN) * BK * 2;
+  constexpr int LDS = S * (BM + BN) * BK * 2;
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  auto kern = gemm_ws_kernel<BM, BN, A_T, B_T, EPI>;
+  auto kern = gemm_ws_kernel<BM, BN, S, A_T, B_T, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -505,9 +511,13 @@ static int launch(const GemmArgs& a, hipStream_t s) {
     // measured on the ViT3D-base shapes (M = 2052): the 64x128 tile wins or ties everywhere (two workgroups per CU, so
     // one block's epilogue overlaps the other's MFMA phase); very large problems prefer 128x128 (less LDS / L2 traffic)
     if (ws == 0 && t128 >= 32) ws = (t128 >= 1024) ? 1 : 3;
-    if (ws == 1) return launch_ws<128, 128, A_T, B_T, EPI>(a, s);
-    if (ws == 2) return launch_ws<128, 64, A_T, B_T, EPI>(a, s);
-    if (ws == 3) return launch_ws<64, 128, A_T, B_T, EPI>(a, s);
+    // ring depth: when the grid gives every CU at most one workgroup, one deep ring (6 x 24 KiB / 4 x 32 KiB) keeps the
+    // same number of bytes in flight as two co-resident 3-stage workgroups would
+    const long t64 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
+    const bool deep = (g_ring_override == 2) || (g_ring_override == 0 && ((ws == 1) ? t128 <= 256 : t64 <= 256));
+    if (ws == 1) return deep ? launch_ws<128, 128, 4, A_T, B_T, EPI>(a, s) : launch_ws<128, 128, 3, A_T, B_T, EPI>(a, s);
+    if (ws == 2) return deep ? launch_ws<128, 64, 6, A_T, B_T, EPI>(a, s) : launch_ws<128, 64, 3, A_T, B_T, EPI>(a, s);
+    if (ws == 3) return deep ? launch_ws<64, 128, 6, A_T, B_T, EPI>(a, s) : launch_ws<64, 128, 3, A_T, B_T, EPI>(a, s);
   }
   int sel = g_tile_override >= 1000 ? g_tile_override : 0;
   if (!sel) {
