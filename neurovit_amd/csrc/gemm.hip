@@ -354,7 +354,12 @@ __device__ __forceinline__ void ws_issue(__amdgpu_buffer_rsrc_t rsrc, const int*
 #define WS_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 template <int PIECES>
 __device__ __forceinline__ void ws_wait_tiles_in_flight(int tiles) {
-  if constexpr (PIECES == 8) {
+  static_assert(PIECES == 4 || PIECES == 6 || PIECES == 8 || PIECES == 12 || PIECES == 16, "unsupported DMA piece count");
+  if constexpr (PIECES == 16) {
+    switch (tiles) { case 0: WS_VM(0); break; case 1: WS_VM(16); break; case 2: WS_VM(32); break; default: WS_VM(48); }
+  } else if constexpr (PIECES == 12) {
+    switch (tiles) { case 0: WS_VM(0); break; case 1: WS_VM(12); break; case 2: WS_VM(24); break; case 3: WS_VM(36); break; default: WS_VM(48); }
+  } else if constexpr (PIECES == 8) {
     switch (tiles) { case 0: WS_VM(0); break; case 1: WS_VM(8); break; case 2: WS_VM(16); break; case 3: WS_VM(24); break; case 4: WS_VM(32); break; default: WS_VM(40); }
   } else if constexpr (PIECES == 6) {
     switch (tiles) { case 0: WS_VM(0); break; case 1: WS_VM(6); break; case 2: WS_VM(12); break; case 3: WS_VM(18); break; case 4: WS_VM(24); break; default: WS_VM(30); }
@@ -364,20 +369,20 @@ __device__ __forceinline__ void ws_wait_tiles_in_flight(int tiles) {
 }
 #undef WS_VM
 
-template <int BM, int BN, int S, bool A_T, bool B_T, int EPI>     // S = LDS ring stages (loaders run S-1 K tiles ahead)
+template <int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>   // S = LDS ring stages, KS = 64-deep sub-tiles per stage
 __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
+  constexpr int A_BYTES = BM * BK * 2, SUB = (BM + BN) * BK * 2, STAGE = KS * SUB;
   constexpr int TM = BM / 2, TN = BN / 2, MI = TM / 16, NI = TN / 16;
-  constexpr int PIECES = BM / 32 + BN / 32;      // DMA instructions per loader wave per K tile
+  constexpr int PIECES = KS * (BM / 32 + BN / 32);      // DMA instructions per loader wave per stage
+  constexpr int D = S - 1;
+  static_assert(S >= 3 && S <= 7 && (KS == 1 || KS == 2), "ring geometry");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (g.col_order ? bid % tiles_m : bid / tiles_n) * BM, n0 = (g.col_order ? bid / tiles_m : bid % tiles_n) * BN;
-  const int nk = (g.K + BK - 1) / BK;
-  constexpr int D = S - 1;
-  static_assert(S >= 3 && S <= 7, "ring depth");
+  const int nk = ((g.K + BK - 1) / BK + KS - 1) / KS;   // ring stages to process
 
   if (wid >= 4) {
     // ------------------------------------------------------------------ loader waves
@@ -390,21 +395,22 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
     ws_offsets<A_T, BM>(g.lda, m0, lw, lane, voA);
     ws_offsets<B_T, BN>(g.ldb, n0, lw, lane, voB);
     const int stepA = (int)((A_T ? (long)BK * g.lda : BK) * 2), stepB = (int)((B_T ? (long)BK * g.ldb : BK) * 2);
-    const int pre = nk < D ? nk : D;
-    for (int t = 0; t < pre; ++t) {
-      ws_issue<BM / 32>(rA, voA, t * stepA, smem + t * STAGE, lw);
-      ws_issue<BN / 32>(rB, voB, t * stepB, smem + t * STAGE + A_BYTES, lw);
-    }
-    ws_wait_tiles_in_flight<PIECES>(pre - 1);
-    __builtin_amdgcn_s_barrier();                       // barrier -1: tile 0 is in LDS
-    int fs = D % S;                                     // ring slot of tile kt + D
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + D < nk) {                // slot of tile kt-1: every consumer read retired at barrier kt-1
-        ws_issue<BM / 32>(rA, voA, (kt + D) * stepA, smem + fs * STAGE, lw);
-        ws_issue<BN / 32>(rB, voB, (kt + D) * stepB, smem + fs * STAGE + A_BYTES, lw);
+    auto issue_stage = [&](int t, char* dst) {
+#pragma unroll
+      for (int u = 0; u < KS; ++u) {
+        ws_issue<BM / 32>(rA, voA, (t * KS + u) * stepA, dst + u * SUB, lw);
+        ws_issue<BN / 32>(rB, voB, (t * KS + u) * stepB, dst + u * SUB + A_BYTES, lw);
       }
-      const int last = (kt + D < nk) ? kt + D : nk - 1; // newest tile issued so far
-      ws_wait_tiles_in_flight<PIECES>(last - (kt + 1) > 0 ? last - (kt + 1) : 0);   // tile kt+1 landed (this wave's share)
+    };
+    const int pre = nk < D ? nk : D;
+    for (int t = 0; t < pre; ++t) issue_stage(t, smem + t * STAGE);
+    ws_wait_tiles_in_flight<PIECES>(pre - 1);
+    __builtin_amdgcn_s_barrier();                       // barrier -1: stage 0 is in LDS
+    int fs = D % S;                                     // ring slot of stage kt + D
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + D < nk) issue_stage(kt + D, smem + fs * STAGE);   // slot of stage kt-1: every consumer read retired at barrier kt-1
+      const int last = (kt + D < nk) ? kt + D : nk - 1; // newest stage issued so far
+      ws_wait_tiles_in_flight<PIECES>(last - (kt + 1) > 0 ? last - (kt + 1) : 0);   // stage kt+1 landed (this wave's share)
       __builtin_amdgcn_s_barrier();                     // barrier kt
       fs = (fs + 1 == S) ? 0 : fs + 1;
     }
@@ -419,34 +425,47 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
-  int ci = 0;                                           // ring slot of the current tile
+  int ci = 0;                                           // ring slot of the current stage
   char* cur = smem;
   char* nxt = smem + STAGE;
 
-#define WS_READ(FA, FB, BUF, KS)                                                                        \
-  _Pragma("unroll") for (int i = 0; i < MI; ++i) FA[i] = read_frag<A_T, BM>(BUF, wm * TM + 16 * i, KS, lane); \
-  _Pragma("unroll") for (int j = 0; j < NI; ++j) FB[j] = read_frag<B_T, BN>(BUF + A_BYTES, wn * TN + 16 * j, KS, lane);
+// half step HS of a stage = sub-tile HS/2, 32-deep k half HS%2
+#define WS_READ(FA, FB, BUF, HS)                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) FA[i] = read_frag<A_T, BM>(BUF + ((HS) >> 1) * SUB, wm * TM + 16 * i, (HS) & 1, lane); \
+  _Pragma("unroll") for (int j = 0; j < NI; ++j) FB[j] = read_frag<B_T, BN>(BUF + ((HS) >> 1) * SUB + A_BYTES, wn * TN + 16 * j, (HS) & 1, lane);
 #define WS_MFMA(FA, FB)                                                       \
   _Pragma("unroll") for (int i = 0; i < MI; ++i)                             \
     _Pragma("unroll") for (int j = 0; j < NI; ++j)                           \
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[i][j], 0, 0, 0);
-#define SB __builtin_amdgcn_sched_barrier(0);   // pin the phase order: [reads][MFMAs][barrier][reads][MFMAs]
+#define SB __builtin_amdgcn_sched_barrier(0);   // pin the phase order: [reads of the next half step][MFMAs of this one]
 
   __builtin_amdgcn_s_barrier();                         // barrier -1
   WS_READ(fa0, fb0, cur, 0)
   for (int kt = 0; kt + 1 < nk; ++kt) {
     WS_READ(fa1, fb1, cur, 1)
     SB WS_MFMA(fa0, fb0) SB
+    if constexpr (KS == 2) {
+      WS_READ(fa0, fb0, cur, 2)
+      SB WS_MFMA(fa1, fb1) SB
+      WS_READ(fa1, fb1, cur, 3)
+      SB WS_MFMA(fa0, fb0) SB
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // all reads of `cur` have returned before it can be refilled
-    __builtin_amdgcn_s_barrier();                       // barrier kt: tile kt+1 complete
+    __builtin_amdgcn_s_barrier();                       // barrier kt: stage kt+1 complete
     SB WS_READ(fa0, fb0, nxt, 0)
     SB WS_MFMA(fa1, fb1) SB
     ci = (ci + 1 == S) ? 0 : ci + 1;
     cur = nxt;
     nxt = smem + ((ci + 1 == S) ? 0 : ci + 1) * STAGE;
   }
-  WS_READ(fa1, fb1, cur, 1)                             // last tile
-  SB WS_MFMA(fa0, fb0)
+  WS_READ(fa1, fb1, cur, 1)                             // last stage
+  SB WS_MFMA(fa0, fb0) SB
+  if constexpr (KS == 2) {
+    WS_READ(fa0, fb0, cur, 2)
+    SB WS_MFMA(fa1, fb1) SB
+    WS_READ(fa1, fb1, cur, 3)
+    SB WS_MFMA(fa0, fb0) SB
+  }
   __builtin_amdgcn_s_barrier();                         // barrier nk-1 (pairs with the loaders' last one)
   WS_MFMA(fa1, fb1)
 #undef WS_READ
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
-static int g_ring_override = 0;   // 0 heuristic, 1 shallow (3 stages), 2 deep
+static int g_ring_override = 0;   // 0 heuristic, 1 = 3 x 64, 2 = deep x 64, 3 = 3 x 128
 static int g_tile_override = 0;   // 0 = heuristic; 1..3 = warp-specialised 128x128 / 128x64 / 64x128; else BM*1000 + BN (small-tile kernel)
 extern "C" int nv_gemm_set_tile(int bm, int bn) {   // tuning aid (tools/gemm_bench.py)
   g_tile_override = (bm == 0) ? 0 : (bm <= 3 ? bm : bm * 1000 + bn);
@@ -481,11 +500,12 @@ static int launch_tile(const GemmArgs& a, hipStream_t s) {
   return NV_OK;
 }
 
-template <int BM, int BN, int S, bool A_T, bool B_T, int EPI>
+template <int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>
 static int launch_ws(const GemmArgs& a, hipStream_t s) {
-  constexpr int LDS = S * (BM + BN) * BK * 2;
+  constexpr int LDS = S * KS * (BM + BN) * BK * 2;
+  static_assert(LDS <= 160 * 1024, "LDS ring too large");
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  auto kern = gemm_ws_kernel<BM, BN, S, A_T, B_T, EPI>;
+  auto kern = gemm_ws_kernel<BM, BN, S, KS, A_T, B_T, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -511,13 +531,18 @@ static int launch(const GemmArgs& a, hipStream_t s) {
     // measured on the ViT3D-base shapes (M = 2052): the 64x128 tile wins or ties everywhere (two workgroups per CU, so
     // one block's epilogue overlaps the other's MFMA phase); very large problems prefer 128x128 (less LDS / L2 traffic)
     if (ws == 0 && t128 >= 32) ws = (t128 >= 1024) ? 1 : 3;
-    // ring depth: when the grid gives every CU at most one workgroup, one deep ring (6 x 24 KiB / 4 x 32 KiB) keeps the
-    // same number of bytes in flight as two co-resident 3-stage workgroups would
-    const long t64 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
-    const bool deep = (g_ring_override == 2) || (g_ring_override == 0 && ((ws == 1) ? t128 <= 256 : t64 <= 256));
-    if (ws == 1) return deep ? launch_ws<128, 128, 4, A_T, B_T, EPI>(a, s) : launch_ws<128, 128, 3, A_T, B_T, EPI>(a, s);
-    if (ws == 2) return deep ? launch_ws<128, 64, 6, A_T, B_T, EPI>(a, s) : launch_ws<128, 64, 3, A_T, B_T, EPI>(a, s);
-    if (ws == 3) return deep ? launch_ws<64, 128, 6, A_T, B_T, EPI>(a, s) : launch_ws<64, 128, 3, A_T, B_T, EPI>(a, s);
+    // ring geometry: 1 = 3 stages x 64-deep, 2 = deep ring (6 / 4 stages x 64), 3 = 3 stages x 128-deep (one barrier per 128 of K;
+    // needs whole 128-deep steps unless both operands are K-strided, where the buffer bounds zero-fill)
+    int ring = g_ring_override;
+    const bool k128_ok = ((a.K % (2 * BK)) == 0) || (A_T && B_T);
+    // measured (profiles/r01_gemm_shapes_tiles.log): 128-deep steps win when the grid leaves one workgroup per CU anyway and
+    // K is long; otherwise two co-resident 3 x 64 workgroups per CU (72 KiB each) overlap each other's epilogue and waits
+    const long t64x128 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
+    if (ring == 0) ring = (k128_ok && t64x128 <= 256 && a.K >= 1536) ? 3 : 1;
+    if (ring == 3 && !k128_ok) ring = 1;
+    if (ws == 1) return ring == 2 ? launch_ws<128, 128, 4, 1, A_T, B_T, EPI>(a, s) : launch_ws<128, 128, 3, 1, A_T, B_T, EPI>(a, s);
+    if (ws == 2) return ring == 3 ? launch_ws<128, 64, 3, 2, A_T, B_T, EPI>(a, s) : (ring == 2 ? launch_ws<128, 64, 6, 1, A_T, B_T, EPI>(a, s) : launch_ws<128, 64, 3, 1, A_T, B_T, EPI>(a, s));
+    if (ws == 3) return ring == 3 ? launch_ws<64, 128, 3, 2, A_T, B_T, EPI>(a, s) : (ring == 2 ? launch_ws<64, 128, 6, 1, A_T, B_T, EPI>(a, s) : launch_ws<64, 128, 3, 1, A_T, B_T, EPI>(a, s));
   }
   int sel = g_tile_override >= 1000 ? g_tile_override : 0;
   if (!sel) {
