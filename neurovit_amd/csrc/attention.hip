@@ -102,17 +102,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t, ks, r, g), qf[ks], s[t], 0, 0, 0);
     }
-    float mloc = -INFINITY;
+    // softmax bookkeeping on the RAW scores (scale_log2e > 0, so max commutes with the scaling); the scaling itself is
+    // folded into one fma in front of exp2.  Only the last key tile can hold out-of-range keys.
+    if (kt == nkt - 1) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = kt * TK + 16 * t + 4 * g + j;
-        const float v = (key < n) ? s[t][j] * scale_log2e : -INFINITY;
-        s[t][j] = v;
-        mloc = fmaxf(mloc, v);
-      }
-    const float mnew = fmaxf(m, group_max(mloc));
+        for (int j = 0; j < 4; ++j)
+          if (kt * TK + 16 * t + 4 * g + j >= n) s[t][j] = -INFINITY;
+    }
+    float mloc = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+    mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3])), fmaxf(fmaxf(s[3][0], s[3][1]), fmaxf(s[3][2], s[3][3]))));
+    const float mnew = fmaxf(m, group_max(mloc) * scale_log2e);
+    const bool moved = mnew != m;                 // running max unchanged for every row of this wave -> skip the rescale
     const float alpha = exp2f(m - mnew);
     m = mnew;
     float psum = 0.f;
@@ -120,11 +122,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float p = exp2f(s[t][j] - mnew);
+        const float p = exp2f(fmaf(s[t][j], scale_log2e, -mnew));
         s[t][j] = p;
         psum += p;
       }
-    l = l * alpha + psum;
+    if (__any(moved)) {
+      l = l * alpha + psum;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[t] *= alpha;
+    } else {
+      l += psum;
+    }
     if (drop.thresh) {      // attention dropout (vit_3d.py:56): mask the probabilities that enter P.V, not the normaliser
       const unsigned long long base = (((unsigned long long)blockIdx.y * n + (q0 + r)) * n) + (unsigned long long)kt * TK;
 #pragma unroll
@@ -132,8 +140,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[t][j] *= drop_factor(drop, base + 16 * t + 4 * g + j);
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) o[t] *= alpha;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const bf16x8 pf = cvt8(s[2 * ks], s[2 * ks + 1]);
@@ -228,9 +234,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int key = kt * TK + 16 * t + 4 * g + j;
-        const float p = (key < n) ? exp2f(s[j] * scale_log2e - lse2) : 0.f;
-        const float f = drop.thresh ? drop_factor(drop, (((unsigned long long)blockIdx.y * n + (q0 + r)) * n) + key) : 1.f;
-        ds[t][j] = p * (dp[j] * f - dl);
+        const float p = (key < n) ? exp2f(fmaf(s[j], scale_log2e, -lse2)) : 0.f;
+        if (drop.thresh) dp[j] *= drop_factor(drop, (((unsigned long long)blockIdx.y * n + (q0 + r)) * n) + key);
+        ds[t][j] = p * (dp[j] - dl);
       }
     }
 #pragma unroll
@@ -317,8 +323,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + 16 * t + 4 * g);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float pv = exp2f(s[j] * scale_log2e - l4[j]);
-        const float f = drop.thresh ? drop_factor(drop, (((unsigned long long)blockIdx.y * n + (qt * TQ + 16 * t + 4 * g + j)) * n) + (key0 + r)) : 1.f;
+        const float pv = exp2f(fmaf(s[j], scale_log2e, -l4[j]));
+        float f = 1.f;
+        if (drop.thresh) f = drop_factor(drop, (((unsigned long long)blockIdx.y * n + (qt * TQ + 16 * t + 4 * g + j)) * n) + (key0 + r));
         p[t][j] = pv * f;
         ds[t][j] = pv * (dp[j] * f - d4[j]);
       }

@@ -88,3 +88,12 @@ class FusedAdamW(torch.optim.Optimizer):
         if not self._bound:
             self._bind()
         self._steps += 1
+
+    @torch.no_grad()
+    def step_rest(self):
+        """Parameters outside the arenas (after the arena ranges were stepped bucket by bucket)."""
+        if self._rest is not None:
+            g0 = self.param_groups[0]
+            for g in self._rest.param_groups:
+                g["lr"] = g0["lr"]
+            self._rest.step()

@@ -28,13 +28,16 @@ def bucket_stages(n_stages: int, n_buckets: int) -> List[Tuple[int, int]]:
 
 
 class GradSync:
-    """All-reduce (SUM) of gradient-arena ranges as they become final.  Device agnostic: with CUDA tensors the
-    collectives run on a dedicated stream behind an event; with CPU tensors (gloo, tests) they run inline."""
+    """All-reduce (SUM) of gradient-arena ranges as they become final, optionally followed by a per-range callback
+    (the fused AdamW of that range) on the same side stream, so both overlap the rest of the backward pass.
+    Device agnostic: with CUDA tensors the work runs on a dedicated stream behind an event; with CPU tensors
+    (gloo, tests) it runs inline.  world_size 1 skips the collective but keeps the overlapped callback."""
 
-    def __init__(self, process_group=None, n_buckets: int = 4):
+    def __init__(self, process_group=None, n_buckets: int = 4, after_bucket=None):
         self.pg = process_group
         self.n_buckets = n_buckets
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.after_bucket = after_bucket          # callable(begin, end) run behind the bucket's all-reduce
         self._comm_stream: Optional[torch.cuda.Stream] = None
         self._works = []
         self.bytes_reduced = 0
@@ -47,10 +50,9 @@ class GradSync:
         self._works = []
 
     def bucket_ready(self, flat_grads: torch.Tensor, begin: int, end: int):
-        if self.world == 1 or end <= begin:
+        if end <= begin or (self.world == 1 and self.after_bucket is None):
             return
         chunk = flat_grads[begin:end]
-        self.bytes_reduced += chunk.numel() * chunk.element_size()
         if chunk.is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=chunk.device)
@@ -58,16 +60,21 @@ class GradSync:
             ev.record(torch.cuda.current_stream())
             self._comm_stream.wait_event(ev)
             with torch.cuda.stream(self._comm_stream):
-                self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if self.world > 1:
+                    self.bytes_reduced += chunk.numel() * chunk.element_size()
+                    dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg)     # enqueued on the side stream
+                if self.after_bucket is not None:
+                    self.after_bucket(begin, end)
         else:
-            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.world > 1:
+                self.bytes_reduced += chunk.numel() * chunk.element_size()
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.after_bucket is not None:
+                self.after_bucket(begin, end)
 
     def finish(self):
         """Make the current stream wait for every outstanding bucket."""
         if self._comm_stream is not None:
-            with torch.cuda.stream(self._comm_stream):
-                for w in self._works:
-                    w.wait()
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         self._works = []
 
