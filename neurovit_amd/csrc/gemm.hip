@@ -171,7 +171,42 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int rc0, int ks, in
   }
 }
 
-// ---- epilogue: lane holds C[m = mb + 16i + (lane&15)][n = nb + 16j + 4*(lane>>4) + 0..3] ---------------------
+// ---- epilogue core: four consecutive output columns (m, n .. n+3) ----------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void epilogue4(f32x4 v, const GemmArgs& g, int m, int n) {
+  if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+  f32x4 keep = f32x4{1.f, 1.f, 1.f, 1.f};
+  if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_DGELU) {
+    if (g.drop.thresh) {
+      const unsigned long long idx = (unsigned long long)m * g.N + n;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) keep[q] = drop_factor(g.drop, idx + q);
+    }
+  }
+  if constexpr (EPI == EPI_STORE_BF16) {
+    *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) = cvt4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (EPI == EPI_STORE_F32) {
+    float* c = (float*)g.C + (long)m * g.ldc + n;
+    if (g.accumulate) v += *reinterpret_cast<const f32x4*>(c);
+    *reinterpret_cast<f32x4*>(c) = v;
+  } else if constexpr (EPI == EPI_BIAS_F32) {
+    *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
+  } else if constexpr (EPI == EPI_BIAS_GELU) {
+    *reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n) = cvt4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
+        cvt4(gelu_f(v[0]) * keep[0], gelu_f(v[1]) * keep[1], gelu_f(v[2]) * keep[2], gelu_f(v[3]) * keep[3]);
+  } else if constexpr (EPI == EPI_BIAS_RESID) {
+    v = v * keep + *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
+    *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
+  } else if constexpr (EPI == EPI_DGELU) {
+    const bf16x4 u = *reinterpret_cast<const bf16x4*>((const bf16*)g.aux_in + (long)m * g.ld_aux_in + n);
+    *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
+        cvt4(v[0] * keep[0] * gelu_grad_f((float)u[0]), v[1] * keep[1] * gelu_grad_f((float)u[1]),
+             v[2] * keep[2] * gelu_grad_f((float)u[2]), v[3] * keep[3] * gelu_grad_f((float)u[3]));
+  }
+}
+
+// ---- register epilogue: lane holds C[m = mb + 16i + (lane&15)][n = nb + 16j + 4*(lane>>4) + 0..3] -----------------
 template <int EPI, int MI, int NI>
 __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmArgs& g, int mb, int nb, int lane) {
   const int lr = lane & 15, lg = lane >> 4;
@@ -183,41 +218,32 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmA
     for (int j = 0; j < NI; ++j) {
       const int n = nb + 16 * j + 4 * lg;
       if (n >= g.N) continue;
-      f32x4 v = acc[i][j];
-      if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
-        v += bv;
-      }
-      f32x4 keep = f32x4{1.f, 1.f, 1.f, 1.f};
-      if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_DGELU) {
-        if (g.drop.thresh) {
-          const unsigned long long idx = (unsigned long long)m * g.N + n;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) keep[q] = drop_factor(g.drop, idx + q);
-        }
-      }
-      if constexpr (EPI == EPI_STORE_BF16) {
-        *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) = cvt4(v[0], v[1], v[2], v[3]);
-      } else if constexpr (EPI == EPI_STORE_F32) {
-        float* c = (float*)g.C + (long)m * g.ldc + n;
-        if (g.accumulate) v += *reinterpret_cast<const f32x4*>(c);
-        *reinterpret_cast<f32x4*>(c) = v;
-      } else if constexpr (EPI == EPI_BIAS_F32) {
-        *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
-      } else if constexpr (EPI == EPI_BIAS_GELU) {
-        *reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n) = cvt4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
-            cvt4(gelu_f(v[0]) * keep[0], gelu_f(v[1]) * keep[1], gelu_f(v[2]) * keep[2], gelu_f(v[3]) * keep[3]);
-      } else if constexpr (EPI == EPI_BIAS_RESID) {
-        v = v * keep + *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
-        *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
-      } else if constexpr (EPI == EPI_DGELU) {
-        const bf16x4 u = *reinterpret_cast<const bf16x4*>((const bf16*)g.aux_in + (long)m * g.ld_aux_in + n);
-        *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
-            cvt4(v[0] * keep[0] * gelu_grad_f((float)u[0]), v[1] * keep[1] * gelu_grad_f((float)u[1]),
-                 v[2] * keep[2] * gelu_grad_f((float)u[2]), v[3] * keep[3] * gelu_grad_f((float)u[3]));
-      }
+      epilogue4<EPI>(acc[i][j], g, m, n);
     }
+  }
+}
+
+// ---- LDS epilogue (warp-specialised kernel): the consumers park their accumulators in LDS as a [BM][BN] fp32 tile, then
+// ALL EIGHT waves (the loaders are idle by now) run the epilogue row-wise: twice the VALU issue capacity for the GELU
+// epilogues, and every wave-instruction reads / writes whole 256-512 byte row segments instead of 16 rows x 32 bytes.
+template <int BN> constexpr int cpitch() { return BN * 4 + 16; }   // bytes; +16 keeps the 16-row accumulator writes conflict free
+template <int MI, int NI, int BN>
+__device__ __forceinline__ void park_acc(const f32x4 (&acc)[MI][NI], char* ctile, int rb, int cb, int lane) {
+  const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      *reinterpret_cast<f32x4*>(ctile + (rb + 16 * i + lr) * cpitch<BN>() + (cb + 16 * j + 4 * lg) * 4) = acc[i][j];
+}
+template <int EPI, int BM, int BN, int NT>
+__device__ __forceinline__ void epilogue_lds(const char* ctile, const GemmArgs& g, int m0, int n0, int tid) {
+  constexpr int CPR = BN / 4;                 // 16-byte chunks per row
+#pragma unroll 4
+  for (int c = tid; c < BM * CPR; c += NT) {
+    const int row = c / CPR, col = (c % CPR) * 4;
+    const int m = m0 + row, n = n0 + col;
+    if (m < g.M && n < g.N) epilogue4<EPI>(*reinterpret_cast<const f32x4*>(ctile + row * cpitch<BN>() + col * 4), g, m, n);
   }
 }
 
@@ -414,6 +440,8 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
       __builtin_amdgcn_s_barrier();                     // barrier kt
       fs = (fs + 1 == S) ? 0 : fs + 1;
     }
+    __builtin_amdgcn_s_barrier();                       // barrier E: the consumers have parked the C tile in LDS
+    epilogue_lds<EPI, BM, BN, WS_THREADS>(smem, g, m0, n0, tid);
     return;
   }
 
@@ -466,12 +494,17 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
     WS_READ(fa1, fb1, cur, 3)
     SB WS_MFMA(fa0, fb0) SB
   }
-  __builtin_amdgcn_s_barrier();                         // barrier nk-1 (pairs with the loaders' last one)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read has returned: the ring may be overwritten
+  __builtin_amdgcn_s_barrier();                         // barrier nk-1 (pairs with the loaders' last one; no DMA in flight any more)
   WS_MFMA(fa1, fb1)
 #undef WS_READ
 #undef WS_MFMA
 #undef SB
-  epilogue<EPI, MI, NI>(acc, g, m0 + wm * TM, n0 + wn * TN, lane);
+  static_assert(BM * cpitch<BN>() <= S * STAGE, "C tile must fit in the ring");
+  park_acc<MI, NI, BN>(acc, smem, wm * TM, wn * TN, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw barrier carries no wait: the parked tile must be written first
+  __builtin_amdgcn_s_barrier();                         // barrier E
+  epilogue_lds<EPI, BM, BN, WS_THREADS>(smem, g, m0, n0, tid);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
