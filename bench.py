@@ -154,9 +154,15 @@ def main():
     gemm = [kinds[k] for k in (0, 1, 2) if k in kinds]
     g_ms, g_fl, g_n = sum(k["ms"] for k in gemm), sum(k["flops"] for k in gemm), sum(k["launches"] for k in gemm)
     achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+    traffic, traffic_src = None, None
+    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tfile):      # PMC counters cannot be read in-process: measured with rocprofv3 --pmc on this same command
+        tj = json.load(open(tfile))
+        traffic, traffic_src = tj["traffic_MB_per_launch"] * 1e6, tj["source"]
     roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel (NT/NN/TN instantiations, all fused epilogues)",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": None, "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches_per_step": g_n // prof_steps,
+                "traffic": traffic, "traffic_unit": "bytes/launch (fabric fetch + write, PMC)", "traffic_source": traffic_src,
+                "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches_per_step": g_n // prof_steps,
                 "gemm_share_of_step": round(g_ms / prof_steps / ms, 3),
                 "by_kernel": {KIND_NAMES[k]: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "avg_us": round(v["ms"] * 1e3 / v["launches"], 2),
                                               "launches_per_step": v["launches"] // prof_steps} for k, v in kinds.items()}}

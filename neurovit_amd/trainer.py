@@ -86,3 +86,127 @@ class TrainStep:
                 self.optimizer.step(grad_scale=scale)
             self._micro = 0
         return loss.detach()
+
+
+class Trainer:
+    """The reference's Trainer shell (src/Trainer.py:14-167) on the native path: same constructor and methods
+    (`run`, `train`, `validate`, `evaluate_samples`), same checkpoint files (plain `state_dict`s, interchangeable
+    with the reference), same logging cadence.  Differences, all deliberate:
+      * the step body is `TrainStep` (fused CE / staged backward / fused AdamW; no GradScaler: bf16 needs none);
+      * wandb is optional (skipped when the package is absent or config['WANDB_ENABLED'] is false);
+      * batches may be the 7-tuples of DatasetADNI or the 6-tuples of DatasetADNI_4D (README.md:100-102 asks users
+        to hand-edit the unpacking): the volume is element 2 and the label the last element in both;
+      * `log_interval = len(dl)//10` is clamped to >= 1 (the reference divides by zero for < 10 batches,
+        Trainer.py:34,89); TRAINING_ACCUMULATION_STEP is honoured as in the commented block (Trainer.py:82-86).
+    """
+
+    def __init__(self, config, model, dataset_train, dataset_val):
+        import os as _os
+        self.config = config
+        self.device = config['DEVICE']
+        self.model = model.to(self.device)
+        self.output_dir = config['GLOBAL_OUTPUT_DIR']
+        self.epochs = config['TRAINING_EPOCHS']
+        self.batch_size = config['TRAINING_BATCH_SIZE']
+        self.num_workers = config['TRAINING_NUM_WORKERS']
+        self.data, self.val_data = dataset_train, dataset_val
+        kw = dict(batch_size=self.batch_size, num_workers=self.num_workers, pin_memory=True)
+        if self.num_workers > 0:
+            kw["prefetch_factor"] = 2
+        self.dataloader = torch.utils.data.DataLoader(self.data, shuffle=True, **kw)
+        self.val_dataloader = torch.utils.data.DataLoader(self.val_data, shuffle=False, **kw)
+        self.criterion = CrossEntropyLoss()
+        self.step = TrainStep(model, accumulation_steps=config.get('TRAINING_ACCUMULATION_STEP', 1) if config.get('USE_ACCUMULATION', False) else 1)
+        self.optimizer = self.step.optimizer
+        self.log_interval = max(1, len(self.dataloader) // 10)
+        self._wandb = None
+        if config.get('WANDB_ENABLED', False):
+            try:
+                import wandb
+                self._wandb = wandb
+            except ImportError:
+                pass
+        total_params = sum(p.numel() for p in self.model.parameters())
+        trainable_params = sum(p.numel() for p in self.model.parameters() if p.requires_grad)
+        print(f'Model total parameters: {total_params/1e6:.2f}M (trainable {trainable_params/1e6:.2f}M and frozen {(total_params-trainable_params)/1e6:.2f}M)')
+        self._os = _os
+
+    @staticmethod
+    def _unpack(batch):
+        return batch[2], batch[-1]
+
+    def _log(self, payload):
+        if self._wandb is not None:
+            self._wandb.log(payload)
+
+    def run(self):
+        import datetime
+        path = f"{self.output_dir}/{datetime.datetime.now().strftime('%Y-%m-%d_%H-%M-%S')}"
+        self._os.makedirs(path, exist_ok=True)
+        self._os.makedirs('./results', exist_ok=True)
+        for epoch in range(self.epochs):
+            self.train(epoch)
+            self.validate(epoch)
+            torch.save(self.model.state_dict(), './results/last_model.pth')
+            torch.save(self.model.state_dict(), f'{path}/model-e{epoch}.pth')
+            print(f"MODEL SAVED to .{path}/model-e{epoch}.pth")
+
+    def train(self, epoch):
+        import time
+        self.model.train()
+        running_loss, correct, total = 0.0, 0, 0
+        start_time = time.time()
+        for i, batch in enumerate(self.dataloader):
+            fMRI, label = self._unpack(batch)
+            fMRI, label = fMRI.to(self.device, non_blocking=True), label.to(self.device, non_blocking=True)
+            loss = self.step(fMRI, label)
+            # the reference syncs twice per step (.item()); here statistics stay on the device until a log line is due
+            running_loss = running_loss + loss
+            with torch.no_grad():
+                correct = correct + (self.model.volume_encoder.vit3d._last_logits.argmax(dim=1) == label).sum() \
+                    if self.config['TRAINING_DIM'] == 3 else correct
+            total += label.size(0)
+            if i != 0 and i % self.log_interval == 0:
+                avg_loss = round(float(running_loss) / self.log_interval, 5)
+                accuracy = round(float(correct) / total, 5)
+                lr = round(self.optimizer.param_groups[0]['lr'], 5)
+                duration = time.time() - start_time
+                print(f"epoch {epoch}\t| batch {i}/{len(self.dataloader)}\t| train_loss: {avg_loss:.5f}\t| train_accuracy: {accuracy:.5f}\t| learning_rate: {lr:.5f}\t| duration: {duration:.2f}s")
+                self._log({"epoch": epoch, "batch": i, "train_loss": avg_loss, "train_accuracy": accuracy, "learning_rate": lr, "duration": duration})
+                correct, total, running_loss = 0, 0, 0.0
+                start_time = time.time()
+
+    def validate(self, epoch):
+        self.model.eval()
+        val_loss, correct, total, i = 0.0, 0, 0, 0
+        with torch.no_grad():
+            for i, batch in enumerate(self.val_dataloader):
+                fMRI, label = self._unpack(batch)
+                fMRI, label = fMRI.to(self.device), label.to(self.device)
+                outputs = self.model(fMRI)
+                val_loss += self.criterion(outputs, label).item()
+                correct += (outputs.argmax(dim=1) == label).sum().item()
+                total += label.size(0)
+        avg_val_loss = round(val_loss / max(1, len(self.val_dataloader)), 5)
+        self.val_loss = avg_val_loss
+        accuracy = round(correct / max(1, total), 5)
+        print(f"[VALIDATION] epoch {epoch}\t| total_batch {i}\t| val_loss {avg_val_loss:.5f}\t| val_accuracy {accuracy:.5f}")
+        self._log({"epoch": epoch, "val_loss": avg_val_loss, "val_accuracy": accuracy})
+        return avg_val_loss, accuracy
+
+    def evaluate_samples(self):
+        self.model.eval()
+        loader = torch.utils.data.DataLoader(self.val_data, batch_size=1, shuffle=False, num_workers=self.num_workers)
+        accuracy, wrong = 0, []
+        with torch.no_grad():
+            for batch in loader:
+                fMRI, label = self._unpack(batch)
+                prediction = self.model(fMRI.to(self.device)).argmax(dim=1).item()
+                actual = int(label.item())
+                if prediction != actual:
+                    wrong.append((batch[0][0] if isinstance(batch[0], (list, tuple)) else batch[0], prediction, actual))
+                accuracy += prediction == actual
+        acc = accuracy / max(1, len(loader)) * 100
+        print(f"Accuracy: {acc:.2f}%")
+        print(f"Wrong predictions: {wrong}")
+        return acc, wrong

@@ -170,6 +170,7 @@ class ViT(nn.Module):
         self._layout = None
         self._plist: List[nn.Parameter] = []
         self._shadow_key = None
+        self._last_logits = None   # most recent forward's logits (the Trainer shell reads them without a second forward)
         self._grad_sync = None     # parallel.GradSync: all-reduce gradient buckets while backward still runs
 
     # ------------------------------------------------------------------ arena management
@@ -242,7 +243,8 @@ class ViT(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             drop = (self._dropout_p[0], self._dropout_p[1], seed)
         self._refresh_shadow()
-        return self._rt.forward(video, self._arena, self._shadow, training=need_grad, dropout=drop)
+        self._last_logits = self._rt.forward(video, self._arena, self._shadow, training=need_grad, dropout=drop)
+        return self._last_logits
 
     def _run_backward(self, dlogits):
         grads = self.flat_gradients()
