@@ -401,7 +401,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
   constexpr int A_BYTES = BM * BK * 2, SUB = (BM + BN) * BK * 2, STAGE = KS * SUB;
   constexpr int TM = BM / 2, TN = BN / 2, MI = TM / 16, NI = TN / 16;
   constexpr int PIECES = KS * (BM / 32 + BN / 32);      // DMA instructions per loader wave per stage
-  constexpr int D = S - 1;
+  constexpr int D = S - 1;                              // loaders run S-1 stages ahead; barrier kt sits at the END of stage kt
   static_assert(S >= 3 && S <= 7 && (KS == 1 || KS == 2), "ring geometry");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -465,41 +465,64 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
   _Pragma("unroll") for (int i = 0; i < MI; ++i)                             \
     _Pragma("unroll") for (int j = 0; j < NI; ++j)                           \
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[i][j], 0, 0, 0);
-#define SB __builtin_amdgcn_sched_barrier(0);   // pin the phase order: [reads of the next half step][MFMAs of this one]
+#define SB __builtin_amdgcn_sched_barrier(0);   // pin the phase order: [reads of a later half step][MFMAs of this one]
+#define WS_ADVANCE ci = (ci + 1 == S) ? 0 : ci + 1; cur = nxt; nxt = smem + ((ci + 1 == S) ? 0 : ci + 1) * STAGE;
 
   __builtin_amdgcn_s_barrier();                         // barrier -1
-  WS_READ(fa0, fb0, cur, 0)
-  for (int kt = 0; kt + 1 < nk; ++kt) {
-    WS_READ(fa1, fb1, cur, 1)
-    SB WS_MFMA(fa0, fb0) SB
-    if constexpr (KS == 2) {
-      WS_READ(fa0, fb0, cur, 2)
-      SB WS_MFMA(fa1, fb1) SB
-      WS_READ(fa1, fb1, cur, 3)
+  if constexpr (KS == 1) {
+    WS_READ(fa0, fb0, cur, 0)
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      WS_READ(fa1, fb1, cur, 1)
       SB WS_MFMA(fa0, fb0) SB
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // all reads of `cur` have returned before it can be refilled
+      __builtin_amdgcn_s_barrier();                     // barrier kt: stage kt+1 complete
+      SB WS_READ(fa0, fb0, nxt, 0)
+      SB WS_MFMA(fa1, fb1) SB
+      WS_ADVANCE
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // all reads of `cur` have returned before it can be refilled
-    __builtin_amdgcn_s_barrier();                       // barrier kt: stage kt+1 complete
-    SB WS_READ(fa0, fb0, nxt, 0)
-    SB WS_MFMA(fa1, fb1) SB
-    ci = (ci + 1 == S) ? 0 : ci + 1;
-    cur = nxt;
-    nxt = smem + ((ci + 1 == S) ? 0 : ci + 1) * STAGE;
-  }
-  WS_READ(fa1, fb1, cur, 1)                             // last stage
-  SB WS_MFMA(fa0, fb0) SB
-  if constexpr (KS == 2) {
-    WS_READ(fa0, fb0, cur, 2)
-    SB WS_MFMA(fa1, fb1) SB
-    WS_READ(fa1, fb1, cur, 3)
+    WS_READ(fa1, fb1, cur, 1)                           // last stage
     SB WS_MFMA(fa0, fb0) SB
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // every fragment read has returned: the ring may be overwritten
+    __builtin_amdgcn_s_barrier();                       // barrier nk-1 (pairs with the loaders' last one; no DMA in flight any more)
+    WS_MFMA(fa1, fb1)
+  } else {
+    // Four half steps per stage and three fragment register sets rotating once per stage ((a,b,c) -> (b,c,a)): three of the
+    // four half steps get their fragments TWO half steps ahead (the 8-16 MFMAs of one half step, 128-256 cycles, alone do
+    // not cover an LDS read under load); only the first half step of a stage, whose reads must follow the barrier, is one
+    // ahead.  Every stage body is branch free (the last stage prefetches two unused half steps from a valid slot), so hipcc
+    // derives exact lgkmcnt values.
+    bf16x8 fa2[MI], fb2[NI];
+#define WS_STAGE(A0, B0, A1, B1, A2, B2)                                      \
+    WS_READ(A2, B2, cur, 2)                                                   \
+    SB WS_MFMA(A0, B0) SB                                                     \
+    WS_READ(A0, B0, cur, 3)                                                   \
+    SB WS_MFMA(A1, B1) SB                                                     \
+    WS_MFMA(A2, B2) SB                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
+    __builtin_amdgcn_s_barrier();                                             \
+    SB WS_READ(A1, B1, nxt, 0)                                                \
+    WS_READ(A2, B2, nxt, 1)                                                   \
+    SB WS_MFMA(A0, B0) SB                                                     \
+    WS_ADVANCE
+    WS_READ(fa0, fb0, cur, 0)
+    WS_READ(fa1, fb1, cur, 1)
+    int kt = 0;
+    for (; kt + 3 <= nk; kt += 3) {
+      WS_STAGE(fa0, fb0, fa1, fb1, fa2, fb2)
+      WS_STAGE(fa1, fb1, fa2, fb2, fa0, fb0)
+      WS_STAGE(fa2, fb2, fa0, fb0, fa1, fb1)
+    }
+    if (kt + 1 <= nk) {
+      WS_STAGE(fa0, fb0, fa1, fb1, fa2, fb2)
+      if (kt + 2 <= nk) { WS_STAGE(fa1, fb1, fa2, fb2, fa0, fb0) }
+    }
+#undef WS_STAGE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the stray prefetches of the last stage have returned
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read has returned: the ring may be overwritten
-  __builtin_amdgcn_s_barrier();                         // barrier nk-1 (pairs with the loaders' last one; no DMA in flight any more)
-  WS_MFMA(fa1, fb1)
 #undef WS_READ
 #undef WS_MFMA
 #undef SB
+#undef WS_ADVANCE
   static_assert(BM * cpitch<BN>() <= S * STAGE, "C tile must fit in the ring");
   park_acc<MI, NI, BN>(acc, smem, wm * TM, wn * TN, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw barrier carries no wait: the parked tile must be written first
