@@ -136,14 +136,16 @@ int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const lo
                    unsigned long drop_seed, float* logits, void* stream);
 int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                     const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
-                    int accumulate, float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream);
+                    int accumulate, float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream, void* aux_stream);
 
-/* Backward split into stages (0 = head, 1+k = layer depth-1-k, depth+1 = patch embedding) so the caller can start the
+/* aux_stream (may be NULL): a second hipStream_t on which the weight-gradient GEMMs run concurrently with the data-gradient
+ * chain; the engine forks / joins with pooled events, and every call returns with `stream` ordered after all of its work.
+ * Backward split into stages (0 = head, 1+k = layer depth-1-k, depth+1 = patch embedding) so the caller can start the
  * data-parallel all-reduce of a stage's gradient range (nv_vit_stage_param_range) while later stages still run. */
 int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                            const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
                            int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
-                           unsigned long drop_seed, void* stream);
+                           unsigned long drop_seed, void* stream, void* aux_stream);
 int nv_vit_stage_param_range(const nv_vit_config* cfg, int stage, long* begin, long* end);
 
 #ifdef __cplusplus

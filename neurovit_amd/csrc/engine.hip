@@ -70,8 +70,8 @@ struct WS {
   long xp, pst, t, est, x0, xh, hst, wpe16;
   std::vector<LayerW> layer;
   // backward scratch
-  long g, g16, dxn, hookg, du, dao, dqkv, delta, dt, dt16, dxp, dwpe, red;
-  long red_bytes, total;
+  long g, g16, g16b, dxn, hookg, du, dao, dqkv, delta, dt, dt16, dxp, dwpe, red, red2;
+  long red_bytes, red2_bytes, total;
 };
 
 void make_ws(const Dims& D, int training, WS& W) {
@@ -100,15 +100,44 @@ void make_ws(const Dims& D, int training, WS& W) {
                r4 = nv_colsum_workspace_bytes(D.M, D.m);
     r = r > r2 ? r : r2; r = r > r3 ? r : r3; r = r > r4 ? r : r4;
     W.red_bytes = r; W.red = add(r);
+    W.g16b = add(M * d * 2);
+    W.red2_bytes = r4; W.red2 = add(r4);       // column-sum scratch of the auxiliary stream
   } else {
-    W.g = W.g16 = W.dxn = W.hookg = W.du = W.dao = W.dqkv = W.delta = W.dt = W.dt16 = W.dxp = W.dwpe = W.red = -1;
-    W.red_bytes = 0;
+    W.g = W.g16 = W.dxn = W.hookg = W.du = W.dao = W.dqkv = W.delta = W.dt = W.dt16 = W.dxp = W.dwpe = W.red = W.g16b = W.red2 = -1;
+    W.red_bytes = W.red2_bytes = 0;
   }
   W.total = cur;
 }
 
 // per-site dropout seeds: site = 4*layer + {0 attention probs, 1 to_out, 2 FF hidden, 3 FF out}; 4*depth = embedding
 inline unsigned long site_seed(unsigned long seed, int site) { return seed ^ (0x9E3779B97F4A7C15ul * (unsigned long)(site + 1)); }
+
+// Fork/join between the main stream and the auxiliary stream that runs the weight-gradient GEMMs (they depend only on
+// buffers the data-gradient chain has already produced, and the chain's kernels - 198-tile GEMMs, attention backward,
+// LayerNorm backward - leave LDS and CUs idle).  Events are pooled (created once, outside any capture).
+struct EventPool {
+  std::vector<hipEvent_t> ev;
+  size_t next = 0;
+  hipEvent_t get() {
+    if (ev.size() < 64) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      ev.push_back(e);
+      return e;
+    }
+    return ev[next++ % ev.size()];
+  }
+};
+EventPool g_events;
+// make `to` wait for everything enqueued so far on `from`
+inline int stream_sync(hipStream_t from, hipStream_t to) {
+  hipEvent_t e = g_events.get();
+  if (!e || hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
+    nv_set_error("nv_vit_backward: event fork/join failed");
+    return NV_ERR_HIP;
+  }
+  return NV_OK;
+}
 
 #define RUN(call)            \
   do {                       \
@@ -220,7 +249,7 @@ extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* vide
 extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                                       const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
                                       int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
-                                      unsigned long drop_seed, void* stream) {
+                                      unsigned long drop_seed, void* stream, void* aux_stream) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 1, W);
@@ -233,9 +262,17 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   float* gr = grads;
   const int M = D.M, d = D.d, acc = accumulate;
   float* g = (float*)(ws + W.g);
-  void* g16 = ws + W.g16;
+  void* g16 = ws + W.g16;      // bf16 residual gradient entering a layer (FC2 backward); rewritten by LN1 backward
+  void* g16b = ws + W.g16b;    // ... after LN2 backward (attention out-projection backward)
   void* red = ws + W.red;
   const float scale = 1.0f / sqrtf((float)D.dh);
+  hipStream_t S = (hipStream_t)stream;
+  hipStream_t A = aux_stream ? (hipStream_t)aux_stream : S;       // weight-gradient stream (== S: fully serial)
+  void* sA = (void*)A;
+  const bool forked = (A != S);
+  void* redA = forked ? (void*)(ws + W.red2) : red;
+  const long redA_bytes = forked ? W.red2_bytes : W.red_bytes;
+  if (forked) RUN(stream_sync(S, A));                              // everything before this call is visible to A
 
   NV_CHECK_ARG(first_stage >= 0 && last_stage <= D.L + 1 && first_stage <= last_stage, "nv_vit_backward_stages: bad stage range [%d, %d]", first_stage, last_stage);
   // head: writes g (zeros + cls rows) and the last layer's FC2 bias gradient (colsum of g)
@@ -254,24 +291,36 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     float* st1 = (float*)(ws + w.st1);
     float* st2 = (float*)(ws + w.st2);
     float* dxn = (float*)(ws + W.dxn);
-    // ---- FeedForward backward (vit_3d.py:16-26)
+    // ---- FeedForward backward (vit_3d.py:16-26).  [A] = auxiliary stream
+    if (forked) RUN(stream_sync(S, A));                                                                                        // g16 ready
+    RUN(nv_gemm_bf16(2, 1, d, D.m, M, g16, d, ws + w.h, D.m, gr + q.w2, D.m, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, sA));                  // [A] dW2 = g^T h
     RUN(nv_gemm_bf16(1, 5, M, D.m, d, g16, d, p16 + q.w2, D.m, ws + W.du, D.m, nullptr, ws + w.u, D.m, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 2), drop_p, stream));   // dU = (g W2 * mask) * gelu'(u)
-    RUN(nv_gemm_bf16(2, 1, d, D.m, M, g16, d, ws + w.h, D.m, gr + q.w2, D.m, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));              // dW2 = g^T h
-    RUN(nv_colsum_bf16(ws + W.du, D.m, M, D.m, gr + q.b1, acc, red, W.red_bytes, stream));                                                       // db1
+    if (forked) RUN(stream_sync(S, A));                                                                                        // dU ready
+    RUN(nv_gemm_bf16(2, 1, D.m, d, M, ws + W.du, D.m, ws + w.xn2, d, gr + q.w1, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, sA));            // [A] dW1 = dU^T xn2
+    RUN(nv_colsum_bf16(ws + W.du, D.m, M, D.m, gr + q.b1, acc, redA, redA_bytes, sA));                                                                 // [A] db1
+    hipEvent_t a1 = nullptr;
+    if (forked) { a1 = g_events.get(); if (!a1 || hipEventRecord(a1, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; } }
     RUN(nv_gemm_bf16(1, 1, M, d, D.m, ws + W.du, D.m, p16 + q.w1, d, dxn, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));                 // dxn2 = dU W1
-    RUN(nv_gemm_bf16(2, 1, D.m, d, M, ws + W.du, D.m, ws + w.xn2, d, gr + q.w1, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));         // dW1 = dU^T xn2
-    RUN(nv_ln_bwd(dxn, d, (float*)(ws + w.x1), d, st2, st2 + M, p + q.n2g, M, d, g, g, d, g16, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, red,
-                  W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream));                                                                                                       // g += dLN2; dbo = colsum(g)
+    RUN(nv_ln_bwd(dxn, d, (float*)(ws + w.x1), d, st2, st2 + M, p + q.n2g, M, d, g, g, d, g16b, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, red,
+                  W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream));                                              // g += dLN2 -> g16b; dbo = colsum(g)
     // ---- Attention backward (vit_3d.py:48-60)
-    RUN(nv_gemm_bf16(1, 0, M, D.inner, d, g16, d, p16 + q.wo, D.inner, ws + W.dao, D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));   // dAO = g Wo
-    RUN(nv_gemm_bf16(2, 1, d, D.inner, M, g16, d, ws + w.ao, D.inner, gr + q.wo, D.inner, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));   // dWo = g^T ao
+    if (forked) RUN(stream_sync(S, A));                                                                                        // g16b ready
+    RUN(nv_gemm_bf16(2, 1, d, D.inner, M, g16b, d, ws + w.ao, D.inner, gr + q.wo, D.inner, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, sA));    // [A] dWo = g^T ao
+    RUN(nv_gemm_bf16(1, 0, M, D.inner, d, g16b, d, p16 + q.wo, D.inner, ws + W.dao, D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));  // dAO = g Wo
     RUN(nv_attn_bwd(ws + w.qkv, 3 * D.inner, ws + w.ao, ws + W.dao, D.inner, (float*)(ws + w.lse), B, D.n, D.heads, D.dh, scale,
                     (float*)(ws + W.delta), ws + W.dqkv, 3 * D.inner, site_seed(drop_seed, 4 * l + 0), drop_p, stream));
+    if (forked) RUN(stream_sync(S, A));                                                                                        // dqkv ready
+    RUN(nv_gemm_bf16(2, 1, 3 * D.inner, d, M, ws + W.dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, sA));   // [A] dWqkv
     float* dxn1 = (l == D.L - 1) ? (float*)(ws + W.hookg) : dxn;    // gradient of the last block's attention-LN output is kept (Grad-CAM hook)
     RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, ws + W.dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
-    RUN(nv_gemm_bf16(2, 1, 3 * D.inner, d, M, ws + W.dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));
+    // LN1 backward rewrites g16 (read by [A] dW2) and the next layer rewrites dU / g16b / dqkv (read by [A] dW1, colsum, dWo,
+    // dWqkv): the main stream joins the auxiliary one here - by now those GEMMs have long finished.
+    if (forked) {
+      if (hipStreamWaitEvent(S, a1, 0) != hipSuccess) { nv_set_error("nv_vit_backward: event wait failed"); return NV_ERR_HIP; }
+    }
     RUN(nv_ln_bwd(dxn1, d, xin, d, st1, st1 + M, p + q.n1g, M, d, g, g, d, g16, d, gr + q.n1g, gr + q.n1b, (l > 0) ? gr + T.layer[l - 1].b2 : nullptr,
                   acc, red, W.red_bytes, site_seed(drop_seed, 4 * (l - 1) + 3), (l > 0) ? drop_p : 0.f, stream));
+    if (forked) RUN(stream_sync(A, S));     // dWo / dWqkv of this layer done before the next layer's kernels overwrite g16b / dqkv
   }
 
   if (last_stage < D.L + 1) return NV_OK;
@@ -298,9 +347,9 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
 
 extern "C" int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                                const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
-                               int accumulate, float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream) {
+                               int accumulate, float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream, void* aux_stream) {
   return nv_vit_backward_stages(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, accumulate, 0,
-                                cfg ? cfg->depth + 1 : 0, drop_p, emb_drop_p, drop_seed, stream);
+                                cfg ? cfg->depth + 1 : 0, drop_p, emb_drop_p, drop_seed, stream, aux_stream);
 }
 
 // Element range [begin, end) of the parameter / gradient arena that is FINAL once backward stage `stage` has run.

@@ -9,6 +9,7 @@ on a few large contiguous ranges instead of ~150 small tensors.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -46,6 +47,8 @@ class VitRuntime:
         self.cfg = cfg
         self._ws: Dict[Tuple[int, int, str], torch.Tensor] = {}
         self._last = None   # (B, training, workspace, video) of the most recent forward
+        self._aux = {}      # device -> auxiliary stream for the weight-gradient GEMMs
+        self.use_aux_stream = os.environ.get("NEUROVIT_AUX_STREAM", "1") != "0"
 
     def workspace(self, B: int, training: bool, device) -> torch.Tensor:
         key = (B, int(training), str(device))
@@ -90,7 +93,16 @@ class VitRuntime:
                                          params16.data_ptr(), ws.data_ptr(), ws.numel(), self._dlogits.data_ptr(),
                                          grads.data_ptr(), int(accumulate), first, last, float(self._dropout[0]),
                                          float(self._dropout[1]), int(self._dropout[2]),
-                                         torch.cuda.current_stream().cuda_stream), "nv_vit_backward_stages")
+                                         torch.cuda.current_stream().cuda_stream, self._aux_stream(video.device)),
+              "nv_vit_backward_stages")
+
+    def _aux_stream(self, device):
+        if not self.use_aux_stream:
+            return None
+        st = self._aux.get(str(device))
+        if st is None:
+            st = self._aux[str(device)] = torch.cuda.Stream(device=device)
+        return st.cuda_stream
 
     def stage_range(self, first: int, last: int) -> Tuple[int, int]:
         """Arena element range [begin, end) that is final after backward stages first..last have run."""
