@@ -92,6 +92,7 @@ int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_h
 int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const void* dout, long ld_out, const float* lse, int B, int n,
                 int heads, int dim_head, float scale, float* delta, void* dqkv, long ld_dqkv, unsigned long drop_seed,
                 float drop_p, void* stream);
+int nv_stream_sync(void* from, void* to);   /* stream `to` waits for everything enqueued so far on `from` (pooled events) */
 
 /* ---- classification head (vit_3d.py:107-110,123-126): cls row -> LayerNorm -> Linear(dim, C), fp32 */
 int nv_head_fwd(const float* x, long row_stride, int B, int d, const float* gamma, const float* beta, float eps,

@@ -76,3 +76,25 @@ extern "C" int nv_prof_summary(int kind, double* ms, double* work, long* count) 
   if (ms) *ms = tms; if (work) *work = tw; if (count) *count = c;
   return 0;
 }
+
+// ---- pooled events for fork / join between two streams (created once, timing disabled) -----------------------
+namespace {
+std::vector<hipEvent_t> g_sync_events;
+size_t g_sync_next = 0;
+}  // namespace
+
+// Make stream `to` wait for everything enqueued so far on stream `from`.  Returns 0 or NV_ERR_HIP (-2).
+extern "C" int nv_stream_sync(void* from, void* to) {
+  hipEvent_t e;
+  if (g_sync_events.size() < 64) {
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { nv_set_error("nv_stream_sync: hipEventCreate failed"); return -2; }
+    g_sync_events.push_back(e);
+  } else {
+    e = g_sync_events[g_sync_next++ % g_sync_events.size()];
+  }
+  if (hipEventRecord(e, (hipStream_t)from) != hipSuccess || hipStreamWaitEvent((hipStream_t)to, e, 0) != hipSuccess) {
+    nv_set_error("nv_stream_sync: record / wait failed");
+    return -2;
+  }
+  return 0;
+}

@@ -2,6 +2,7 @@
 // backward as ONE C-ABI call each, over a flat parameter arena and a caller-owned workspace.
 // Host-side only (no kernels here): a native "executor" so the Python layer issues 1 call per
 // forward / backward instead of ~100 per-op launches.  Never allocates, never synchronises.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -115,28 +116,18 @@ inline unsigned long site_seed(unsigned long seed, int site) { return seed ^ (0x
 // Fork/join between the main stream and the auxiliary stream that runs the weight-gradient GEMMs (they depend only on
 // buffers the data-gradient chain has already produced, and the chain's kernels - 198-tile GEMMs, attention backward,
 // LayerNorm backward - leave LDS and CUs idle).  Events are pooled (created once, outside any capture).
-struct EventPool {
-  std::vector<hipEvent_t> ev;
-  size_t next = 0;
-  hipEvent_t get() {
-    if (ev.size() < 64) {
-      hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-      ev.push_back(e);
-      return e;
-    }
-    return ev[next++ % ev.size()];
+inline int stream_sync(hipStream_t from, hipStream_t to) { return nv_stream_sync((void*)from, (void*)to); }
+// deferred join: record a point on the auxiliary stream now, make the main stream wait for it later
+inline hipEvent_t deferred_event() {
+  static std::vector<hipEvent_t> pool;
+  static size_t next = 0;
+  if (pool.size() < 32) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    pool.push_back(e);
+    return e;
   }
-};
-EventPool g_events;
-// make `to` wait for everything enqueued so far on `from`
-inline int stream_sync(hipStream_t from, hipStream_t to) {
-  hipEvent_t e = g_events.get();
-  if (!e || hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
-    nv_set_error("nv_vit_backward: event fork/join failed");
-    return NV_ERR_HIP;
-  }
-  return NV_OK;
+  return pool[next++ % pool.size()];
 }
 
 #define RUN(call)            \
@@ -299,7 +290,7 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     RUN(nv_gemm_bf16(2, 1, D.m, d, M, ws + W.du, D.m, ws + w.xn2, d, gr + q.w1, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, sA));            // [A] dW1 = dU^T xn2
     RUN(nv_colsum_bf16(ws + W.du, D.m, M, D.m, gr + q.b1, acc, redA, redA_bytes, sA));                                                                 // [A] db1
     hipEvent_t a1 = nullptr;
-    if (forked) { a1 = g_events.get(); if (!a1 || hipEventRecord(a1, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; } }
+    if (forked) { a1 = deferred_event(); if (!a1 || hipEventRecord(a1, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; } }
     RUN(nv_gemm_bf16(1, 1, M, d, D.m, ws + W.du, D.m, p16 + q.w1, d, dxn, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));                 // dxn2 = dU W1
     RUN(nv_ln_bwd(dxn, d, (float*)(ws + w.x1), d, st2, st2 + M, p + q.n2g, M, d, g, g, d, g16b, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, red,
                   W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream));                                              // g += dLN2 -> g16b; dbo = colsum(g)
@@ -315,9 +306,7 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, ws + W.dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
     // LN1 backward rewrites g16 (read by [A] dW2) and the next layer rewrites dU / g16b / dqkv (read by [A] dW1, colsum, dWo,
     // dWqkv): the main stream joins the auxiliary one here - by now those GEMMs have long finished.
-    if (forked) {
-      if (hipStreamWaitEvent(S, a1, 0) != hipSuccess) { nv_set_error("nv_vit_backward: event wait failed"); return NV_ERR_HIP; }
-    }
+    if (forked && hipStreamWaitEvent(S, a1, 0) != hipSuccess) { nv_set_error("nv_vit_backward: event wait failed"); return NV_ERR_HIP; }
     RUN(nv_ln_bwd(dxn1, d, xin, d, st1, st1 + M, p + q.n1g, M, d, g, g, d, g16, d, gr + q.n1g, gr + q.n1b, (l > 0) ? gr + T.layer[l - 1].b2 : nullptr,
                   acc, red, W.red_bytes, site_seed(drop_seed, 4 * (l - 1) + 3), (l > 0) ? drop_p : 0.f, stream));
     if (forked) RUN(stream_sync(A, S));     // dWo / dWqkv of this layer done before the next layer's kernels overwrite g16b / dqkv
