@@ -36,7 +36,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="volumes per GPU (BASELINE.json configs[1]: 4)")
     ap.add_argument("--preset", default="base", choices=["tiny", "base", "large"])
     ap.add_argument("--buckets", type=int, default=4, help="gradient all-reduce buckets")
+    ap.add_argument("--overlap-optimizer", action="store_true", help="AdamW per gradient bucket on the side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (forward-only, fwd+bwd, dropout)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -111,7 +113,7 @@ def main():
     torch.manual_seed(42)                                   # main.py:86-88
     model = NeuroEncoder(config)
     model.train()
-    step = TrainStep(model, process_group=None, n_buckets=a.buckets)
+    step = TrainStep(model, process_group=None, n_buckets=a.buckets, overlap_optimizer=a.overlap_optimizer)
     B = a.batch
     x, y = make_batch(B, S, device, 42 + rank)
 
@@ -136,6 +138,43 @@ def main():
         elapsed = t.item()
     ms = elapsed / a.steps * 1e3
     value = B * world * a.steps / elapsed
+
+    # ---- secondary lines SURVEY 8(d) asks for (single rank; not the headline): forward-only (validate, Trainer.py:101-118),
+    #      fwd+bwd without the optimizer, and the full step with the config's default dropout 0.1
+    also = None
+    if world == 1 and not a.no_extras:
+        def timed(fn, n):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return B * n / (time.perf_counter() - t)
+
+        crit = step.criterion
+
+        def fwd_bwd():
+            step.optimizer.zero_grad(set_to_none=True)
+            crit(model(x), y).backward()
+
+        def fwd_only():
+            with torch.no_grad():
+                model(x)
+
+        also = {"fwd_bwd_no_optimizer_volumes_s": round(timed(fwd_bwd, a.steps), 1)}
+        model.eval()
+        also["forward_only_eval_volumes_s"] = round(timed(fwd_only, a.steps), 1)
+        model.train()
+        torch.manual_seed(7)
+        dcfg = dict(config, TRAINING_DROPOUT=0.1)
+        dmodel = NeuroEncoder(dcfg)
+        dmodel.train()
+        dstep = TrainStep(dmodel, process_group=None, n_buckets=a.buckets)
+        also["train_step_dropout_0.1_volumes_s"] = round(timed(lambda: dstep(x, y), a.steps), 1)
+        del dstep, dmodel
+        log(f"extras: {also}")
 
     log(f"{ms:.3f} ms/step, {value:.1f} volumes/s; roofline leg")
     # ---- roofline leg: per-launch hipEvent durations of the dominant kernel family, same steps, same stream
@@ -179,6 +218,10 @@ def main():
                       "global_batch": B * world, "parallelism": f"dp{world}", "grad_buckets": a.buckets},
            "mfma_frac_step": round(value / world * f_step / (PEAK_BF16_TFLOPS * 1e12), 4),
            "loss": round(float(loss), 5), "roofline": roofline}
+    if also is not None:
+        f_fwd = flops_forward(ViTCfg(**vcfg))
+        also["forward_only_mfma_frac"] = round(also["forward_only_eval_volumes_s"] * f_fwd / (PEAK_BF16_TFLOPS * 1e12), 4)
+        out["also"] = also
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline leg")
         out["cpu_baseline"] = cpu_baseline(model, vcfg, B, S, a.cpu_steps)

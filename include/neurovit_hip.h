@@ -63,7 +63,9 @@ long nv_ln_bwd_workspace_bytes(int M, int d);
 int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd, const float* gamma,
               int M, int d, const float* g_in, float* g_out, long ldg, void* g16, long ldg16, float* dgamma, float* dbeta,
               float* dcolsum, int accumulate, void* workspace, long ws_bytes, unsigned long drop_seed, float drop_p,
-              void* stream);
+              void* stream, void* reduce_stream);
+/* reduce_stream (null = stream): where the dgamma / dbeta / dcolsum reduction of the per-workgroup partials runs; it is
+ * ordered after the main kernel by an event, and `workspace` must stay untouched until that stream has executed it. */
 
 /* ---- patch embedding front end (vit_3d.py:92-93 + the permute of NeuroEncoder.py:200-202)
  * video [B,C,F,H,W] f32 with arbitrary element strides (pass the strides of the permuted VIEW of the
@@ -112,7 +114,9 @@ int nv_colsum_bf16(const void* X, long ld, int M, int N, float* out, int accumul
 int nv_ce_loss(const float* logits, const long* target, int B, int C, float grad_scale, float* loss, float* dlogits,
                void* stream);
 int nv_adamw_step(float* p, const float* grad, float* m, float* v, void* p16, long count, int step, double lr, double beta1,
-                  double beta2, double eps, double weight_decay, float grad_scale, void* stream);
+                  double beta2, double eps, double weight_decay, float grad_scale, int max_blocks, void* stream);
+/* max_blocks > 0 caps the grid (256-thread workgroups, grid-stride): used when the update of one gradient bucket runs on a
+   side stream beside the backward pass, so that it takes a slice of the chip instead of queueing ahead of the GEMMs. */
 int nv_cast_bf16_2d(const float* src, long ld_src, int rows, int cols, void* dst, long ld_dst, void* stream);
 int nv_copy_2d_f32(const float* src, long ld_src, int rows, int cols, float* dst, long ld_dst, int accumulate, void* stream);
 

@@ -71,7 +71,7 @@ struct WS {
   long xp, pst, t, est, x0, xh, hst, wpe16;
   std::vector<LayerW> layer;
   // backward scratch
-  long g, g16, g16b, dxn, hookg, du, dao, dqkv, delta, dt, dt16, dxp, dwpe, red, red2;
+  long g, g16, g16b, dxn, hookg, du, dao, dqkv, delta, dt, dt16, dxp, dwpe, red, red2, red3;
   long red_bytes, red2_bytes, total;
 };
 
@@ -103,8 +103,9 @@ void make_ws(const Dims& D, int training, WS& W) {
     W.red_bytes = r; W.red = add(r);
     W.g16b = add(M * d * 2);
     W.red2_bytes = r4; W.red2 = add(r4);       // column-sum scratch of the auxiliary stream
+    W.red3 = add(nv_ln_bwd_workspace_bytes(D.M, D.d));   // LN1-backward partials (reduced on the auxiliary stream one layer late)
   } else {
-    W.g = W.g16 = W.dxn = W.hookg = W.du = W.dao = W.dqkv = W.delta = W.dt = W.dt16 = W.dxp = W.dwpe = W.red = W.g16b = W.red2 = -1;
+    W.g = W.g16 = W.dxn = W.hookg = W.du = W.dao = W.dqkv = W.delta = W.dt = W.dt16 = W.dxp = W.dwpe = W.red = W.g16b = W.red2 = W.red3 = -1;
     W.red_bytes = W.red2_bytes = 0;
   }
   W.total = cur;
@@ -293,7 +294,7 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     if (forked) { a1 = deferred_event(); if (!a1 || hipEventRecord(a1, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; } }
     RUN(nv_gemm_bf16(1, 1, M, d, D.m, ws + W.du, D.m, p16 + q.w1, d, dxn, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));                 // dxn2 = dU W1
     RUN(nv_ln_bwd(dxn, d, (float*)(ws + w.x1), d, st2, st2 + M, p + q.n2g, M, d, g, g, d, g16b, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, red,
-                  W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream));                                              // g += dLN2 -> g16b; dbo = colsum(g)
+                  W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream, forked ? sA : nullptr));                       // g += dLN2 -> g16b; [A] reduce: dbo = colsum(g), dLN2 affine
     // ---- Attention backward (vit_3d.py:48-60)
     if (forked) RUN(stream_sync(S, A));                                                                                        // g16b ready
     RUN(nv_gemm_bf16(2, 1, d, D.inner, M, g16b, d, ws + w.ao, D.inner, gr + q.wo, D.inner, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, sA));    // [A] dWo = g^T ao
@@ -307,10 +308,17 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     // LN1 backward rewrites g16 (read by [A] dW2) and the next layer rewrites dU / g16b / dqkv (read by [A] dW1, colsum, dWo,
     // dWqkv): the main stream joins the auxiliary one here - by now those GEMMs have long finished.
     if (forked && hipStreamWaitEvent(S, a1, 0) != hipSuccess) { nv_set_error("nv_vit_backward: event wait failed"); return NV_ERR_HIP; }
+    // join point of this layer, taken on [A] BEFORE the LN1 reduction is queued there: the main stream must not wait for that
+    // reduction (it only finishes parameter gradients); its partials live in red3, rewritten one whole layer later.
+    hipEvent_t a2 = nullptr;
+    if (forked) { a2 = deferred_event(); if (!a2 || hipEventRecord(a2, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; } }
     RUN(nv_ln_bwd(dxn1, d, xin, d, st1, st1 + M, p + q.n1g, M, d, g, g, d, g16, d, gr + q.n1g, gr + q.n1b, (l > 0) ? gr + T.layer[l - 1].b2 : nullptr,
-                  acc, red, W.red_bytes, site_seed(drop_seed, 4 * (l - 1) + 3), (l > 0) ? drop_p : 0.f, stream));
-    if (forked) RUN(stream_sync(A, S));     // dWo / dWqkv of this layer done before the next layer's kernels overwrite g16b / dqkv
+                  acc, forked ? (void*)(ws + W.red3) : red, W.red_bytes, site_seed(drop_seed, 4 * (l - 1) + 3), (l > 0) ? drop_p : 0.f, stream,
+                  forked ? sA : nullptr));
+    // dWo / dWqkv of this layer done before the next layer's kernels overwrite g16b / dqkv
+    if (forked && hipStreamWaitEvent(S, a2, 0) != hipSuccess) { nv_set_error("nv_vit_backward: event wait failed"); return NV_ERR_HIP; }
   }
+  if (forked) RUN(stream_sync(A, S));       // every gradient written on [A] (weight GEMMs, reductions) is ordered before what follows on the main stream
 
   if (last_stage < D.L + 1) return NV_OK;
   // ---- patch embedding backward (vit_3d.py:91-96,116-118)

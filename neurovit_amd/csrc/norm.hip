@@ -82,7 +82,9 @@ extern "C" int nv_ln_fwd(const float* x, long ldx, int M, int d, const float* ga
 
 // --------------------------------------------------------------------------------------- ln_bwd
 // g_out = g_in + LN'(dy);  g16 = bf16(g_out * dropmask);  partials[blk][0] = sum dy*xhat, [1] = sum dy, [2] = sum g_out * dropmask.
-template <int NV>
+// ROWS rows per wave are in flight together (x, dy and the incoming residual gradient are all requested before the first
+// use): the kernel is one dependent memory round trip, not 2 * ROWS of them.
+template <int NV, int ROWS>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, int M, int d, const float* g_in, float* g_out,
@@ -98,38 +100,51 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     gm[v] = (c < d) ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     a_g[v] = a_b[v] = a_c[v] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int row = blockIdx.x * WAVES_PER_BLOCK + wid; row < M; row += nw) {
-    f32x4 xv[NV], dv[NV];
-    row_load<NV>(x + (long)row * ldx, d, lane, xv);
-    row_load<NV>(dy + (long)row * lddy, d, lane, dv);
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    float s1 = 0.f, s2 = 0.f;
+  for (int base = blockIdx.x * WAVES_PER_BLOCK + wid; base < M; base += ROWS * nw) {
+    f32x4 xv[ROWS][NV], dv[ROWS][NV], gi[ROWS][NV];
+    float mean[ROWS], rstd[ROWS];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      xv[v] = (xv[v] - mean) * rstd;           // xhat (zero-padded lanes hold -mean*rstd but dv = 0 there)
-      const f32x4 dyh = dv[v] * gm[v];
-      s1 += (dyh[0] + dyh[1]) + (dyh[2] + dyh[3]);
-      const f32x4 t = dyh * xv[v];
-      s2 += (t[0] + t[1]) + (t[2] + t[3]);
-      a_g[v] += dv[v] * xv[v];
-      a_b[v] += dv[v];
+    for (int r = 0; r < ROWS; ++r) {
+      const int row = base + r * nw;
+      const int rr = row < M ? row : base;       // out-of-range slots re-read the first row; their results are dropped
+      row_load<NV>(x + (long)rr * ldx, d, lane, xv[r]);
+      row_load<NV>(dy + (long)rr * lddy, d, lane, dv[r]);
+      if (g_in) row_load<NV>(g_in + (long)rr * ldg, d, lane, gi[r]);
+      mean[r] = mean_in[rr]; rstd[r] = rstd_in[rr];
     }
-    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int c = (lane + 64 * v) * 4;
-      if (c < d) {
-        f32x4 o = (dv[v] * gm[v] - c1 - xv[v] * c2) * rstd;
-        if (g_in) o += *reinterpret_cast<const f32x4*>(g_in + (long)row * ldg + c);
-        *reinterpret_cast<f32x4*>(g_out + (long)row * ldg + c) = o;
-        // g16 / colsum feed the backward of the Linear whose (dropped-out) output was added to this residual stream
-        if (drop.thresh) {
-          const unsigned long long idx = (unsigned long long)row * d + c;
+    for (int r = 0; r < ROWS; ++r) {
+      const int row = base + r * nw;
+      if (row < M) {                              // wave-uniform
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] *= drop_factor(drop, idx + q);
+        for (int v = 0; v < NV; ++v) {
+          xv[r][v] = (xv[r][v] - mean[r]) * rstd[r];   // xhat (zero-padded lanes hold -mean*rstd but dv = 0 there)
+          const f32x4 dyh = dv[r][v] * gm[v];
+          s1 += (dyh[0] + dyh[1]) + (dyh[2] + dyh[3]);
+          const f32x4 t = dyh * xv[r][v];
+          s2 += (t[0] + t[1]) + (t[2] + t[3]);
+          a_g[v] += dv[r][v] * xv[r][v];
+          a_b[v] += dv[r][v];
         }
-        if (g16) *reinterpret_cast<bf16x4*>(g16 + (long)row * ldg16 + c) = cvt4(o[0], o[1], o[2], o[3]);
-        a_c[v] += o;
+        const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int c = (lane + 64 * v) * 4;
+          if (c < d) {
+            f32x4 o = (dv[r][v] * gm[v] - c1 - xv[r][v] * c2) * rstd[r];
+            if (g_in) o += gi[r][v];
+            *reinterpret_cast<f32x4*>(g_out + (long)row * ldg + c) = o;
+            // g16 / colsum feed the backward of the Linear whose (dropped-out) output was added to this residual stream
+            if (drop.thresh) {
+              const unsigned long long idx = (unsigned long long)row * d + c;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] *= drop_factor(drop, idx + q);
+            }
+            if (g16) *reinterpret_cast<bf16x4*>(g16 + (long)row * ldg16 + c) = cvt4(o[0], o[1], o[2], o[3]);
+            a_c[v] += o;
+          }
+        }
       }
     }
   }
@@ -191,7 +206,7 @@ extern "C" long nv_ln_bwd_workspace_bytes(int M, int d) { return (long)ln_bwd_bl
 extern "C" int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
                          const float* gamma, int M, int d, const float* g_in, float* g_out, long ldg, void* g16, long ldg16,
                          float* dgamma, float* dbeta, float* dcolsum, int accumulate, void* workspace, long ws_bytes,
-                         unsigned long drop_seed, float drop_p, void* stream) {
+                         unsigned long drop_seed, float drop_p, void* stream, void* reduce_stream) {
   NV_CHECK_ARG(M > 0 && d > 0 && (d % 4) == 0 && d <= 2048, "nv_ln_bwd: d=%d must be a multiple of 4 and <= 2048", d);
   const DropCfg drop = make_drop(drop_seed, drop_p);
   NV_CHECK_ARG(ws_bytes >= nv_ln_bwd_workspace_bytes(M, d), "nv_ln_bwd: workspace too small");
@@ -200,12 +215,18 @@ extern "C" int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, c
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)WAVES_PER_BLOCK * 3 * d * sizeof(float);
   if (d <= 1024)
-    hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
+    hipLaunchKernelGGL((ln_bwd_kernel<4, 2>), dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
                        (bf16*)g16, ldg16, (float*)workspace, drop);
   else
-    hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
+    hipLaunchKernelGGL((ln_bwd_kernel<8, 1>), dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
                        (bf16*)g16, ldg16, (float*)workspace, drop);
   NV_CHECK_LAUNCH("nv_ln_bwd");
+  // the parameter-gradient reduction is off the data path: it may run on another stream (the caller then owns `workspace`
+  // until that stream has passed this point)
+  if (reduce_stream && reduce_stream != stream) {
+    if (nv_stream_sync(stream, reduce_stream) != NV_OK) return NV_ERR_HIP;
+    s = (hipStream_t)reduce_stream;
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 31) / 32), dim3(256), 0, s, (const float*)workspace, nb, d, 3, dgamma,
                      dbeta, dcolsum, accumulate);
   NV_CHECK_LAUNCH("nv_ln_bwd/reduce");
@@ -479,7 +500,7 @@ extern "C" int nv_embed_finish_bwd(const float* g, long ldg, const float* t, lon
   for (int b = 0; b < B; ++b) {
     const int rc = nv_ln_bwd(g + ((long)b * n + 1) * ldg, ldg, t + (long)b * N * ldt, ldt, mean + (long)b * N, rstd + (long)b * N, gamma, N,
                              d, nullptr, dt + (long)b * N * lddt, lddt, dt16 ? (char*)dt16 + (long)b * N * lddt16 * 2 : nullptr, lddt16, dgamma,
-                             dbeta, dbias_pe, (accumulate || b > 0) ? 1 : 0, workspace, ws_bytes, 0, 0.f, stream);
+                             dbeta, dbias_pe, (accumulate || b > 0) ? 1 : 0, workspace, ws_bytes, 0, 0.f, stream, nullptr);
     if (rc) return rc;
   }
   const long tot = (long)n * d;

@@ -15,8 +15,9 @@ struct AdamArgs {   // every derived constant is formed in double on the host, a
 // denom = sqrt(v)/bc2_sqrt + eps; param.addcdiv_) so results track the reference optimizer to fp32 rounding.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ p16, long n4, AdamArgs a) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
+  // grid-stride: a full-size grid runs one iteration per thread; a capped grid (max_blocks) streams the range with a
+  // fraction of the chip's wave slots so that it can run beside compute-bound kernels of another stream
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
   f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
   f32x4 gv = reinterpret_cast<const f32x4*>(grad)[i] * a.grad_scale;
   f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
@@ -30,11 +31,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   reinterpret_cast<f32x4*>(m)[i] = mv;
   reinterpret_cast<f32x4*>(v)[i] = vv;
   if (p16) reinterpret_cast<bf16x4*>(p16)[i] = cvt4(pv[0], pv[1], pv[2], pv[3]);
+  }
 }
 
 // count must be a multiple of 4 (arena segments are padded); step >= 1.
 extern "C" int nv_adamw_step(float* p, const float* grad, float* m, float* v, void* p16, long count, int step, double lr, double beta1,
-                             double beta2, double eps, double weight_decay, float grad_scale, void* stream) {
+                             double beta2, double eps, double weight_decay, float grad_scale, int max_blocks, void* stream) {
   NV_CHECK_ARG(count > 0 && (count % 4) == 0 && step >= 1, "nv_adamw_step: count=%ld must be a positive multiple of 4", count);
   NV_CHECK_ARG(nv_aligned16(p) && nv_aligned16(grad) && nv_aligned16(m) && nv_aligned16(v) && (!p16 || ((uintptr_t)p16 & 7) == 0),
                "nv_adamw_step: alignment");
@@ -45,7 +47,9 @@ extern "C" int nv_adamw_step(float* p, const float* grad, float* m, float* v, vo
   a.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
   a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
   const long n4 = count / 4;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (bf16*)p16, n4, a);
+  long blocks = (n4 + 255) / 256;
+  if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (bf16*)p16, n4, a);
   NV_CHECK_LAUNCH("nv_adamw_step");
   return NV_OK;
 }

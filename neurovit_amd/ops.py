@@ -76,7 +76,7 @@ def ln_bwd(dy, x, st, gamma, g_in=None, want_g16=True, accumulate=False, dgamma=
     nb = lib.nv_ln_bwd_workspace_bytes(M, d)
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
     check(lib.nv_ln_bwd(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(st[0]), _p(st[1]), _p(gamma), M, d, _p(g_in), _p(g_out), d, _p(g16), d,
-                        _p(dgamma), _p(dbeta), _p(dcolsum), int(accumulate), _p(ws), nb, drop_seed, drop_p, _stream()), "nv_ln_bwd")
+                        _p(dgamma), _p(dbeta), _p(dcolsum), int(accumulate), _p(ws), nb, drop_seed, drop_p, _stream(), None), "nv_ln_bwd")
     return g_out, g16, dgamma, dbeta, dcolsum
 
 
@@ -189,9 +189,9 @@ def ce_loss(logits: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0,
     return loss, dl
 
 
-def adamw_step(p, grad, m, v, p16, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+def adamw_step(p, grad, m, v, p16, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0, max_blocks=0):
     check(lib.nv_adamw_step(_p(p), _p(grad), _p(m), _p(v), _p(p16), p.numel(), step, lr, betas[0], betas[1], eps, weight_decay, grad_scale,
-                            _stream()), "nv_adamw_step")
+                            int(max_blocks), _stream()), "nv_adamw_step")
 
 
 def cast_bf16(src: torch.Tensor, ld_dst: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

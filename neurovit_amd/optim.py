@@ -71,7 +71,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self._rest.step()
         return None
 
-    def step_range(self, vit: ViT, begin: int, end: int, grad_scale: float = 1.0):
+    def step_range(self, vit: ViT, begin: int, end: int, grad_scale: float = 1.0, max_blocks: int = 0):
         """AdamW on arena elements [begin, end) only (DP: run per gradient bucket behind its all-reduce).
         The caller advances the step counter once per optimizer step with `begin_step()`."""
         arena, shadow = vit.flat_parameters()
@@ -82,7 +82,7 @@ class FusedAdamW(torch.optim.Optimizer):
         m, v = self._state_mv[key]
         g0 = self.param_groups[0]
         ops.adamw_step(arena[begin:end], grads[begin:end], m[begin:end], v[begin:end], shadow[begin:end], self._steps, g0["lr"],
-                       g0["betas"], g0["eps"], g0["weight_decay"], grad_scale)
+                       g0["betas"], g0["eps"], g0["weight_decay"], grad_scale, max_blocks)
 
     def begin_step(self):
         if not self._bound:

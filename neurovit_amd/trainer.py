@@ -10,6 +10,7 @@ No host synchronisation happens inside a step; `loss` is returned as a device te
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -43,6 +44,7 @@ class TrainStep:
         # (740 vs 777 volumes/s: the HBM-bound optimizer slows the concurrent GEMMs more than it hides), so it is off.
         self.sync = None
         self._overlap_opt = bool(overlap_optimizer)
+        self._opt_blocks = int(os.environ.get("NEUROVIT_OPT_BLOCKS", "0"))
         if self._arena_trainable and (world > 1 or overlap_optimizer):
             self.sync = GradSync(process_group, n_buckets, after_bucket=self._bucket_update if overlap_optimizer else None)
         if world > 1:
@@ -56,7 +58,7 @@ class TrainStep:
         vit._grad_sync = None
 
     def _bucket_update(self, begin: int, end: int):
-        self.optimizer.step_range(self._vit, begin, end, grad_scale=1.0 / self.world)
+        self.optimizer.step_range(self._vit, begin, end, grad_scale=1.0 / self.world, max_blocks=self._opt_blocks)
 
     def __call__(self, fmri: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         model, vit = self.model, self._vit

@@ -159,6 +159,9 @@ class ViT(nn.Module):
                                       "path is cubic: NeuroEncoder.py:183-186)")
         if pool != 'cls':
             raise NotImplementedError("neurovit_amd: pool='mean' is not on the hot path (NeuroEncoder.py:194 uses 'cls')")
+        if heads == 1 and dim_head == dim:
+            raise NotImplementedError("neurovit_amd: heads == 1 with dim_head == dim drops to_out (vit_3d.py:32,43-46); the "
+                                      "engine's parameter table always carries to_out - not on the NeuroEncoder path")
         self._dropout_p = (float(dropout), float(emb_dropout))
         self._cfg = engine.make_config(image_size=image_height, image_patch_size=patch_height, frames=frames,
                                        frame_patch_size=frame_patch_size, num_classes=num_classes, dim=dim, depth=depth,

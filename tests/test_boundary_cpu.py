@@ -137,13 +137,24 @@ def test_ctor_asserts_like_reference():
 def test_no_cpu_fallback():
     """The product path must fail loudly without a GPU - never route through the oracle or eager torch."""
     from neurovit_amd.NeuroEncoder import NeuroEncoder
-    m = NeuroEncoder(W.neuro_config(16, 8, TRAINING_VIT_DIM=64, TRAINING_VIT_DEPTH=1, TRAINING_VIT_HEADS=1, TRAINING_VIT_MLP_DIM=64))
+    m = NeuroEncoder(W.neuro_config(16, 8, TRAINING_VIT_DIM=64, TRAINING_VIT_DEPTH=1, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=64))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 16, 16, 16))
     import neurovit_amd
     src = "".join(open(os.path.join(os.path.dirname(neurovit_amd.__file__), f)).read()
                   for f in os.listdir(os.path.dirname(neurovit_amd.__file__)) if f.endswith(".py"))
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_unsupported_constructions_raise():
+    """Outside the NeuroEncoder path the module refuses at construction instead of computing something else."""
+    from neurovit_amd.vit_3d import ViT
+    with pytest.raises(NotImplementedError):
+        ViT(**dict(W.MICRO, dim=64, heads=1))            # to_out becomes Identity in the reference (vit_3d.py:32)
+    with pytest.raises(NotImplementedError):
+        ViT(**dict(W.MICRO, pool="mean"))
+    with pytest.raises(AssertionError):
+        ViT(**dict(W.MICRO, image_size=30))              # vit_3d.py:83 divisibility assert
 
 
 def test_arena_views_survive_load_state_dict_and_track_to():

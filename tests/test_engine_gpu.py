@@ -142,6 +142,53 @@ def test_odd_patch_size_like_reference_default(eng):
     run_case(eng, "p9", cfgdict, (5, 6))
 
 
+def test_inner_dim_differs_from_dim(eng):
+    """heads * dim_head != dim, as in the reference's hard-coded encoder (NeuroEncoder.py:187-190: dim 1024, heads 8 ->
+    inner 512): to_qkv is [3*inner, dim], to_out.0 is [dim, inner]."""
+    run_case(eng, "inner<dim", dict(W.MICRO, dim=192, heads=1, mlp_dim=320), (7, 8))
+    run_case(eng, "inner>dim", dict(W.MICRO, dim=64, heads=3, mlp_dim=192), (9, 10))
+
+
+def test_reference_default_geometry(eng):
+    """configs/config.yaml:39-40 + NeuroEncoder.py:187-190 at full width: 90^3 volume, patch 9 (P = 729, n = 1001),
+    dim 1024, heads 8 (inner 512), mlp 2048; depth cut from 6 to 2 so the CPU oracles finish in seconds."""
+    cfgdict = dict(image_size=90, image_patch_size=9, frames=90, frame_patch_size=9, num_classes=2, dim=1024,
+                   depth=2, heads=8, mlp_dim=2048, channels=1, dim_head=64, pool="cls")
+    run_case(eng, "ref-default(L2)", cfgdict, (11, 12), B=1)
+
+
+def test_large_geometry_properties(eng):
+    """BASELINE.json configs[4] geometry (128^3, patch 8 -> n = 4097 tokens, dim 1024, heads 16, mlp 4096), depth cut
+    to 2: logits vs the bf16-emulating and fp32 oracles on one volume, determinism, and finite gradients of the right size
+    (long-sequence attention: 65 key tiles, ragged last tile)."""
+    cfgdict = dict(image_size=128, image_patch_size=8, frames=128, frame_patch_size=8, num_classes=2, dim=1024,
+                   depth=2, heads=16, mlp_dim=4096, channels=1, dim_head=64, pool="cls")
+    sd = W.make_tensors(W.vit_param_spec(**cfgdict), 13)
+    cfg, off, num, arena = load_arena(eng, cfgdict, sd)
+    params = arena.cuda()
+    p16 = params.to(torch.bfloat16)
+    rt = eng.VitRuntime(cfg)
+    fmri = W.make_volume((2, 128, 128, 128), 14)
+    video = ref_cpu.fmri_to_video(fmri.cuda())
+    a = rt.forward(video, params, p16, training=True).clone()
+    grads = torch.zeros_like(params)
+    dlogits = torch.tensor([[1.0, -1.0], [0.5, 0.25]], device="cuda")
+    rt.backward(dlogits, params, p16, grads, False)
+    g1 = grads.clone()
+    b = rt.forward(video, params, p16, training=True).clone()
+    grads.zero_()
+    rt.backward(dlogits, params, p16, grads, False)
+    assert torch.equal(a, b) and torch.equal(g1, grads)          # run-to-run deterministic, forward and backward
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    with torch.no_grad():
+        ocfg = ref_cpu.ViTCfg(**cfgdict)
+        ref = ref_cpu.vit_forward(sd, ocfg, ref_cpu.fmri_to_video(fmri[:1]), emulate_bf16=True)
+        ref32 = ref_cpu.vit_forward(sd, ocfg, ref_cpu.fmri_to_video(fmri[:1]))
+    e, e32 = rel_err(a[:1], ref), rel_err(a[:1], ref32)
+    report(f"large-geometry(L2) fwd logits vs emulating oracle: rel {e:.3e}; vs fp32 oracle: rel {e32:.3e}")
+    assert e <= MAXREL and e32 < 1e-2
+
+
 def test_inference_mode_matches_training_forward(eng):
     cfgdict = dict(W.MICRO)
     sd = W.make_tensors(W.vit_param_spec(**cfgdict), 1)
