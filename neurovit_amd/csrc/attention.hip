@@ -50,6 +50,9 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* img, int t, int ks, int r,
   const bf16x4 hi = lds_read_tr(img + img128_off(32 * ks + 16 + 4 * g + q, ch) + sub);
   return cat4(lo, hi);
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// bare v_exp_f32: arguments here are <= 0 and results in [0, 1]; results below 2^-126 flush to zero (they vanish in the sums)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float group_max(float v) {   // over the 4 lane groups sharing r
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -60,6 +63,76 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// one 64-key tile of the forward pass for one wave (16 query rows); shared by the streaming and the resident kernels.
+// The softmax is VALU-bound (head dim 64: 16 MFMAs per tile against ~16 scores per lane), so it is written for the
+// packed fp32 pipe (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32), v_max3_f32 and the bare v_exp_f32.
+__device__ __forceinline__ void fwd_tile(const char* sK, const char* sV, int kt, bool last, int n, const bf16x8 (&qf)[2], f32x4 (&o)[4],
+                                         float& m, float& l, float scale_log2e, const DropCfg& drop, int bh, int qabs, int r, int g) {
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t, ks, r, g), qf[ks], s[t], 0, 0, 0);
+    }
+    // softmax bookkeeping on the RAW scores (scale_log2e > 0, so max commutes with the scaling); the scaling itself is
+    // folded into one fma in front of exp2.  Only the last key tile can hold out-of-range keys.
+    if (last) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (kt * TK + 16 * t + 4 * g + j >= n) s[t][j] = -INFINITY;
+    }
+    float mloc = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+    mloc = fmaxf(fmaxf(mloc, s[0][3]), s[1][0]);
+#pragma unroll
+    for (int t = 1; t < 4; ++t) {
+      if (t > 1) mloc = fmaxf(fmaxf(mloc, s[t - 1][3]), s[t][0]);
+      mloc = fmaxf(fmaxf(mloc, s[t][1]), s[t][2]);
+    }
+    mloc = fmaxf(mloc, s[3][3]);
+    const float mnew = fmaxf(m, group_max(mloc) * scale_log2e);
+    const bool moved = mnew != m;                 // running max unchanged for every row of this wave -> skip the rescale
+    const float alpha = fast_exp2(m - mnew);
+    m = mnew;
+    const f32x2 c2 = {scale_log2e, scale_log2e}, m2 = {-mnew, -mnew};
+    f32x2 ps = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x2 x = {s[t][2 * hh], s[t][2 * hh + 1]};
+        x = __builtin_elementwise_fma(x, c2, m2);
+        x[0] = fast_exp2(x[0]);
+        x[1] = fast_exp2(x[1]);
+        ps += x;
+        s[t][2 * hh] = x[0];
+        s[t][2 * hh + 1] = x[1];
+      }
+    const float psum = ps[0] + ps[1];
+    if (__any(moved)) {
+      l = l * alpha + psum;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[t] *= alpha;
+    } else {
+      l += psum;
+    }
+    if (drop.thresh) {      // attention dropout (vit_3d.py:56): mask the probabilities that enter P.V, not the normaliser
+      const unsigned long long base = (((unsigned long long)bh * n + qabs) * n) + (unsigned long long)kt * TK;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[t][j] *= drop_factor(drop, base + 16 * t + 4 * g + j);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 pf = cvt8(s[2 * ks], s[2 * ks + 1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sV, t, ks, r, g), pf, o[t], 0, 0, 0);
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
                                                        bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
@@ -95,57 +168,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       tile_gload(K, ld, (kt + 1) * TK, n, tid, rk);
       tile_gload(V, ld, (kt + 1) * TK, n, tid, rv);
     }
-    f32x4 s[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t, ks, r, g), qf[ks], s[t], 0, 0, 0);
-    }
-    // softmax bookkeeping on the RAW scores (scale_log2e > 0, so max commutes with the scaling); the scaling itself is
-    // folded into one fma in front of exp2.  Only the last key tile can hold out-of-range keys.
-    if (kt == nkt - 1) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (kt * TK + 16 * t + 4 * g + j >= n) s[t][j] = -INFINITY;
-    }
-    float mloc = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-    mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3])), fmaxf(fmaxf(s[3][0], s[3][1]), fmaxf(s[3][2], s[3][3]))));
-    const float mnew = fmaxf(m, group_max(mloc) * scale_log2e);
-    const bool moved = mnew != m;                 // running max unchanged for every row of this wave -> skip the rescale
-    const float alpha = exp2f(m - mnew);
-    m = mnew;
-    float psum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float p = exp2f(fmaf(s[t][j], scale_log2e, -mnew));
-        s[t][j] = p;
-        psum += p;
-      }
-    if (__any(moved)) {
-      l = l * alpha + psum;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) o[t] *= alpha;
-    } else {
-      l += psum;
-    }
-    if (drop.thresh) {      // attention dropout (vit_3d.py:56): mask the probabilities that enter P.V, not the normaliser
-      const unsigned long long base = (((unsigned long long)blockIdx.y * n + (q0 + r)) * n) + (unsigned long long)kt * TK;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[t][j] *= drop_factor(drop, base + 16 * t + 4 * g + j);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 pf = cvt8(s[2 * ks], s[2 * ks + 1]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sV, t, ks, r, g), pf, o[t], 0, 0, 0);
-    }
+    fwd_tile(sK, sV, kt, kt == nkt - 1, n, qf, o, m, l, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
   }
   const float ltot = group_sum(l);
   const float inv = 1.0f / ltot;
@@ -159,6 +182,87 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   }
 }
 
+// ================================================================================================ resident variants
+// For n <= 576 (ViT3D-base: n = 513) the whole K and V of one (batch, head) - or Q and dO for the dK/dV pass - fit in
+// the CU's LDS (2 x 9 tiles x 8 KiB = 144 KiB).  One 512-thread workgroup streams them in ONCE with LDS-DMA (buffer
+// bounds zero-fill the rows beyond n), then its eight waves each own one 16-row group and run the same per-tile steps as
+// the streaming kernels with no further global loads and no barriers: the streaming kernels expose one L2 round trip
+// and two barriers per 64-key tile (9 of them at n = 513), which is where their time went.  Row groups are spread evenly
+// over ceil(groups / 8) workgroups per (batch, head): n = 513 -> 33 groups -> 5 workgroups of 7,7,7,6,6.
+// Results are bit-identical to the streaming kernels (same tile order, same arithmetic).
+typedef __attribute__((address_space(3))) void lds_void_t;
+constexpr int RES_THREADS = 512;
+constexpr int RES_MAX_TILES = 9;
+
+// all eight waves: DMA rows 0 .. 64*nt-1 of X (row stride ld elements, 64 bf16 per row) into nt swizzled 8 KiB images
+__device__ __forceinline__ void res_dma(const bf16* X, long ld, int n, int nt, char* img, int wid, int lane) {
+  const unsigned bytes = (unsigned)((((long)n - 1) * ld + DH) * 2);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, bytes, 0x00020000);
+  const int row = lane >> 3;                                          // 8 rows x 8 chunks per wave-instruction
+  const int voff = (int)((((long)(wid * 8 + row)) * ld + ((((lane & 7) ^ (row & 7))) << 3)) * 2);   // img128_off inverse
+  const int step = (int)(64 * ld * 2);
+  for (int t = 0; t < nt; ++t)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(img + t * IMG + wid * 1024), 16, voff, t * step, 0, 0);
+}
+// this wave's 16-row group, or -1
+__device__ __forceinline__ int res_group(int n, int wid) {
+  const int groups = (n + 15) >> 4;
+  const int g0 = (int)((long)blockIdx.x * groups / gridDim.x), g1 = (int)((long)(blockIdx.x + 1) * groups / gridDim.x);
+  return (g0 + wid < g1) ? g0 + wid : -1;
+}
+
+__global__ __launch_bounds__(RES_THREADS) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads,
+                                                                   float scale_log2e, bf16* __restrict__ out, long ldo,
+                                                                   float* __restrict__ lse, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char rsmem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const int nkt = (n + TK - 1) / TK;
+  char* sK = rsmem;
+  char* sV = rsmem + nkt * IMG;
+  res_dma(Q + inner, ld, n, nkt, sK, wid, lane);
+  res_dma(Q + 2 * inner, ld, n, nkt, sV, wid, lane);
+  const int grp = res_group(n, wid);
+  const int q0 = (grp < 0 ? 0 : grp) * 16;
+  const int qrow = min(q0 + r, n - 1);
+  bf16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+  __syncthreads();                                   // drains the DMA (vmcnt(0)) of every wave
+  if (grp < 0) return;
+
+  f32x4 o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  for (int kt = 0; kt < nkt; ++kt)
+    fwd_tile(sK + kt * IMG, sV + kt * IMG, kt, kt == nkt - 1, n, qf, o, m, l, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
+  const float ltot = group_sum(l);
+  const float inv = 1.0f / ltot;
+  const int q = q0 + r;
+  if (q < n) {
+    bf16* orow = out + ((long)b * n + q) * ldo + h * DH;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<bf16x4*>(orow + 16 * t + 4 * g) = cvt4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
+    if (g == 0 && lse) lse[((long)b * heads + h) * n + q] = (m + log2f(ltot)) * 0.69314718055994530942f;
+  }
+}
+
+static int g_attn_mode = 0;    // 0 = heuristic, 1 = streaming kernels, 2 = resident kernels (tests compare the two bit for bit)
+extern "C" int nv_attn_set_mode(int mode) { g_attn_mode = mode; return 0; }
+static bool attn_resident(int n) {
+  const int nt = (n + TK - 1) / TK;
+  return g_attn_mode != 1 && nt <= RES_MAX_TILES;
+}
+static int attn_res_blocks(int n) { return (((n + 15) >> 4) + 7) / 8; }
+template <typename Kern>
+static void attn_res_attr(Kern kern, int lds) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
 extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
                            float* lse, unsigned long drop_seed, float drop_p, void* stream) {
   NV_CHECK_ARG(dim_head == DH, "nv_attn_fwd: dim_head=%d unsupported (only 64)", dim_head);
@@ -166,6 +270,14 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
                "nv_attn_fwd: bad dims");
   NV_CHECK_ARG(nv_aligned16(qkv) && nv_aligned16(out), "nv_attn_fwd: alignment");
   const int slot = nv_prof_begin(3, 4.0 * B * heads * (double)n * n * DH, stream);
+  if (attn_resident(n)) {
+    NV_CHECK_ARG((long)n * ld_qkv < (1L << 30), "nv_attn_fwd: operand too large for 32-bit buffer offsets");
+    const int lds = 2 * ((n + TK - 1) / TK) * IMG;
+    static bool attr = false;
+    if (!attr) { attn_res_attr(attn_fwd_res_kernel, 2 * RES_MAX_TILES * IMG); attr = true; }
+    hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(attn_res_blocks(n), B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream, (const bf16*)qkv,
+                       ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
+  } else
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((n + TQ - 1) / TQ, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
                      heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
   nv_prof_end(slot, stream);
@@ -174,6 +286,50 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
+// one 64-key tile of the dQ pass for one wave (16 query rows)
+__device__ __forceinline__ void dq_tile(const char* sK, const char* sV, int kt, int n, const bf16x8 (&qf)[2], const bf16x8 (&dof)[2],
+                                        f32x4 (&dq)[4], float dl, float lse2, float scale_log2e, const DropCfg& drop, int bh, int qabs,
+                                        int r, int g) {
+    f32x4 ds[4];
+    const f32x2 c2 = {scale_log2e, scale_log2e}, l2 = {-lse2, -lse2}, d2 = {-dl, -dl};
+    const bool ragged = kt * TK + TK > n;         // only the last key tile can hold out-of-range (zero-filled) keys
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t, ks, r, g), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sV, t, ks, r, g), dof[ks], dp, 0, 0, 0);
+      }
+      if (drop.thresh) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          dp[j] *= drop_factor(drop, (((unsigned long long)bh * n + qabs) * n) + (kt * TK + 16 * t + 4 * g + j));
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x2 x = {s[2 * hh], s[2 * hh + 1]};
+        x = __builtin_elementwise_fma(x, c2, l2);
+        f32x2 pv = {fast_exp2(x[0]), fast_exp2(x[1])};
+        const f32x2 dpv = {dp[2 * hh], dp[2 * hh + 1]};
+        const f32x2 dsv = pv * (dpv + d2);
+        ds[t][2 * hh] = dsv[0];
+        ds[t][2 * hh + 1] = dsv[1];
+      }
+      if (ragged) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (kt * TK + 16 * t + 4 * g + j >= n) ds[t][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 dsf = cvt8(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sK, t, ks, r, g), dsf, dq[t], 0, 0, 0);
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
                                                           const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse, int n,
                                                           int heads, float scale, float* __restrict__ delta, bf16* __restrict__ dqkv,
@@ -222,29 +378,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       tile_gload(K, ld, (kt + 1) * TK, n, tid, rk);
       tile_gload(V, ld, (kt + 1) * TK, n, tid, rv);
     }
-    f32x4 ds[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t, ks, r, g), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sV, t, ks, r, g), dof[ks], dp, 0, 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = kt * TK + 16 * t + 4 * g + j;
-        const float p = (key < n) ? exp2f(fmaf(s[j], scale_log2e, -lse2)) : 0.f;
-        if (drop.thresh) dp[j] *= drop_factor(drop, (((unsigned long long)blockIdx.y * n + (q0 + r)) * n) + key);
-        ds[t][j] = p * (dp[j] - dl);
-      }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 dsf = cvt8(ds[2 * ks], ds[2 * ks + 1]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sK, t, ks, r, g), dsf, dq[t], 0, 0, 0);
-    }
+    dq_tile(sK, sV, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
   }
   const int q = q0 + r;
   if (q < n) {
@@ -256,6 +390,53 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
+// one 64-query tile of the dK/dV pass for one wave (16 keys); sL / sDl hold this tile's 64 log2-domain lse and delta values
+__device__ __forceinline__ void dkv_tile(const char* sQ, const char* sD, const float* sL, const float* sDl, int qt, int n,
+                                         const bf16x8 (&kf)[2], const bf16x8 (&vf)[2], f32x4 (&dk)[4], f32x4 (&dv)[4], float scale_log2e,
+                                         const DropCfg& drop, int bh, int keyabs, int r, int g) {
+    f32x4 p[4], ds[4];
+    const f32x2 c2 = {scale_log2e, scale_log2e};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sQ, t, ks, r, g), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sD, t, ks, r, g), vf[ks], dp, 0, 0, 0);
+      }
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 16 * t + 4 * g);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + 16 * t + 4 * g);
+      f32x4 f = {1.f, 1.f, 1.f, 1.f};
+      if (drop.thresh) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          f[j] = drop_factor(drop, (((unsigned long long)bh * n + (qt * TQ + 16 * t + 4 * g + j)) * n) + keyabs);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x2 x = {s[2 * hh], s[2 * hh + 1]};
+        const f32x2 lv = {-l4[2 * hh], -l4[2 * hh + 1]}, dlv = {d4[2 * hh], d4[2 * hh + 1]};
+        const f32x2 fv = {f[2 * hh], f[2 * hh + 1]}, dpv = {dp[2 * hh], dp[2 * hh + 1]};
+        x = __builtin_elementwise_fma(x, c2, lv);
+        const f32x2 pv = {fast_exp2(x[0]), fast_exp2(x[1])};
+        const f32x2 pd = pv * fv;
+        const f32x2 dsv = pv * (dpv * fv - dlv);
+        p[t][2 * hh] = pd[0]; p[t][2 * hh + 1] = pd[1];
+        ds[t][2 * hh] = dsv[0]; ds[t][2 * hh + 1] = dsv[1];
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 pf = cvt8(p[2 * ks], p[2 * ks + 1]);
+      const bf16x8 dsf = cvt8(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sD, t, ks, r, g), pf, dv[t], 0, 0, 0);
+        dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQ, t, ks, r, g), dsf, dk[t], 0, 0, 0);
+      }
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout, long ldo,
                                                            const float* __restrict__ lse, const float* __restrict__ delta, int n,
                                                            int heads, float scale, bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
@@ -310,37 +491,113 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
       tile_gload(dO, ldo, (qt + 1) * TQ, n, tid, rd);
       stats_load(qt + 1);
     }
-    f32x4 p[4], ds[4];
+    dkv_tile(sQ, sD, sL, sDl, qt, n, kf, vf, dk, dv, scale_log2e, drop, blockIdx.y, key0 + r, r, g);
+  }
+  const int key = key0 + r;
+  if (key < n) {
+    bf16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sQ, t, ks, r, g), kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sD, t, ks, r, g), vf[ks], dp, 0, 0, 0);
-      }
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 16 * t + 4 * g);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + 16 * t + 4 * g);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float pv = exp2f(fmaf(s[j], scale_log2e, -l4[j]));
-        float f = 1.f;
-        if (drop.thresh) f = drop_factor(drop, (((unsigned long long)blockIdx.y * n + (qt * TQ + 16 * t + 4 * g + j)) * n) + (key0 + r));
-        p[t][j] = pv * f;
-        ds[t][j] = pv * (dp[j] * f - d4[j]);
-      }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 pf = cvt8(p[2 * ks], p[2 * ks + 1]);
-      const bf16x8 dsf = cvt8(ds[2 * ks], ds[2 * ks + 1]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sD, t, ks, r, g), pf, dv[t], 0, 0, 0);
-        dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQ, t, ks, r, g), dsf, dk[t], 0, 0, 0);
-      }
+      *reinterpret_cast<bf16x4*>(drow + inner + 16 * t + 4 * g) = cvt4(dk[t][0] * scale, dk[t][1] * scale, dk[t][2] * scale, dk[t][3] * scale);
+      *reinterpret_cast<bf16x4*>(drow + 2 * inner + 16 * t + 4 * g) = cvt4(dv[t][0], dv[t][1], dv[t][2], dv[t][3]);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ resident backward kernels
+__global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
+                                                                      const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse,
+                                                                      int n, int heads, float scale, float* __restrict__ delta,
+                                                                      bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char rsmem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const int nkt = (n + TK - 1) / TK;
+  char* sK = rsmem;
+  char* sV = rsmem + nkt * IMG;
+  res_dma(Q + inner, ld, n, nkt, sK, wid, lane);
+  res_dma(Q + 2 * inner, ld, n, nkt, sV, wid, lane);
+  const int grp = res_group(n, wid);
+  const int q0 = (grp < 0 ? 0 : grp) * 16;
+  const int qrow = min(q0 + r, n - 1);
+  const float scale_log2e = scale * 1.44269504088896340736f;
+
+  bf16x8 qf[2], dof[2];
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+    const long off = ((long)b * n + qrow) * ldo + h * DH + 32 * ks + 8 * g;
+    dof[ks] = *reinterpret_cast<const bf16x8*>(dout + off);
+    const bf16x8 of = *reinterpret_cast<const bf16x8*>(out + off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[j];
+  }
+  dl = group_sum(dl);
+  const float lse2 = lse[((long)b * heads + h) * n + qrow] * 1.44269504088896340736f;
+  __syncthreads();                                   // drains the DMA (vmcnt(0)) of every wave
+  if (grp < 0) return;
+  if (g == 0 && q0 + r < n) delta[((long)b * heads + h) * n + q0 + r] = dl;
+
+  f32x4 dq[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < nkt; ++kt)
+    dq_tile(sK + kt * IMG, sV + kt * IMG, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
+  const int q = q0 + r;
+  if (q < n) {
+    bf16* drow = dqkv + ((long)b * n + q) * ldd + h * DH;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<bf16x4*>(drow + 16 * t + 4 * g) = cvt4(dq[t][0] * scale, dq[t][1] * scale, dq[t][2] * scale, dq[t][3] * scale);
+  }
+}
+
+__global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout,
+                                                                       long ldo, const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                       int n, int heads, float scale, bf16* __restrict__ dqkv, long ldd,
+                                                                       DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char rsmem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const bf16* K = Q + inner;
+  const bf16* V = Q + 2 * inner;
+  const bf16* dO = dout + (long)b * n * ldo + h * DH;
+  const float* L = lse + ((long)b * heads + h) * n;
+  const float* Dl = delta + ((long)b * heads + h) * n;
+  const int nqt = (n + TQ - 1) / TQ;
+  char* sQ = rsmem;
+  char* sD = rsmem + nqt * IMG;
+  float* sL = reinterpret_cast<float*>(rsmem + 2 * nqt * IMG);
+  float* sDl = sL + nqt * TQ;
+  res_dma(Q, ld, n, nqt, sQ, wid, lane);
+  res_dma(dO, ldo, n, nqt, sD, wid, lane);
+  for (int q = tid; q < nqt * TQ; q += RES_THREADS) {
+    sL[q] = (q < n) ? L[q] * 1.44269504088896340736f : INFINITY;   // exp2(x - inf) = 0 masks padded query rows
+    sDl[q] = (q < n) ? Dl[q] : 0.f;
+  }
+  const int grp = res_group(n, wid);
+  const int key0 = (grp < 0 ? 0 : grp) * 16;
+  const int krow = min(key0 + r, n - 1);
+  const float scale_log2e = scale * 1.44269504088896340736f;
+  bf16x8 kf[2], vf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(K + (long)krow * ld + 32 * ks + 8 * g);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(V + (long)krow * ld + 32 * ks + 8 * g);
+  }
+  __syncthreads();                                   // DMA drained, sL / sDl written
+  if (grp < 0) return;
+
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int qt = 0; qt < nqt; ++qt)
+    dkv_tile(sQ + qt * IMG, sD + qt * IMG, sL + qt * TQ, sDl + qt * TQ, qt, n, kf, vf, dk, dv, scale_log2e, drop, blockIdx.y, key0 + r, r, g);
   const int key = key0 + r;
   if (key < n) {
     bf16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
@@ -364,6 +621,25 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((n + TQ - 1) / TQ, B * heads);
   const int slot = nv_prof_begin(4, 10.0 * B * heads * (double)n * n * DH, stream);   // algorithmic: 5 products
+  if (attn_resident(n)) {
+    NV_CHECK_ARG((long)n * ld_qkv < (1L << 30) && (long)n * ld_out < (1L << 30), "nv_attn_bwd: operand too large for 32-bit buffer offsets");
+    const int nt = (n + TK - 1) / TK;
+    static bool attr = false;
+    if (!attr) {
+      attn_res_attr(attn_bwd_dq_res_kernel, 2 * RES_MAX_TILES * IMG);
+      attn_res_attr(attn_bwd_dkv_res_kernel, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
+      attr = true;
+    }
+    const dim3 rgrid(attn_res_blocks(n), B * heads);
+    hipLaunchKernelGGL(attn_bwd_dq_res_kernel, rgrid, dim3(RES_THREADS), 2 * nt * IMG, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
+                       (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+    NV_CHECK_LAUNCH("nv_attn_bwd/dq(resident)");
+    hipLaunchKernelGGL(attn_bwd_dkv_res_kernel, rgrid, dim3(RES_THREADS), 2 * nt * IMG + 2 * nt * TQ * 4, s, (const bf16*)qkv, ld_qkv,
+                       (const bf16*)dout, ld_out, lse, delta, n, heads, scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+    nv_prof_end(slot, stream);
+    NV_CHECK_LAUNCH("nv_attn_bwd/dkv(resident)");
+    return NV_OK;
+  }
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out, lse, n,
                      heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
   NV_CHECK_LAUNCH("nv_attn_bwd/dq");

@@ -278,6 +278,28 @@ def test_attention_fwd_bwd(ops, B, n, heads):
     assert_close_stat(dqkv, dref, "attn.dqkv")
 
 
+@pytest.mark.parametrize("B,n,heads,drop", [(2, 513, 3, 0.0), (1, 576, 2, 0.0), (3, 65, 2, 0.1), (2, 9, 1, 0.0), (1, 500, 1, 0.2)])
+def test_attention_resident_equals_streaming(ops, B, n, heads, drop):
+    """n <= 576: the LDS-resident kernels (K/V - or Q/dO - of one head loaded once) must reproduce the streaming kernels
+    bit for bit: same tile order, same arithmetic, same dropout counters."""
+    from neurovit_amd._cabi import lib
+    inner = heads * 64
+    qkv = dev(bf(rnd(B * n, 3 * inner, seed=n + heads)))
+    do = dev(bf(rnd(B * n, inner, seed=3)))
+    res = {}
+    try:
+        for mode in (1, 2):
+            lib.nv_attn_set_mode(mode)
+            out, lse = ops.attn_fwd(qkv, B, n, heads, drop_seed=99, drop_p=drop)
+            dqkv, delta = ops.attn_bwd(qkv, out, do, lse, B, n, heads, drop_seed=99, drop_p=drop)
+            res[mode] = (out, lse, dqkv, delta)
+    finally:
+        lib.nv_attn_set_mode(0)
+    for a, b, name in zip(res[1], res[2], ("out", "lse", "dqkv", "delta")):
+        assert torch.equal(a, b), name
+    assert torch.isfinite(res[2][2].float()).all()
+
+
 def test_attention_rescale_branch(ops):
     """Force the online-softmax rescale: one key in the LAST tile dominates one query row."""
     B, n, heads, dh = 1, 200, 1, 64

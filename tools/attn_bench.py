@@ -27,7 +27,11 @@ def timeit(fn, iters=50):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-tf = timeit(lambda: ops.attn_fwd(qkv, B, n, heads))
-tb = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, B, n, heads))
+from neurovit_amd._cabi import lib  # noqa: E402
 fl = 4.0 * B * heads * n * n * 64
-print(f"attn fwd {tf:7.2f} us ({fl / tf / 1e6:6.1f} TFLOP/s)   bwd (dq+dkv) {tb:7.2f} us ({2.5 * fl / tb / 1e6:6.1f} TFLOP/s algorithmic)")
+for mode, name in ((1, "streaming"), (2, "resident ")):
+    lib.nv_attn_set_mode(mode)
+    tf = timeit(lambda: ops.attn_fwd(qkv, B, n, heads))
+    tb = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, B, n, heads))
+    print(f"{name}: attn fwd {tf:7.2f} us ({fl / tf / 1e6:6.1f} TFLOP/s)   bwd (dq+dkv) {tb:7.2f} us ({2.5 * fl / tb / 1e6:6.1f} TFLOP/s algorithmic)")
+lib.nv_attn_set_mode(0)
