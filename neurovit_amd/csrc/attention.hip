@@ -63,19 +63,39 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-// one 64-key tile of the forward pass for one wave (16 query rows); shared by the streaming and the resident kernels.
+// One 64-key tile of the forward pass for one wave (16 query rows), in pieces so that the resident kernel can software-
+// pipeline the LDS fragment reads of the NEXT products under the softmax arithmetic; the streaming kernel runs the same
+// pieces back to back (identical arithmetic, bit-identical results).
 // The softmax is VALU-bound (head dim 64: 16 MFMAs per tile against ~16 scores per lane), so it is written for the
 // packed fp32 pipe (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32), v_max3_f32 and the bare v_exp_f32.
-__device__ __forceinline__ void fwd_tile(const char* sK, const char* sV, int kt, bool last, int n, const bf16x8 (&qf)[2], f32x4 (&o)[4],
-                                         float& m, float& l, float scale_log2e, const DropCfg& drop, int bh, int qabs, int r, int g) {
-    f32x4 s[4];
+struct RowFrags { bf16x8 f[2][4]; };    // [ks][t]: fragments of one 64-row operand tile
+__device__ __forceinline__ void load_row_frags(const char* img, int r, int g, RowFrags& F) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t, ks, r, g), qf[ks], s[t], 0, 0, 0);
-    }
-    // softmax bookkeeping on the RAW scores (scale_log2e > 0, so max commutes with the scaling); the scaling itself is
+    for (int t = 0; t < 4; ++t) F.f[ks][t] = frag_row(img, t, ks, r, g);
+}
+__device__ __forceinline__ void load_tr_frags(const char* img, int r, int g, RowFrags& F) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) F.f[ks][t] = frag_tr(img, t, ks, r, g);
+}
+// acc[t] (+)= X_tile[16t.., :] . y   (ks outer: four independent accumulators between dependent MFMAs)
+__device__ __forceinline__ void mfma_rows(const RowFrags& F, const bf16x8 (&y)[2], f32x4 (&acc)[4], bool zero) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (zero) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.f[ks][t], y[ks], acc[t], 0, 0, 0);
+}
+// online softmax of one tile's raw scores s (in place -> probabilities, dropout applied), running max m / sum l, rescale of o
+__device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4], int kt, bool last, int n, f32x4 (&o)[4], float& m, float& l, float scale_log2e,
+                                            const DropCfg& drop, int bh, int qabs, int g) {
+    // bookkeeping on the RAW scores (scale_log2e > 0, so max commutes with the scaling); the scaling itself is
     // folded into one fma in front of exp2.  Only the last key tile can hold out-of-range keys.
     if (last) {
 #pragma unroll
@@ -125,12 +145,21 @@ __device__ __forceinline__ void fwd_tile(const char* sK, const char* sV, int kt,
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[t][j] *= drop_factor(drop, base + 16 * t + 4 * g + j);
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 pf = cvt8(s[2 * ks], s[2 * ks + 1]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sV, t, ks, r, g), pf, o[t], 0, 0, 0);
-    }
+}
+// o[t] += V_tile^T[16t.., :] . P^T   (the probability accumulators are the MFMA B operand)
+__device__ __forceinline__ void fwd_pv(const RowFrags& V, const f32x4 (&s)[4], f32x4 (&o)[4]) {
+  const bf16x8 pf[2] = {cvt8(s[0], s[1]), cvt8(s[2], s[3])};
+  mfma_rows(V, pf, o, false);
+}
+__device__ __forceinline__ void fwd_tile(const char* sK, const char* sV, int kt, bool last, int n, const bf16x8 (&qf)[2], f32x4 (&o)[4],
+                                         float& m, float& l, float scale_log2e, const DropCfg& drop, int bh, int qabs, int r, int g) {
+  RowFrags F;
+  f32x4 s[4];
+  load_row_frags(sK, r, g, F);
+  mfma_rows(F, qf, s, true);
+  fwd_softmax(s, kt, last, n, o, m, l, scale_log2e, drop, bh, qabs, g);
+  load_tr_frags(sV, r, g, F);
+  fwd_pv(F, s, o);
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
@@ -237,8 +266,21 @@ __global__ __launch_bounds__(RES_THREADS) void attn_fwd_res_kernel(const bf16* _
 #pragma unroll
   for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
-  for (int kt = 0; kt < nkt; ++kt)
-    fwd_tile(sK + kt * IMG, sV + kt * IMG, kt, kt == nkt - 1, n, qf, o, m, l, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
+  // software pipeline: the V fragments of this tile and the K fragments of the next one are requested from LDS before the
+  // softmax arithmetic, so the ds_read latency sits under ~130 VALU instructions instead of in front of the MFMAs
+  RowFrags KF, VF;
+  f32x4 sc[4];
+  load_row_frags(sK, r, g, KF);
+  for (int kt = 0; kt < nkt; ++kt) {
+    mfma_rows(KF, qf, sc, true);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tr_frags(sV + kt * IMG, r, g, VF);
+    load_row_frags(sK + (kt + 1 < nkt ? kt + 1 : kt) * IMG, r, g, KF);
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_softmax(sc, kt, kt == nkt - 1, n, o, m, l, scale_log2e, drop, blockIdx.y, q0 + r, g);
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_pv(VF, sc, o);
+  }
   const float ltot = group_sum(l);
   const float inv = 1.0f / ltot;
   const int q = q0 + r;

@@ -102,7 +102,7 @@ void make_ws(const Dims& D, int training, WS& W) {
     r = r > r2 ? r : r2; r = r > r3 ? r : r3; r = r > r4 ? r : r4;
     W.red_bytes = r; W.red = add(r);
     W.g16b = add(M * d * 2);
-    W.red2_bytes = r4; W.red2 = add(r4);       // column-sum scratch of the auxiliary stream
+    W.red2_bytes = r4 > r2 ? r4 : r2; W.red2 = add(W.red2_bytes);       // reduction scratch of the auxiliary stream (column sums, patch-LN backward)
     W.red3 = add(nv_ln_bwd_workspace_bytes(D.M, D.d));   // LN1-backward partials (reduced on the auxiliary stream one layer late)
   } else {
     W.g = W.g16 = W.dxn = W.hookg = W.du = W.dao = W.dqkv = W.delta = W.dt = W.dt16 = W.dxp = W.dwpe = W.red = W.g16b = W.red2 = W.red3 = -1;
@@ -329,16 +329,20 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   // patch_dim not a multiple of 8 (reference default 90^3 / p 9 -> P = 729): operands are zero padded to Ppad columns;
   // the weight gradient is produced in a padded scratch matrix and its valid columns copied / added into the arena.
   const void* wpe = (D.P != D.Ppad) ? (const void*)(ws + W.wpe16) : (const void*)(p16 + T.pe_w);
+  // [A] gradient of the patch LayerNorm's affine parameters (needs dxp = dt Wpe and a second gather of the volume);
+  // the main stream meanwhile produces the patch-embedding weight gradient
+  if (forked) RUN(stream_sync(S, A));                                                                                          // dt16 ready
+  RUN(nv_gemm_bf16(1, 1, D.T, D.Ppad, d, ws + W.dt16, d, wpe, D.Ppad, ws + W.dxp, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, sA));              // [A] dxp = dt Wpe
+  RUN(nv_patch_ln_bwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
+                      cfg->image_patch_size, cfg->frame_patch_size, (float*)(ws + W.dxp), D.Ppad, pst, pst + D.T, gr + T.pe_g, gr + T.pe_b, acc, redA,
+                      redA_bytes, sA));                                                                                         // [A]
   if (D.P != D.Ppad) {
     RUN(nv_gemm_bf16(2, 1, d, D.Ppad, D.T, ws + W.dt16, d, ws + W.xp, D.Ppad, ws + W.dwpe, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
     RUN(nv_copy_2d_f32((float*)(ws + W.dwpe), D.Ppad, d, D.P, gr + T.pe_w, D.P, acc, stream));
   } else {
     RUN(nv_gemm_bf16(2, 1, d, D.P, D.T, ws + W.dt16, d, ws + W.xp, D.Ppad, gr + T.pe_w, D.P, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));   // dWpe = dt^T xp
   }
-  RUN(nv_gemm_bf16(1, 1, D.T, D.Ppad, d, ws + W.dt16, d, wpe, D.Ppad, ws + W.dxp, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));           // dxp = dt Wpe
-  RUN(nv_patch_ln_bwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
-                      cfg->image_patch_size, cfg->frame_patch_size, (float*)(ws + W.dxp), D.Ppad, pst, pst + D.T, gr + T.pe_g, gr + T.pe_b, acc, red,
-                      W.red_bytes, stream));
+  if (forked) RUN(stream_sync(A, S));
   return NV_OK;
 }
 

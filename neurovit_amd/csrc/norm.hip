@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, int M, int d, const float* g_in, float* g_out,
                                                      long ldg, bf16* __restrict__ g16, long ldg16, float* __restrict__ partials,
-                                                     DropCfg drop) {
+                                                     DropCfg drop, int seg_rows, int seg_skip) {
+  // seg_rows > 0: dy is segmented - after every seg_rows rows seg_skip rows are skipped (token rows of a [B, 1+N, d] tensor)
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][3][d]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nw = gridDim.x * WAVES_PER_BLOCK;
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       const int row = base + r * nw;
       const int rr = row < M ? row : base;       // out-of-range slots re-read the first row; their results are dropped
       row_load<NV>(x + (long)rr * ldx, d, lane, xv[r]);
-      row_load<NV>(dy + (long)rr * lddy, d, lane, dv[r]);
+      const long dyr = seg_rows ? (long)rr + (long)(rr / seg_rows) * seg_skip : (long)rr;
+      row_load<NV>(dy + dyr * lddy, d, lane, dv[r]);
       if (g_in) row_load<NV>(g_in + (long)rr * ldg, d, lane, gi[r]);
       mean[r] = mean_in[rr]; rstd[r] = rstd_in[rr];
     }
@@ -203,10 +205,10 @@ static int ln_bwd_blocks(int M) {
 extern "C" long nv_ln_bwd_workspace_bytes(int M, int d) { return (long)ln_bwd_blocks(M) * 3 * d * sizeof(float); }
 
 // dgamma/dbeta/dcolsum may be null (skipped).  g_in may be null (g_out = dx) or equal g_out (in place).
-extern "C" int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
-                         const float* gamma, int M, int d, const float* g_in, float* g_out, long ldg, void* g16, long ldg16,
-                         float* dgamma, float* dbeta, float* dcolsum, int accumulate, void* workspace, long ws_bytes,
-                         unsigned long drop_seed, float drop_p, void* stream, void* reduce_stream) {
+static int ln_bwd_launch(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd, const float* gamma,
+                         int M, int d, const float* g_in, float* g_out, long ldg, void* g16, long ldg16, float* dgamma, float* dbeta,
+                         float* dcolsum, int accumulate, void* workspace, long ws_bytes, unsigned long drop_seed, float drop_p,
+                         void* stream, void* reduce_stream, int seg_rows, int seg_skip) {
   NV_CHECK_ARG(M > 0 && d > 0 && (d % 4) == 0 && d <= 2048, "nv_ln_bwd: d=%d must be a multiple of 4 and <= 2048", d);
   const DropCfg drop = make_drop(drop_seed, drop_p);
   NV_CHECK_ARG(ws_bytes >= nv_ln_bwd_workspace_bytes(M, d), "nv_ln_bwd: workspace too small");
@@ -216,10 +218,10 @@ extern "C" int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, c
   const size_t lds = (size_t)WAVES_PER_BLOCK * 3 * d * sizeof(float);
   if (d <= 1024)
     hipLaunchKernelGGL((ln_bwd_kernel<4, 2>), dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
-                       (bf16*)g16, ldg16, (float*)workspace, drop);
+                       (bf16*)g16, ldg16, (float*)workspace, drop, seg_rows, seg_skip);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<8, 1>), dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
-                       (bf16*)g16, ldg16, (float*)workspace, drop);
+                       (bf16*)g16, ldg16, (float*)workspace, drop, seg_rows, seg_skip);
   NV_CHECK_LAUNCH("nv_ln_bwd");
   // the parameter-gradient reduction is off the data path: it may run on another stream (the caller then owns `workspace`
   // until that stream has passed this point)
@@ -231,6 +233,14 @@ extern "C" int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, c
                      dbeta, dcolsum, accumulate);
   NV_CHECK_LAUNCH("nv_ln_bwd/reduce");
   return NV_OK;
+}
+
+extern "C" int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
+                         const float* gamma, int M, int d, const float* g_in, float* g_out, long ldg, void* g16, long ldg16,
+                         float* dgamma, float* dbeta, float* dcolsum, int accumulate, void* workspace, long ws_bytes,
+                         unsigned long drop_seed, float drop_p, void* stream, void* reduce_stream) {
+  return ln_bwd_launch(dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg, g16, ldg16, dgamma, dbeta, dcolsum, accumulate, workspace,
+                       ws_bytes, drop_seed, drop_p, stream, reduce_stream, 0, 0);
 }
 
 // --------------------------------------------------------------------------------------- patch gather + LN(patch_dim)
@@ -489,18 +499,14 @@ extern "C" int nv_embed_finish_bwd(const float* g, long ldg, const float* t, lon
     hipLaunchKernelGGL(apply_drop_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, (float*)g, count, drop);
     NV_CHECK_LAUNCH("nv_embed_finish_bwd/drop");
   }
-  // token rows of volume b are rows b*n+1 .. b*n+N of g: one strided LN backward per volume keeps the kernel generic.
-  // (B launches of a memory-bound kernel; B is the per-GPU batch.)  Partials of all volumes are reduced together.
   NV_CHECK_ARG(B > 0 && N > 0 && (d % 4) == 0 && d <= 2048, "nv_embed_finish_bwd: bad dims");
   const int n = N + 1;
   const long need = nv_embed_finish_bwd_workspace_bytes(B, N, d);
   NV_CHECK_ARG(ws_bytes >= need, "nv_embed_finish_bwd: workspace too small");
-  // Treat g's token rows as one [B*N] row set by launching over a virtual row map: row r -> g row (r/N)*n + 1 + r%N.
-  // Implemented by B calls writing disjoint partial blocks; the first call overwrites / later calls accumulate.
-  for (int b = 0; b < B; ++b) {
-    const int rc = nv_ln_bwd(g + ((long)b * n + 1) * ldg, ldg, t + (long)b * N * ldt, ldt, mean + (long)b * N, rstd + (long)b * N, gamma, N,
-                             d, nullptr, dt + (long)b * N * lddt, lddt, dt16 ? (char*)dt16 + (long)b * N * lddt16 * 2 : nullptr, lddt16, dgamma,
-                             dbeta, dbias_pe, (accumulate || b > 0) ? 1 : 0, workspace, ws_bytes, 0, 0.f, stream, nullptr);
+  // g's token rows (row b*n + 1 + i) form one segmented [B*N] row set: a single LN backward over all volumes
+  {
+    const int rc = ln_bwd_launch(g + ldg, ldg, t, ldt, mean, rstd, gamma, B * N, d, nullptr, dt, lddt, dt16, lddt16, dgamma, dbeta, dbias_pe,
+                                 accumulate, workspace, ws_bytes, 0, 0.f, stream, nullptr, N, 1);
     if (rc) return rc;
   }
   const long tot = (long)n * d;
