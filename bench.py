@@ -166,6 +166,22 @@ def main():
         also = {"fwd_bwd_no_optimizer_volumes_s": round(timed(fwd_bwd, a.steps), 1)}
         model.eval()
         also["forward_only_eval_volumes_s"] = round(timed(fwd_only, a.steps), 1)
+        # BASELINE.json configs[3] shape: one 4D sample = T = 20 volumes through the (frozen) encoder, forward only
+        x20 = make_batch(20, S, device, 77)[0]
+
+        def fwd20():
+            with torch.no_grad():
+                model(x20)
+
+        for _ in range(2):
+            fwd20()
+        torch.cuda.synchronize()
+        t20 = time.perf_counter()
+        for _ in range(10):
+            fwd20()
+        torch.cuda.synchronize()
+        also["forward_only_batch20_volumes_s"] = round(20 * 10 / (time.perf_counter() - t20), 1)
+        del x20
         model.train()
         torch.manual_seed(7)
         dcfg = dict(config, TRAINING_DROPOUT=0.1)

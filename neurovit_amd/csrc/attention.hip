@@ -328,32 +328,24 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
-// one 64-key tile of the dQ pass for one wave (16 query rows)
-__device__ __forceinline__ void dq_tile(const char* sK, const char* sV, int kt, int n, const bf16x8 (&qf)[2], const bf16x8 (&dof)[2],
-                                        f32x4 (&dq)[4], float dl, float lse2, float scale_log2e, const DropCfg& drop, int bh, int qabs,
-                                        int r, int g) {
-    f32x4 ds[4];
+// one 64-key tile of the dQ pass for one wave (16 query rows), in pieces (see fwd_tile)
+__device__ __forceinline__ void dq_softmax_grad(const f32x4 (&sc)[4], f32x4 (&dp)[4], f32x4 (&ds)[4], int kt, int n, float dl, float lse2,
+                                                float scale_log2e, const DropCfg& drop, int bh, int qabs, int g) {
     const f32x2 c2 = {scale_log2e, scale_log2e}, l2 = {-lse2, -lse2}, d2 = {-dl, -dl};
     const bool ragged = kt * TK + TK > n;         // only the last key tile can hold out-of-range (zero-filled) keys
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t, ks, r, g), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sV, t, ks, r, g), dof[ks], dp, 0, 0, 0);
-      }
       if (drop.thresh) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          dp[j] *= drop_factor(drop, (((unsigned long long)bh * n + qabs) * n) + (kt * TK + 16 * t + 4 * g + j));
+          dp[t][j] *= drop_factor(drop, (((unsigned long long)bh * n + qabs) * n) + (kt * TK + 16 * t + 4 * g + j));
       }
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        f32x2 x = {s[2 * hh], s[2 * hh + 1]};
+        f32x2 x = {sc[t][2 * hh], sc[t][2 * hh + 1]};
         x = __builtin_elementwise_fma(x, c2, l2);
         f32x2 pv = {fast_exp2(x[0]), fast_exp2(x[1])};
-        const f32x2 dpv = {dp[2 * hh], dp[2 * hh + 1]};
+        const f32x2 dpv = {dp[t][2 * hh], dp[t][2 * hh + 1]};
         const f32x2 dsv = pv * (dpv + d2);
         ds[t][2 * hh] = dsv[0];
         ds[t][2 * hh + 1] = dsv[1];
@@ -364,12 +356,20 @@ __device__ __forceinline__ void dq_tile(const char* sK, const char* sV, int kt, 
           if (kt * TK + 16 * t + 4 * g + j >= n) ds[t][j] = 0.f;
       }
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 dsf = cvt8(ds[2 * ks], ds[2 * ks + 1]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sK, t, ks, r, g), dsf, dq[t], 0, 0, 0);
-    }
+}
+__device__ __forceinline__ void dq_tile(const char* sK, const char* sV, int kt, int n, const bf16x8 (&qf)[2], const bf16x8 (&dof)[2],
+                                        f32x4 (&dq)[4], float dl, float lse2, float scale_log2e, const DropCfg& drop, int bh, int qabs,
+                                        int r, int g) {
+  RowFrags F;
+  f32x4 sc[4], dp[4], ds[4];
+  load_row_frags(sK, r, g, F);
+  mfma_rows(F, qf, sc, true);
+  load_row_frags(sV, r, g, F);
+  mfma_rows(F, dof, dp, true);
+  dq_softmax_grad(sc, dp, ds, kt, n, dl, lse2, scale_log2e, drop, bh, qabs, g);
+  load_tr_frags(sK, r, g, F);
+  const bf16x8 dsf[2] = {cvt8(ds[0], ds[1]), cvt8(ds[2], ds[3])};
+  mfma_rows(F, dsf, dq, false);
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
@@ -433,19 +433,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // one 64-query tile of the dK/dV pass for one wave (16 keys); sL / sDl hold this tile's 64 log2-domain lse and delta values
-__device__ __forceinline__ void dkv_tile(const char* sQ, const char* sD, const float* sL, const float* sDl, int qt, int n,
-                                         const bf16x8 (&kf)[2], const bf16x8 (&vf)[2], f32x4 (&dk)[4], f32x4 (&dv)[4], float scale_log2e,
-                                         const DropCfg& drop, int bh, int keyabs, int r, int g) {
-    f32x4 p[4], ds[4];
+__device__ __forceinline__ void dkv_softmax_grad(const f32x4 (&sc)[4], const f32x4 (&dp)[4], f32x4 (&p)[4], f32x4 (&ds)[4], const float* sL,
+                                                 const float* sDl, int qt, int n, float scale_log2e, const DropCfg& drop, int bh, int keyabs,
+                                                 int g) {
     const f32x2 c2 = {scale_log2e, scale_log2e};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sQ, t, ks, r, g), kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sD, t, ks, r, g), vf[ks], dp, 0, 0, 0);
-      }
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 16 * t + 4 * g);
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + 16 * t + 4 * g);
       f32x4 f = {1.f, 1.f, 1.f, 1.f};
@@ -456,9 +449,9 @@ __device__ __forceinline__ void dkv_tile(const char* sQ, const char* sD, const f
       }
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        f32x2 x = {s[2 * hh], s[2 * hh + 1]};
+        f32x2 x = {sc[t][2 * hh], sc[t][2 * hh + 1]};
         const f32x2 lv = {-l4[2 * hh], -l4[2 * hh + 1]}, dlv = {d4[2 * hh], d4[2 * hh + 1]};
-        const f32x2 fv = {f[2 * hh], f[2 * hh + 1]}, dpv = {dp[2 * hh], dp[2 * hh + 1]};
+        const f32x2 fv = {f[2 * hh], f[2 * hh + 1]}, dpv = {dp[t][2 * hh], dp[t][2 * hh + 1]};
         x = __builtin_elementwise_fma(x, c2, lv);
         const f32x2 pv = {fast_exp2(x[0]), fast_exp2(x[1])};
         const f32x2 pd = pv * fv;
@@ -467,16 +460,23 @@ __device__ __forceinline__ void dkv_tile(const char* sQ, const char* sD, const f
         ds[t][2 * hh] = dsv[0]; ds[t][2 * hh + 1] = dsv[1];
       }
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 pf = cvt8(p[2 * ks], p[2 * ks + 1]);
-      const bf16x8 dsf = cvt8(ds[2 * ks], ds[2 * ks + 1]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sD, t, ks, r, g), pf, dv[t], 0, 0, 0);
-        dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQ, t, ks, r, g), dsf, dk[t], 0, 0, 0);
-      }
-    }
+}
+__device__ __forceinline__ void dkv_tile(const char* sQ, const char* sD, const float* sL, const float* sDl, int qt, int n,
+                                         const bf16x8 (&kf)[2], const bf16x8 (&vf)[2], f32x4 (&dk)[4], f32x4 (&dv)[4], float scale_log2e,
+                                         const DropCfg& drop, int bh, int keyabs, int r, int g) {
+  RowFrags F, G;
+  f32x4 sc[4], dp[4], p[4], ds[4];
+  load_row_frags(sQ, r, g, F);
+  load_row_frags(sD, r, g, G);
+  mfma_rows(F, kf, sc, true);
+  mfma_rows(G, vf, dp, true);
+  dkv_softmax_grad(sc, dp, p, ds, sL, sDl, qt, n, scale_log2e, drop, bh, keyabs, g);
+  load_tr_frags(sD, r, g, G);
+  load_tr_frags(sQ, r, g, F);
+  const bf16x8 pf[2] = {cvt8(p[0], p[1]), cvt8(p[2], p[3])};
+  const bf16x8 dsf[2] = {cvt8(ds[0], ds[1]), cvt8(ds[2], ds[3])};
+  mfma_rows(G, pf, dv, false);
+  mfma_rows(F, dsf, dk, false);
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout, long ldo,
@@ -586,6 +586,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const bf16
   f32x4 dq[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (software-pipelining the fragment reads as in the forward kernel measured slower inside the train step: 901 vs 923 volumes/s)
   for (int kt = 0; kt < nkt; ++kt)
     dq_tile(sK + kt * IMG, sV + kt * IMG, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
   const int q = q0 + r;
