@@ -67,6 +67,14 @@ int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float*
 /* reduce_stream (null = stream): where the dgamma / dbeta / dcolsum reduction of the per-workgroup partials runs; it is
  * ordered after the main kernel by an event, and `workspace` must stay untouched until that stream has executed it. */
 
+/* ---- input contract (src/data/DatasetADNI.py:212-213, DatasetADNI_4D.py:86-87): crop of the raw volume + z-score
+ * (x - mean) / (std + eps), population std over the whole cropped sample, statistics accumulated in double.
+ * raw [B,X,Y,Z,T] with element strides (T = 1 for 3D), dtype 0 = float32 / 1 = int16; crop8 = {x0,y0,z0,t0,Sx,Sy,Sz,St};
+ * out dense float32 [B,Sx,Sy,Sz,St]; stats (optional) [B,2] = mean, std. */
+long nv_zscore_crop_workspace_bytes(int B);
+int nv_zscore_crop(const void* raw, int dtype, const long* strides5, int B, const int* crop8, float eps, float* out,
+                   float* stats, void* workspace, long ws_bytes, void* stream);
+
 /* ---- patch embedding front end (vit_3d.py:92-93 + the permute of NeuroEncoder.py:200-202)
  * video [B,C,F,H,W] f32 with arbitrary element strides (pass the strides of the permuted VIEW of the
  * [B,H,W,D] dataset tensor - no copy); out bf16 [B*N, ldo] = LayerNorm(patch_dim)(patches). */

@@ -215,6 +215,16 @@ def patchify(video: torch.Tensor, p1: int, p2: int, pf: int) -> torch.Tensor:
     return v.reshape(B, f * h * w, p1 * p2 * pf * C)
 
 
+def zscore_crop(raw: np.ndarray, crop=((1, None), (10, -9), (1, None)), eps: float = 1e-8) -> np.ndarray:
+    """Row A0: the dataset's crop + z-score, one sample at a time (src/data/DatasetADNI.py:212-213 for [X,Y,Z],
+    src/data/DatasetADNI_4D.py:86-87 for [X,Y,Z,T]): numpy mean / population std over the cropped sample, float32 result."""
+    out = []
+    for sample in raw:
+        c = sample[tuple(slice(lo, hi) for lo, hi in crop)]
+        out.append(((c - c.mean()) / (c.std() + eps)).astype(np.float32))
+    return np.stack(out)
+
+
 def fmri_to_video(fmri: torch.Tensor) -> torch.Tensor:
     """ViT3DEncoder.forward (NeuroEncoder.py:200-202): [B,H,W,D] -> [B,1,D,H,W] (a view)."""
     return fmri.permute(0, 3, 1, 2).unsqueeze(1)

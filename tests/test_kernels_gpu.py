@@ -368,3 +368,30 @@ def test_adamw_matches_oracle(ops):
         assert_close_f32(m, opt.m["w"], "adamw.m", 1e-6)
         assert_close_f32(v, opt.v["w"], "adamw.v", 1e-6)
         assert torch.equal(p16.cpu(), bf(p.cpu()))
+
+
+# ------------------------------------------------------------------------------------------ input contract (A0 / F3)
+@pytest.mark.parametrize("dtype,four_d", [("float32", False), ("int16", False), ("float32", True), ("int16", True)])
+def test_zscore_crop_matches_dataset_preprocessing(dtype, four_d):
+    """DatasetADNI.py:212-213 / DatasetADNI_4D.py:86-87: raw 91 x 109 x 91 grid -> [1:, 10:-9, 1:] -> 90^3, z-score with
+    the population std over the whole cropped sample (all timepoints for 4D).  Parity with the numpy statement: 2e-6."""
+    from neurovit_amd.preprocess import zscore_crop
+    g = np.random.default_rng(5)
+    shape = (2, 91, 109, 91, 3) if four_d else (2, 91, 109, 91)
+    raw = (g.normal(800.0, 300.0, size=shape)).astype(np.float32)
+    if dtype == "int16":
+        raw = np.clip(raw, 0, 32000).astype(np.int16)
+    ref = ref_cpu.zscore_crop(raw)
+    out, stats = zscore_crop(torch.from_numpy(raw).cuda(), return_stats=True)
+    assert out.shape == ref.shape and out.dtype == torch.float32 and out.is_contiguous()
+    err = float((out.cpu() - torch.from_numpy(ref)).abs().max())
+    assert err < 2e-6, err
+    flat = ref.reshape(ref.shape[0], -1)
+    assert np.allclose(flat.mean(1), 0, atol=1e-5) and np.allclose(flat.std(1), 1, atol=1e-5)
+    # strided input (a permuted view) goes through the same kernel
+    if not four_d:
+        view = torch.from_numpy(raw).cuda().permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)
+        assert torch.equal(zscore_crop(view), out)
+    # constant volume: std = 0 -> (x - mean) / 1e-8 = 0, no NaN (DatasetADNI.py:213 adds 1e-8 for exactly this)
+    const = torch.full((1, 91, 109, 91), 7.0, device="cuda")
+    assert torch.count_nonzero(zscore_crop(const)) == 0

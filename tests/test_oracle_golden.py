@@ -200,3 +200,19 @@ def test_neuro4d(golden):
         vols = x.permute(0, 4, 1, 2, 3).reshape(2 * T, S, S, S)
         vl = ref_cpu.neuro_forward(sd, W.neuro_config(S, p, dim=3), vols)
     assert rel_err(vl, g["volume_logits"]) < TOL
+
+
+def test_zscore_crop_restatement():
+    """Row A0: per-sample z-score of the cropped volume: zero mean / unit population std per sample, 90^3 from the MNI grid,
+    and the statistic of a 4D sample is taken over all of its timepoints (DatasetADNI_4D.py:87), not per timepoint."""
+    g = np.random.default_rng(0)
+    raw = g.normal(500.0, 100.0, size=(2, 91, 109, 91)).astype(np.float32)
+    out = ref_cpu.zscore_crop(raw)
+    assert out.shape == (2, 90, 90, 90) and out.dtype == np.float32
+    assert np.allclose(out.reshape(2, -1).mean(1), 0, atol=1e-5) and np.allclose(out.reshape(2, -1).std(1), 1, atol=1e-5)
+    c = raw[0, 1:, 10:-9, 1:]
+    assert np.allclose(out[0], (c - c.mean()) / (c.std() + 1e-8), atol=1e-6)
+    raw4 = g.normal(500.0, 100.0, size=(1, 91, 109, 91, 2)).astype(np.float32)
+    raw4[..., 1] += 50.0
+    out4 = ref_cpu.zscore_crop(raw4)
+    assert out4.shape == (1, 90, 90, 90, 2) and abs(float(out4[..., 1].mean() - out4[..., 0].mean()) - 50.0 / float(raw4[0, 1:, 10:-9, 1:].std())) < 1e-3
