@@ -139,11 +139,10 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4], int kt, bool last, in
       l += psum;
     }
     if (drop.thresh) {      // attention dropout (vit_3d.py:56): mask the probabilities that enter P.V, not the normaliser
-      const unsigned long long base = (((unsigned long long)bh * n + qabs) * n) + (unsigned long long)kt * TK;
+      // element (bh, q, key) has index (bh * n + q) * npad + key with npad = n rounded up to 4: every lane's four keys share one hash
+      const unsigned long long base = (((unsigned long long)bh * n + qabs) * ((n + 3) & ~3)) + (unsigned long long)kt * TK;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[t][j] *= drop_factor(drop, base + 16 * t + 4 * g + j);
+      for (int t = 0; t < 4; ++t) s[t] *= drop_factor4(drop, base + 16 * t + 4 * g);
     }
 }
 // o[t] += V_tile^T[16t.., :] . P^T   (the probability accumulators are the MFMA B operand)
@@ -336,9 +335,7 @@ __device__ __forceinline__ void dq_softmax_grad(const f32x4 (&sc)[4], f32x4 (&dp
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (drop.thresh) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          dp[t][j] *= drop_factor(drop, (((unsigned long long)bh * n + qabs) * n) + (kt * TK + 16 * t + 4 * g + j));
+        dp[t] *= drop_factor4(drop, (((unsigned long long)bh * n + qabs) * ((n + 3) & ~3)) + (kt * TK + 16 * t + 4 * g));
       }
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -445,7 +442,7 @@ __device__ __forceinline__ void dkv_softmax_grad(const f32x4 (&sc)[4], const f32
       if (drop.thresh) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          f[j] = drop_factor(drop, (((unsigned long long)bh * n + (qt * TQ + 16 * t + 4 * g + j)) * n) + keyabs);
+          f[j] = drop_factor(drop, (((unsigned long long)bh * n + (qt * TQ + 16 * t + 4 * g + j)) * ((n + 3) & ~3)) + keyabs);
       }
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {

@@ -99,33 +99,47 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// Counter-based dropout RNG: one 32-bit hash per element index (murmur3 finaliser over a
-// seed/offset mix).  keep(idx) is recomputable in backward, nothing is stored.
-__device__ __forceinline__ uint32_t nv_hash32(uint64_t seed, uint64_t idx) {
-  uint64_t x = (idx + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull ^ seed;
+// Counter-based dropout RNG: one 64-bit hash (splitmix64 finaliser over a seed/group mix) decides FOUR consecutive elements,
+// one 16-bit field each: element idx keeps iff field[idx & 3] of hash(seed, idx >> 2) >= thresh (= p * 2^16), and kept values
+// are scaled by 1/(1-p).  Everything on the path handles four consecutive elements per lane, so a mask costs a quarter of a
+// hash per element; it is recomputed in backward from (seed, idx) - nothing is stored.  oracle/ref_cpu.py::drop_mask restates it.
+__device__ __forceinline__ uint64_t nv_hash64(uint64_t seed, uint64_t grp) {
+  uint64_t x = (grp + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull ^ seed;
   x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
   x ^= x >> 27; x *= 0x94D049BB133111EBull;
   x ^= x >> 31;
-  return (uint32_t)(x >> 16);
+  return x;
 }
 
-// Dropout configuration of one site: keep element idx iff hash(seed, idx) >= thresh; kept values are scaled by 1/(1-p).
-// thresh == 0 means "no dropout" (kernels skip the hash).  The mask is recomputed in backward from (seed, idx).
+// Dropout configuration of one site.  thresh == 0 means "no dropout" (kernels skip the hash).
 struct DropCfg {
   unsigned long long seed;
-  unsigned thresh;
+  unsigned thresh;      // p * 65536, in [0, 65536]
   float scale;
 };
 static inline DropCfg make_drop(unsigned long long seed, float p) {
   DropCfg d;
   d.seed = seed;
   if (p <= 0.f) { d.thresh = 0; d.scale = 1.f; }
-  else if (p >= 1.f) { d.thresh = 0xFFFFFFFFu; d.scale = 0.f; }
-  else { d.thresh = (unsigned)((double)p * 4294967296.0); d.scale = 1.0f / (1.0f - p); }
+  else if (p >= 1.f) { d.thresh = 0x10000u; d.scale = 0.f; }
+  else { d.thresh = (unsigned)((double)p * 65536.0); d.scale = 1.0f / (1.0f - p); }
   return d;
 }
+// factors of elements idx4 .. idx4 + 3 (idx4 % 4 == 0)
+__device__ __forceinline__ f32x4 drop_factor4(const DropCfg& d, unsigned long long idx4) {
+  const uint64_t h = nv_hash64(d.seed, idx4 >> 2);
+  const unsigned lo = (unsigned)h, hi = (unsigned)(h >> 32);
+  f32x4 f;
+  f[0] = ((lo & 0xFFFFu) >= d.thresh) ? d.scale : 0.f;
+  f[1] = ((lo >> 16) >= d.thresh) ? d.scale : 0.f;
+  f[2] = ((hi & 0xFFFFu) >= d.thresh) ? d.scale : 0.f;
+  f[3] = ((hi >> 16) >= d.thresh) ? d.scale : 0.f;
+  return f;
+}
 __device__ __forceinline__ float drop_factor(const DropCfg& d, unsigned long long idx) {
-  return (nv_hash32(d.seed, idx) >= d.thresh) ? d.scale : 0.f;
+  const uint64_t h = nv_hash64(d.seed, idx >> 2);
+  const unsigned field = (unsigned)(h >> (16 * (unsigned)(idx & 3))) & 0xFFFFu;
+  return (field >= d.thresh) ? d.scale : 0.f;
 }
 
 // XCD-aware bijective remap of a 1-D block id: blocks b, b+8, ... share an XCD (round-robin dispatch),

@@ -178,9 +178,7 @@ __device__ __forceinline__ void epilogue4(f32x4 v, const GemmArgs& g, int m, int
   f32x4 keep = f32x4{1.f, 1.f, 1.f, 1.f};
   if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_DGELU) {
     if (g.drop.thresh) {
-      const unsigned long long idx = (unsigned long long)m * g.N + n;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) keep[q] = drop_factor(g.drop, idx + q);
+      keep = drop_factor4(g.drop, (unsigned long long)m * g.N + n);      // N % 8 == 0, n % 4 == 0
     }
   }
   if constexpr (EPI == EPI_STORE_BF16) {

@@ -139,9 +139,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             *reinterpret_cast<f32x4*>(g_out + (long)row * ldg + c) = o;
             // g16 / colsum feed the backward of the Linear whose (dropped-out) output was added to this residual stream
             if (drop.thresh) {
-              const unsigned long long idx = (unsigned long long)row * d + c;
-#pragma unroll
-              for (int q = 0; q < 4; ++q) o[q] *= drop_factor(drop, idx + q);
+              o *= drop_factor4(drop, (unsigned long long)row * d + c);
             }
             if (g16) *reinterpret_cast<bf16x4*>(g16 + (long)row * ldg16 + c) = cvt4(o[0], o[1], o[2], o[3]);
             a_c[v] += o;
@@ -414,8 +412,7 @@ __global__ __launch_bounds__(256) void embed_finish_fwd_kernel(const float* __re
       if (c < d) {
         f32x4 o = *reinterpret_cast<const f32x4*>(cls + c) + *reinterpret_cast<const f32x4*>(pos + c);
         if (drop.thresh) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] *= drop_factor(drop, (unsigned long long)r * d + c + q);
+          o *= drop_factor4(drop, (unsigned long long)r * d + c);
         }
         *reinterpret_cast<f32x4*>(xrow + c) = o;
       }
@@ -436,8 +433,7 @@ __global__ __launch_bounds__(256) void embed_finish_fwd_kernel(const float* __re
       // same association as the reference: (LN output) + pos   (vit_3d.py:118 `x += pos_embedding`), then emb dropout (:119)
       f32x4 o = ((xv[v] - mean) * rstd * gm + bt) + pe;
       if (drop.thresh) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] *= drop_factor(drop, (unsigned long long)r * d + c + q);
+          o *= drop_factor4(drop, (unsigned long long)r * d + c);
       }
       *reinterpret_cast<f32x4*>(xrow + c) = o;
     }
@@ -478,8 +474,7 @@ __global__ void apply_drop_kernel(float* __restrict__ g, long count, DropCfg dro
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= count) return;
   f32x4 v = *reinterpret_cast<f32x4*>(g + i);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] *= drop_factor(drop, (unsigned long long)(i + q));
+  v *= drop_factor4(drop, (unsigned long long)i);
   *reinterpret_cast<f32x4*>(g + i) = v;
 }
 

@@ -173,8 +173,8 @@ class _AttnEmu(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- dropout masks of the HIP path
-# The product uses a counter-based mask (csrc/common.h nv_hash32 / DropCfg): element idx of a site is kept iff
-# hash(site_seed, idx) >= p * 2^32 and scaled by 1/(1-p).  Restated here bit for bit so that dropout runs can be
+# The product uses a counter-based mask (csrc/common.h nv_hash64 / DropCfg): element idx of a site is kept iff
+# a 16-bit field of hash(site_seed, idx >> 2) >= p * 2^16 and scaled by 1/(1-p).  Restated here bit for bit so that dropout runs can be
 # checked against the oracle with IDENTICAL masks (torch's Philox stream cannot be matched - SURVEY.md 5 "RNG").
 _M64 = (1 << 64) - 1
 
@@ -185,20 +185,29 @@ def site_seed(seed: int, site: int) -> int:
 
 
 def drop_mask(seed: int, p: float, shape) -> torch.Tensor:
-    """fp32 tensor of `shape` holding 0 or 1/(1-p); element index = row-major position."""
+    """fp32 tensor of `shape` holding 0 or 1/(1-p); element index = row-major position (csrc/common.h::drop_factor4):
+    one 64-bit hash per group of four consecutive elements, one 16-bit field per element, keep iff field >= p * 2^16."""
     if p <= 0:
         return torch.ones(shape)
     n = int(np.prod(shape))
     with np.errstate(over="ignore"):
         idx = np.arange(n, dtype=np.uint64)
-        x = ((idx + np.uint64(0x9E3779B97F4A7C15)) * np.uint64(0xBF58476D1CE4E5B9)) ^ np.uint64(seed)
+        grp, lane = idx >> np.uint64(2), idx & np.uint64(3)
+        x = ((grp + np.uint64(0x9E3779B97F4A7C15)) * np.uint64(0xBF58476D1CE4E5B9)) ^ np.uint64(seed)
         x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
         x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
         x ^= x >> np.uint64(31)
-        h = (x >> np.uint64(16)) & np.uint64(0xFFFFFFFF)
-    thresh = np.uint64(0xFFFFFFFF) if p >= 1 else np.uint64(int(np.float32(p).astype(np.float64) * 4294967296.0))
+        h = (x >> (np.uint64(16) * lane)) & np.uint64(0xFFFF)
+    thresh = np.uint64(0x10000) if p >= 1 else np.uint64(int(np.float32(p).astype(np.float64) * 65536.0))
     scale = 0.0 if p >= 1 else float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
     return torch.from_numpy(np.where(h >= thresh, np.float32(scale), np.float32(0)).astype(np.float32).reshape(shape))
+
+
+def attn_drop_mask(seed: int, p: float, B: int, heads: int, n: int) -> torch.Tensor:
+    """Mask of the attention probabilities [B, heads, n, n]: the kernels index element (bh, q, key) as
+    (bh * n + q) * npad + key with npad = n rounded up to a multiple of 4 (csrc/attention.hip::fwd_softmax)."""
+    npad = (n + 3) // 4 * 4
+    return drop_mask(seed, p, (B, heads, n, npad))[..., :n].contiguous()
 
 
 # --------------------------------------------------------------------------- A1: patchify
@@ -273,7 +282,7 @@ def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None, drop=None):
     # 'b n (h d) -> b h n d'
     q, k, v = (t.reshape(B, n, heads, dim_head).permute(0, 2, 1, 3) for t in (q, k, v))
     scale = dim_head ** -0.5
-    amask = drop_mask(drop[1], drop[0], (B, heads, n, n)) if drop else None
+    amask = attn_drop_mask(drop[1], drop[0], B, heads, n) if drop else None
     if emulate:
         out = _AttnEmu.apply(q, k, v, scale, amask)
     else:

@@ -216,3 +216,24 @@ def test_zscore_crop_restatement():
     raw4[..., 1] += 50.0
     out4 = ref_cpu.zscore_crop(raw4)
     assert out4.shape == (1, 90, 90, 90, 2) and abs(float(out4[..., 1].mean() - out4[..., 0].mean()) - 50.0 / float(raw4[0, 1:, 10:-9, 1:].std())) < 1e-3
+
+
+def test_dropout_mask_generator_statistics():
+    """The counter-based mask restated in oracle/ref_cpu.py::drop_mask (one 64-bit hash -> four 16-bit decisions): keep rate
+    1 - p within 4 sigma, the four fields of a hash are uncorrelated, different seeds decorrelate, p = 0 / p = 1 are exact."""
+    n = 1 << 20
+    for p in (0.1, 0.2, 0.5):
+        m = (ref_cpu.drop_mask(1234, p, (n,)) > 0).numpy()
+        q = 1 - int(np.float32(p).astype(np.float64) * 65536) / 65536
+        assert abs(m.mean() - q) < 4 * np.sqrt(q * (1 - q) / n), (p, m.mean())
+        assert np.allclose(ref_cpu.drop_mask(1234, p, (n,)).unique().numpy(), [0, np.float32(1) / (np.float32(1) - np.float32(p))])
+        lanes = m.reshape(-1, 4).astype(np.float64)
+        c = np.corrcoef(lanes.T)
+        assert np.abs(c - np.eye(4)).max() < 0.01
+        m2 = (ref_cpu.drop_mask(1235, p, (n,)) > 0).numpy()
+        assert abs(np.corrcoef(m, m2)[0, 1]) < 0.01
+    assert torch.equal(ref_cpu.drop_mask(7, 0.0, (5, 8)), torch.ones(5, 8))
+    assert torch.count_nonzero(ref_cpu.drop_mask(7, 1.0, (5, 8))) == 0
+    a = ref_cpu.attn_drop_mask(9, 0.3, 1, 2, 5)               # n = 5 -> rows padded to 8 in the index space
+    full = ref_cpu.drop_mask(9, 0.3, (1, 2, 5, 8))
+    assert a.shape == (1, 2, 5, 5) and torch.equal(a, full[..., :5])
