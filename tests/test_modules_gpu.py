@@ -286,3 +286,40 @@ def test_gradient_accumulation_matches_one_big_step(nv):
     pa, _ = a.volume_encoder.vit3d.flat_parameters()
     pb, _ = b.volume_encoder.vit3d.flat_parameters()
     assert rel_err(pa, pb) < 1e-6
+
+
+@pytest.mark.parametrize("B", [1, 3, 5])
+def test_ragged_batch_sizes_match_oracle(nv, B):
+    """Batch sizes that are not a multiple of anything (last DataLoader batch of an epoch): loss, logits and the first AdamW
+    step of the fused TrainStep against the CPU oracle's train step on the same weights."""
+    from neurovit_amd.trainer import TrainStep
+    model = _micro_model(nv)
+    sd = {k[len("volume_encoder.vit3d."):]: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    x = W.make_volume((B, 32, 32, 32), 40 + B)
+    y = torch.arange(B) % 2
+    step = TrainStep(model, lr=1e-3, weight_decay=1e-2)
+    loss = step(x.cuda(), y.cuda())
+    ocfg = ref_cpu.ViTCfg(**W.MICRO)
+    opt = train_step.AdamW(sd, lr=1e-3, weight_decay=1e-2)
+    before = {k: v.clone() for k, v in sd.items()}
+    ref_loss, _ = train_step.train_step(sd, ocfg, opt, ref_cpu.fmri_to_video(x), y)[:2]
+    assert abs(float(loss) - float(ref_loss)) < 5e-3 * max(1.0, abs(float(ref_loss)))
+    new = {k[len("volume_encoder.vit3d."):]: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    # first Adam step moves every element by ~lr * sign(grad): compare the UPDATE, tolerant to sign flips of near-zero gradients
+    num = sum(float(((new[k] - before[k]) - (sd[k] - before[k])).pow(2).sum()) for k in sd)
+    den = sum(float((sd[k] - before[k]).pow(2).sum()) for k in sd)
+    assert (num / den) ** 0.5 < 0.3
+
+
+def test_validate_path_eval_no_grad_matches_training_forward(nv):
+    """Trainer.validate (Trainer.py:101-118): eval + no_grad forward, CE and argmax; same logits as the training-mode forward
+    when dropout is 0, no autograd graph, no activation workspace retained for backward."""
+    model = _micro_model(nv)
+    x = W.make_volume((3, 32, 32, 32), 50).cuda()
+    model.train()
+    a = model(x).detach().clone()
+    model.eval()
+    with torch.no_grad():
+        b = model(x)
+    assert not b.requires_grad and torch.equal(a, b)
+    assert b.argmax(dim=1).shape == (3,)
