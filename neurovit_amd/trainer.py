@@ -90,12 +90,52 @@ class TrainStep:
         return loss.detach()
 
 
+class DevicePrefetcher:
+    """Iterates a DataLoader one batch ahead: batch i+1 is copied host -> device on a side stream while step i computes.
+    A 4-volume 128^3 batch is 33.5 MB = 0.53 ms over PCIe, 12 % of a 4.35 ms train step if it sits on the compute stream
+    (the reference's `fMRI.to(device)` in the loop, Trainer.py:66).  Tensors in the batch move to the device, everything else
+    (subject ids, strings) passes through.  With a CPU device it degenerates to the plain iterator."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _move(self, batch):
+        if self._stream is None:
+            return [b.to(self.device) if torch.is_tensor(b) else b for b in batch]
+        with torch.cuda.stream(self._stream):
+            return [b.to(self.device, non_blocking=True) if torch.is_tensor(b) else b for b in batch]
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._move(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur = nxt
+            if self._stream is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self._stream)
+                for b in cur:
+                    if torch.is_tensor(b):
+                        b.record_stream(torch.cuda.current_stream(self.device))
+            try:
+                nxt = self._move(next(it))       # overlaps the step the caller runs on `cur`
+            except StopIteration:
+                nxt = None
+            yield cur
+
+
 class Trainer:
     """The reference's Trainer shell (src/Trainer.py:14-167) on the native path: same constructor and methods
     (`run`, `train`, `validate`, `evaluate_samples`), same checkpoint files (plain `state_dict`s, interchangeable
     with the reference), same logging cadence.  Differences, all deliberate:
       * the step body is `TrainStep` (fused CE / staged backward / fused AdamW; no GradScaler: bf16 needs none);
       * wandb is optional (skipped when the package is absent or config['WANDB_ENABLED'] is false);
+      * the host -> device copy of the next batch runs on a side stream under the current step (`DevicePrefetcher`);
       * batches may be the 7-tuples of DatasetADNI or the 6-tuples of DatasetADNI_4D (README.md:100-102 asks users
         to hand-edit the unpacking): the volume is element 2 and the label the last element in both;
       * `log_interval = len(dl)//10` is clamped to >= 1 (the reference divides by zero for < 10 batches,
@@ -158,9 +198,8 @@ class Trainer:
         self.model.train()
         running_loss, correct, total = 0.0, 0, 0
         start_time = time.time()
-        for i, batch in enumerate(self.dataloader):
+        for i, batch in enumerate(DevicePrefetcher(self.dataloader, self.device)):     # H2D of batch i+1 under step i
             fMRI, label = self._unpack(batch)
-            fMRI, label = fMRI.to(self.device, non_blocking=True), label.to(self.device, non_blocking=True)
             loss = self.step(fMRI, label)
             # the reference syncs twice per step (.item()); here statistics stay on the device until a log line is due
             running_loss = running_loss + loss

@@ -171,3 +171,16 @@ def test_arena_views_survive_load_state_dict_and_track_to():
     assert not m._arena_ok()
     a2, _ = m.flat_parameters()
     assert m._arena_ok() and torch.equal(a2, arena)
+
+
+def test_device_prefetcher_preserves_order_and_passthrough():
+    """Host-side logic of the Trainer's prefetcher (CPU device: plain iteration): every batch, in order, tensors intact,
+    non-tensor fields untouched, empty loaders and single-batch loaders handled."""
+    from neurovit_amd.trainer import DevicePrefetcher
+    batches = [("sub%d" % i, torch.full((2, 3), float(i)), torch.tensor([i, i + 1])) for i in range(5)]
+    out = list(DevicePrefetcher(batches, "cpu"))
+    assert len(out) == 5 and len(DevicePrefetcher(batches, "cpu")) == 5
+    for i, b in enumerate(out):
+        assert b[0] == "sub%d" % i and torch.equal(b[1], batches[i][1]) and torch.equal(b[2], batches[i][2])
+    assert list(DevicePrefetcher([], "cpu")) == []
+    assert len(list(DevicePrefetcher(batches[:1], "cpu"))) == 1
