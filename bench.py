@@ -35,16 +35,20 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="volumes per GPU (BASELINE.json configs[1]: 4)")
     ap.add_argument("--preset", default="base", choices=["tiny", "base", "large"])
-    ap.add_argument("--buckets", type=int, default=13,
-                    help="gradient all-reduce buckets (13 = one per transformer layer + head/embedding: 28 MB fp32 messages whose "
-                         "all-reduce keeps pace with one layer's backward, and only the small embedding bucket is exposed at the end)")
+    ap.add_argument("--buckets", type=int, default=7,
+                    help="gradient all-reduce buckets (7 = two transformer layers each: 28 MB bf16 messages, large enough for RCCL to "
+                         "run near its bandwidth, and only the last one (layer 0 + embedding) is exposed after backward)")
     ap.add_argument("--overlap-optimizer", action="store_true", help="AdamW per gradient bucket on the side stream")
+    ap.add_argument("--grad-comm", default="bf16", choices=["bf16", "fp32"],
+                    help="dtype of the gradient all-reduce messages (N > 1 only; compute and optimizer are unaffected)")
     ap.add_argument("--dropout", type=float, default=0.0, help="TRAINING_DROPOUT of the timed model (headline: 0, SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (forward-only, fwd+bwd, dropout)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--same-data", action="store_true", help="rehearsal: every rank gets rank 0's batch (with --grad-comm fp32 the "
+                                                              "averaged gradients, hence the loss curve, must equal the 1-GPU run bit for bit)")
     return ap.parse_args()
 
 
@@ -116,9 +120,10 @@ def main():
     torch.manual_seed(42)                                   # main.py:86-88
     model = NeuroEncoder(config)
     model.train()
-    step = TrainStep(model, process_group=None, n_buckets=a.buckets, overlap_optimizer=a.overlap_optimizer)
+    step = TrainStep(model, process_group=None, n_buckets=a.buckets, overlap_optimizer=a.overlap_optimizer,
+                     grad_comm_dtype=torch.bfloat16 if a.grad_comm == "bf16" else torch.float32)
     B = a.batch
-    x, y = make_batch(B, S, device, 42 + rank)
+    x, y = make_batch(B, S, device, 42 + (0 if a.same_data else rank))
 
     def barrier():
         if world > 1:
@@ -254,7 +259,8 @@ def main():
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"ViT3D-{a.preset} {S}^3 patch {p}, train step (fwd+bwd+AdamW), batch {B}/GPU, dropout {a.dropout:g}",
-                      "global_batch": B * world, "parallelism": f"dp{world}", "grad_buckets": a.buckets},
+                      "global_batch": B * world, "parallelism": f"dp{world}", "grad_buckets": a.buckets,
+                      "grad_allreduce": ("none (1 GPU)" if world == 1 else f"{a.grad_comm} messages, sum, overlapped with backward")},
            "mfma_frac_step": round(value / world * f_step / (PEAK_BF16_TFLOPS * 1e12), 4),
            "loss": round(float(loss), 5), "roofline": roofline}
     if also is not None:

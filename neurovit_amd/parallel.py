@@ -33,7 +33,14 @@ class GradSync:
     Device agnostic: with CUDA tensors the work runs on a dedicated stream behind an event; with CPU tensors
     (gloo, tests) it runs inline.  world_size 1 skips the collective but keeps the overlapped callback."""
 
-    def __init__(self, process_group=None, n_buckets: int = 4, after_bucket=None):
+    def __init__(self, process_group=None, n_buckets: int = 4, after_bucket=None, comm_dtype: torch.dtype = torch.float32):
+        """comm_dtype = torch.bfloat16 sends each bucket as bf16 (cast on the side stream, sum, cast back): half the xGMI
+        bytes (177 MB instead of 354 MB per step for ViT3D-base).  The rounding (2^-9 relative per element) is
+        below the bf16 noise the gradients already carry from the MFMA operands; replicas stay bit-identical because every
+        rank receives the same reduced values."""
+        assert comm_dtype in (torch.float32, torch.bfloat16)
+        self.comm_dtype = comm_dtype
+        self._comm_buf: Optional[torch.Tensor] = None
         self.pg = process_group
         self.n_buckets = n_buckets
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -49,6 +56,19 @@ class GradSync:
     def begin(self):
         self._works = []
 
+    def _reduce(self, flat_grads: torch.Tensor, chunk: torch.Tensor, begin: int, end: int):
+        if self.comm_dtype == torch.float32:
+            self.bytes_reduced += chunk.numel() * 4
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        if self._comm_buf is None or self._comm_buf.numel() != flat_grads.numel() or self._comm_buf.device != flat_grads.device:
+            self._comm_buf = torch.empty(flat_grads.numel(), dtype=torch.bfloat16, device=flat_grads.device)
+        buf = self._comm_buf[begin:end]
+        buf.copy_(chunk)
+        self.bytes_reduced += buf.numel() * 2
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+        chunk.copy_(buf)
+
     def bucket_ready(self, flat_grads: torch.Tensor, begin: int, end: int):
         if end <= begin or (self.world == 1 and self.after_bucket is None):
             return
@@ -61,14 +81,12 @@ class GradSync:
             self._comm_stream.wait_event(ev)
             with torch.cuda.stream(self._comm_stream):
                 if self.world > 1:
-                    self.bytes_reduced += chunk.numel() * chunk.element_size()
-                    dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg)     # enqueued on the side stream
+                    self._reduce(flat_grads, chunk, begin, end)                     # enqueued on the side stream
                 if self.after_bucket is not None:
                     self.after_bucket(begin, end)
         else:
             if self.world > 1:
-                self.bytes_reduced += chunk.numel() * chunk.element_size()
-                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg)
+                self._reduce(flat_grads, chunk, begin, end)
             if self.after_bucket is not None:
                 self.after_bucket(begin, end)
 

@@ -24,7 +24,8 @@ from .parallel import GradSync, broadcast_parameters
 
 class TrainStep:
     def __init__(self, model: NeuroEncoder, lr: Optional[float] = None, weight_decay: Optional[float] = None, process_group=None,
-                 n_buckets: int = 4, accumulation_steps: int = 1, overlap_optimizer: bool = False):
+                 n_buckets: int = 4, accumulation_steps: int = 1, overlap_optimizer: bool = False,
+                 grad_comm_dtype: torch.dtype = torch.float32):
         cfg = model.config
         self.model = model
         self.criterion = CrossEntropyLoss()
@@ -46,7 +47,8 @@ class TrainStep:
         self._overlap_opt = bool(overlap_optimizer)
         self._opt_blocks = int(os.environ.get("NEUROVIT_OPT_BLOCKS", "0"))
         if self._arena_trainable and (world > 1 or overlap_optimizer):
-            self.sync = GradSync(process_group, n_buckets, after_bucket=self._bucket_update if overlap_optimizer else None)
+            self.sync = GradSync(process_group, n_buckets, after_bucket=self._bucket_update if overlap_optimizer else None,
+                                 comm_dtype=grad_comm_dtype)
         if world > 1:
             arena, _ = vit.flat_parameters()
             broadcast_parameters(arena, process_group)

@@ -36,6 +36,20 @@ def _worker(rank, world, port, q):
             sync.bucket_ready(grads, b, e)
         sync.finish()
         ok = torch.allclose(grads, expect) and sync.bytes_reduced == n * 4
+        # bf16 messages (half the xGMI bytes): the sum is exact up to bf16 rounding of each rank's contribution and of the result,
+        # and every rank ends with the SAME values
+        g16 = torch.randn(n)
+        exact = g16.clone()
+        dist.all_reduce(exact)
+        s16 = GradSync(None, n_buckets=2, comm_dtype=torch.bfloat16)
+        s16.begin()
+        for b, e in [(500, 1000), (0, 500)]:
+            s16.bucket_ready(g16, b, e)
+        s16.finish()
+        ok = ok and s16.bytes_reduced == n * 2 and float((g16 - exact).abs().max()) <= 2.0 ** -7 * float(exact.abs().max()) and g16.dtype == torch.float32
+        both = [torch.empty_like(g16) for _ in range(world)]
+        dist.all_gather(both, g16)
+        ok = ok and torch.equal(both[0], both[1])
         # replicas stay identical after a (restated) averaged SGD update
         params -= 0.1 * grads * sync.grad_scale
         gathered = [torch.empty_like(params) for _ in range(world)]
