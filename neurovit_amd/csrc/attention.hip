@@ -161,6 +161,21 @@ __device__ __forceinline__ void fwd_tile(const char* sK, const char* sV, int kt,
   fwd_pv(F, s, o);
 }
 
+// merge of two online-softmax states of the same rows (key range split in two): shared by the streaming kernel (which keeps
+// both states in one wave) and the resident kernel (partner waves), so the two stay bit-identical
+__device__ __forceinline__ void softmax_merge(float& m, float& l, f32x4 (&o)[4], float m1, float l1, const f32x4 (&o1)[4]) {
+  const float mn = fmaxf(m, m1);
+  const float a0 = fast_exp2(m - mn), a1 = fast_exp2(m1 - mn);
+  m = mn;
+  l = __builtin_fmaf(l1, a1, l * a0);          // explicit fma shapes: identical rounding in every kernel that inlines this
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[t][j] = __builtin_fmaf(o1[t][j], a1, o[t][j] * a0);
+}
+// first key tile of the second half of the key range
+__device__ __forceinline__ int attn_half_tiles(int nkt) { return (nkt + 1) >> 1; }
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
                                                        bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
@@ -178,12 +193,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
 
-  f32x4 o[4];
+  f32x4 o[4], o0[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, l = 0.f;
+  for (int t = 0; t < 4; ++t) o[t] = o0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f, m0 = -INFINITY, l0 = 0.f;
 
   const int nkt = (n + TK - 1) / TK;
+  const int nh = attn_half_tiles(nkt);   // the key range is processed as two independent online-softmax states merged at the end,
+                                         // exactly as the resident kernel's partner waves do (bit-identical results)
   uint4 rk[2], rv[2];
   tile_gload(K, ld, 0, n, tid, rk);
   tile_gload(V, ld, 0, n, tid, rv);
@@ -196,8 +213,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       tile_gload(K, ld, (kt + 1) * TK, n, tid, rk);
       tile_gload(V, ld, (kt + 1) * TK, n, tid, rv);
     }
+    if (kt == nh) {                      // second half starts: park the first state
+      m0 = m; l0 = l; m = -INFINITY; l = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { o0[t] = o[t]; o[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
     fwd_tile(sK, sV, kt, kt == nkt - 1, n, qf, o, m, l, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
   }
+  if (nkt <= nh) {                       // single tile: the (empty) second state is merged all the same
+    m0 = m; l0 = l; m = -INFINITY; l = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { o0[t] = o[t]; o[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  softmax_merge(m0, l0, o0, m, l, o);
+  m = m0; l = l0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = o0[t];
   const float ltot = group_sum(l);
   const float inv = 1.0f / ltot;
   const int q = q0 + r;
@@ -239,46 +270,99 @@ __device__ __forceinline__ int res_group(int n, int wid) {
   return (g0 + wid < g1) ? g0 + wid : -1;
 }
 
-__global__ __launch_bounds__(RES_THREADS) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads,
-                                                                   float scale_log2e, bf16* __restrict__ out, long ldo,
-                                                                   float* __restrict__ lse, DropCfg drop) {
+// SPLIT = 2: sixteen waves; waves w and w + 8 share a row group and take one half of the key tiles each (four waves per
+// SIMD instead of two hide the softmax's dependent-instruction latency), then merge (m, l, o) through LDS.
+template <int SPLIT>
+__global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads,
+                                                                           float scale_log2e, bf16* __restrict__ out, long ldo,
+                                                                           float* __restrict__ lse, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char rsmem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = wid & 7, half = wid >> 3;          // half is 0 when SPLIT == 1
   const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
   const bf16* Q = qkv + (long)b * n * ld + h * DH;
   const int nkt = (n + TK - 1) / TK;
   char* sK = rsmem;
   char* sV = rsmem + nkt * IMG;
-  res_dma(Q + inner, ld, n, nkt, sK, wid, lane);
-  res_dma(Q + 2 * inner, ld, n, nkt, sV, wid, lane);
-  const int grp = res_group(n, wid);
+  if (SPLIT == 1 || half == 0) res_dma(Q + inner, ld, n, nkt, sK, slot, lane);
+  if (SPLIT == 1 || half == 1) res_dma(Q + 2 * inner, ld, n, nkt, sV, slot, lane);
+  const int grp = res_group(n, slot);
   const int q0 = (grp < 0 ? 0 : grp) * 16;
   const int qrow = min(q0 + r, n - 1);
   bf16x8 qf[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
   __syncthreads();                                   // drains the DMA (vmcnt(0)) of every wave
-  if (grp < 0) return;
+  if (SPLIT == 1 && grp < 0) return;
 
   f32x4 o[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
-  // software pipeline: the V fragments of this tile and the K fragments of the next one are requested from LDS before the
-  // softmax arithmetic, so the ds_read latency sits under ~130 VALU instructions instead of in front of the MFMAs
-  RowFrags KF, VF;
-  f32x4 sc[4];
-  load_row_frags(sK, r, g, KF);
-  for (int kt = 0; kt < nkt; ++kt) {
-    mfma_rows(KF, qf, sc, true);
-    __builtin_amdgcn_sched_barrier(0);
-    load_tr_frags(sV + kt * IMG, r, g, VF);
-    load_row_frags(sK + (kt + 1 < nkt ? kt + 1 : kt) * IMG, r, g, KF);
-    __builtin_amdgcn_sched_barrier(0);
-    fwd_softmax(sc, kt, kt == nkt - 1, n, o, m, l, scale_log2e, drop, blockIdx.y, q0 + r, g);
-    __builtin_amdgcn_sched_barrier(0);
-    fwd_pv(VF, sc, o);
+  const int nh = attn_half_tiles(nkt);
+  // both halves exist for every n (the streaming kernel uses the same split point), a one-wave block walks them in turn
+  for (int part = 0; part < 2; ++part) {
+    if (SPLIT == 2 && part != half) continue;
+    const int k0 = part ? nh : 0, k1 = part ? nkt : nh;
+    f32x4 o1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m1 = -INFINITY, l1 = 0.f;
+    if (SPLIT == 2) {
+      // four waves per SIMD hide the LDS latency by themselves; the plain tile step keeps the kernel within 128 VGPRs
+      if (grp >= 0)
+        for (int kt = k0; kt < k1; ++kt)
+          fwd_tile(sK + kt * IMG, sV + kt * IMG, kt, kt == nkt - 1, n, qf, o1, m1, l1, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
+    } else if (grp >= 0 && k0 < k1) {
+      // software pipeline: the V fragments of this tile and the K fragments of the next one are requested from LDS before the
+      // softmax arithmetic, so the ds_read latency sits under ~130 VALU instructions instead of in front of the MFMAs
+      RowFrags KF, VF;
+      f32x4 sc[4];
+      load_row_frags(sK + k0 * IMG, r, g, KF);
+      for (int kt = k0; kt < k1; ++kt) {
+        mfma_rows(KF, qf, sc, true);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tr_frags(sV + kt * IMG, r, g, VF);
+        load_row_frags(sK + (kt + 1 < k1 ? kt + 1 : kt) * IMG, r, g, KF);
+        __builtin_amdgcn_sched_barrier(0);
+        fwd_softmax(sc, kt, kt == nkt - 1, n, o1, m1, l1, scale_log2e, drop, blockIdx.y, q0 + r, g);
+        __builtin_amdgcn_sched_barrier(0);
+        fwd_pv(VF, sc, o1);
+      }
+    }
+    if (SPLIT == 1) {
+      if (part == 0) {
+        m = m1; l = l1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = o1[t];
+      } else {
+        softmax_merge(m, l, o, m1, l1, o1);
+      }
+    } else {
+      // partner exchange through LDS (the K/V images are dead after the barrier): [slot][18][64 lanes] floats
+      __syncthreads();
+      float* xch = reinterpret_cast<float*>(rsmem) + slot * 18 * 64 + lane;
+      if (half == 1) {
+        xch[0] = m1; xch[64] = l1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xch[(2 + 4 * t + j) * 64] = o1[t][j];
+      }
+      __syncthreads();
+      if (half == 1 || grp < 0) return;
+      m = m1; l = l1;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[t] = o1[t];
+      float m2 = xch[0], l2 = xch[64];
+      f32x4 o2[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o2[t][j] = xch[(2 + 4 * t + j) * 64];
+      softmax_merge(m, l, o, m2, l2, o2);
+    }
   }
   const float ltot = group_sum(l);
   const float inv = 1.0f / ltot;
@@ -293,7 +377,13 @@ __global__ __launch_bounds__(RES_THREADS) void attn_fwd_res_kernel(const bf16* _
 }
 
 static int g_attn_mode = 0;    // 0 = heuristic, 1 = streaming kernels, 2 = resident kernels (tests compare the two bit for bit)
-extern "C" int nv_attn_set_mode(int mode) { g_attn_mode = mode; return 0; }
+static int g_attn_split = 1;   // resident forward: waves per row group.  Two (partner waves split the key range, four waves per
+                               // SIMD) measured the same 13.5 us as one at n = 513: the kernel is VALU/MFMA-issue bound, not latency bound
+extern "C" int nv_attn_set_mode(int mode) {
+  g_attn_mode = mode % 10;
+  g_attn_split = (mode / 10 == 2) ? 2 : 1;
+  return 0;
+}
 static bool attn_resident(int n) {
   const int nt = (n + TK - 1) / TK;
   return g_attn_mode != 1 && nt <= RES_MAX_TILES;
@@ -315,9 +405,17 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
     NV_CHECK_ARG((long)n * ld_qkv < (1L << 30), "nv_attn_fwd: operand too large for 32-bit buffer offsets");
     const int lds = 2 * ((n + TK - 1) / TK) * IMG;
     static bool attr = false;
-    if (!attr) { attn_res_attr(attn_fwd_res_kernel, 2 * RES_MAX_TILES * IMG); attr = true; }
-    hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(attn_res_blocks(n), B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream, (const bf16*)qkv,
-                       ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
+    if (!attr) {
+      attn_res_attr(attn_fwd_res_kernel<1>, 2 * RES_MAX_TILES * IMG);
+      attn_res_attr(attn_fwd_res_kernel<2>, 2 * RES_MAX_TILES * IMG);
+      attr = true;
+    }
+    if (g_attn_split == 2)
+      hipLaunchKernelGGL(attn_fwd_res_kernel<2>, dim3(attn_res_blocks(n), B * heads), dim3(2 * RES_THREADS), lds, (hipStream_t)stream,
+                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
+    else
+      hipLaunchKernelGGL(attn_fwd_res_kernel<1>, dim3(attn_res_blocks(n), B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
+                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
   } else
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((n + TQ - 1) / TQ, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
                      heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));

@@ -121,7 +121,7 @@ class _GeluEmu(torch.autograd.Function):
 class _AttnEmu(torch.autograd.Function):
     """Flash-style attention with the HIP kernel's cast points.
 
-    forward : online softmax over 64-key tiles: S = q k^T (fp32 acc), p = exp(scale*S - m_running),
+    forward : online softmax over 64-key tiles (two half-range states merged at the end): S = q k^T (fp32 acc), p = exp(scale*S - m_running),
               l += sum p (fp32), O += bf16(p) @ v (both rescaled when the running max moves),
               returns bf16(O / l) and LSE.
     backward: delta = rowsum(dO*O); P = exp(scale*S - LSE); dV = bf16(P)^T dO;
@@ -136,19 +136,32 @@ class _AttnEmu(torch.autograd.Function):
     def forward(ctx, q, k, v, scale, mask=None):
         # Online softmax over 64-key tiles, exactly the kernel's schedule: P is rounded to bf16 relative to
         # the RUNNING row max of its tile (r(c*x) != c*r(x), so the rounding point matters at the 1e-3 level).
+        # The key tiles are processed as TWO independent online-softmax states (tiles [0, nh) and [nh, nkt), nh = ceil(nkt / 2):
+        # in the LDS-resident kernel two partner waves take one half each) that are merged at the end.
         n = k.shape[-2]
-        m = torch.full(q.shape[:-1] + (1,), float("-inf"), dtype=q.dtype)
-        l = torch.zeros_like(m)
-        o = torch.zeros_like(q)
-        for k0 in range(0, n, _AttnEmu.TK):
-            s = torch.matmul(q, k[..., k0:k0 + _AttnEmu.TK, :].transpose(-1, -2)) * scale
-            mnew = torch.maximum(m, s.amax(dim=-1, keepdim=True))
-            alpha = torch.exp(m - mnew)
-            p = torch.exp(s - mnew)
-            l = l * alpha + p.sum(dim=-1, keepdim=True)
-            pm = p if mask is None else p * mask[..., k0:k0 + _AttnEmu.TK]      # dropout hits P.V, not the normaliser
-            o = o * alpha + torch.matmul(_r(pm), v[..., k0:k0 + _AttnEmu.TK, :])
-            m = mnew
+        nkt = (n + _AttnEmu.TK - 1) // _AttnEmu.TK
+        nh = (nkt + 1) // 2
+        states = []
+        for t0, t1 in ((0, nh), (nh, nkt)):
+            m = torch.full(q.shape[:-1] + (1,), float("-inf"), dtype=q.dtype)
+            l = torch.zeros_like(m)
+            o = torch.zeros_like(q)
+            for kt in range(t0, t1):
+                k0 = kt * _AttnEmu.TK
+                s = torch.matmul(q, k[..., k0:k0 + _AttnEmu.TK, :].transpose(-1, -2)) * scale
+                mnew = torch.maximum(m, s.amax(dim=-1, keepdim=True))
+                alpha = torch.exp(m - mnew)
+                p = torch.exp(s - mnew)
+                l = l * alpha + p.sum(dim=-1, keepdim=True)
+                pm = p if mask is None else p * mask[..., k0:k0 + _AttnEmu.TK]      # dropout hits P.V, not the normaliser
+                o = o * alpha + torch.matmul(_r(pm), v[..., k0:k0 + _AttnEmu.TK, :])
+                m = mnew
+            states.append((m, l, o))
+        (m0, l0, o0), (m1, l1, o1) = states
+        m = torch.maximum(m0, m1)
+        a0, a1 = torch.exp(m0 - m), torch.exp(m1 - m)          # exp(-inf) = 0 when the second half is empty (n <= 64)
+        l = l0 * a0 + l1 * a1
+        o = o0 * a0 + o1 * a1
         o = _r(o / l)
         lse = m + torch.log(l)
         ctx.save_for_backward(q, k, v, o, lse)

@@ -50,7 +50,7 @@ def _worker(rank, world, port, mode, q):
         seeds = (7, 8) if mode == "same" else ((7, 8) if rank == 0 else (17, 18))
         comm = torch.bfloat16 if mode == "bf16" else torch.float32
         p = _run_steps(model, [_data(s) for s in seeds], n_buckets=3, grad_comm_dtype=comm)
-        q.put((rank, p))
+        q.put((rank, p.numpy()))          # by value: a tensor would travel as a shared-memory handle that dies with this process
     finally:
         dist.destroy_process_group()
 
@@ -62,7 +62,7 @@ def _spawn(mode):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=240) for _ in procs)
+    res = {rank: torch.from_numpy(arr) for rank, arr in (q.get(timeout=240) for _ in procs)}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -189,9 +189,14 @@ def test_fused_step_equals_stock_optimizer_step(nv):
             o.zero_grad(set_to_none=True)
             torch.nn.functional.cross_entropy(m(x), y).backward()
             o.step()
-    pa, _ = a.volume_encoder.vit3d.flat_parameters()
-    pb, _ = b.volume_encoder.vit3d.flat_parameters()
-    assert rel_err(pa, pb) < 1e-6
+        pa, _ = a.volume_encoder.vit3d.flat_parameters()
+        pb, _ = b.volume_encoder.vit3d.flat_parameters()
+        assert rel_err(pa, pb) < 1e-6
+        # resynchronise: a 1-ulp difference between the two optimizers would otherwise be amplified by the next step's bf16
+        # forward / backward (sign flips of near-zero gradients) - this test is about the optimizers on EQUAL gradients
+        with torch.no_grad():
+            pb.copy_(pa)
+        b.volume_encoder.vit3d._shadow_key = None
 
 
 def test_dropout_train_eval_semantics(nv):

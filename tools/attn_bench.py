@@ -29,7 +29,7 @@ def timeit(fn, iters=50):
 
 from neurovit_amd._cabi import lib  # noqa: E402
 fl = 4.0 * B * heads * n * n * 64
-for mode, name in ((1, "streaming"), (2, "resident ")):
+for mode, name in ((1, "streaming      "), (2, "resident x1    "), (22, "resident x2    ")):
     lib.nv_attn_set_mode(mode)
     tf = timeit(lambda: ops.attn_fwd(qkv, B, n, heads))
     tb = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, B, n, heads))
