@@ -255,7 +255,8 @@ def main():
                 depth=size["TRAINING_VIT_DEPTH"], heads=size["TRAINING_VIT_HEADS"], mlp_dim=size["TRAINING_VIT_MLP_DIM"], channels=1, dim_head=64)
     f_step = 3.0 * flops_forward(ViTCfg(**vcfg))           # fwd + bwd = 3 x fwd algorithmic FLOPs
 
-    out = {"metric": "fMRI volumes/sec (fwd+bwd+AdamW) ViT3D 128^3 p16 d768 L12", "value": round(value, 2), "unit": "volumes/s",
+    metric = f"fMRI volumes/sec (fwd+bwd+AdamW) ViT3D {S}^3 p{p} d{size['TRAINING_VIT_DIM']} L{size['TRAINING_VIT_DEPTH']}"   # base: BASELINE.json's metric
+    out = {"metric": metric, "value": round(value, 2), "unit": "volumes/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"ViT3D-{a.preset} {S}^3 patch {p}, train step (fwd+bwd+AdamW), batch {B}/GPU, dropout {a.dropout:g}",
