@@ -51,6 +51,18 @@ int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void* A, long l
                  long ldc, const float* bias, const void* aux_in, long ld_aux_in, void* aux_out, long ld_aux_out,
                  int accumulate, float alpha, unsigned long drop_seed, float drop_p, void* stream);
 
+/* Up to four independent problems of one layout / epilogue in ONE launch (provided for layout 2 / TN with epilogue 1: the
+ * four weight-gradient GEMMs of a transformer layer, vit_3d.py:19,22,41,44 backward).  Same arithmetic per tile as
+ * nv_gemm_bf16; the point is occupancy: 864 tiles together instead of 72-288 at a time. */
+typedef struct nv_gemm_problem {
+  int M, N, K;
+  const void* A; long lda;     /* A[K, M] bf16 (layout 2) */
+  const void* B; long ldb;     /* B[K, N] bf16 */
+  void* C; long ldc;           /* C[M, N] f32 */
+  int accumulate;              /* C += instead of C = */
+} nv_gemm_problem;
+int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gemm_problem* problems, void* stream);
+
 /* tuning aid: force the workgroup tile (bm, bn in {64, 128}); bm = 0 restores the built-in heuristic */
 int nv_gemm_set_tile(int bm, int bn);
 

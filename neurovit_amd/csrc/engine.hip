@@ -72,6 +72,7 @@ struct WS {
   std::vector<LayerW> layer;
   // backward scratch
   long g, g16, g16b, dxn, hookg, du, dao, dqkv, delta, dt, dt16, dxp, dwpe, red, red2, red3;
+  long alt[7];   // second copy (odd layers) of g16, g16b, du, dqkv, red, red2, red3: the auxiliary stream works one layer behind
   long red_bytes, red2_bytes, total;
 };
 
@@ -104,8 +105,11 @@ void make_ws(const Dims& D, int training, WS& W) {
     W.g16b = add(M * d * 2);
     W.red2_bytes = r4 > r2 ? r4 : r2; W.red2 = add(W.red2_bytes);       // reduction scratch of the auxiliary stream (column sums, patch-LN backward)
     W.red3 = add(nv_ln_bwd_workspace_bytes(D.M, D.d));   // LN1-backward partials (reduced on the auxiliary stream one layer late)
+    W.alt[0] = add(M * d * 2); W.alt[1] = add(M * d * 2); W.alt[2] = add(M * D.m * 2); W.alt[3] = add(M * 3 * D.inner * 2);
+    W.alt[4] = add(W.red_bytes); W.alt[5] = add(W.red2_bytes); W.alt[6] = add(nv_ln_bwd_workspace_bytes(D.M, D.d));
   } else {
     W.g = W.g16 = W.dxn = W.hookg = W.du = W.dao = W.dqkv = W.delta = W.dt = W.dt16 = W.dxp = W.dwpe = W.red = W.g16b = W.red2 = W.red3 = -1;
+    for (int i = 0; i < 7; ++i) W.alt[i] = -1;
     W.red_bytes = W.red2_bytes = 0;
   }
   W.total = cur;
@@ -254,26 +258,32 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   float* gr = grads;
   const int M = D.M, d = D.d, acc = accumulate;
   float* g = (float*)(ws + W.g);
-  void* g16 = ws + W.g16;      // bf16 residual gradient entering a layer (FC2 backward); rewritten by LN1 backward
-  void* g16b = ws + W.g16b;    // ... after LN2 backward (attention out-projection backward)
+  // Buffers the auxiliary stream reads exist twice (even / odd layers): layer l's weight-gradient work runs while the main
+  // stream is already in layer l-1, which writes the other copy.
+  auto G16 = [&](int l) -> void* { return ws + ((l & 1) ? W.alt[0] : W.g16); };     // bf16 residual gradient entering layer l
+  auto G16B = [&](int l) -> void* { return ws + ((l & 1) ? W.alt[1] : W.g16b); };   // ... after LN2 backward
+  auto DU = [&](int l) -> void* { return ws + ((l & 1) ? W.alt[2] : W.du); };
+  auto DQKV = [&](int l) -> void* { return ws + ((l & 1) ? W.alt[3] : W.dqkv); };
+  auto RED = [&](int l) -> void* { return ws + ((l & 1) ? W.alt[4] : W.red); };
+  auto RED2 = [&](int l) -> void* { return ws + ((l & 1) ? W.alt[5] : W.red2); };
+  auto RED3 = [&](int l) -> void* { return ws + ((l & 1) ? W.alt[6] : W.red3); };
   void* red = ws + W.red;
   const float scale = 1.0f / sqrtf((float)D.dh);
   hipStream_t S = (hipStream_t)stream;
   hipStream_t A = aux_stream ? (hipStream_t)aux_stream : S;       // weight-gradient stream (== S: fully serial)
   void* sA = (void*)A;
   const bool forked = (A != S);
-  void* redA = forked ? (void*)(ws + W.red2) : red;
-  const long redA_bytes = forked ? W.red2_bytes : W.red_bytes;
   if (forked) RUN(stream_sync(S, A));                              // everything before this call is visible to A
 
   NV_CHECK_ARG(first_stage >= 0 && last_stage <= D.L + 1 && first_stage <= last_stage, "nv_vit_backward_stages: bad stage range [%d, %d]", first_stage, last_stage);
   // head: writes g (zeros + cls rows) and the last layer's FC2 bias gradient (colsum of g)
   const float* xlast = (float*)(ws + W.layer[D.L - 1].x2);
   if (first_stage == 0)
-  RUN(nv_head_bwd(dlogits, B, D.C, p + T.hw, xlast, (long)D.n * d, (float*)(ws + W.hst), (float*)(ws + W.xh), p + T.hg, d, D.n, g, d, g16, d,
+  RUN(nv_head_bwd(dlogits, B, D.C, p + T.hw, xlast, (long)D.n * d, (float*)(ws + W.hst), (float*)(ws + W.xh), p + T.hg, d, D.n, g, d, G16(D.L - 1), d,
                   gr + T.hg, gr + T.hb, gr + T.hw, gr + T.hbias, gr + T.layer[D.L - 1].b2, acc, red, W.red_bytes,
                   site_seed(drop_seed, 4 * (D.L - 1) + 3), drop_p, stream));
 
+  hipEvent_t prev_done = nullptr;     // everything the previous (higher) layer queued on [A]
   for (int l = D.L - 1; l >= 0; --l) {
     const int stage = D.L - l;
     if (stage < first_stage || stage > last_stage) continue;
@@ -283,40 +293,41 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     float* st1 = (float*)(ws + w.st1);
     float* st2 = (float*)(ws + w.st2);
     float* dxn = (float*)(ws + W.dxn);
+    void* g16 = G16(l);
+    void* g16b = G16B(l);
+    void* du = DU(l);
+    void* dqkv = DQKV(l);
     // ---- FeedForward backward (vit_3d.py:16-26).  [A] = auxiliary stream
-    if (forked) RUN(stream_sync(S, A));                                                                                        // g16 ready
-    RUN(nv_gemm_bf16(2, 1, d, D.m, M, g16, d, ws + w.h, D.m, gr + q.w2, D.m, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, sA));                  // [A] dW2 = g^T h
-    RUN(nv_gemm_bf16(1, 5, M, D.m, d, g16, d, p16 + q.w2, D.m, ws + W.du, D.m, nullptr, ws + w.u, D.m, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 2), drop_p, stream));   // dU = (g W2 * mask) * gelu'(u)
+    RUN(nv_gemm_bf16(1, 5, M, D.m, d, g16, d, p16 + q.w2, D.m, du, D.m, nullptr, ws + w.u, D.m, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 2), drop_p, stream));   // dU = (g W2 * mask) * gelu'(u)
     if (forked) RUN(stream_sync(S, A));                                                                                        // dU ready
-    RUN(nv_gemm_bf16(2, 1, D.m, d, M, ws + W.du, D.m, ws + w.xn2, d, gr + q.w1, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, sA));            // [A] dW1 = dU^T xn2
-    RUN(nv_colsum_bf16(ws + W.du, D.m, M, D.m, gr + q.b1, acc, redA, redA_bytes, sA));                                                                 // [A] db1
-    hipEvent_t a1 = nullptr;
-    if (forked) { a1 = deferred_event(); if (!a1 || hipEventRecord(a1, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; } }
-    RUN(nv_gemm_bf16(1, 1, M, d, D.m, ws + W.du, D.m, p16 + q.w1, d, dxn, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));                 // dxn2 = dU W1
-    RUN(nv_ln_bwd(dxn, d, (float*)(ws + w.x1), d, st2, st2 + M, p + q.n2g, M, d, g, g, d, g16b, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, red,
+    RUN(nv_colsum_bf16(du, D.m, M, D.m, gr + q.b1, acc, RED2(l), W.red2_bytes, sA));                                           // [A] db1
+    RUN(nv_gemm_bf16(1, 1, M, d, D.m, du, D.m, p16 + q.w1, d, dxn, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));                        // dxn2 = dU W1
+    RUN(nv_ln_bwd(dxn, d, (float*)(ws + w.x1), d, st2, st2 + M, p + q.n2g, M, d, g, g, d, g16b, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, RED(l),
                   W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream, forked ? sA : nullptr));                       // g += dLN2 -> g16b; [A] reduce: dbo = colsum(g), dLN2 affine
     // ---- Attention backward (vit_3d.py:48-60)
-    if (forked) RUN(stream_sync(S, A));                                                                                        // g16b ready
-    RUN(nv_gemm_bf16(2, 1, d, D.inner, M, g16b, d, ws + w.ao, D.inner, gr + q.wo, D.inner, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, sA));    // [A] dWo = g^T ao
     RUN(nv_gemm_bf16(1, 0, M, D.inner, d, g16b, d, p16 + q.wo, D.inner, ws + W.dao, D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));  // dAO = g Wo
     RUN(nv_attn_bwd(ws + w.qkv, 3 * D.inner, ws + w.ao, ws + W.dao, D.inner, (float*)(ws + w.lse), B, D.n, D.heads, D.dh, scale,
-                    (float*)(ws + W.delta), ws + W.dqkv, 3 * D.inner, site_seed(drop_seed, 4 * l + 0), drop_p, stream));
-    if (forked) RUN(stream_sync(S, A));                                                                                        // dqkv ready
-    RUN(nv_gemm_bf16(2, 1, 3 * D.inner, d, M, ws + W.dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, sA));   // [A] dWqkv
+                    (float*)(ws + W.delta), dqkv, 3 * D.inner, site_seed(drop_seed, 4 * l + 0), drop_p, stream));
+    if (forked) RUN(stream_sync(S, A));                                                                                        // dqkv (and g16b, dU, g16) ready
+    // [A] the four weight gradients of the layer in ONE grouped launch (864 tiles keep two workgroups resident on every CU;
+    // launched one by one their 72-288 tiles leave the CUs half empty and latency bound)
+    {
+      nv_gemm_problem pr[4];
+      pr[0] = {d, D.m, M, g16, d, ws + w.h, D.m, gr + q.w2, D.m, acc};                     // dW2 = g^T h
+      pr[1] = {D.m, d, M, du, D.m, ws + w.xn2, d, gr + q.w1, d, acc};                      // dW1 = dU^T xn2
+      pr[2] = {d, D.inner, M, g16b, d, ws + w.ao, D.inner, gr + q.wo, D.inner, acc};       // dWo = g^T ao
+      pr[3] = {3 * D.inner, d, M, dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, acc};  // dWqkv = dqkv^T xn1
+      RUN(nv_gemm_bf16_grouped(2, 1, 4, pr, sA));
+    }
     float* dxn1 = (l == D.L - 1) ? (float*)(ws + W.hookg) : dxn;    // gradient of the last block's attention-LN output is kept (Grad-CAM hook)
-    RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, ws + W.dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
-    // LN1 backward rewrites g16 (read by [A] dW2) and the next layer rewrites dU / g16b / dqkv (read by [A] dW1, colsum, dWo,
-    // dWqkv): the main stream joins the auxiliary one here - by now those GEMMs have long finished.
-    if (forked && hipStreamWaitEvent(S, a1, 0) != hipSuccess) { nv_set_error("nv_vit_backward: event wait failed"); return NV_ERR_HIP; }
-    // join point of this layer, taken on [A] BEFORE the LN1 reduction is queued there: the main stream must not wait for that
-    // reduction (it only finishes parameter gradients); its partials live in red3, rewritten one whole layer later.
-    hipEvent_t a2 = nullptr;
-    if (forked) { a2 = deferred_event(); if (!a2 || hipEventRecord(a2, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; } }
-    RUN(nv_ln_bwd(dxn1, d, xin, d, st1, st1 + M, p + q.n1g, M, d, g, g, d, g16, d, gr + q.n1g, gr + q.n1b, (l > 0) ? gr + T.layer[l - 1].b2 : nullptr,
-                  acc, forked ? (void*)(ws + W.red3) : red, W.red_bytes, site_seed(drop_seed, 4 * (l - 1) + 3), (l > 0) ? drop_p : 0.f, stream,
+    RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+    // LN1 backward writes the residual gradient of layer l-1 into the buffer copy layer l+1 used: the auxiliary work of layer
+    // l+1 (a whole layer behind by now) must have finished reading it.  Every later writer of that copy follows this point.
+    if (forked && prev_done && hipStreamWaitEvent(S, prev_done, 0) != hipSuccess) { nv_set_error("nv_vit_backward: event wait failed"); return NV_ERR_HIP; }
+    RUN(nv_ln_bwd(dxn1, d, xin, d, st1, st1 + M, p + q.n1g, M, d, g, g, d, G16(l - 1), d, gr + q.n1g, gr + q.n1b, (l > 0) ? gr + T.layer[l - 1].b2 : nullptr,
+                  acc, RED3(l), nv_ln_bwd_workspace_bytes(M, d), site_seed(drop_seed, 4 * (l - 1) + 3), (l > 0) ? drop_p : 0.f, stream,
                   forked ? sA : nullptr));
-    // dWo / dWqkv of this layer done before the next layer's kernels overwrite g16b / dqkv
-    if (forked && hipStreamWaitEvent(S, a2, 0) != hipSuccess) { nv_set_error("nv_vit_backward: event wait failed"); return NV_ERR_HIP; }
+    if (forked) { prev_done = deferred_event(); if (!prev_done || hipEventRecord(prev_done, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; } }
   }
   if (forked) RUN(stream_sync(A, S));       // every gradient written on [A] (weight GEMMs, reductions) is ordered before what follows on the main stream
 
@@ -329,6 +340,8 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   // patch_dim not a multiple of 8 (reference default 90^3 / p 9 -> P = 729): operands are zero padded to Ppad columns;
   // the weight gradient is produced in a padded scratch matrix and its valid columns copied / added into the arena.
   const void* wpe = (D.P != D.Ppad) ? (const void*)(ws + W.wpe16) : (const void*)(p16 + T.pe_w);
+  void* redA = forked ? (void*)(ws + W.red2) : red;
+  const long redA_bytes = forked ? W.red2_bytes : W.red_bytes;
   // [A] gradient of the patch LayerNorm's affine parameters (needs dxp = dt Wpe and a second gather of the volume);
   // the main stream meanwhile produces the patch-embedding weight gradient
   if (forked) RUN(stream_sync(S, A));                                                                                          // dt16 ready

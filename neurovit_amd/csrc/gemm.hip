@@ -394,7 +394,7 @@ __device__ __forceinline__ void ws_wait_tiles_in_flight(int tiles) {
 #undef WS_VM
 
 template <int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>   // S = LDS ring stages, KS = 64-deep sub-tiles per stage
-__global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, const int bid) {   // bid = logical tile of this workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_BYTES = BM * BK * 2, SUB = (BM + BN) * BK * 2, STAGE = KS * SUB;
   constexpr int TM = BM / 2, TN = BN / 2, MI = TM / 16, NI = TN / 16;
@@ -404,7 +404,6 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (g.col_order ? bid % tiles_m : bid / tiles_n) * BM, n0 = (g.col_order ? bid / tiles_m : bid % tiles_n) * BN;
   const int nk = ((g.K + BK - 1) / BK + KS - 1) / KS;   // ring stages to process
 
@@ -526,6 +525,29 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw barrier carries no wait: the parked tile must be written first
   __builtin_amdgcn_s_barrier();                         // barrier E
   epilogue_lds<EPI, BM, BN, WS_THREADS>(smem, g, m0, n0, tid);
+}
+
+template <int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>
+__global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
+  gemm_ws_body<BM, BN, S, KS, A_T, B_T, EPI>(g, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Grouped launch: up to four independent problems of one layout / epilogue in ONE grid.  The four weight-gradient GEMMs of a
+// transformer layer have 72-288 tiles each: launched one by one each leaves half of the CUs' two workgroup slots empty and
+// its workgroups run latency-bound; together (864 tiles) every CU holds two co-resident workgroups that hide each other's
+// LDS / DMA latency, and three launch ramps disappear.
+constexpr int GROUP_MAX = 4;
+struct GemmGroup {
+  GemmArgs p[GROUP_MAX];
+  int tile_end[GROUP_MAX];   // exclusive prefix sums of the problems' tile counts
+  int count;
+};
+template <int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>
+__global__ __launch_bounds__(WS_THREADS) void gemm_ws_grouped_kernel(const GemmGroup G) {
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int p = 0;
+  while (p + 1 < G.count && bid >= G.tile_end[p]) ++p;      // workgroup-uniform
+  gemm_ws_body<BM, BN, S, KS, A_T, B_T, EPI>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
@@ -655,4 +677,46 @@ extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void
   }
   nv_set_error("nv_gemm_bf16: unsupported layout/epilogue combination (%d, %d)", layout, epi);
   return NV_ERR_ARG;
+}
+
+// Grouped weight-gradient GEMMs (layout 2 / TN, fp32 store or accumulate): see gemm_ws_grouped_kernel.
+extern "C" int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gemm_problem* pr, void* stream) {
+  NV_CHECK_ARG(layout == 2 && epi == EPI_STORE_F32, "nv_gemm_bf16_grouped: only layout 2 (TN) with epilogue 1 (fp32 store) is provided");
+  NV_CHECK_ARG(pr && count >= 1 && count <= GROUP_MAX, "nv_gemm_bf16_grouped: 1..%d problems", GROUP_MAX);
+  constexpr int BM = 64, BN = 128;
+  GemmGroup G;
+  G.count = count;
+  int tiles = 0;
+  double flops = 0.0;
+  for (int i = 0; i < count; ++i) {
+    const nv_gemm_problem& q = pr[i];
+    NV_CHECK_ARG(q.M > 0 && q.N > 0 && q.K > 0 && q.A && q.B && q.C, "nv_gemm_bf16_grouped: empty problem %d", i);
+    NV_CHECK_ARG(nv_aligned16(q.A) && nv_aligned16(q.B) && nv_aligned16(q.C) && (q.lda % 8) == 0 && (q.ldb % 8) == 0 && (q.ldc % 4) == 0 &&
+                     (q.M % 8) == 0 && (q.N % 8) == 0 && q.lda >= q.M && q.ldb >= q.N && q.ldc >= q.N,
+                 "nv_gemm_bf16_grouped: problem %d: alignment / leading dimensions", i);
+    NV_CHECK_ARG((long)q.K * q.lda < (1L << 30) && (long)q.K * q.ldb < (1L << 30), "nv_gemm_bf16_grouped: problem %d too large for 32-bit offsets", i);
+    GemmArgs& a = G.p[i];
+    a.A = (const bf16*)q.A; a.B = (const bf16*)q.B; a.C = q.C; a.bias = nullptr; a.aux_in = nullptr; a.aux_out = nullptr;
+    a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ld_aux_in = 0; a.ld_aux_out = 0;
+    a.M = q.M; a.N = q.N; a.K = q.K; a.accumulate = q.accumulate; a.alpha = 1.f;
+    a.drop = make_drop(0, 0.f);
+    a.col_order = (q.N > q.M) ? 1 : 0;
+    tiles += ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN);
+    G.tile_end[i] = tiles;
+    flops += 2.0 * q.M * q.N * q.K;
+  }
+  for (int i = count; i < GROUP_MAX; ++i) { G.p[i] = G.p[0]; G.tile_end[i] = tiles; }
+  constexpr int LDS = 3 * (BM + BN) * BK * 2;
+  auto kern = gemm_ws_grouped_kernel<BM, BN, 3, 1, true, true, EPI_STORE_F32>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int slot = nv_prof_begin(2, flops, s);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(WS_THREADS), LDS, s, G);
+  nv_prof_end(slot, s);
+  NV_CHECK_LAUNCH("nv_gemm_bf16_grouped");
+  return NV_OK;
 }

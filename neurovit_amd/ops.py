@@ -56,6 +56,23 @@ def gemm(layout: int, epi: int, A: torch.Tensor, B: torch.Tensor, *, out: Option
     return out
 
 
+class GemmProblem(ctypes.Structure):          # include/neurovit_hip.h::nv_gemm_problem
+    _fields_ = [("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("A", ctypes.c_void_p), ("lda", ctypes.c_long),
+                ("B", ctypes.c_void_p), ("ldb", ctypes.c_long), ("C", ctypes.c_void_p), ("ldc", ctypes.c_long), ("accumulate", ctypes.c_int)]
+
+
+def gemm_tn_grouped(problems) -> None:
+    """problems: up to four (A[K, M] bf16, B[K, N] bf16, C[M, N] f32, accumulate) - C (+)= A^T B, one launch."""
+    arr = (GemmProblem * len(problems))()
+    for i, (A, B, C, acc) in enumerate(problems):
+        _need_cuda(A)
+        K, M = A.shape
+        N = B.shape[1]
+        assert B.shape[0] == K and C.shape == (M, N) and C.dtype == torch.float32
+        arr[i] = GemmProblem(M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0), int(acc))
+    check(lib.nv_gemm_bf16_grouped(TN, EPI_STORE_F32, len(problems), ctypes.cast(arr, ctypes.c_void_p), _stream()), "nv_gemm_bf16_grouped")
+
+
 def ln_fwd(x: torch.Tensor, gamma, beta, eps: float = 1e-5):
     _need_cuda(x)
     M, d = x.shape

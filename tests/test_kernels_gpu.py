@@ -112,6 +112,31 @@ def test_gemm_tn_ragged_tokens(ops):
     assert_close_f32(ops.gemm(ops.TN, ops.EPI_STORE_F32, dev(At), dev(B2)), At.double().T @ B2.double(), "tn_ragged", 1e-5)
 
 
+def test_gemm_tn_grouped_equals_single_launches(ops):
+    """The four weight-gradient GEMMs of a layer in ONE grouped launch (csrc/gemm.hip::gemm_ws_grouped_kernel): every problem
+    bit-identical to its own nv_gemm_bf16 launch through the same 64x128 kernel (store and accumulate), ragged token count."""
+    from neurovit_amd._cabi import lib
+    K = 2052
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    probs, singles = [], []
+    lib.nv_gemm_set_tile(3, 1)            # the grouped kernel's configuration: warp-specialised 64x128, 3 x 64-deep ring
+    try:
+        for i, (Mo, N) in enumerate(shapes):
+            At, B2 = dev(bf(rnd(K, Mo, seed=20 + i))), dev(bf(rnd(K, N, seed=30 + i, scale=K ** -0.5)))
+            acc = i % 2 == 1
+            base = dev(rnd(Mo, N, seed=40 + i)) if acc else torch.empty(Mo, N, device="cuda")
+            C1 = base.clone()
+            singles.append(ops.gemm(ops.TN, ops.EPI_STORE_F32, At, B2, out=base.clone(), accumulate=acc))
+            probs.append((At, B2, C1, acc))
+    finally:
+        lib.nv_gemm_set_tile(0, 0)
+    ops.gemm_tn_grouped(probs)
+    for (At, B2, C1, acc), ref in zip(probs, singles):
+        assert torch.equal(C1, ref)
+    ops.gemm_tn_grouped(probs[2:3])                                   # a group of one
+    assert_close_f32(probs[2][2], probs[2][0].double().T @ probs[2][1].double(), "grouped_single", 1e-5)
+
+
 @pytest.mark.parametrize("ws", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 264, 192), (130, 136, 128), (2052, 768, 768), (300, 8, 64)])
 def test_gemm_warp_specialised_kernel_forced(ops, M, N, K, ws):
