@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      long ldg, bf16* __restrict__ g16, long ldg16, float* __restrict__ partials,
                                                      DropCfg drop, int seg_rows, int seg_skip) {
   // seg_rows > 0: dy is segmented - after every seg_rows rows seg_skip rows are skipped (token rows of a [B, 1+N, d] tensor)
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][3][d]
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][d]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nw = gridDim.x * WAVES_PER_BLOCK;
   f32x4 gm[NV], a_g[NV], a_b[NV], a_c[NV];
@@ -148,20 +148,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       }
     }
   }
-  // deterministic in-block reduction of the three column accumulators
+  // deterministic in-block reduction of the three column accumulators, one array at a time through a [4 waves][d] buffer:
+  // 12 KiB at d = 768 instead of 36, so that these workgroups fit on a CU beside two 72 KiB GEMM workgroups of the other stream
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int c = (lane + 64 * v) * 4;
-    if (c < d) {
-      *reinterpret_cast<f32x4*>(red + (wid * 3 + 0) * d + c) = a_g[v];
-      *reinterpret_cast<f32x4*>(red + (wid * 3 + 1) * d + c) = a_b[v];
-      *reinterpret_cast<f32x4*>(red + (wid * 3 + 2) * d + c) = a_c[v];
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = (lane + 64 * v) * 4;
+      if (c < d) *reinterpret_cast<f32x4*>(red + wid * d + c) = (a == 0) ? a_g[v] : (a == 1 ? a_b[v] : a_c[v]);
     }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 3 * d; i += 256) {
-    const float t = (red[i] + red[3 * d + i]) + (red[6 * d + i] + red[9 * d + i]);
-    partials[(long)blockIdx.x * 3 * d + i] = t;
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += 256)
+      partials[(long)blockIdx.x * 3 * d + a * d + i] = (red[i] + red[d + i]) + (red[2 * d + i] + red[3 * d + i]);
+    __syncthreads();
   }
 }
 
@@ -213,7 +212,7 @@ static int ln_bwd_launch(const float* dy, long lddy, const float* x, long ldx, c
   NV_CHECK_ARG((lddy % 4) == 0 && (ldx % 4) == 0 && (ldg % 4) == 0 && (ldg16 % 4) == 0, "nv_ln_bwd: leading dims must be multiples of 4");
   const int nb = ln_bwd_blocks(M);
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = (size_t)WAVES_PER_BLOCK * 3 * d * sizeof(float);
+  const size_t lds = (size_t)WAVES_PER_BLOCK * d * sizeof(float);
   if (d <= 1024)
     hipLaunchKernelGGL((ln_bwd_kernel<4, 2>), dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
                        (bf16*)g16, ldg16, (float*)workspace, drop, seg_rows, seg_skip);
