@@ -77,7 +77,11 @@ int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float*
               float* dcolsum, int accumulate, void* workspace, long ws_bytes, unsigned long drop_seed, float drop_p,
               void* stream, void* reduce_stream);
 /* reduce_stream (null = stream): where the dgamma / dbeta / dcolsum reduction of the per-workgroup partials runs; it is
- * ordered after the main kernel by an event, and `workspace` must stay untouched until that stream has executed it. */
+ * ordered after the main kernel by an event, and `workspace` must stay untouched until that stream has executed it.
+ * NV_LN_NO_REDUCE leaves the reduction to a later nv_ln_bwd_reduce (same M, d, workspace) on a stream the caller has
+ * ordered after this call - lets several reductions share one cross-stream event. */
+#define NV_LN_NO_REDUCE ((void*)(-1L))
+int nv_ln_bwd_reduce(const void* workspace, int M, int d, float* dgamma, float* dbeta, float* dcolsum, int accumulate, void* stream);
 
 /* ---- input contract (src/data/DatasetADNI.py:212-213, DatasetADNI_4D.py:86-87): crop of the raw volume + z-score
  * (x - mean) / (std + eps), population std over the whole cropped sample, statistics accumulated in double.

@@ -128,7 +128,7 @@ inline hipEvent_t deferred_event() {
   static size_t next = 0;
   if (pool.size() < 32) {
     hipEvent_t e;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&e, nv_sync_event_flags()) != hipSuccess) return nullptr;
     pool.push_back(e);
     return e;
   }
@@ -283,7 +283,16 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
                   gr + T.hg, gr + T.hb, gr + T.hw, gr + T.hbias, gr + T.layer[D.L - 1].b2, acc, red, W.red_bytes,
                   site_seed(drop_seed, 4 * (D.L - 1) + 3), drop_p, stream));
 
+  // One cross-stream event per layer in each direction (an event record costs several microseconds of queue time): the main
+  // stream signals once, after the attention backward; the auxiliary stream then runs, one layer behind the main stream,
+  // [db1 column sum, LN2 reduction, LN1 reduction of the layer above, grouped weight-gradient GEMMs] and signals back once.
   hipEvent_t prev_done = nullptr;     // everything the previous (higher) layer queued on [A]
+  int pending_ln1 = -1;               // layer whose LN1-backward partials still wait for their reduction
+  auto reduce_ln1 = [&](int lp) -> int {
+    const LayerP& qp = T.layer[lp];
+    return nv_ln_bwd_reduce(RED3(lp), M, d, gr + qp.n1g, gr + qp.n1b, (lp > 0) ? gr + T.layer[lp - 1].b2 : nullptr, acc, sA);
+  };
+  void* const ln_reduce = forked ? NV_LN_NO_REDUCE : nullptr;
   for (int l = D.L - 1; l >= 0; --l) {
     const int stage = D.L - l;
     if (stage < first_stage || stage > last_stage) continue;
@@ -297,21 +306,23 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     void* g16b = G16B(l);
     void* du = DU(l);
     void* dqkv = DQKV(l);
-    // ---- FeedForward backward (vit_3d.py:16-26).  [A] = auxiliary stream
+    // ---- FeedForward backward (vit_3d.py:16-26)
     RUN(nv_gemm_bf16(1, 5, M, D.m, d, g16, d, p16 + q.w2, D.m, du, D.m, nullptr, ws + w.u, D.m, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 2), drop_p, stream));   // dU = (g W2 * mask) * gelu'(u)
-    if (forked) RUN(stream_sync(S, A));                                                                                        // dU ready
-    RUN(nv_colsum_bf16(du, D.m, M, D.m, gr + q.b1, acc, RED2(l), W.red2_bytes, sA));                                           // [A] db1
     RUN(nv_gemm_bf16(1, 1, M, d, D.m, du, D.m, p16 + q.w1, d, dxn, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));                        // dxn2 = dU W1
     RUN(nv_ln_bwd(dxn, d, (float*)(ws + w.x1), d, st2, st2 + M, p + q.n2g, M, d, g, g, d, g16b, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, RED(l),
-                  W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream, forked ? sA : nullptr));                       // g += dLN2 -> g16b; [A] reduce: dbo = colsum(g), dLN2 affine
+                  W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream, ln_reduce));                                   // g += dLN2 -> g16b
     // ---- Attention backward (vit_3d.py:48-60)
     RUN(nv_gemm_bf16(1, 0, M, D.inner, d, g16b, d, p16 + q.wo, D.inner, ws + W.dao, D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));  // dAO = g Wo
     RUN(nv_attn_bwd(ws + w.qkv, 3 * D.inner, ws + w.ao, ws + W.dao, D.inner, (float*)(ws + w.lse), B, D.n, D.heads, D.dh, scale,
                     (float*)(ws + W.delta), dqkv, 3 * D.inner, site_seed(drop_seed, 4 * l + 0), drop_p, stream));
-    if (forked) RUN(stream_sync(S, A));                                                                                        // dqkv (and g16b, dU, g16) ready
-    // [A] the four weight gradients of the layer in ONE grouped launch (864 tiles keep two workgroups resident on every CU;
-    // launched one by one their 72-288 tiles leave the CUs half empty and latency bound)
+    // ---- [A] everything of this layer that only finishes parameter gradients
+    if (forked) RUN(stream_sync(S, A));                                                                                        // dU, g16b, dqkv (and the LN partials) ready
+    RUN(nv_colsum_bf16(du, D.m, M, D.m, gr + q.b1, acc, RED2(l), W.red2_bytes, sA));                                           // [A] db1
+    if (forked) RUN(nv_ln_bwd_reduce(RED(l), M, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, sA));                               // [A] dLN2 affine, dbo = colsum(g)
+    if (forked && pending_ln1 >= 0) { RUN(reduce_ln1(pending_ln1)); pending_ln1 = -1; }                                        // [A] dLN1 affine + db2 of the layer above
     {
+      // the four weight gradients of the layer in ONE grouped launch (864 tiles keep two workgroups resident on every CU;
+      // launched one by one their 72-288 tiles leave the CUs half empty and latency bound)
       nv_gemm_problem pr[4];
       pr[0] = {d, D.m, M, g16, d, ws + w.h, D.m, gr + q.w2, D.m, acc};                     // dW2 = g^T h
       pr[1] = {D.m, d, M, du, D.m, ws + w.xn2, d, gr + q.w1, d, acc};                      // dW1 = dU^T xn2
@@ -319,17 +330,22 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
       pr[3] = {3 * D.inner, d, M, dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, acc};  // dWqkv = dqkv^T xn1
       RUN(nv_gemm_bf16_grouped(2, 1, 4, pr, sA));
     }
+    hipEvent_t done = nullptr;
+    if (forked) { done = deferred_event(); if (!done || hipEventRecord(done, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; } }
     float* dxn1 = (l == D.L - 1) ? (float*)(ws + W.hookg) : dxn;    // gradient of the last block's attention-LN output is kept (Grad-CAM hook)
     RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
-    // LN1 backward writes the residual gradient of layer l-1 into the buffer copy layer l+1 used: the auxiliary work of layer
-    // l+1 (a whole layer behind by now) must have finished reading it.  Every later writer of that copy follows this point.
+    // LN1 backward writes the residual gradient of layer l-1 into the buffer copy layer l+1 used (and layer l-1 then rewrites
+    // the rest of that copy): the auxiliary work of layer l+1 - a whole layer behind by now - must have finished with it.
     if (forked && prev_done && hipStreamWaitEvent(S, prev_done, 0) != hipSuccess) { nv_set_error("nv_vit_backward: event wait failed"); return NV_ERR_HIP; }
     RUN(nv_ln_bwd(dxn1, d, xin, d, st1, st1 + M, p + q.n1g, M, d, g, g, d, G16(l - 1), d, gr + q.n1g, gr + q.n1b, (l > 0) ? gr + T.layer[l - 1].b2 : nullptr,
-                  acc, RED3(l), nv_ln_bwd_workspace_bytes(M, d), site_seed(drop_seed, 4 * (l - 1) + 3), (l > 0) ? drop_p : 0.f, stream,
-                  forked ? sA : nullptr));
-    if (forked) { prev_done = deferred_event(); if (!prev_done || hipEventRecord(prev_done, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; } }
+                  acc, RED3(l), nv_ln_bwd_workspace_bytes(M, d), site_seed(drop_seed, 4 * (l - 1) + 3), (l > 0) ? drop_p : 0.f, stream, ln_reduce));
+    if (forked) pending_ln1 = l;
+    prev_done = done;
   }
-  if (forked) RUN(stream_sync(A, S));       // every gradient written on [A] (weight GEMMs, reductions) is ordered before what follows on the main stream
+  if (forked) {
+    if (pending_ln1 >= 0) { RUN(stream_sync(S, A)); RUN(reduce_ln1(pending_ln1)); }
+    RUN(stream_sync(A, S));       // every gradient written on [A] (weight GEMMs, reductions) is ordered before what follows on the main stream
+  }
 
   if (last_stage < D.L + 1) return NV_OK;
   // ---- patch embedding backward (vit_3d.py:91-96,116-118)

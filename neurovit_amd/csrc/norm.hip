@@ -221,7 +221,8 @@ static int ln_bwd_launch(const float* dy, long lddy, const float* x, long ldx, c
                        (bf16*)g16, ldg16, (float*)workspace, drop, seg_rows, seg_skip);
   NV_CHECK_LAUNCH("nv_ln_bwd");
   // the parameter-gradient reduction is off the data path: it may run on another stream (the caller then owns `workspace`
-  // until that stream has passed this point)
+  // until that stream has passed this point), or be left to a later nv_ln_bwd_reduce call (reduce_stream = NV_LN_NO_REDUCE)
+  if (reduce_stream == NV_LN_NO_REDUCE) return NV_OK;
   if (reduce_stream && reduce_stream != stream) {
     if (nv_stream_sync(stream, reduce_stream) != NV_OK) return NV_ERR_HIP;
     s = (hipStream_t)reduce_stream;
@@ -229,6 +230,15 @@ static int ln_bwd_launch(const float* dy, long lddy, const float* x, long ldx, c
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 31) / 32), dim3(256), 0, s, (const float*)workspace, nb, d, 3, dgamma,
                      dbeta, dcolsum, accumulate);
   NV_CHECK_LAUNCH("nv_ln_bwd/reduce");
+  return NV_OK;
+}
+
+// second half of nv_ln_bwd(..., reduce_stream = NV_LN_NO_REDUCE): the caller orders `stream` after the main kernel
+extern "C" int nv_ln_bwd_reduce(const void* workspace, int M, int d, float* dgamma, float* dbeta, float* dcolsum, int accumulate, void* stream) {
+  NV_CHECK_ARG(workspace && M > 0 && d > 0 && (d % 4) == 0 && d <= 2048, "nv_ln_bwd_reduce: bad arguments");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, ln_bwd_blocks(M),
+                     d, 3, dgamma, dbeta, dcolsum, accumulate);
+  NV_CHECK_LAUNCH("nv_ln_bwd_reduce");
   return NV_OK;
 }
 
