@@ -342,17 +342,20 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     if (forked) pending_ln1 = l;
     prev_done = done;
   }
-  if (forked) {
-    if (pending_ln1 >= 0) { RUN(stream_sync(S, A)); RUN(reduce_ln1(pending_ln1)); }
-    RUN(stream_sync(A, S));       // every gradient written on [A] (weight GEMMs, reductions) is ordered before what follows on the main stream
+  if (last_stage < D.L + 1) {
+    if (forked) {
+      if (pending_ln1 >= 0) { RUN(stream_sync(S, A)); RUN(reduce_ln1(pending_ln1)); }
+      RUN(stream_sync(A, S));     // every gradient written on [A] (weight GEMMs, reductions) is ordered before what follows on the main stream
+    }
+    return NV_OK;
   }
-
-  if (last_stage < D.L + 1) return NV_OK;
-  // ---- patch embedding backward (vit_3d.py:91-96,116-118)
+  // ---- patch embedding backward (vit_3d.py:91-96,116-118).  The main stream does NOT join the auxiliary one first: layer 0's
+  // grouped weight gradients keep running beside it.  Its reduction scratch is the odd copy, which the auxiliary stream
+  // released before the main stream was allowed into layer 0's LN1 backward.
   float* est = (float*)(ws + W.est);
   float* pst = (float*)(ws + W.pst);
   RUN(nv_embed_finish_bwd(g, d, (float*)(ws + W.t), d, est, est + D.T, p + T.pe_g2, B, D.N, d, (float*)(ws + W.dt), d, ws + W.dt16, d, gr + T.pe_g2,
-                          gr + T.pe_b2, gr + T.pe_bias, gr + T.pos, gr + T.cls, acc, red, W.red_bytes, site_seed(drop_seed, 4 * D.L), emb_drop_p, stream));
+                          gr + T.pe_b2, gr + T.pe_bias, gr + T.pos, gr + T.cls, acc, RED(1), W.red_bytes, site_seed(drop_seed, 4 * D.L), emb_drop_p, stream));
   // patch_dim not a multiple of 8 (reference default 90^3 / p 9 -> P = 729): operands are zero padded to Ppad columns;
   // the weight gradient is produced in a padded scratch matrix and its valid columns copied / added into the arena.
   const void* wpe = (D.P != D.Ppad) ? (const void*)(ws + W.wpe16) : (const void*)(p16 + T.pe_w);
@@ -360,7 +363,8 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   const long redA_bytes = forked ? W.red2_bytes : W.red_bytes;
   // [A] gradient of the patch LayerNorm's affine parameters (needs dxp = dt Wpe and a second gather of the volume);
   // the main stream meanwhile produces the patch-embedding weight gradient
-  if (forked) RUN(stream_sync(S, A));                                                                                          // dt16 ready
+  if (forked) RUN(stream_sync(S, A));                                                                                          // dt16 and layer 0's LN1 partials ready
+  if (forked && pending_ln1 >= 0) RUN(reduce_ln1(pending_ln1));
   RUN(nv_gemm_bf16(1, 1, D.T, D.Ppad, d, ws + W.dt16, d, wpe, D.Ppad, ws + W.dxp, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, sA));              // [A] dxp = dt Wpe
   RUN(nv_patch_ln_bwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
                       cfg->image_patch_size, cfg->frame_patch_size, (float*)(ws + W.dxp), D.Ppad, pst, pst + D.T, gr + T.pe_g, gr + T.pe_b, acc, redA,
