@@ -139,8 +139,9 @@ int nv_colsum_bf16(const void* X, long ld, int M, int N, float* out, int accumul
 /* ---- loss / optimizer (Trainer.py:30-31,70,75): nn.CrossEntropyLoss (mean) and torch.optim.AdamW */
 int nv_ce_loss(const float* logits, const long* target, int B, int C, float grad_scale, float* loss, float* dlogits,
                void* stream);
-int nv_adamw_step(float* p, const float* grad, float* m, float* v, void* p16, long count, int step, double lr, double beta1,
-                  double beta2, double eps, double weight_decay, float grad_scale, int max_blocks, void* stream);
+int nv_adamw_step(float* p, const void* grad, int grad_bf16, float* m, float* v, void* p16, long count, int step, double lr,
+                  double beta1, double beta2, double eps, double weight_decay, float grad_scale, int max_blocks, void* stream);
+/* grad_bf16 = 1: `grad` is a bf16 buffer (the gradient all-reduce ran on bf16 messages): no cast back to fp32 is needed. */
 /* max_blocks > 0 caps the grid (256-thread workgroups, grid-stride): used when the update of one gradient bucket runs on a
    side stream beside the backward pass, so that it takes a slice of the chip instead of queueing ahead of the GEMMs. */
 int nv_cast_bf16_2d(const float* src, long ld_src, int rows, int cols, void* dst, long ld_dst, void* stream);
@@ -170,13 +171,17 @@ int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const l
                     int accumulate, float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream, void* aux_stream);
 
 /* aux_stream (may be NULL): a second hipStream_t on which the weight-gradient GEMMs run concurrently with the data-gradient
- * chain; the engine forks / joins with pooled events, and every call returns with `stream` ordered after all of its work.
+ * chain; the engine forks / joins with pooled events.
  * Backward split into stages (0 = head, 1+k = layer depth-1-k, depth+1 = patch embedding) so the caller can start the
- * data-parallel all-reduce of a stage's gradient range (nv_vit_stage_param_range) while later stages still run. */
+ * data-parallel all-reduce of a stage's gradient range (nv_vit_stage_param_range) while later stages still run.
+ * join_aux = 1: the call returns with `stream` ordered after all of its work on both streams.  join_aux = 0 (allowed for
+ * ranges that do not contain the last stage): `stream` is NOT made to wait for the auxiliary stream - the range's gradients
+ * are complete once BOTH streams have executed what this call enqueued, so the consumer (the all-reduce) must be ordered
+ * after both; the next call on the same workspace picks the dependency up where this one left it. */
 int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                            const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
                            int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
-                           unsigned long drop_seed, void* stream, void* aux_stream);
+                           unsigned long drop_seed, void* stream, void* aux_stream, int join_aux);
 int nv_vit_stage_param_range(const nv_vit_config* cfg, int stage, long* begin, long* end);
 
 #ifdef __cplusplus

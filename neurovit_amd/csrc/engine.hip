@@ -135,6 +135,11 @@ inline hipEvent_t deferred_event() {
   return pool[next++ % pool.size()];
 }
 
+// nv_vit_backward_stages(join_aux = 0) leaves the auxiliary stream running; the next call on the same workspace must order
+// its first buffer reuse after that work: the event recorded at the end of the unjoined call is carried over here.
+void* g_carry_ws = nullptr;
+hipEvent_t g_carry_done = nullptr;
+
 #define RUN(call)            \
   do {                       \
     const int rc__ = (call); \
@@ -245,7 +250,7 @@ extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* vide
 extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                                       const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
                                       int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
-                                      unsigned long drop_seed, void* stream, void* aux_stream) {
+                                      unsigned long drop_seed, void* stream, void* aux_stream, int join_aux) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 1, W);
@@ -287,6 +292,9 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   // stream signals once, after the attention backward; the auxiliary stream then runs, one layer behind the main stream,
   // [db1 column sum, LN2 reduction, LN1 reduction of the layer above, grouped weight-gradient GEMMs] and signals back once.
   hipEvent_t prev_done = nullptr;     // everything the previous (higher) layer queued on [A]
+  if (g_carry_ws == workspace) prev_done = g_carry_done;      // ... in the previous, unjoined call
+  g_carry_ws = nullptr;
+  bool layers_here = false;
   int pending_ln1 = -1;               // layer whose LN1-backward partials still wait for their reduction
   auto reduce_ln1 = [&](int lp) -> int {
     const LayerP& qp = T.layer[lp];
@@ -341,14 +349,23 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
                   acc, RED3(l), nv_ln_bwd_workspace_bytes(M, d), site_seed(drop_seed, 4 * (l - 1) + 3), (l > 0) ? drop_p : 0.f, stream, ln_reduce));
     if (forked) pending_ln1 = l;
     prev_done = done;
+    layers_here = true;
   }
   if (last_stage < D.L + 1) {
     if (forked) {
       if (pending_ln1 >= 0) { RUN(stream_sync(S, A)); RUN(reduce_ln1(pending_ln1)); }
-      RUN(stream_sync(A, S));     // every gradient written on [A] (weight GEMMs, reductions) is ordered before what follows on the main stream
+      if (join_aux) {
+        RUN(stream_sync(A, S));   // every gradient written on [A] (weight GEMMs, reductions) is ordered before what follows on the main stream
+      } else {                    // the caller orders the consumer of this range after BOTH streams; the next call inherits the dependency
+        hipEvent_t e = deferred_event();
+        if (!e || hipEventRecord(e, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; }
+        g_carry_ws = workspace; g_carry_done = e;
+      }
     }
     return NV_OK;
   }
+  // a call that starts at the embedding stage behind an unjoined call: its scratch may still be in use over there
+  if (forked && !layers_here && prev_done && hipStreamWaitEvent(S, prev_done, 0) != hipSuccess) { nv_set_error("nv_vit_backward: event wait failed"); return NV_ERR_HIP; }
   // ---- patch embedding backward (vit_3d.py:91-96,116-118).  The main stream does NOT join the auxiliary one first: layer 0's
   // grouped weight gradients keep running beside it.  Its reduction scratch is the odd copy, which the auxiliary stream
   // released before the main stream was allowed into layer 0's LN1 backward.
@@ -383,7 +400,7 @@ extern "C" int nv_vit_backward(const nv_vit_config* cfg, int B, const float* vid
                                const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
                                int accumulate, float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream, void* aux_stream) {
   return nv_vit_backward_stages(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, accumulate, 0,
-                                cfg ? cfg->depth + 1 : 0, drop_p, emb_drop_p, drop_seed, stream, aux_stream);
+                                cfg ? cfg->depth + 1 : 0, drop_p, emb_drop_p, drop_seed, stream, aux_stream, 1);
 }
 
 // Element range [begin, end) of the parameter / gradient arena that is FINAL once backward stage `stage` has run.

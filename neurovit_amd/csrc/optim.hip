@@ -13,13 +13,22 @@ struct AdamArgs {   // every derived constant is formed in double on the host, a
 
 // Same operation order as torch's single-tensor AdamW (param.mul_; exp_avg.lerp_; exp_avg_sq.mul_.addcmul_;
 // denom = sqrt(v)/bc2_sqrt + eps; param.addcdiv_) so results track the reference optimizer to fp32 rounding.
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
+// G16: the gradient is read from a bf16 buffer (the data-parallel all-reduce ran on bf16 messages; reading them here saves the
+// cast back to fp32 - a full extra pass over the arena - and 2 of the 16 bytes this kernel reads per parameter)
+template <bool G16>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const void* __restrict__ grad, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ p16, long n4, AdamArgs a) {
   // grid-stride: a full-size grid runs one iteration per thread; a capped grid (max_blocks) streams the range with a
   // fraction of the chip's wave slots so that it can run beside compute-bound kernels of another stream
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
   f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
-  f32x4 gv = reinterpret_cast<const f32x4*>(grad)[i] * a.grad_scale;
+  f32x4 gv;
+  if constexpr (G16) {
+    const bf16x4 g4 = reinterpret_cast<const bf16x4*>(grad)[i];
+    gv = f32x4{(float)g4[0], (float)g4[1], (float)g4[2], (float)g4[3]} * a.grad_scale;
+  } else {
+    gv = reinterpret_cast<const f32x4*>(grad)[i] * a.grad_scale;
+  }
   f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
   f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
   pv *= a.decay;
@@ -35,10 +44,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 // count must be a multiple of 4 (arena segments are padded); step >= 1.
-extern "C" int nv_adamw_step(float* p, const float* grad, float* m, float* v, void* p16, long count, int step, double lr, double beta1,
-                             double beta2, double eps, double weight_decay, float grad_scale, int max_blocks, void* stream) {
+extern "C" int nv_adamw_step(float* p, const void* grad, int grad_bf16, float* m, float* v, void* p16, long count, int step, double lr,
+                             double beta1, double beta2, double eps, double weight_decay, float grad_scale, int max_blocks, void* stream) {
   NV_CHECK_ARG(count > 0 && (count % 4) == 0 && step >= 1, "nv_adamw_step: count=%ld must be a positive multiple of 4", count);
-  NV_CHECK_ARG(nv_aligned16(p) && nv_aligned16(grad) && nv_aligned16(m) && nv_aligned16(v) && (!p16 || ((uintptr_t)p16 & 7) == 0),
+  NV_CHECK_ARG(nv_aligned16(p) && (grad_bf16 ? ((uintptr_t)grad & 7) == 0 : nv_aligned16(grad)) && nv_aligned16(m) && nv_aligned16(v) &&
+                   (!p16 || ((uintptr_t)p16 & 7) == 0),
                "nv_adamw_step: alignment");
   AdamArgs a;
   a.decay = (float)(1.0 - lr * weight_decay);
@@ -49,7 +59,8 @@ extern "C" int nv_adamw_step(float* p, const float* grad, float* m, float* v, vo
   const long n4 = count / 4;
   long blocks = (n4 + 255) / 256;
   if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (bf16*)p16, n4, a);
+  if (grad_bf16) hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (bf16*)p16, n4, a);
+  else hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (bf16*)p16, n4, a);
   NV_CHECK_LAUNCH("nv_adamw_step");
   return NV_OK;
 }

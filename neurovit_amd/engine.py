@@ -82,8 +82,10 @@ class VitRuntime:
         return logits
 
     def backward(self, dlogits: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, grads: torch.Tensor,
-                 accumulate: bool, stages: Optional[Tuple[int, int]] = None) -> None:
-        """Whole backward, or only stages [first, last] (0 = head, 1+k = layer depth-1-k, depth+1 = embedding)."""
+                 accumulate: bool, stages: Optional[Tuple[int, int]] = None, join_aux: bool = True) -> None:
+        """Whole backward, or only stages [first, last] (0 = head, 1+k = layer depth-1-k, depth+1 = embedding).
+        join_aux=False (only for ranges before the last stage): the current stream is not made to wait for the auxiliary
+        stream - order the consumer of the range's gradients after `aux_stream_object()` as well."""
         assert self._last is not None and self._last[1], "backward needs a preceding forward(training=True)"
         B, _, ws, video = self._last
         first, last = (0, self.cfg.depth + 1) if stages is None else stages
@@ -93,8 +95,12 @@ class VitRuntime:
                                          params16.data_ptr(), ws.data_ptr(), ws.numel(), self._dlogits.data_ptr(),
                                          grads.data_ptr(), int(accumulate), first, last, float(self._dropout[0]),
                                          float(self._dropout[1]), int(self._dropout[2]),
-                                         torch.cuda.current_stream().cuda_stream, self._aux_stream(video.device)),
+                                         torch.cuda.current_stream().cuda_stream, self._aux_stream(video.device), int(join_aux)),
               "nv_vit_backward_stages")
+
+    def aux_stream_object(self, device) -> Optional[torch.cuda.Stream]:
+        """The torch stream object behind the engine's auxiliary stream (None when the engine runs single-stream)."""
+        return self._aux.get(str(device)) if self.use_aux_stream else None
 
     def _aux_stream(self, device):
         if not self.use_aux_stream:

@@ -207,8 +207,10 @@ def ce_loss(logits: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0,
 
 
 def adamw_step(p, grad, m, v, p16, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0, max_blocks=0):
-    check(lib.nv_adamw_step(_p(p), _p(grad), _p(m), _p(v), _p(p16), p.numel(), step, lr, betas[0], betas[1], eps, weight_decay, grad_scale,
-                            int(max_blocks), _stream()), "nv_adamw_step")
+    """grad may be fp32 or bf16 (same numel as p)."""
+    assert grad.dtype in (torch.float32, torch.bfloat16) and grad.numel() == p.numel()
+    check(lib.nv_adamw_step(_p(p), _p(grad), int(grad.dtype == torch.bfloat16), _p(m), _p(v), _p(p16), p.numel(), step, lr, betas[0], betas[1],
+                            eps, weight_decay, grad_scale, int(max_blocks), _stream()), "nv_adamw_step")
 
 
 def cast_bf16(src: torch.Tensor, ld_dst: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

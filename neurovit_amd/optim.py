@@ -51,7 +51,9 @@ class FusedAdamW(torch.optim.Optimizer):
         self._bound = True
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0):
+    def step(self, closure=None, grad_scale: float = 1.0, reduced_bf16=None):
+        """reduced_bf16: {id(vit): flat bf16 gradient buffer} - when the data-parallel all-reduce ran on bf16 messages the
+        optimizer reads the reduced gradients straight from that buffer (no cast back into the fp32 gradient arena)."""
         if not self._bound:
             self._bind()
         self._steps += 1
@@ -63,6 +65,8 @@ class FusedAdamW(torch.optim.Optimizer):
             if key not in self._state_mv or self._state_mv[key][0].data_ptr() == 0 or self._state_mv[key][0].device != arena.device:
                 self._state_mv[key] = (torch.zeros_like(arena), torch.zeros_like(arena))
             m, v = self._state_mv[key]
+            if reduced_bf16 is not None and key in reduced_bf16:
+                grads = reduced_bf16[key]
             ops.adamw_step(arena, grads, m, v, shadow, self._steps, g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"], grad_scale)
             vit.mark_shadow_fresh()
         if self._rest is not None:

@@ -40,6 +40,8 @@ class GradSync:
         rank receives the same reduced values."""
         assert comm_dtype in (torch.float32, torch.bfloat16)
         self.comm_dtype = comm_dtype
+        self.write_back = True      # bf16 messages: cast the reduced values back into the fp32 gradients (False: the consumer
+                                    # reads `reduced_buffer()` itself, e.g. the fused AdamW - saves a pass over the arena)
         self._comm_buf: Optional[torch.Tensor] = None
         self.pg = process_group
         self.n_buckets = n_buckets
@@ -56,20 +58,29 @@ class GradSync:
     def begin(self):
         self._works = []
 
+    def message_buffer(self, flat_grads: torch.Tensor) -> Optional[torch.Tensor]:
+        """bf16 messages: the arena-shaped bf16 buffer the buckets are sent from (allocated on first use)."""
+        if self.comm_dtype != torch.bfloat16:
+            return None
+        if self._comm_buf is None or self._comm_buf.numel() != flat_grads.numel() or self._comm_buf.device != flat_grads.device:
+            self._comm_buf = torch.empty(flat_grads.numel(), dtype=torch.bfloat16, device=flat_grads.device)
+        return self._comm_buf
+
     def _reduce(self, flat_grads: torch.Tensor, chunk: torch.Tensor, begin: int, end: int):
         if self.comm_dtype == torch.float32:
             self.bytes_reduced += chunk.numel() * 4
             dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg)
             return
-        if self._comm_buf is None or self._comm_buf.numel() != flat_grads.numel() or self._comm_buf.device != flat_grads.device:
-            self._comm_buf = torch.empty(flat_grads.numel(), dtype=torch.bfloat16, device=flat_grads.device)
-        buf = self._comm_buf[begin:end]
+        buf = self.message_buffer(flat_grads)[begin:end]
         buf.copy_(chunk)
         self.bytes_reduced += buf.numel() * 2
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
-        chunk.copy_(buf)
+        if self.write_back:
+            chunk.copy_(buf)
 
-    def bucket_ready(self, flat_grads: torch.Tensor, begin: int, end: int):
+    def bucket_ready(self, flat_grads: torch.Tensor, begin: int, end: int, also_after: Optional["torch.cuda.Stream"] = None):
+        """also_after: a second stream whose enqueued work also writes this range (the engine's auxiliary stream when the
+        backward call did not join it)."""
         if end <= begin or (self.world == 1 and self.after_bucket is None):
             return
         chunk = flat_grads[begin:end]
@@ -79,6 +90,8 @@ class GradSync:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self._comm_stream.wait_event(ev)
+            if also_after is not None:
+                self._comm_stream.wait_stream(also_after)
             with torch.cuda.stream(self._comm_stream):
                 if self.world > 1:
                     self._reduce(flat_grads, chunk, begin, end)                     # enqueued on the side stream
@@ -89,6 +102,10 @@ class GradSync:
                 self._reduce(flat_grads, chunk, begin, end)
             if self.after_bucket is not None:
                 self.after_bucket(begin, end)
+
+    def reduced_buffer(self) -> Optional[torch.Tensor]:
+        """The flat bf16 buffer holding the reduced gradients of every bucket of this step (bf16 messages only)."""
+        return self._comm_buf if self.comm_dtype == torch.bfloat16 else None
 
     def finish(self):
         """Make the current stream wait for every outstanding bucket."""

@@ -49,6 +49,9 @@ class TrainStep:
         if self._arena_trainable and (world > 1 or overlap_optimizer):
             self.sync = GradSync(process_group, n_buckets, after_bucket=self._bucket_update if overlap_optimizer else None,
                                  comm_dtype=grad_comm_dtype)
+            # bf16 messages: the fused AdamW reads the reduced bf16 gradients directly; param.grad then keeps the LOCAL
+            # (pre-reduction) gradients, which nothing downstream of this fused step reads
+            self.sync.write_back = bool(overlap_optimizer) or grad_comm_dtype != torch.bfloat16
         if world > 1:
             arena, _ = vit.flat_parameters()
             broadcast_parameters(arena, process_group)
@@ -87,7 +90,8 @@ class TrainStep:
                 vit.mark_shadow_fresh()                # every range was updated (and its bf16 shadow refreshed) by the buckets
                 self.optimizer.step_rest()
             else:
-                self.optimizer.step(grad_scale=scale)
+                red = self.sync.reduced_buffer() if (pipelined and not self.sync.write_back) else None
+                self.optimizer.step(grad_scale=scale, reduced_bf16=None if red is None else {id(vit): red})
             self._micro = 0
         return loss.detach()
 

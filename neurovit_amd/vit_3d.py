@@ -275,10 +275,14 @@ class ViT(nn.Module):
             return
         from .parallel import bucket_stages
         sync.begin()
+        last_stage = self._cfg.depth + 1
         for first, last in bucket_stages(self._cfg.depth + 2, sync.n_buckets):
-            self._rt.backward(dlogits, self._arena, self._shadow, grads, accumulate=accumulate, stages=(first, last))
+            # intermediate buckets do not stall the main stream on the auxiliary (weight-gradient) stream: the bucket's
+            # all-reduce is ordered after both streams instead
+            self._rt.backward(dlogits, self._arena, self._shadow, grads, accumulate=accumulate, stages=(first, last),
+                              join_aux=(last == last_stage))
             begin, end = self._rt.stage_range(first, last)
-            sync.bucket_ready(grads, begin, end)
+            sync.bucket_ready(grads, begin, end, also_after=None if last == last_stage else self._rt.aux_stream_object(grads.device))
         sync.finish()
 
     def forward(self, video):

@@ -396,6 +396,23 @@ def test_adamw_matches_oracle(ops):
         assert torch.equal(p16.cpu(), bf(p.cpu()))
 
 
+def test_adamw_reads_bf16_gradients(ops):
+    """Data-parallel runs with bf16 gradient messages hand the reduced bf16 buffer straight to the optimizer: the update
+    must equal the fp32-gradient update on the same (bf16-representable) values bit for bit, capped grid included."""
+    n = 8192 + 16
+    p0 = rnd(n, seed=4)
+    g = bf(rnd(n, seed=5) * 0.1)                       # fp32 storage, bf16-representable values
+    outs = []
+    for grad, blocks in ((dev(g), 0), (dev(g).bfloat16(), 0), (dev(g).bfloat16(), 3)):
+        p, m, v = dev(p0.clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        p16 = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        ops.adamw_step(p, grad, m, v, p16, 1, 1e-3, weight_decay=1e-2, grad_scale=0.5, max_blocks=blocks)
+        outs.append((p, m, v, p16))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------ input contract (A0 / F3)
 @pytest.mark.parametrize("dtype,four_d", [("float32", False), ("int16", False), ("float32", True), ("int16", True)])
 def test_zscore_crop_matches_dataset_preprocessing(dtype, four_d):
