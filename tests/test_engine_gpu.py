@@ -189,6 +189,12 @@ def test_large_geometry_properties(eng):
     assert e <= MAXREL and e32 < 1e-2
 
 
+def test_base_config_forward_and_gradients_one_volume(eng):
+    """BASELINE.json configs[1] at full size (128^3, p16, d768, L12, h12), one volume: every forward stage, the logits and EVERY
+    parameter gradient through the same three-way gates as the small configurations (the two CPU oracle passes take ~1 min)."""
+    run_case(eng, "base(B=1)", dict(W.BASE), (31, 32), B=1)
+
+
 def test_inference_mode_matches_training_forward(eng):
     cfgdict = dict(W.MICRO)
     sd = W.make_tensors(W.vit_param_spec(**cfgdict), 1)
