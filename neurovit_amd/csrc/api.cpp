@@ -49,7 +49,9 @@ extern "C" int nv_prof_begin(int kind, double work, void* stream) {
   if (g_used == g_pool.size()) {
     if (g_pool.size() >= 65536) return -1;
     Rec r; r.kind = kind; r.work = work;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+    // timing-only events: without the system-scope fence a default event carries, which would both lengthen the measured interval
+    // and disturb the work that follows (hip_runtime_api.h, hipEventDisableSystemFence)
+    if (hipEventCreateWithFlags(&r.a, hipEventDisableSystemFence) != hipSuccess || hipEventCreateWithFlags(&r.b, hipEventDisableSystemFence) != hipSuccess) return -1;
     g_pool.push_back(r);
   }
   Rec& r = g_pool[g_used];
