@@ -11,6 +11,8 @@ struct AdamArgs {   // every derived constant is formed in double on the host, a
   float decay, one_minus_b1, beta2, one_minus_b2, eps, step_size, bc2_sqrt, grad_scale;
 };
 
+// Streaming kernel: every byte is touched once per step, so loads and stores carry the non-temporal hint (5.8 vs 5.4 TB/s
+// back to back on MI355X); the bf16 shadow is stored normally - the next forward pass reads it.
 // Same operation order as torch's single-tensor AdamW (param.mul_; exp_avg.lerp_; exp_avg_sq.mul_.addcmul_;
 // denom = sqrt(v)/bc2_sqrt + eps; param.addcdiv_) so results track the reference optimizer to fp32 rounding.
 // G16: the gradient is read from a bf16 buffer (the data-parallel all-reduce ran on bf16 messages; reading them here saves the
@@ -21,24 +23,24 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   // grid-stride: a full-size grid runs one iteration per thread; a capped grid (max_blocks) streams the range with a
   // fraction of the chip's wave slots so that it can run beside compute-bound kernels of another stream
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-  f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+  f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p) + i);
   f32x4 gv;
   if constexpr (G16) {
     const bf16x4 g4 = reinterpret_cast<const bf16x4*>(grad)[i];
     gv = f32x4{(float)g4[0], (float)g4[1], (float)g4[2], (float)g4[3]} * a.grad_scale;
   } else {
-    gv = reinterpret_cast<const f32x4*>(grad)[i] * a.grad_scale;
+    gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grad) + i) * a.grad_scale;
   }
-  f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
-  f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+  f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m) + i);
+  f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v) + i);
   pv *= a.decay;
   mv += (gv - mv) * a.one_minus_b1;
   vv = vv * a.beta2 + (gv * a.one_minus_b2) * gv;
 #pragma unroll
   for (int j = 0; j < 4; ++j) pv[j] -= a.step_size * (mv[j] / (sqrtf(vv[j]) / a.bc2_sqrt + a.eps));
-  reinterpret_cast<f32x4*>(p)[i] = pv;
-  reinterpret_cast<f32x4*>(m)[i] = mv;
-  reinterpret_cast<f32x4*>(v)[i] = vv;
+  __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(p) + i);
+  __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m) + i);
+  __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v) + i);
   if (p16) reinterpret_cast<bf16x4*>(p16)[i] = cvt4(pv[0], pv[1], pv[2], pv[3]);
   }
 }
