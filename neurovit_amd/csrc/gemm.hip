@@ -190,7 +190,8 @@ __device__ __forceinline__ void epilogue4(f32x4 v, const GemmArgs& g, int m, int
   } else if constexpr (EPI == EPI_BIAS_F32) {
     *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
   } else if constexpr (EPI == EPI_BIAS_GELU) {
-    *reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n) = cvt4(v[0], v[1], v[2], v[3]);
+    // the pre-activation is only read again in the backward pass, milliseconds later: non-temporal store
+    __builtin_nontemporal_store(cvt4(v[0], v[1], v[2], v[3]), reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n));
     *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
         cvt4(gelu_f(v[0]) * keep[0], gelu_f(v[1]) * keep[1], gelu_f(v[2]) * keep[2], gelu_f(v[3]) * keep[3]);
   } else if constexpr (EPI == EPI_BIAS_RESID) {
