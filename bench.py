@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="volumes per GPU (BASELINE.json configs[1]: 4)")
-    ap.add_argument("--preset", default="base", choices=["tiny", "base", "large"])
+    ap.add_argument("--preset", default="base", choices=["tiny", "base", "large", "reference"])
     ap.add_argument("--buckets", type=int, default=7,
                     help="gradient all-reduce buckets (7 = two transformer layers each: 28 MB bf16 messages, large enough for RCCL to "
                          "run near its bandwidth, and only the last one (layer 0 + embedding) is exposed after backward)")

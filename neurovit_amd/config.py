@@ -42,5 +42,8 @@ def preset(name: str) -> dict:
                      TRAINING_VIT_HEADS=12, TRAINING_VIT_MLP_DIM=3072),
         "large": dict(TRAINING_VIT_INPUT_SIZE=128, TRAINING_VIT_PATCH_SIZE=8, TRAINING_VIT_DIM=1024, TRAINING_VIT_DEPTH=24,
                       TRAINING_VIT_HEADS=16, TRAINING_VIT_MLP_DIM=4096),
+        # what the reference ships: configs/config.yaml:39-40 (90^3, patch 9) with the constants of NeuroEncoder.py:187-190
+        "reference": dict(TRAINING_VIT_INPUT_SIZE=90, TRAINING_VIT_PATCH_SIZE=9, TRAINING_VIT_DIM=1024, TRAINING_VIT_DEPTH=6,
+                          TRAINING_VIT_HEADS=8, TRAINING_VIT_MLP_DIM=2048),
     }
     return dict(presets[name])
