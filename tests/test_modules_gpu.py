@@ -328,3 +328,47 @@ def test_validate_path_eval_no_grad_matches_training_forward(nv):
         b = model(x)
     assert not b.requires_grad and torch.equal(a, b)
     assert b.argmax(dim=1).shape == (3,)
+
+
+def test_neuro4d_full_size_config(nv):
+    """BASELINE.json configs[3]: the 4D NeuroEncoder at full size - ViT3D-base spatial encoder (frozen, loaded from a 3D
+    checkpoint exactly as NeuroEncoder.py:23-36 does) over T = 20 timepoints of a 128^3 volume, TemporalTransformer + mean +
+    ProjectionHead on top, gradient accumulation over 4 samples as config4D.yaml asks.  Size-independent properties: the
+    B*T = 20 encoder forwards equal the encoder applied volume by volume, only the temporal head receives gradients, and
+    accumulating 4 single-sample backward passes equals one backward pass on the batch of 4."""
+    from neurovit_amd import config as nvcfg
+    size = nvcfg.preset("base")
+    S, T = 128, 20
+    base3 = W.neuro_config(S, 16, DEVICE="cuda", **size)
+    with tempfile.TemporaryDirectory() as td:
+        torch.manual_seed(5)
+        m3 = nv.NeuroEncoder(base3)
+        torch.save(m3.state_dict(), os.path.join(td, "best3d.pth"))
+        torch.manual_seed(6)
+        model = nv.NeuroEncoder(W.neuro_config(S, 16, dim=4, DEVICE="cuda", GLOBAL_BASE_PATH=td, BEST_MODEL_PATH="best3d.pth", **size))
+    assert not model.volume_encoder.training and all(not q.requires_grad for q in model.volume_encoder.parameters())
+    for k, v in m3.state_dict().items():                          # strict load of the filtered checkpoint
+        assert torch.equal(v, model.state_dict()[k])
+    model.temporal_transformer.eval()                             # deterministic head (its torch-default dropout 0.1 off)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, S, S, S, T, generator=g).cuda()
+    out = model(x)
+    assert out.shape == (2, 2) and torch.isfinite(out).all()
+    with torch.no_grad():
+        # (.contiguous(): a T-strided view would take the scalar gather path, whose LayerNorm sums are ordered differently)
+        per_volume = torch.stack([model.volume_encoder(x[0, ..., t].contiguous()[None]) for t in (0, 7, 19)])[:, 0]
+        batched = model.volume_encoder(x.permute(0, 4, 1, 2, 3).reshape(2 * T, S, S, S))
+        assert torch.equal(per_volume, batched[[0, 7, 19]])       # batch independence at M = 20 * 513 rows
+    y = torch.tensor([0, 1], device="cuda")
+    crit = torch.nn.CrossEntropyLoss()
+    model.zero_grad()
+    crit(out, y).backward()
+    whole = {k: q.grad.clone() for k, q in model.named_parameters() if q.requires_grad}
+    assert whole and all(k.startswith(("temporal_transformer.", "projection_head.")) for k in whole)
+    assert all(q.grad is None for q in model.volume_encoder.parameters())
+    model.zero_grad()
+    for b in range(2):                                            # accumulation over single samples (sum of per-sample mean losses / 2)
+        (crit(model(x[b:b + 1]), y[b:b + 1]) / 2).backward()
+    for k, q in model.named_parameters():
+        if q.requires_grad:
+            assert torch.allclose(q.grad, whole[k], rtol=1e-4, atol=1e-6), k
