@@ -15,13 +15,16 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# torch is imported by the RANK processes only (see launch_ranks): the launcher parent never loads it, so it cannot
+# create a HIP context that a child would inherit or that an exec would trip over.
+torch = None
 
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 KIND_NAMES = {0: "gemm_ws_kernel NT (forward linears)", 1: "gemm_ws_kernel NN (data gradients)",
@@ -44,12 +47,40 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.0, help="TRAINING_DROPOUT of the timed model (headline: 0, SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (forward-only, fwd+bwd, dropout)")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--same-data", action="store_true", help="rehearsal: every rank gets rank 0's batch (with --grad-comm fp32 the "
                                                               "averaged gradients, hence the loss curve, must equal the 1-GPU run bit for bit)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous rehearsal without a GPU: every rank joins the process group, "
+                                                            "runs the barrier + max-over-ranks timing plumbing around an empty step and rank 0 "
+                                                            "prints the JSON line with value null (tests/test_bench_launcher_cpu.py)")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a torchrun environment: start N rank processes (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set the way `python -m torch.distributed.run` sets them) BEFORE anything in this process touches
+    the GPU, relay rank 0's JSON line, exit with the worst return code.  This parent never imports torch."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    log(f"launcher: starting {a.gpus} ranks (127.0.0.1:{port}); parent has torch loaded: {'torch' in sys.modules}")
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    rc = max((abs(c) for c in rcs), default=0)
+    if rc:
+        log(f"launcher: rank return codes {rcs}")
+    sys.exit(rc)
 
 
 def make_batch(B, S, device, seed):
@@ -61,9 +92,20 @@ def make_batch(B, S, device, seed):
     return x.to(device), y.to(device)
 
 
-def cpu_baseline(model, vcfg, B, S, steps):
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(model, vcfg, B, S, steps, warmup=3):
     """The oracle's restatement of the same train step (eager PyTorch CPU fp32 = the reference's own CPU path,
-    SURVEY.md 8d), timed on this host's cores on a bounded sample: `steps` steps of the same workload."""
+    SURVEY.md 8d), timed on this host's cores on a bounded sample: `warmup` + `steps` steps of the bench workload, plus
+    BASELINE.json configs[0] (ViT3D tiny, batch 2: the reference's own CPU-runnable case) as a second line."""
     from oracle import ref_cpu, train_step
     try:
         nthreads = len(os.sched_getaffinity(0))
@@ -71,30 +113,78 @@ def cpu_baseline(model, vcfg, B, S, steps):
         nthreads = os.cpu_count() or 1
     nthreads = max(1, min(nthreads, 16))       # the GPU box grants a 16-core share per GPU
     torch.set_num_threads(nthreads)
+
+    def run(sd, cfg, batch, n_warm, n_timed, seed):
+        opt = train_step.AdamW(sd, lr=1e-4, weight_decay=1e-2)
+        x, y = make_batch(batch, cfg.image_size, "cpu", seed)
+        video = ref_cpu.fmri_to_video(x)
+        for _ in range(n_warm):
+            train_step.train_step(sd, cfg, opt, video, y)
+        t0 = time.perf_counter()
+        for _ in range(n_timed):
+            train_step.train_step(sd, cfg, opt, video, y)
+        return batch * n_timed / (time.perf_counter() - t0)
+
     sd = {k[len("volume_encoder.vit3d."):]: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
-    cfg = ref_cpu.ViTCfg(**vcfg)
-    opt = train_step.AdamW(sd, lr=1e-4, weight_decay=1e-2)
-    x, y = make_batch(B, S, "cpu", 4242)
-    video = ref_cpu.fmri_to_video(x)
-    train_step.train_step(sd, cfg, opt, video, y)            # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        train_step.train_step(sd, cfg, opt, video, y)
-    dt = time.perf_counter() - t0
-    return {"value": B * steps / dt, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} train steps (fwd+bwd+AdamW, fp32 eager PyTorch CPU) of the same workload, batch {B}, after 1 warm-up step"}
+    value = run(sd, ref_cpu.ViTCfg(**vcfg), B, warmup, steps, 4242)
+    # tiny: random weights of the right shapes (timing only)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import weights as W
+    tcfg = ref_cpu.ViTCfg(**W.TINY)
+    tsd = W.make_tensors(W.vit_param_spec(**W.TINY), 3)
+    tiny = run(tsd, tcfg, 2, warmup, max(steps, 20), 4243)
+    return {"value": value, "unit": "volumes/s", "cores": torch.get_num_threads(), "cpu_model": _cpu_model(), "kind": "port",
+            "sample": f"{steps} train steps (fwd+bwd+AdamW, fp32 eager PyTorch CPU) of the same workload, batch {B}, after {warmup} warm-up steps",
+            "tiny_config": {"value": tiny, "unit": "volumes/s",
+                            "workload": "BASELINE.json configs[0]: ViT3D tiny 64^3 patch 16 dim 192 depth 4 heads 3 mlp 384, batch 2, train step",
+                            "sample": f"{max(steps, 20)} steps after {warmup} warm-up steps"}}
 
 
 def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+def dry_run(a, world, rank):
+    """--dry-run: the N-rank plumbing of the timed region (process group, barrier, max over ranks, one JSON line) with an
+    empty step - runs without a GPU (gloo)."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(a.backend if a.backend != "nccl" else "gloo", rank=rank, world_size=world)
+    n = dist.get_world_size() if world > 1 else 1
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher rehearsal, no GPU work)", "value": None, "unit": "volumes/s", "n_gpus": n,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / max(a.steps, 1) * 1e3,
+                          "config": {"workload": "none", "parallelism": f"dp{n}"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
+    global torch
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a)                                     # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        log(f"--gpus {a.gpus} does not match WORLD_SIZE={world} of the launch environment")
+        sys.exit(2)
+    import torch as _torch
+    torch = _torch
     import torch.distributed as dist
+    if a.dry_run:
+        return dry_run(a, world, rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.same_device:
@@ -104,6 +194,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
+        world = dist.get_world_size()                       # n_gpus of the JSON line = what the process group reports
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -250,10 +341,11 @@ def main():
                 "by_kernel": {KIND_NAMES[k]: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "avg_us": round(v["ms"] * 1e3 / v["launches"], 2),
                                               "launches_per_step": v["launches"] // prof_steps} for k, v in kinds.items()}}
 
-    from oracle.ref_cpu import ViTCfg, flops_forward
+    from neurovit_amd.engine import flops_forward, make_config
     vcfg = dict(image_size=S, image_patch_size=p, frames=S, frame_patch_size=p, num_classes=2, dim=size["TRAINING_VIT_DIM"],
                 depth=size["TRAINING_VIT_DEPTH"], heads=size["TRAINING_VIT_HEADS"], mlp_dim=size["TRAINING_VIT_MLP_DIM"], channels=1, dim_head=64)
-    f_step = 3.0 * flops_forward(ViTCfg(**vcfg))           # fwd + bwd = 3 x fwd algorithmic FLOPs
+    f_fwd = flops_forward(make_config(**vcfg))
+    f_step = 3.0 * f_fwd                                    # fwd + bwd = 3 x fwd algorithmic FLOPs
 
     # BASELINE.json's metric is "fMRI volumes/sec (fwd+bwd) ViT3D 128^3 p16 d768 L12"; the timed step is the reference's whole train
     # step (Trainer.py:65-79), i.e. it also contains the AdamW update - said in the string so the number is not read as fwd+bwd only
@@ -268,7 +360,6 @@ def main():
            "mfma_frac_step": round(value / world * f_step / (PEAK_BF16_TFLOPS * 1e12), 4),
            "loss": round(float(loss), 5), "roofline": roofline}
     if also is not None:
-        f_fwd = flops_forward(ViTCfg(**vcfg))
         also["forward_only_mfma_frac"] = round(also["forward_only_eval_volumes_s"] * f_fwd / (PEAK_BF16_TFLOPS * 1e12), 4)
         out["also"] = also
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -145,7 +145,19 @@ int nv_adamw_step(float* p, const void* grad, int grad_bf16, float* m, float* v,
 /* max_blocks > 0 caps the grid (256-thread workgroups, grid-stride): used when the update of one gradient bucket runs on a
    side stream beside the backward pass, so that it takes a slice of the chip instead of queueing ahead of the GEMMs. */
 int nv_cast_bf16_2d(const float* src, long ld_src, int rows, int cols, void* dst, long ld_dst, void* stream);
+/* out16 (bf16) / out32 (f32), either may be NULL: x[M,N] f32 times the nn.Dropout mask of one site (same mask as the GEMM
+ * epilogues, element index m*N + n; drop_p = 0: plain cast / copy).  Standalone Attention / FeedForward modules (vit_3d.py:23,45). */
+int nv_dropout_apply(const float* x, long ldx, int M, int N, unsigned long drop_seed, float drop_p, void* out16, long ld16,
+                     float* out32, long ld32, void* stream);
 int nv_copy_2d_f32(const float* src, long ld_src, int rows, int cols, float* dst, long ld_dst, int accumulate, void* stream);
+
+/* ---- Grad-CAM reduction (src/models/NeuroEncoder.py:101-116): act bf16 [B,n,d] = output of the last block's attention
+ * LayerNorm, grad f32 [B,n,d] = its gradient -> cam f32 [B, n-1]: relu(mean_d(grad) * sum_d(act)) of the patch tokens
+ * (cls dropped), min-max normalised over the whole map ((x - min) / (max - min + 1e-8)); minmax (optional) [2] = the raw
+ * min / max.  One launch; the percentile threshold and the trilinear upsampling of the G^3 map stay with the caller. */
+long nv_gradcam_workspace_bytes(int B, int n);
+int nv_gradcam_reduce(const void* act, const float* grad, int B, int n, int d, float* cam, float* minmax, void* workspace,
+                      long ws_bytes, void* stream);
 
 /* ---- whole-encoder engine: ViT.forward / its backward as ONE call each (vit_3d.py:112-126)
  * Parameters live in one flat fp32 arena (+ a bf16 shadow with identical element offsets) laid out by
@@ -161,10 +173,13 @@ int nv_vit_param_table(const nv_vit_config* cfg, long* offsets, long* numels, in
 long nv_vit_workspace_bytes(const nv_vit_config* cfg, int B, int training);
 /* byte offset of a named activation inside the workspace (-1 if unknown); layer < 0 for global buffers */
 long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int training, const char* name, int layer);
-/* drop_p / emb_drop_p / drop_seed: nn.Dropout of the blocks (vit_3d.py:21,23,39,45) and of the embedding (:100); both 0
+/* shape5 = {B, C, F, H, W} of `video`: must equal {B, cfg.channels, cfg.frames, cfg.image_size, cfg.image_size} (the reference
+ * fails in einops / the pos_embedding add for any other volume, vit_3d.py:92,118; here a wrong extent would be gathered out of
+ * bounds, so it is rejected with NV_ERR_ARG).
+ * drop_p / emb_drop_p / drop_seed: nn.Dropout of the blocks (vit_3d.py:21,23,39,45) and of the embedding (:100); both 0
  * in eval mode.  backward must be given the forward's values. */
-int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
-                   const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
+int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
+                   const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
                    unsigned long drop_seed, float* logits, void* stream);
 int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                     const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,

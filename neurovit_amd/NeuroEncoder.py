@@ -12,7 +12,6 @@ from __future__ import annotations
 
 import os
 
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -54,19 +53,17 @@ class NeuroEncoder(nn.Module):
 
     def forward(self, fmri):
         if self.config['TRAINING_DIM'] == 3:
-            fmri_encoding = self.volume_encoder(fmri)
-        elif self.config['TRAINING_DIM'] == 4:
-            fmri = fmri.to(self.device).permute(0, 4, 1, 2, 3)   # [B, H, W, D, T] -> [B, T, H, W, D]
-            B, T, H, W, D = fmri.shape
-            volumes = fmri.reshape(B * T, H, W, D)
-            volumes_encoding = self.volume_encoder(volumes)       # [B*T, 2]
-            volumes_encoding = volumes_encoding.reshape(B, T, -1)
-
-            fmri_encodings = self.temporal_transformer(volumes_encoding)
-            fmri_encoding = fmri_encodings.mean(dim=1)
-            fmri_encoding = self.projection_head(fmri_encoding)   # [B, 2]
-
-        return fmri_encoding
+            return self.volume_encoder(fmri)                          # NeuroEncoder.py:50-51
+        if self.config['TRAINING_DIM'] != 4:
+            raise ValueError(f"TRAINING_DIM must be 3 or 4, got {self.config['TRAINING_DIM']!r}")
+        # 4D (NeuroEncoder.py:53-66): every timepoint is an independent volume for the frozen ViT3D, so the time axis is
+        # folded into the batch; the B*T logit pairs then form a length-T sequence for the temporal transformer.
+        series = fmri.to(self.device)
+        n_samples, n_time = series.shape[0], series.shape[-1]
+        as_volumes = series.movedim(-1, 1).flatten(0, 1)              # [B, H, W, D, T] -> [B*T, H, W, D]
+        per_volume = self.volume_encoder(as_volumes).unflatten(0, (n_samples, n_time))
+        pooled = self.temporal_transformer(per_volume).mean(dim=1)
+        return self.projection_head(pooled)
 
     # ---- Grad-CAM contract (NeuroEncoder.py:70-82): activation / gradient of the last block's attention-LN output.
     # The reference copies both to the CPU on EVERY forward / backward (a blocking D2H sync per step); here they stay
@@ -92,7 +89,8 @@ class NeuroEncoder(nn.Module):
         if 'gradients' in self._hook_override:
             return self._hook_override['gradients']
         vit = self.volume_encoder.vit3d
-        if vit._rt._last is None or not vit._rt._last[1]:
+        # the buffer holds the gradient only once a backward pass of the most recent training-mode forward has run
+        if vit._rt._last is None or not vit._rt._last[1] or not vit._rt.backward_done:
             return {}
         return vit.last_attn_norm_grad().detach().cpu()
 
@@ -101,73 +99,52 @@ class NeuroEncoder(nn.Module):
         self._hook_override['gradients'] = value
 
     def get_attention_map(self, x):
-        """NeuroEncoder.py:84-133."""
-        grid_size = self.config['TRAINING_VIT_INPUT_SIZE']
-        patch_size = self.config['TRAINING_VIT_PATCH_SIZE']
-        threshold = self.config['GRADCAM_THRESHOLD']
+        """Grad-CAM of the predicted class on the patch grid, thresholded and upsampled to the volume
+        (same contract as NeuroEncoder.py:84-133: returns (cam[S,S,S] on the CPU, class_idx)).
 
-        output = self.forward(x)
-        class_idx = output.argmax(dim=1)
+        The [B,n,d] activation and gradient never leave the device: `nv_gradcam_reduce` (csrc/gradcam.hip) turns them
+        into the normalised G^3 map in one launch, and only those G^3 floats cross PCIe for the percentile / upsampling."""
+        from . import ops
+        size = self.config['TRAINING_VIT_INPUT_SIZE']
+        cells = size // self.config['TRAINING_VIT_PATCH_SIZE']
+        keep_percent = self.config['GRADCAM_THRESHOLD']
 
-        one_hot = torch.zeros_like(output)
-        one_hot[torch.arange(output.size(0)), class_idx] = 1
+        logits = self.forward(x)
+        predicted = logits.argmax(dim=1)
+        logits.backward(gradient=F.one_hot(predicted, logits.shape[1]).to(logits.dtype), retain_graph=True)
 
-        output.backward(gradient=one_hot, retain_graph=True)
-        gradients = self.gradients
-        activations = self.activations
+        vit = self.volume_encoder.vit3d
+        if 'activations' in self._hook_override or 'gradients' in self._hook_override:      # user-assigned hook tensors win
+            act, grad = self.activations.float(), self.gradients.float()
+            token_map = torch.relu(grad.mean(dim=2) * act.sum(dim=2))[:, 1:]
+            token_map = (token_map - token_map.min()) / (token_map.max() - token_map.min() + 1e-8)
+        else:
+            token_map, _ = ops.gradcam_reduce(vit.last_attn_norm_output_raw(), vit.last_attn_norm_grad_raw())
+            token_map = token_map.cpu()
+        grid = token_map.reshape(1, cells, cells, cells)               # one sample, as in the reference
 
-        weights = gradients.mean(dim=2, keepdim=True)
-        cam = (weights * activations).sum(dim=2)
-        cam = cam[:, 1:]
-
-        cam_size = grid_size // patch_size
-        cam = cam.reshape(1, cam_size, cam_size, cam_size)
-
-        cam = F.relu(cam)
-        cam = (cam - cam.min()) / (cam.max() - cam.min() + 1e-8)
-        threshold_value = np.percentile(cam, 100 - threshold)
-        thresholded_map = np.where(cam >= threshold_value, cam, 0)
-        thresholded_map = torch.from_numpy(thresholded_map).unsqueeze(0)
-
-        cam_3d = F.interpolate(
-            thresholded_map,
-            size=(grid_size, grid_size, grid_size),
-            mode='trilinear',
-            align_corners=False
-        ).squeeze()
-
-        return cam_3d, class_idx
+        # keep the top `keep_percent` % of the cells (linear-interpolated percentile, as numpy.percentile), zero the rest
+        cut = torch.quantile(grid.double().flatten(), 1.0 - keep_percent / 100.0).to(grid.dtype)
+        sparse = torch.where(grid >= cut, grid, torch.zeros_like(grid))
+        volume = F.interpolate(sparse[None], size=(size,) * 3, mode='trilinear', align_corners=False)
+        return volume[0, 0], predicted
 
     def visualize_slice(self, cam_3d, original_volume):
-        """NeuroEncoder.py:135-168."""
-        slice_dim = self.config['GRADCAM_SLICE_DIM']
-        slice_idx = self.config['GRADCAM_SLICE_IDX']
-
+        """One 2-D slice of the volume and of its CAM along GRADCAM_SLICE_DIM at GRADCAM_SLICE_IDX
+        (contract of NeuroEncoder.py:135-168: returns (img, attn), or None after printing why not)."""
+        axis, index = self.config['GRADCAM_SLICE_DIM'], self.config['GRADCAM_SLICE_IDX']
         if cam_3d is None:
             print("Error: No CAM computed")
-            return
-
-        original = original_volume.squeeze()
-        original = original.detach().cpu().numpy()
-
-        if original.ndim != 3 or cam_3d.ndim != 3:
-            print(f"Shape mismatch: original {original.shape}, CAM {cam_3d.shape}")
-            return
-
-        if slice_dim == 0:
-            img = original[slice_idx]
-            attn = cam_3d[slice_idx]
-        elif slice_dim == 1:
-            img = original[:, slice_idx]
-            attn = cam_3d[:, slice_idx]
-        elif slice_dim == 2:
-            img = original[:, :, slice_idx]
-            attn = cam_3d[:, :, slice_idx]
-        else:
-            print(f"Invalid slice dimension: {slice_dim}")
-            return
-
-        return img, attn
+            return None
+        volume = original_volume.squeeze().detach().cpu().numpy()
+        if volume.ndim != 3 or cam_3d.ndim != 3:
+            print(f"Shape mismatch: original {volume.shape}, CAM {cam_3d.shape}")
+            return None
+        if axis not in (0, 1, 2):
+            print(f"Invalid slice dimension: {axis}")
+            return None
+        pick = tuple(index if a == axis else slice(None) for a in range(3))
+        return volume[pick], cam_3d[pick]
 
 
 class ViT3DEncoder(nn.Module):

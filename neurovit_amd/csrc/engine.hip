@@ -187,13 +187,16 @@ extern "C" long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int tra
   return -1;
 }
 
-extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
-                              const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
+extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
+                              const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
                               unsigned long drop_seed, float* logits, void* stream) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, training, W);
-  NV_CHECK_ARG(video && strides5 && params && params16 && workspace && logits, "nv_vit_forward: null pointer");
+  NV_CHECK_ARG(video && shape5 && strides5 && params && params16 && workspace && logits, "nv_vit_forward: null pointer");
+  NV_CHECK_ARG(shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == cfg->image_size,
+               "nv_vit_forward: video is [%ld,%ld,%ld,%ld,%ld], the model was built for [%d,%d,%d,%d,%d] (B, channels, frames, height, width)",
+               shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size);
   NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_forward: workspace too small (%ld < %ld)", ws_bytes, W.total);
   NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params) && nv_aligned16(params16), "nv_vit_forward: alignment");
   char* ws = (char*)workspace;

@@ -92,6 +92,33 @@ extern "C" int nv_cast_bf16_2d(const float* src, long ld_src, int rows, int cols
   return NV_OK;
 }
 
+// out16[m, n] = bf16(x[m, n] * mask(m, n)), out32 likewise (either may be null): the nn.Dropout mask of one site (same
+// counter-based mask the GEMM epilogues apply, element index m*N + n) - used by the standalone Attention / FeedForward
+// modules, whose last Dropout (vit_3d.py:23,45) has no residual epilogue to ride in.
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, long ldx, int M, int N, DropCfg dc, bf16* __restrict__ out16,
+                                                            long ld16, float* __restrict__ out32, long ld32) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per 4 columns
+  const long per_row = N / 4;
+  if (idx >= (long)M * per_row) return;
+  const long m = idx / per_row;
+  const int n = (int)(idx - m * per_row) * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(x + m * ldx + n);
+  if (dc.thresh) v = v * drop_factor4(dc, (unsigned long long)m * N + n);
+  if (out16) *reinterpret_cast<bf16x4*>(out16 + m * ld16 + n) = cvt4(v[0], v[1], v[2], v[3]);
+  if (out32) *reinterpret_cast<f32x4*>(out32 + m * ld32 + n) = v;
+}
+
+extern "C" int nv_dropout_apply(const float* x, long ldx, int M, int N, unsigned long drop_seed, float drop_p, void* out16, long ld16,
+                                float* out32, long ld32, void* stream) {
+  NV_CHECK_ARG(x && M > 0 && N > 0 && (N % 4) == 0 && (ldx % 4) == 0 && nv_aligned16(x), "nv_dropout_apply: N and ldx must be multiples of 4");
+  NV_CHECK_ARG((!out16 || ((ld16 % 4) == 0 && ((uintptr_t)out16 & 7) == 0)) && (!out32 || ((ld32 % 4) == 0 && nv_aligned16(out32))), "nv_dropout_apply: output alignment");
+  const long tot = (long)M * (N / 4);
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, make_drop(drop_seed, drop_p),
+                     (bf16*)out16, ld16, out32, ld32);
+  NV_CHECK_LAUNCH("nv_dropout_apply");
+  return NV_OK;
+}
+
 // loss = mean_b( logsumexp(logits[b]) - logits[b, target[b]] );  dlogits = (softmax - onehot) * grad_scale / B
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const long* __restrict__ target, int B, int C,
                                                       float grad_scale, float* __restrict__ loss, float* __restrict__ dlogits) {
@@ -115,8 +142,12 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     __syncthreads();
     se = (red[0] + red[1]) + (red[2] + red[3]);
     __syncthreads();
-    const int t = (int)target[b];
-    total += (mx + logf(se)) - row[t];
+    // torch raises a device-side assert for a label outside [0, C); here nothing may read out of bounds or abort the
+    // stream: the loss is poisoned with NaN (visible at the first .item()) and the row's gradient is that of no target
+    const long tl = target[b];
+    const bool t_ok = tl >= 0 && tl < (long)C;
+    const int t = t_ok ? (int)tl : -1;
+    total += t_ok ? (mx + logf(se)) - row[t] : __builtin_nanf("");
     if (dlogits)
       for (int c = tid; c < C; c += 256) dlogits[(long)b * C + c] = (expf(row[c] - mx) / se - (c == t ? 1.f : 0.f)) * (grad_scale / (float)B);
   }

@@ -40,6 +40,19 @@ def param_layout(cfg: VitConfig) -> Tuple[List[int], List[int], int]:
     return list(off[:cnt]), list(num[:cnt]), int(total)
 
 
+def flops_forward(cfg: VitConfig) -> float:
+    """Algorithmic FLOPs per volume of one ViT forward (2 x MAC of the patch embedding, the four linears and the two
+    attention products of every block, and the head; LayerNorm / softmax / GELU / bias excluded) - SURVEY.md 8(d).
+    A train step counts 3 x this (backward = 2 x forward)."""
+    g = cfg.image_size // cfg.image_patch_size
+    N = (cfg.frames // cfg.frame_patch_size) * g * g
+    n = N + 1
+    P = cfg.channels * cfg.image_patch_size * cfg.image_patch_size * cfg.frame_patch_size
+    d, inner, m = cfg.dim, cfg.heads * cfg.dim_head, cfg.mlp_dim
+    per_layer = 2 * n * d * 3 * inner + 2 * n * n * inner + 2 * n * n * inner + 2 * n * inner * d + 4 * n * d * m
+    return 2.0 * N * P * d + cfg.depth * per_layer + 2 * d * cfg.num_classes
+
+
 class VitRuntime:
     """Executes ViT forward / backward through the native engine on caller-provided arenas."""
 
@@ -47,6 +60,8 @@ class VitRuntime:
         self.cfg = cfg
         self._ws: Dict[Tuple[int, int, str], torch.Tensor] = {}
         self._last = None   # (B, training, workspace, video) of the most recent forward
+        self.generation = 0          # counts forwards: a backward may only run against the forward that filled the workspace
+        self.backward_done = False   # a backward of the most recent forward has run (gates the Grad-CAM gradient tap)
         self._aux = {}      # device -> auxiliary stream for the weight-gradient GEMMs
         self.use_aux_stream = os.environ.get("NEUROVIT_AUX_STREAM", "1") != "0"
 
@@ -71,13 +86,19 @@ class VitRuntime:
             raise RuntimeError("neurovit_amd: ViT forward needs a CUDA/HIP tensor on MI355X - there is no CPU fallback")
         assert video.dtype == torch.float32 and video.dim() == 5
         B = video.shape[0]
+        want = (self.cfg.channels, self.cfg.frames, self.cfg.image_size, self.cfg.image_size)
+        if tuple(video.shape[1:]) != want:
+            raise ValueError(f"neurovit_amd: video of shape {tuple(video.shape)} does not match the model's "
+                             f"[B, channels, frames, height, width] = [B, {', '.join(map(str, want))}]")
         ws = self.workspace(B, training, video.device)
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
-        check(lib.nv_vit_forward(ctypes.byref(self.cfg), B, video.data_ptr(), ops.strides5(video), params.data_ptr(),
-                                 params16.data_ptr(), ws.data_ptr(), ws.numel(), int(training), float(dropout[0]),
+        check(lib.nv_vit_forward(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
+                                 params.data_ptr(), params16.data_ptr(), ws.data_ptr(), ws.numel(), int(training), float(dropout[0]),
                                  float(dropout[1]), int(dropout[2]), logits.data_ptr(),
                                  torch.cuda.current_stream().cuda_stream), "nv_vit_forward")
         self._last = (B, training, ws, video)
+        self.generation += 1
+        self.backward_done = False
         self._dropout = dropout
         return logits
 

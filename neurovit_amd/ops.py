@@ -30,6 +30,11 @@ def _need_cuda(*ts):
             raise RuntimeError("neurovit_amd ops run on MI355X only (got a CPU tensor); there is no CPU fallback")
 
 
+def shape5(video: torch.Tensor):
+    assert video.dim() == 5
+    return (ctypes.c_long * 5)(*video.shape)
+
+
 def strides5(video: torch.Tensor):
     assert video.dim() == 5
     return (ctypes.c_long * 5)(*video.stride())
@@ -223,3 +228,26 @@ def cast_bf16(src: torch.Tensor, ld_dst: Optional[int] = None, out: Optional[tor
     dst = torch.empty((rows, ld_dst), dtype=torch.bfloat16, device=src.device) if out is None else out
     check(lib.nv_cast_bf16_2d(_p(src), src.stride(0), rows, cols, _p(dst), ld_dst, _stream()), "nv_cast_bf16_2d")
     return dst
+
+
+def gradcam_reduce(act: torch.Tensor, grad: torch.Tensor):
+    """act bf16 [B, n, d], grad f32 [B, n, d] (device) -> (cam f32 [B, n-1] min-max normalised, minmax f32 [2]); one launch."""
+    _need_cuda(act, grad)
+    assert act.dtype == torch.bfloat16 and grad.dtype == torch.float32 and act.shape == grad.shape and act.is_contiguous() and grad.is_contiguous()
+    B, n, d = act.shape
+    cam = torch.empty((B, n - 1), dtype=torch.float32, device=act.device)
+    mm = torch.empty(2, dtype=torch.float32, device=act.device)
+    nb = lib.nv_gradcam_workspace_bytes(B, n)
+    ws = torch.empty(nb, dtype=torch.uint8, device=act.device)
+    check(lib.nv_gradcam_reduce(_p(act), _p(grad), B, n, d, _p(cam), _p(mm), _p(ws), nb, _stream()), "nv_gradcam_reduce")
+    return cam, mm
+
+
+def dropout_apply(x: torch.Tensor, drop_seed: int = 0, drop_p: float = 0.0, want16: bool = True, want32: bool = False):
+    """x f32 [M, N] times the dropout mask of one site -> (bf16 copy or None, f32 copy or None)."""
+    _need_cuda(x)
+    M, N = x.shape
+    o16 = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if want16 else None
+    o32 = torch.empty((M, N), dtype=torch.float32, device=x.device) if want32 else None
+    check(lib.nv_dropout_apply(_p(x), x.stride(0), M, N, drop_seed, drop_p, _p(o16), N, _p(o32), N, _stream()), "nv_dropout_apply")
+    return o16, o32

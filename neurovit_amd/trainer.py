@@ -44,6 +44,7 @@ class TrainStep:
         # additionally runs the fused AdamW of that range on the side stream; measured on one MI355X this LOSES 5 %
         # (740 vs 777 volumes/s: the HBM-bound optimizer slows the concurrent GEMMs more than it hides), so it is off.
         self.sync = None
+        self.last_outputs = None
         self._overlap_opt = bool(overlap_optimizer)
         self._opt_blocks = int(os.environ.get("NEUROVIT_OPT_BLOCKS", "0"))
         if self._arena_trainable and (world > 1 or overlap_optimizer):
@@ -74,6 +75,7 @@ class TrainStep:
         if pipelined and self._overlap_opt:
             self.optimizer.begin_step()
         outputs = model(fmri)
+        self.last_outputs = outputs.detach()           # the Trainer shell counts accuracy from these (3D and 4D alike)
         loss = self.criterion(outputs, labels)
         if self._micro == 0:
             self.optimizer.zero_grad(set_to_none=True)
@@ -82,10 +84,16 @@ class TrainStep:
         if last_micro:
             scale = 1.0 / self.world
             if self.world > 1:
-                for p in model.parameters():           # stragglers outside the arena: tiny, reduce inline
-                    if p.grad is not None and not any(p is q for q in vit._plist):
+                # stragglers, reduced inline: parameters outside the arena (the 10 k-parameter temporal head), and - when the
+                # ViT is only PARTIALLY trainable, so that no bucket pipeline runs over the arena - its trainable parameters
+                arena_synced = self.sync is not None
+                for p in model.parameters():
+                    in_arena = any(p is q for q in vit._plist)
+                    if p.grad is not None and not (in_arena and arena_synced):
                         dist.all_reduce(p.grad, group=self._pg)
                         p.grad.mul_(scale)
+                if not arena_synced:
+                    scale = 1.0                        # already averaged above
             if pipelined and self._overlap_opt:
                 vit.mark_shadow_fresh()                # every range was updated (and its bf16 shadow refreshed) by the buckets
                 self.optimizer.step_rest()
@@ -209,9 +217,8 @@ class Trainer:
             loss = self.step(fMRI, label)
             # the reference syncs twice per step (.item()); here statistics stay on the device until a log line is due
             running_loss = running_loss + loss
-            with torch.no_grad():
-                correct = correct + (self.model.volume_encoder.vit3d._last_logits.argmax(dim=1) == label).sum() \
-                    if self.config['TRAINING_DIM'] == 3 else correct
+            with torch.no_grad():                      # Trainer.py:78-79, from the step's own outputs (no second forward, no sync)
+                correct = correct + (self.step.last_outputs.argmax(dim=1) == label.to(self.step.last_outputs.device)).sum()
             total += label.size(0)
             if i != 0 and i % self.log_interval == 0:
                 avg_loss = round(float(running_loss) / self.log_interval, 5)

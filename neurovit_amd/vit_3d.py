@@ -26,6 +26,92 @@ def pair(t):
     return t if isinstance(t, tuple) else (t, t)
 
 
+def _w16(w: torch.Tensor) -> torch.Tensor:
+    """bf16 MFMA operand copy of an fp32 [out, in] weight (standalone modules; inside a ViT the arena's shadow serves)."""
+    return ops.cast_bf16(w.detach().reshape(w.shape[0], -1).float())
+
+
+def _new_seed(p: float, training: bool) -> int:
+    return int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p > 0) else 0
+
+
+def _as_rows(x: torch.Tensor):
+    if not x.is_cuda:
+        raise RuntimeError("neurovit_amd: module inputs must live on the MI355X (cuda) device - there is no CPU fallback")
+    d = x.shape[-1]
+    return x.reshape(-1, d).float().contiguous(), d
+
+
+class _FeedForwardFn(torch.autograd.Function):
+    """vit_3d.py:16-26 standalone: LayerNorm -> Linear -> exact-erf GELU -> Dropout -> Linear -> Dropout, the same gfx950
+    kernels (and cast points) the fused engine runs, one C-ABI call per stage."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w1, b1, w2, b2, p, seeds):
+        x2, d = _as_rows(x)
+        xn, st = ops.ln_fwd(x2, gamma.detach(), beta.detach())
+        w1_16, w2_16 = _w16(w1), _w16(w2)
+        u = torch.empty((x2.shape[0], w1.shape[0]), dtype=torch.bfloat16, device=x.device)
+        h = ops.gemm(ops.NT, ops.EPI_BIAS_GELU, xn, w1_16, bias=b1.detach(), aux_out=u, drop_seed=seeds[0], drop_p=p if seeds[0] else 0.0)
+        y = ops.gemm(ops.NT, ops.EPI_BIAS_F32, h, w2_16, bias=b2.detach())
+        if seeds[1]:
+            y = ops.dropout_apply(y, seeds[1], p, want16=False, want32=True)[1]
+        ctx.save_for_backward(x2, xn, st, u, h, w1_16, w2_16, gamma.detach())
+        ctx.p, ctx.seeds, ctx.shape = p, seeds, x.shape
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xn, st, u, h, w1_16, w2_16, gamma = ctx.saved_tensors
+        p, seeds = ctx.p, ctx.seeds
+        dy2 = dy.reshape(-1, dy.shape[-1]).float().contiguous()
+        dy16 = ops.dropout_apply(dy2, seeds[1], p if seeds[1] else 0.0)[0]
+        dw2 = ops.gemm(ops.TN, ops.EPI_STORE_F32, dy16, h)
+        db2 = ops.colsum_bf16(dy16)
+        du = ops.gemm(ops.NN, ops.EPI_DGELU, dy16, w2_16, aux_in=u, drop_seed=seeds[0], drop_p=p if seeds[0] else 0.0)
+        dw1 = ops.gemm(ops.TN, ops.EPI_STORE_F32, du, xn)
+        db1 = ops.colsum_bf16(du)
+        dxn = ops.gemm(ops.NN, ops.EPI_STORE_F32, du, w1_16)
+        dx, _, dgamma, dbeta, _ = ops.ln_bwd(dxn, x2, st, gamma, want_g16=False)
+        return dx.view(ctx.shape), dgamma, dbeta, dw1, db1, dw2, db2, None, None
+
+
+class _AttentionFn(torch.autograd.Function):
+    """vit_3d.py:48-60 standalone: LayerNorm -> to_qkv -> softmax(q k^T * scale) (+Dropout) -> attn v -> to_out (+Dropout)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, wqkv, wo, bo, heads, dim_head, p, seeds):
+        if x.dim() != 3:
+            raise ValueError("neurovit_amd.Attention: expected x of shape [batch, tokens, dim]")
+        B, n, _ = x.shape
+        x2, d = _as_rows(x)
+        xn, st = ops.ln_fwd(x2, gamma.detach(), beta.detach())
+        wqkv16, wo16 = _w16(wqkv), _w16(wo)
+        qkv = ops.gemm(ops.NT, ops.EPI_STORE_BF16, xn, wqkv16)
+        ao, lse = ops.attn_fwd(qkv, B, n, heads, dim_head, drop_seed=seeds[0], drop_p=p if seeds[0] else 0.0)
+        y = ops.gemm(ops.NT, ops.EPI_BIAS_F32, ao, wo16, bias=bo.detach())
+        if seeds[1]:
+            y = ops.dropout_apply(y, seeds[1], p, want16=False, want32=True)[1]
+        ctx.save_for_backward(x2, xn, st, qkv, ao, lse, wqkv16, wo16, gamma.detach())
+        ctx.meta = (B, n, heads, dim_head, p, seeds, x.shape)
+        return y.view(B, n, wo.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xn, st, qkv, ao, lse, wqkv16, wo16, gamma = ctx.saved_tensors
+        B, n, heads, dim_head, p, seeds, shape = ctx.meta
+        dy2 = dy.reshape(-1, dy.shape[-1]).float().contiguous()
+        dy16 = ops.dropout_apply(dy2, seeds[1], p if seeds[1] else 0.0)[0]
+        dwo = ops.gemm(ops.TN, ops.EPI_STORE_F32, dy16, ao)
+        dbo = ops.colsum_bf16(dy16)
+        dao = ops.gemm(ops.NN, ops.EPI_STORE_BF16, dy16, wo16)
+        dqkv, _ = ops.attn_bwd(qkv, ao, dao, lse, B, n, heads, dim_head, drop_seed=seeds[0], drop_p=p if seeds[0] else 0.0)
+        dwqkv = ops.gemm(ops.TN, ops.EPI_STORE_F32, dqkv, xn)
+        dxn = ops.gemm(ops.NN, ops.EPI_STORE_F32, dqkv, wqkv16)
+        dx, _, dgamma, dbeta, _ = ops.ln_bwd(dxn, x2, st, gamma, want_g16=False)
+        return dx.view(shape), dgamma, dbeta, dwqkv, dwo, dbo, None, None, None, None
+
+
 class FeedForward(nn.Module):
     """vit_3d.py:14-26 - parameter container (net.0 LayerNorm, net.1 Linear, net.4 Linear)."""
 
@@ -41,8 +127,12 @@ class FeedForward(nn.Module):
         )
 
     def forward(self, x):
-        raise NotImplementedError("neurovit_amd: FeedForward runs fused inside ViT.forward (native engine); "
-                                  "standalone use is not provided on this path")
+        """Standalone use (vit_3d.py:25-26; inside ViT.forward the block runs fused in the native engine): x [..., dim] fp32
+        on the device -> net(x), differentiable, dropout honoured in train mode."""
+        ln, fc1, fc2 = self.net[0], self.net[1], self.net[4]
+        p = float(self.net[3].p)
+        seeds = (_new_seed(p, self.training), _new_seed(p, self.training))
+        return _FeedForwardFn.apply(x, ln.weight, ln.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, p, seeds)
 
 
 class Attention(nn.Module):
@@ -53,6 +143,7 @@ class Attention(nn.Module):
         inner_dim = dim_head * heads
         project_out = not (heads == 1 and dim_head == dim)
         self.heads = heads
+        self.dim_head = dim_head
         self.scale = dim_head ** -0.5
         self.norm = nn.LayerNorm(dim)
         self.attend = nn.Softmax(dim=-1)
@@ -64,8 +155,16 @@ class Attention(nn.Module):
         ) if project_out else nn.Identity()
 
     def forward(self, x):
-        raise NotImplementedError("neurovit_amd: Attention runs fused inside ViT.forward (native engine); "
-                                  "standalone use is not provided on this path")
+        """Standalone use (vit_3d.py:48-60): x [batch, tokens, dim] fp32 on the device -> to_out(attention(norm(x)))."""
+        if isinstance(self.to_out, nn.Identity):
+            raise NotImplementedError("neurovit_amd: heads == 1 with dim_head == dim (no output projection) is not provided")
+        if self.dim_head != 64:
+            raise NotImplementedError("neurovit_amd: the gfx950 attention kernels are written for dim_head = 64 "
+                                      "(the only value the NeuroEncoder path uses: vit_3d.py:78 default)")
+        p = float(self.dropout.p)
+        seeds = (_new_seed(p, self.training), _new_seed(p, self.training))
+        return _AttentionFn.apply(x, self.norm.weight, self.norm.bias, self.to_qkv.weight, self.to_out[0].weight, self.to_out[0].bias,
+                                  self.heads, self.dim_head, p, seeds)
 
 
 class Transformer(nn.Module):
@@ -81,7 +180,11 @@ class Transformer(nn.Module):
             ]))
 
     def forward(self, x):
-        raise NotImplementedError("neurovit_amd: Transformer runs fused inside ViT.forward (native engine)")
+        """Standalone use (vit_3d.py:72-75): pre-norm residual blocks, no final LayerNorm."""
+        for attn, ff in self.layers:
+            x = attn(x) + x
+            x = ff(x) + x
+        return x
 
 
 class PatchRearrange(nn.Module):
@@ -107,11 +210,20 @@ class _ViTFunction(torch.autograd.Function):
         # grad mode is always off inside Function.forward: needs_input_grad tells whether a graph is being built
         need_grad = any(ctx.needs_input_grad[2:])
         ctx.module = module
-        return module._run_forward(video, need_grad)
+        out = module._run_forward(video, need_grad)
+        ctx.generation = module._rt.generation     # the workspace holds THIS forward's activations until the next forward
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
+        rt = ctx.module._rt
+        if ctx.generation != rt.generation:
+            raise RuntimeError(
+                "neurovit_amd.ViT: backward() of a forward pass whose activations have been overwritten - the engine keeps ONE "
+                f"workspace per module and forward #{rt.generation} has run since forward #{ctx.generation}. Call backward() "
+                "before the next forward of the same module (siamese / two-forward losses need one module instance per branch).")
         ctx.module._run_backward(dlogits)
+        rt.backward_done = True
         return (None, None) + (None,) * len(ctx.module._plist)
 
 
@@ -288,6 +400,12 @@ class ViT(nn.Module):
     def forward(self, video):
         if not video.is_cuda:
             raise RuntimeError("neurovit_amd.ViT: input must live on the MI355X (cuda) device - there is no CPU fallback")
+        c = self._cfg
+        if video.dim() != 5 or tuple(video.shape[1:]) != (c.channels, c.frames, c.image_size, c.image_size):
+            # the reference fails here too (einops Rearrange / the pos_embedding add, vit_3d.py:92,118); the gather kernel
+            # takes its extents from the config, so a wrong-sized volume must never reach it
+            raise ValueError(f"neurovit_amd.ViT: expected video [B, {c.channels}, {c.frames}, {c.image_size}, {c.image_size}] "
+                             f"(channels, frames, height, width), got {tuple(video.shape)}")
         if not self._arena_ok():
             self._build_arena()
         if self._arena.device != video.device:
@@ -295,12 +413,22 @@ class ViT(nn.Module):
         return _ViTFunction.apply(self, video.float(), *self._plist)
 
     # activations / gradients of the last block's attention LayerNorm output (Grad-CAM contract, NeuroEncoder.py:70-82)
-    def last_attn_norm_output(self) -> torch.Tensor:
+    def last_attn_norm_output_raw(self) -> torch.Tensor:
+        """bf16 [B, n, d] view into the workspace of the most recent forward (no copy)."""
         B = self._rt._last[0]
         n, d = self.pos_embedding.shape[1], self.pos_embedding.shape[2]
-        return self._rt.tap("xn1", self._cfg.depth - 1, (B, n, d), torch.bfloat16).float()
+        return self._rt.tap("xn1", self._cfg.depth - 1, (B, n, d), torch.bfloat16)
+
+    def last_attn_norm_grad_raw(self) -> torch.Tensor:
+        """fp32 [B, n, d] view into the workspace; valid once a backward of the most recent training forward has run."""
+        if not self._rt.backward_done:
+            raise RuntimeError("neurovit_amd.ViT: no backward pass has run for the most recent forward - the hook gradient is not available")
+        B = self._rt._last[0]
+        n, d = self.pos_embedding.shape[1], self.pos_embedding.shape[2]
+        return self._rt.tap("hookg", -1, (B, n, d), torch.float32)
+
+    def last_attn_norm_output(self) -> torch.Tensor:
+        return self.last_attn_norm_output_raw().float()
 
     def last_attn_norm_grad(self) -> torch.Tensor:
-        B = self._rt._last[0]
-        n, d = self.pos_embedding.shape[1], self.pos_embedding.shape[2]
-        return self._rt.tap("hookg", -1, (B, n, d), torch.float32).clone()
+        return self.last_attn_norm_grad_raw().clone()

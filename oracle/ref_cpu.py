@@ -79,8 +79,16 @@ def strip_prefix(sd: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Te
 
 # --------------------------------------------------------------------------- bf16 emulation helpers
 
-def _r(x: torch.Tensor) -> torch.Tensor:
+# Named forward cast points of the HIP path (tools/cast_point_ablation.py switches them off one at a time to attribute the
+# logits error to its sources): "xp" patch-LN output, "w" weights, "xn1"/"xn2" block LayerNorm outputs, "qkv", "p" softmax
+# probabilities, "ao" attention output, "h" GELU output.  A point listed in CAST_OFF keeps fp32 there.
+CAST_OFF = set()
+
+
+def _r(x: torch.Tensor, point: Optional[str] = None) -> torch.Tensor:
     """Round-to-nearest-even to bf16, keep fp32 storage.  Autograd: identity."""
+    if point is not None and point in CAST_OFF:
+        return x
     return x.to(torch.bfloat16).to(torch.float32)
 
 
@@ -110,7 +118,7 @@ class _GeluEmu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, mask):
         ctx.save_for_backward(_r(u), mask)
-        return _r(F.gelu(u) * mask)
+        return _r(F.gelu(u) * mask, "h")
 
     @staticmethod
     def backward(ctx, dh):
@@ -154,7 +162,7 @@ class _AttnEmu(torch.autograd.Function):
                 p = torch.exp(s - mnew)
                 l = l * alpha + p.sum(dim=-1, keepdim=True)
                 pm = p if mask is None else p * mask[..., k0:k0 + _AttnEmu.TK]      # dropout hits P.V, not the normaliser
-                o = o * alpha + torch.matmul(_r(pm), v[..., k0:k0 + _AttnEmu.TK, :])
+                o = o * alpha + torch.matmul(_r(pm, "p"), v[..., k0:k0 + _AttnEmu.TK, :])
                 m = mnew
             states.append((m, l, o))
         (m0, l0, o0), (m1, l1, o1) = states
@@ -162,7 +170,7 @@ class _AttnEmu(torch.autograd.Function):
         a0, a1 = torch.exp(m0 - m), torch.exp(m1 - m)          # exp(-inf) = 0 when the second half is empty (n <= 64)
         l = l0 * a0 + l1 * a1
         o = o0 * a0 + o1 * a1
-        o = _r(o / l)
+        o = _r(o / l, "ao")
         lse = m + torch.log(l)
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.scale = scale
@@ -271,9 +279,9 @@ def patch_index_map(S: int, p: int) -> np.ndarray:
 
 # --------------------------------------------------------------------------- blocks
 
-def _linear(x, w, b, emulate):
+def _linear(x, w, b, emulate, xpoint=None):
     if emulate:
-        y = _RoundGrad.apply(F.linear(_r(x), _r(w)))
+        y = _RoundGrad.apply(F.linear(_r(x, xpoint), _r(w, "w")))
         return y if b is None else y + b
     return F.linear(x, w, b)
 
@@ -287,8 +295,8 @@ def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None, drop=None):
     if taps is not None:
         taps[pre + "norm.out"] = xn
     if emulate:
-        xn = _r(xn)
-        qkv = _r(_linear(xn, sd[pre + "to_qkv.weight"], None, True))
+        xn = _r(xn, "xn1")
+        qkv = _r(_linear(xn, sd[pre + "to_qkv.weight"], None, True, "xn1"), "qkv")
     else:
         qkv = F.linear(xn, sd[pre + "to_qkv.weight"])
     q, k, v = qkv.chunk(3, dim=-1)
@@ -310,7 +318,7 @@ def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None, drop=None):
         taps[pre + "q"], taps[pre + "k"], taps[pre + "v"] = q, k, v
         taps[pre + "attn.out"] = out
     if (pre + "to_out.0.weight") in sd:            # project_out (vit_3d.py:32,43-46)
-        out = _linear(out, sd[pre + "to_out.0.weight"], sd[pre + "to_out.0.bias"], emulate)
+        out = _linear(out, sd[pre + "to_out.0.weight"], sd[pre + "to_out.0.bias"], emulate, "ao")
         if drop:
             out = out * drop_mask(drop[2], drop[0], (B * n, out.shape[-1])).reshape(out.shape)
     return out
@@ -324,9 +332,9 @@ def feed_forward(sd, pre, x, emulate=False, drop=None):
     omask = drop_mask(drop[2], drop[0], (rows, d)).reshape(x.shape) if drop else None
     xn = F.layer_norm(x, (d,), sd[pre + "net.0.weight"], sd[pre + "net.0.bias"], LN_EPS)
     if emulate:
-        u = _linear(_r(xn), sd[pre + "net.1.weight"], sd[pre + "net.1.bias"], True)
+        u = _linear(_r(xn, "xn2"), sd[pre + "net.1.weight"], sd[pre + "net.1.bias"], True, "xn2")
         h = _GeluEmu.apply(u, torch.ones(()) if hmask is None else hmask)
-        y = _linear(h, sd[pre + "net.4.weight"], sd[pre + "net.4.bias"], True)
+        y = _linear(h, sd[pre + "net.4.weight"], sd[pre + "net.4.bias"], True, "h")
         return y if omask is None else y * omask
     h = F.gelu(F.linear(xn, sd[pre + "net.1.weight"], sd[pre + "net.1.bias"]))
     if hmask is not None:
@@ -340,7 +348,7 @@ def patch_embed(sd, cfg: ViTCfg, video, emulate=False, taps=None, drop=None):
     tok = patchify(video, cfg.image_patch_size, cfg.image_patch_size, cfg.frame_patch_size)
     P, d = cfg.patch_dim, cfg.dim
     a2 = F.layer_norm(tok, (P,), sd["to_patch_embedding.1.weight"], sd["to_patch_embedding.1.bias"], LN_EPS)
-    a3 = _linear(a2, sd["to_patch_embedding.2.weight"], sd["to_patch_embedding.2.bias"], emulate)
+    a3 = _linear(a2, sd["to_patch_embedding.2.weight"], sd["to_patch_embedding.2.bias"], emulate, "xp")
     a4 = F.layer_norm(a3, (d,), sd["to_patch_embedding.3.weight"], sd["to_patch_embedding.3.bias"], LN_EPS)
     B, n, _ = a4.shape
     cls = sd["cls_token"].expand(B, 1, d)

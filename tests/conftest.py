@@ -59,3 +59,11 @@ def rel_l2(a, b):
         return torch.as_tensor(np.asarray(t)).double()
     a, b = cv(a), cv(b)
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def report(line):
+    """Append a measured value to gpurun_out/parity_report.txt (kept under profiles/ per round) when that directory exists."""
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_report.txt"), "a") as f:
+            f.write(line + "\n")

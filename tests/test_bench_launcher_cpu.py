@@ -1,0 +1,37 @@
+"""bench.py --gpus N must start N ranks itself: the parent spawns the rank processes before anything
+touches the GPU and never imports torch; n_gpus of the JSON line is the world size the process group reports."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300, env=e)
+
+
+def test_gpus2_launches_two_ranks_and_parent_stays_torch_free():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "0", "--backend", "gloo", "--dry-run"])
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                        # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3
+    assert "parent has torch loaded: False" in r.stderr
+
+
+def test_gpus_flag_must_match_torchrun_world_size():
+    r = _run(["--gpus", "4", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0
+    assert "does not match WORLD_SIZE" in r.stderr
+
+
+def test_default_is_one_rank_without_launcher():
+    r = _run(["--dry-run", "--steps", "1"])
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    assert "launcher" not in r.stderr

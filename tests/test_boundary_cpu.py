@@ -184,3 +184,29 @@ def test_device_prefetcher_preserves_order_and_passthrough():
         assert b[0] == "sub%d" % i and torch.equal(b[1], batches[i][1]) and torch.equal(b[2], batches[i][2])
     assert list(DevicePrefetcher([], "cpu")) == []
     assert len(list(DevicePrefetcher(batches[:1], "cpu"))) == 1
+
+
+def test_nv_vit_forward_rejects_wrong_extents_before_touching_memory():
+    """the gather kernel takes its extents from the config, so a volume of another size must be refused
+    (the reference raises in einops / the pos_embedding add, vit_3d.py:92,118).  Host-side check: runs without a GPU."""
+    from neurovit_amd import engine
+    from neurovit_amd._cabi import last_error, lib
+    cfg = engine.make_config(**W.MICRO)                      # 32^3 volumes, 1 channel
+    dummy = (ctypes.c_char * 64)()
+    ptr = ctypes.addressof(dummy)
+    for shape in ((2, 1, 16, 16, 16), (2, 3, 32, 32, 32), (2, 1, 33, 51, 33), (3, 1, 32, 32, 32)):
+        shp = (ctypes.c_long * 5)(*shape)
+        strides = (ctypes.c_long * 5)(1, 1, 1, 1, 1)
+        rc = lib.nv_vit_forward(ctypes.byref(cfg), 2, ptr, shp, strides, ptr, ptr, ptr, 1 << 40, 0, 0.0, 0.0, 0, ptr, None)
+        assert rc == -1, shape
+        assert "the model was built for" in last_error()
+
+
+def test_flops_formula_in_package_equals_survey_numbers():
+    """bench.py takes its FLOP count from the package (not from oracle/): SURVEY 8(d) values."""
+    from neurovit_amd import engine
+    from oracle import ref_cpu
+    for cfgdict in (W.MICRO, W.TINY, W.BASE):
+        c = {k: v for k, v in cfgdict.items() if k != "pool"}
+        assert engine.flops_forward(engine.make_config(**c)) == ref_cpu.flops_forward(ref_cpu.ViTCfg(**cfgdict))
+    assert abs(engine.flops_forward(engine.make_config(**{k: v for k, v in W.BASE.items() if k != "pool"})) / 1e9 - 100.07) < 0.01
