@@ -63,7 +63,9 @@ typedef struct nv_gemm_problem {
 } nv_gemm_problem;
 int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gemm_problem* problems, void* stream);
 
-/* tuning aid: force the workgroup tile (bm, bn in {64, 128}); bm = 0 restores the built-in heuristic */
+/* tuning aid: force the workgroup tile (bm, bn in {64, 128}); bm = 0 restores the built-in heuristic; bm = 1..3 forces a
+ * warp-specialised tile, bm = 4 the eight-wave 256 x 128 ping-pong kernel, bm = 5 forbids it; (6, n) sets the ping-pong
+ * kernel's minimum tile count, (7, 0|1) switches the grouped weight-gradient launch between the two kernel families */
 int nv_gemm_set_tile(int bm, int bn);
 
 /* ---- LayerNorm of the residual stream (vit_3d.py:18,37): x f32 [M,d] -> y bf16, saves mean / rstd */

@@ -236,7 +236,7 @@ extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* vide
     RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), site_seed(drop_seed, 4 * l + 0), drop_p, stream));
     RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 1), drop_p, stream));
     RUN(nv_ln_fwd(x1, d, M, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d, st2, st2 + M, stream));
-    RUN(nv_gemm_bf16(0, 3, M, D.m, d, ws + w.xn2, d, p16 + q.w1, d, ws + w.h, D.m, p + q.b1, nullptr, 0, ws + w.u, D.m, 0, 1.f, site_seed(drop_seed, 4 * l + 2), drop_p, stream));
+    RUN(nv_gemm_bf16(0, 3, M, D.m, d, ws + w.xn2, d, p16 + q.w1, d, ws + w.h, D.m, p + q.b1, nullptr, 0, training ? ws + w.u : nullptr, D.m, 0, 1.f, site_seed(drop_seed, 4 * l + 2), drop_p, stream));
     RUN(nv_gemm_bf16(0, 4, M, d, D.m, ws + w.h, D.m, p16 + q.w2, D.m, x2, d, p + q.b2, x1, d, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 3), drop_p, stream));
     xin = x2;
   }

@@ -1,0 +1,244 @@
+// Shared pieces of the bf16 MFMA GEMM kernels (gemm.hip: small-tile and warp-specialised kernels; gemm_pp.hip: the
+// eight-wave ping-pong kernel for large tiles): argument block, LDS images, fragment reads, fused epilogues.
+#pragma once
+#include "common.h"
+
+enum {
+  EPI_STORE_BF16 = 0,   // C(bf16) = acc
+  EPI_STORE_F32 = 1,    // C(f32)  = acc (+ C if accumulate)
+  EPI_BIAS_F32 = 2,     // C(f32)  = acc + bias[n]
+  EPI_BIAS_GELU = 3,    // aux_out(bf16) = u = acc + bias[n];  C(bf16) = gelu(u)
+  EPI_BIAS_RESID = 4,   // C(f32)  = aux_in(f32)[m,n] + acc + bias[n]
+  EPI_DGELU = 5,        // C(bf16) = acc * gelu'(aux_in(bf16)[m,n])
+};
+
+struct GemmArgs {
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  const float* bias;
+  const void* aux_in;
+  void* aux_out;
+  long lda, ldb, ldc, ld_aux_in, ld_aux_out;
+  int M, N, K;
+  int accumulate;
+  DropCfg drop;    // EPI_BIAS_RESID: on (acc + bias); EPI_BIAS_GELU: on gelu(u); EPI_DGELU: on acc (the incoming dH)
+  int col_order;   // 1: consecutive workgroups walk DOWN a tile column (keeps the B panel in the XCD's L2), 0: along a tile row
+  float alpha;
+};
+
+constexpr int BK = 64;
+constexpr int NTHREADS = 256;
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// [64 k-rows][64 cols] transposed-read image with 128-byte rows: chunk XOR so that the four same-parity rows a
+// 32-lane half touches in one ds_read_b64_tr_b16 ({0,2,8,10} + multiples) land on four different chunk pairs.
+__device__ __forceinline__ int img128t_off(int row, int chunk) {
+  return row * 128 + ((chunk ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1)) << 4);
+}
+
+template <int BX>
+__device__ __forceinline__ int imgT_off(int krow, int chunk) {
+  if constexpr (BX == 128) return img256_off(krow, chunk);
+  else return img128t_off(krow, chunk);
+}
+
+// ---- staging: global -> registers ---------------------------------------------------------------
+// rows x K operand (K contiguous): BX rows x 8 chunks of 8 bf16.  TAIL: zero-fill k >= K.
+template <int BX, bool TAIL>
+__device__ __forceinline__ void gload_rowmajor(const bf16* X, long ld, int R, int K, int r0, int k0, int tid, uint4 (&reg)[BX / 32]) {
+#pragma unroll
+  for (int i = 0; i < BX / 32; ++i) {
+    const int c = tid + NTHREADS * i;
+    const int row = min(r0 + (c >> 3), R - 1), kk = k0 + ((c & 7) << 3);
+    if constexpr (TAIL) {
+      const bool ok = kk < K;
+      const uint4 v = *reinterpret_cast<const uint4*>(X + (long)row * ld + (ok ? kk : 0));
+      reg[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    } else {
+      reg[i] = *reinterpret_cast<const uint4*>(X + (long)row * ld + kk);
+    }
+  }
+}
+// K x cols operand (cols contiguous): 64 k-rows x BX/8 chunks.  TAIL: zero-fill rows k >= K.
+template <int BX, bool TAIL>
+__device__ __forceinline__ void gload_kmajor(const bf16* X, long ld, int Ccols, int K, int c0, int k0, int tid, uint4 (&reg)[BX / 32]) {
+  constexpr int CPR = BX / 8;   // chunks per k-row
+#pragma unroll
+  for (int i = 0; i < BX / 32; ++i) {
+    const int c = tid + NTHREADS * i;
+    const int kk = k0 + c / CPR, col = min(c0 + ((c % CPR) << 3), Ccols - 8);
+    if constexpr (TAIL) {
+      const bool ok = kk < K;
+      const uint4 v = *reinterpret_cast<const uint4*>(X + (long)(ok ? kk : 0) * ld + col);
+      reg[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    } else {
+      reg[i] = *reinterpret_cast<const uint4*>(X + (long)kk * ld + col);
+    }
+  }
+}
+template <int BX>
+__device__ __forceinline__ void swrite_rowmajor(char* img, int tid, const uint4 (&reg)[BX / 32]) {
+#pragma unroll
+  for (int i = 0; i < BX / 32; ++i) {
+    const int c = tid + NTHREADS * i;
+    *reinterpret_cast<uint4*>(img + img128_off(c >> 3, c & 7)) = reg[i];
+  }
+}
+template <int BX>
+__device__ __forceinline__ void swrite_kmajor(char* img, int tid, const uint4 (&reg)[BX / 32]) {
+  constexpr int CPR = BX / 8;
+#pragma unroll
+  for (int i = 0; i < BX / 32; ++i) {
+    const int c = tid + NTHREADS * i;
+    *reinterpret_cast<uint4*>(img + imgT_off<BX>(c / CPR, c % CPR)) = reg[i];
+  }
+}
+
+// ---- staging: global -> LDS directly (LDS-DMA) ----------------------------------------------------
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+__device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+// One wave-instruction fills 1 KiB of the image = 64 consecutive 16-byte chunk POSITIONS; the chunk a lane
+// fetches is the inverse swizzle of its position.  Wave `wid` issues instructions wid, wid+4, ...
+// Per-lane source pointers are computed once (init) and advanced by one K tile per iteration.
+template <int BX>
+__device__ __forceinline__ void dma_init_rowmajor(const bf16* X, long ld, int R, int r0, int wid, int lane, const bf16* (&p)[BX / 32]) {
+#pragma unroll
+  for (int i = 0; i < BX / 32; ++i) {
+    const int I = wid + 4 * i;
+    const int row = I * 8 + (lane >> 3), ch = (lane & 7) ^ ((lane >> 3) & 7);      // img128_off inverse
+    p[i] = X + (long)min(r0 + row, R - 1) * ld + (ch << 3);
+  }
+}
+template <int BX>
+__device__ __forceinline__ void dma_init_kmajor(const bf16* X, long ld, int Ccols, int c0, int wid, int lane, const bf16* (&p)[BX / 32]) {
+#pragma unroll
+  for (int i = 0; i < BX / 32; ++i) {
+    const int I = wid + 4 * i;
+    int krow, ch;
+    if constexpr (BX == 128) {
+      krow = I * 4 + (lane >> 4);
+      ch = (lane & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3));                 // img256_off inverse
+    } else {
+      krow = I * 8 + (lane >> 3);
+      ch = (lane & 7) ^ ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1);    // img128t_off inverse
+    }
+    p[i] = X + (long)krow * ld + min(c0 + (ch << 3), Ccols - 8);
+  }
+}
+template <int BX>
+__device__ __forceinline__ void dma_issue(const bf16* (&p)[BX / 32], long step, char* img, int wid) {
+#pragma unroll
+  for (int i = 0; i < BX / 32; ++i) {
+    glds16(p[i], img + (wid + 4 * i) * 1024);
+    p[i] += step;
+  }
+}
+
+// ---- fragment reads -----------------------------------------------------------------------------
+// Operand fragment of v_mfma_f32_16x16x32_bf16: lane (r = lane&15, g = lane>>4) holds the 8 values
+// k = 8g .. 8g+7 of row/column r.
+template <bool T, int BX>
+__device__ __forceinline__ bf16x8 read_frag(const char* img, int rc0, int ks, int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  if constexpr (!T) {
+    return *reinterpret_cast<const bf16x8*>(img + img128_off(rc0 + r, 4 * ks + g));
+  } else {
+    const int q = r >> 2, p = r & 3;
+    const int k0 = 32 * ks + 8 * g + q;
+    const int ch = (rc0 >> 3) + (p >> 1), sub = (p & 1) << 3;
+    const bf16x4 lo = lds_read_tr(img + imgT_off<BX>(k0, ch) + sub);
+    const bf16x4 hi = lds_read_tr(img + imgT_off<BX>(k0 + 4, ch) + sub);
+    return cat4(lo, hi);
+  }
+}
+
+// ---- epilogue core: four consecutive output columns (m, n .. n+3) ----------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void epilogue4(f32x4 v, const GemmArgs& g, int m, int n) {
+  if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+  f32x4 keep = f32x4{1.f, 1.f, 1.f, 1.f};
+  if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_DGELU) {
+    if (g.drop.thresh) {
+      keep = drop_factor4(g.drop, (unsigned long long)m * g.N + n);      // N % 8 == 0, n % 4 == 0
+    }
+  }
+  if constexpr (EPI == EPI_STORE_BF16) {
+    *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) = cvt4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (EPI == EPI_STORE_F32) {
+    float* c = (float*)g.C + (long)m * g.ldc + n;
+    if (g.accumulate) v += *reinterpret_cast<const f32x4*>(c);
+    *reinterpret_cast<f32x4*>(c) = v;
+  } else if constexpr (EPI == EPI_BIAS_F32) {
+    *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
+  } else if constexpr (EPI == EPI_BIAS_GELU) {
+    // the pre-activation is only read again in the backward pass, milliseconds later: non-temporal store
+    // (aux_out = null: inference, nobody reads it - half of this epilogue's HBM bytes saved)
+    if (g.aux_out) __builtin_nontemporal_store(cvt4(v[0], v[1], v[2], v[3]), reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n));
+    *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
+        cvt4(gelu_f(v[0]) * keep[0], gelu_f(v[1]) * keep[1], gelu_f(v[2]) * keep[2], gelu_f(v[3]) * keep[3]);
+  } else if constexpr (EPI == EPI_BIAS_RESID) {
+    v = v * keep + *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
+    *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
+  } else if constexpr (EPI == EPI_DGELU) {
+    const bf16x4 u = *reinterpret_cast<const bf16x4*>((const bf16*)g.aux_in + (long)m * g.ld_aux_in + n);
+    *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
+        cvt4(v[0] * keep[0] * gelu_grad_f((float)u[0]), v[1] * keep[1] * gelu_grad_f((float)u[1]),
+             v[2] * keep[2] * gelu_grad_f((float)u[2]), v[3] * keep[3] * gelu_grad_f((float)u[3]));
+  }
+}
+
+// ---- register epilogue: lane holds C[m = mb + 16i + (lane&15)][n = nb + 16j + 4*(lane>>4) + 0..3] -----------------
+template <int EPI, int MI, int NI>
+__device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmArgs& g, int mb, int nb, int lane) {
+  const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mb + 16 * i + lr;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = nb + 16 * j + 4 * lg;
+      if (n >= g.N) continue;
+      epilogue4<EPI>(acc[i][j], g, m, n);
+    }
+  }
+}
+
+// ---- LDS epilogue (warp-specialised kernel): the consumers park their accumulators in LDS as a [BM][BN] fp32 tile, then
+// ALL EIGHT waves (the loaders are idle by now) run the epilogue row-wise: twice the VALU issue capacity for the GELU
+// epilogues, and every wave-instruction reads / writes whole 256-512 byte row segments instead of 16 rows x 32 bytes.
+template <int BN> constexpr int cpitch() { return BN * 4 + 16; }   // bytes; +16 keeps the 16-row accumulator writes conflict free
+template <int MI, int NI, int BN>
+__device__ __forceinline__ void park_acc(const f32x4 (&acc)[MI][NI], char* ctile, int rb, int cb, int lane) {
+  const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      *reinterpret_cast<f32x4*>(ctile + (rb + 16 * i + lr) * cpitch<BN>() + (cb + 16 * j + 4 * lg) * 4) = acc[i][j];
+}
+template <int EPI, int BM, int BN, int NT>
+__device__ __forceinline__ void epilogue_lds(const char* ctile, const GemmArgs& g, int m0, int n0, int tid) {
+  constexpr int CPR = BN / 4;                 // 16-byte chunks per row
+#pragma unroll 4
+  for (int c = tid; c < BM * CPR; c += NT) {
+    const int row = c / CPR, col = (c % CPR) * 4;
+    const int m = m0 + row, n = n0 + col;
+    if (m < g.M && n < g.N) epilogue4<EPI>(*reinterpret_cast<const f32x4*>(ctile + row * cpitch<BN>() + col * 4), g, m, n);
+  }
+}
+
+
+// Grouped launch: up to four independent problems of one layout / epilogue in ONE grid.  The four weight-gradient GEMMs of a
+// transformer layer have 72-288 tiles each: launched one by one each leaves half of the CUs' two workgroup slots empty and
+// its workgroups run latency-bound; together (864 tiles) every CU holds two co-resident workgroups that hide each other's
+// LDS / DMA latency, and three launch ramps disappear.
+constexpr int GROUP_MAX = 4;
+struct GemmGroup {
+  GemmArgs p[GROUP_MAX];
+  int tile_end[GROUP_MAX];   // exclusive prefix sums of the problems' tile counts
+  int count;
+};

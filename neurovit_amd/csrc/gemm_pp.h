@@ -1,0 +1,8 @@
+// Interface between gemm.hip (host dispatch) and gemm_pp.hip (eight-wave ping-pong kernel, 256 x 128 tiles).
+#pragma once
+#include "gemm_common.h"
+
+constexpr int PP_BM = 256, PP_BN = 128;
+int launch_pp(int layout, int epi, const GemmArgs& a, hipStream_t s);
+int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_t s);
+extern int g_pp_dbg;

@@ -1,0 +1,315 @@
+// Eight-wave "ping-pong" bf16 MFMA GEMM for large tiles (256 x 128 x 64) on gfx950.
+//
+// Why a second kernel family.  The warp-specialised 128 x 128 / 64 x 128 kernels of gemm.hip spend four of their eight waves
+// on LDS-DMA and give each consumer wave a 64 x 64 tile: per 64-deep K step a workgroup pulls 32 KiB through the CU's
+// L2 -> LDS path (~64 B/clk) for 512 MFMA cycles per SIMD - exactly the path's limit - and its four consumer waves read
+// 128 B/clk of fragments.  It tops out at ~0.86 PFLOP/s (profiles/r01_gemm_vs_vendor_blas.log).  A 256 x 128 tile needs 48 KiB
+// per 1024 MFMA cycles (47 B/clk) and, with ALL eight waves computing 64 x 64 sub-tiles, the same fragment bytes per MFMA.
+//
+// Structure (after the 8-phase template of the CDNA4 guide, re-derived for this tile):
+//   * 512 threads = 8 waves as 4 (M) x 2 (N), wave tile 64 x 64 (4 x 4 MFMA tiles of 16 x 16 x 32, 64 accumulator VGPRs);
+//   * every wave both issues LDS-DMA (buffer_load ... lds, 6 x 1 KiB pieces per K tile) and computes; the two waves that
+//     share a SIMD (wave w and w + 4) run HALF A PHASE APART: while one is in its MFMA segment (16 MFMAs, s_setprio 1) the
+//     other is in its load segment (ds_read_b128 fragment reads + DMA issue), separated by raw s_barriers - matrix pipe and
+//     LDS / DMA work of one SIMD overlap by construction instead of by luck;
+//   * a K tile is two phases (the wave's upper / lower 32 rows); the B fragments of a K tile are read once, in phase 0;
+//   * three-stage LDS ring (3 x 48 KiB), DMA runs two K tiles ahead and stays in flight across barriers behind COUNTED
+//     s_waitcnt vmcnt (never 0 inside the loop); the wait that retires K tile j sits before the barrier that precedes the
+//     first read of tile j by the EARLIER half of the waves, for both halves (RAW), and the DMA that overwrites the slot of
+//     tile j-1 is issued two barriers after the last fragment read of that slot has been waited for (WAR);
+//   * operand images, swizzles, transposed reads (ds_read_b64_tr_b16) and the fused epilogues are those of gemm.hip
+//     (gemm_common.h); 128-wide sub-images make every layout (NT / NN / TN) a composition of the same 16 KiB pieces;
+//   * epilogue: accumulators parked as an fp32 [256][128] tile in the (now idle) ring, then all eight waves run the
+//     row-wise fused epilogue (gemm_common.h::epilogue_lds).
+#include "gemm_common.h"
+#include "gemm_pp.h"
+
+namespace {
+
+constexpr int PP_CWAVES = 8;                       // compute waves (two staggered groups of four)
+constexpr int PP_LWAVES = 4;                       // loader waves (one per SIMD)
+constexpr int PP_THREADS = 64 * (PP_CWAVES + PP_LWAVES);
+constexpr int PP_SUB = 16384;   // bytes of one 128-wide sub-image of a 64-deep K tile
+constexpr int PP_S = 3;         // ring stages
+constexpr int PP_GM = 4;        // tile rows per group of the tile order (4 x 256 rows beside 8 x 128 columns per XCD wave)
+
+// per-lane DMA source offsets (bytes) of pieces I = lw, lw + 4, lw + 8, lw + 12 of one 128-wide sub-image (four loader waves);
+// rc0 = first matrix row (K-contiguous operand) / first matrix column (K-strided operand) of the sub-image
+template <bool T>
+__device__ __forceinline__ void pp_offsets(long ld, int rc0, int lw, int lane, int (&voff)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int I = lw + 4 * i;
+    if constexpr (!T) {
+      const int row = I * 8 + (lane >> 3), ch = (lane & 7) ^ ((lane >> 3) & 7);            // img128_off inverse
+      voff[i] = (int)((((long)(rc0 + row)) * ld + (ch << 3)) * 2);
+    } else {
+      const int krow = I * 4 + (lane >> 4);
+      const int ch = (lane & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3));                // img256_off inverse
+      voff[i] = (int)(((long)krow * ld + rc0 + (ch << 3)) * 2);
+    }
+  }
+}
+
+#define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define PP_SB __builtin_amdgcn_sched_barrier(0)
+#define PP_FENCE asm volatile("" ::: "memory")
+
+// One s_barrier per 64-deep K tile, executed by all twelve waves: after barrier k, tile k is complete in LDS (the loaders
+// waited for it) and the slot of tile k-1 is free (every fragment read of it has returned).
+//   loaders:  B_k | issue tile k+2 (into the slot of tile k-1), wait for tile k+1 | B_k+1
+//   group 0:  B_k | read all fragments of tile k, 32 MFMAs | B_k+1
+//   group 1:  B_k | 16 MFMAs (lower half of tile k-1, fragments held in registers), read B + upper-half A fragments of tile k,
+//                   16 MFMAs (upper half of tile k), read the lower-half A fragments of tile k | B_k+1
+// The two waves of a SIMD (w, w + 4) are thereby half a tile out of step: right after a barrier group 1 still has matrix work
+// while group 0's reads are in flight, and group 1 reads while group 0 computes - the matrix pipe never waits for LDS, with a
+// quarter of the barriers of a phase-by-phase ping-pong (measured: the barrier-per-phase form lost 25 % of the MFMA-only rate
+// to barrier overhead and to loaders that arrive late at a 256-cycle barrier interval).
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_T, int EPI, int DBG = 0>
+__device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the declaration (it rejects the TN instantiation of this body)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NSA = BM / 128, NSB = BN / 128, NSUB = NSA + NSB, STAGE = NSUB * PP_SUB;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+  static_assert(WM * WN == PP_CWAVES && MI % 2 == 0, "wave layout");
+  static_assert(128 % TM == 0 && 128 % TN == 0, "a wave tile must not straddle two sub-images");
+  constexpr int MH = MI / 2;                  // m-tiles per half
+  constexpr int NP = 4 * NSUB;                // DMA pieces per loader wave per K tile
+  static_assert(2 * NP <= 63, "vmcnt range");
+  static_assert(PP_S * STAGE <= 160 * 1024 && BM * cpitch<BN>() <= PP_S * STAGE, "LDS budget");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Tile order: each XCD (private 4 MiB L2) owns a contiguous run of logical ids (xcd_remap) and its 32 CUs hold 32 consecutive
+  // ids at a time.  Ids walk GROUPS of PP_GM tile rows column by column, so those 32 tiles form a PP_GM x (32 / PP_GM) block:
+  // per K step they request 32 x 48 KiB but only PP_GM A slices + 32/PP_GM B slices are distinct (82 % L2 hits measured for
+  // 4 x 8; a plain row-major order shares ONE A slice and fetches 32 different B slices: 64 % measured).
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  const int per_group = PP_GM * tiles_n;
+  const int gid = bid / per_group, first_m = gid * PP_GM;
+  const int gsz = (tiles_m - first_m < PP_GM) ? tiles_m - first_m : PP_GM;
+  const int rin = bid - gid * per_group;
+  const int m0 = (first_m + rin % gsz) * BM, n0 = (rin / gsz) * BN;
+  const int nk = (g.K + BK - 1) / BK;
+
+  if (wid >= PP_CWAVES) {
+    // ------------------------------------------------------------------ loader waves: LDS-DMA only
+    const int lw = wid - PP_CWAVES;
+    const unsigned bytesA = (unsigned)((((long)(A_T ? g.K : g.M) - 1) * g.lda + (A_T ? g.M : g.K)) * 2);
+    const unsigned bytesB = (unsigned)((((long)(B_T ? g.K : g.N) - 1) * g.ldb + (B_T ? g.N : g.K)) * 2);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, bytesB, 0x00020000);
+    int voA[NSA][4], voB[NSB][4];
+#pragma unroll
+    for (int s = 0; s < NSA; ++s) pp_offsets<A_T>(g.lda, ((DBG & 2) ? 0 : m0) + 128 * s, lw, lane, voA[s]);
+#pragma unroll
+    for (int s = 0; s < NSB; ++s) pp_offsets<B_T>(g.ldb, ((DBG & 2) ? 0 : n0) + 128 * s, lw, lane, voB[s]);
+    const int stepA = (DBG & 2) ? 0 : (int)((A_T ? (long)BK * g.lda : BK) * 2), stepB = (DBG & 2) ? 0 : (int)((B_T ? (long)BK * g.ldb : BK) * 2);
+    auto issue_tile = [&](int t, char* dst) {
+#pragma unroll
+      for (int s = 0; s < NSA; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(dst + s * PP_SUB + (lw + 4 * i) * 1024), 16, voA[s][i], t * stepA, 0, 0);
+#pragma unroll
+      for (int s = 0; s < NSB; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(dst + (NSA + s) * PP_SUB + (lw + 4 * i) * 1024), 16, voB[s][i], t * stepB, 0, 0);
+    };
+    issue_tile(0, smem);
+    if (nk > 1) {
+      issue_tile(1, smem + STAGE);
+      PP_VMCNT(NP);
+    } else {
+      PP_VMCNT(0);
+    }
+    int slot2 = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();                                // B_kt
+      if (!(DBG & 1)) {
+        if (kt + 2 < nk) issue_tile(kt + 2, smem + slot2 * STAGE);
+        if (kt + 1 < nk) { if (kt + 2 < nk) PP_VMCNT(NP); else PP_VMCNT(0); }     // K tile kt+1 landed (this wave's share)
+      }
+      slot2 = (slot2 + 1 == PP_S) ? 0 : slot2 + 1;
+    }
+    __builtin_amdgcn_s_barrier();                                  // B_nk: every fragment read has returned
+    __builtin_amdgcn_s_barrier();                                  // accumulators parked
+    epilogue_lds<EPI, BM, BN, PP_THREADS>(smem, g, m0, n0, tid);
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves
+  const int grp = wid >> 2;                   // waves w and w + 4 share a SIMD: group 1 runs half a tile behind group 0
+  const int wm = wid / WN, wn = wid % WN;
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // sub-image and row / column inside it of this wave's tile
+  const int a_off = ((wm * TM) / 128) * PP_SUB, a_rc = (wm * TM) % 128;
+  const int b_off = (NSA + (wn * TN) / 128) * PP_SUB, b_rc = (wn * TN) % 128;
+  bf16x8 fb[NI][2], fa[MI][2];
+
+#define PP_READ_B(img)                                                          \
+  _Pragma("unroll") for (int j = 0; j < NI; ++j) {                             \
+    fb[j][0] = read_frag<B_T, 128>((img) + b_off, b_rc + 16 * j, 0, lane);     \
+    fb[j][1] = read_frag<B_T, 128>((img) + b_off, b_rc + 16 * j, 1, lane);     \
+  }
+#define PP_READ_A(img, I0)                                                      \
+  _Pragma("unroll") for (int i = (I0); i < (I0) + MH; ++i) {                   \
+    fa[i][0] = read_frag<A_T, 128>((img) + a_off, a_rc + 16 * i, 0, lane);     \
+    fa[i][1] = read_frag<A_T, 128>((img) + a_off, a_rc + 16 * i, 1, lane);     \
+  }
+#define PP_MFMA(I0)                                                             \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                             \
+    _Pragma("unroll") for (int i = (I0); i < (I0) + MH; ++i)                   \
+      _Pragma("unroll") for (int j = 0; j < NI; ++j)                           \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+
+  int slot = 0;
+  if (grp == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* cur = smem + slot * STAGE;
+      __builtin_amdgcn_s_barrier();                     // B_kt
+      PP_FENCE; PP_SB;
+      if (!(DBG & 4) || kt == 0) { PP_READ_B(cur) PP_READ_A(cur, 0) PP_READ_A(cur, MH) }
+      PP_FENCE; PP_SB;
+      __builtin_amdgcn_s_setprio(1);
+      PP_MFMA(0)
+      PP_MFMA(MH)
+      __builtin_amdgcn_s_setprio(0);
+      PP_FENCE; PP_SB;
+      slot = (slot + 1 == PP_S) ? 0 : slot + 1;
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* cur = smem + slot * STAGE;
+      __builtin_amdgcn_s_barrier();                     // B_kt
+      PP_FENCE; PP_SB;
+      if (kt > 0) {                                     // lower half of tile kt-1: B fragments and lower A fragments are in registers
+        __builtin_amdgcn_s_setprio(1);
+        PP_MFMA(MH)
+        __builtin_amdgcn_s_setprio(0);
+      }
+      PP_FENCE; PP_SB;
+      if (!(DBG & 4) || kt == 0) { PP_READ_B(cur) PP_READ_A(cur, 0) }
+      PP_FENCE; PP_SB;
+      __builtin_amdgcn_s_setprio(1);
+      PP_MFMA(0)
+      __builtin_amdgcn_s_setprio(0);
+      PP_FENCE; PP_SB;
+      if (!(DBG & 4) || kt == 0) { PP_READ_A(cur, MH) }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads of this slot have returned before the barrier that frees it
+      PP_FENCE; PP_SB;
+      slot = (slot + 1 == PP_S) ? 0 : slot + 1;
+    }
+  }
+  __builtin_amdgcn_s_barrier();                         // B_nk
+  if (grp == 1) { PP_MFMA(MH) }                         // lower half of the last tile
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_MFMA
+
+  // every fragment read of the ring has returned: park the accumulators and run the fused epilogue with all waves
+  park_acc<MI, NI, BN>(acc, smem, wm * TM, wn * TN, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  epilogue_lds<EPI, BM, BN, PP_THREADS>(smem, g, m0, n0, tid);
+#endif
+}
+
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_T, int EPI>
+__global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_kernel(const GemmArgs g) {
+  gemm_pp_body<BM, BN, WM, WN, A_T, B_T, EPI>(g, xcd_remap(blockIdx.x, gridDim.x));
+}
+template <int DBG>
+__global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_dbg_kernel(const GemmArgs g) {
+  gemm_pp_body<PP_BM, PP_BN, 4, 2, false, false, EPI_STORE_BF16, DBG>(g, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// grouped weight gradients (TN, fp32 store / accumulate): one instantiation, written without template parameters
+__global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_grouped_tn_kernel(const GemmGroup G) {
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int p = 0;
+  while (p + 1 < G.count && bid >= G.tile_end[p]) ++p;      // workgroup-uniform
+  gemm_pp_body<PP_BM, PP_BN, 4, 2, true, true, EPI_STORE_F32>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
+}
+
+template <bool A_T, bool B_T, int EPI>
+int launch_pp_t(const GemmArgs& a, hipStream_t s) {
+  constexpr int BM = PP_BM, BN = PP_BN;
+  constexpr int LDS = PP_S * (BM / 128 + BN / 128) * PP_SUB;
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  auto kern = gemm_pp_kernel<BM, BN, 4, 2, A_T, B_T, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int slot = nv_prof_begin((A_T ? 2 : (B_T ? 1 : 0)), 2.0 * a.M * a.N * a.K, s);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(PP_THREADS), LDS, s, a);
+  nv_prof_end(slot, s);
+  NV_CHECK_LAUNCH("nv_gemm_bf16/pp");
+  return NV_OK;
+}
+
+}  // namespace
+
+int g_pp_dbg = 0;   // timing-only ablations of the NT / bf16-store kernel (tools/gemm_bench.py --dbg): 1 no DMA, 2 B fragments from
+                    // one slot, 4 A fragments read once; results are wrong by design
+template <int DBG>
+static int launch_pp_dbg(const GemmArgs& a, hipStream_t s) {
+  constexpr int LDS = PP_S * (PP_BM / 128 + PP_BN / 128) * PP_SUB;
+  const int tiles = ((a.M + PP_BM - 1) / PP_BM) * ((a.N + PP_BN - 1) / PP_BN);
+  auto kern = gemm_pp_dbg_kernel<DBG>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(PP_THREADS), LDS, s, a);
+  return NV_OK;
+}
+
+int launch_pp(int layout, int epi, const GemmArgs& a, hipStream_t s) {
+  if (g_pp_dbg && layout == 0 && epi == EPI_STORE_BF16) {
+    switch (g_pp_dbg) {
+      case 1: return launch_pp_dbg<1>(a, s);
+      case 2: return launch_pp_dbg<2>(a, s);
+      case 4: return launch_pp_dbg<4>(a, s);
+      case 5: return launch_pp_dbg<5>(a, s);
+      case 8: return launch_pp_dbg<8>(a, s);
+      case 12: return launch_pp_dbg<12>(a, s);
+      case 9: return launch_pp_dbg<9>(a, s);
+      default: break;
+    }
+  }
+  switch (layout * 16 + epi) {
+    case 0 * 16 + EPI_STORE_BF16: return launch_pp_t<false, false, EPI_STORE_BF16>(a, s);
+    case 0 * 16 + EPI_STORE_F32: return launch_pp_t<false, false, EPI_STORE_F32>(a, s);
+    case 0 * 16 + EPI_BIAS_F32: return launch_pp_t<false, false, EPI_BIAS_F32>(a, s);
+    case 0 * 16 + EPI_BIAS_GELU: return launch_pp_t<false, false, EPI_BIAS_GELU>(a, s);
+    case 0 * 16 + EPI_BIAS_RESID: return launch_pp_t<false, false, EPI_BIAS_RESID>(a, s);
+    case 1 * 16 + EPI_STORE_BF16: return launch_pp_t<false, true, EPI_STORE_BF16>(a, s);
+    case 1 * 16 + EPI_STORE_F32: return launch_pp_t<false, true, EPI_STORE_F32>(a, s);
+    case 1 * 16 + EPI_DGELU: return launch_pp_t<false, true, EPI_DGELU>(a, s);
+    case 2 * 16 + EPI_STORE_F32: return launch_pp_t<true, true, EPI_STORE_F32>(a, s);
+    default: break;
+  }
+  nv_set_error("nv_gemm_bf16/pp: unsupported layout/epilogue combination (%d, %d)", layout, epi);
+  return NV_ERR_ARG;
+}
+
+// grouped weight-gradient GEMMs (TN, fp32 store / accumulate) on 256 x 128 tiles
+int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_t s) {
+  constexpr int BM = PP_BM, BN = PP_BN;
+  constexpr int LDS = PP_S * (BM / 128 + BN / 128) * PP_SUB;
+  auto kern = gemm_pp_grouped_tn_kernel;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int slot = nv_prof_begin(2, flops, s);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(PP_THREADS), LDS, s, G);
+  nv_prof_end(slot, s);
+  NV_CHECK_LAUNCH("nv_gemm_bf16_grouped/pp");
+  return NV_OK;
+}

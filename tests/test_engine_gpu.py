@@ -9,8 +9,12 @@ whole-model gates are therefore three-way, against the exact fp32 oracle (itself
   G3a  err(HIP, fp32) <= 1.5 * err(emulating oracle, fp32) + 2e-4   per stage, logits and per gradient (relative L2):
        the HIP path is as close to the fp32 truth as an exact emulation of its own cast points is;
   G3b  err(HIP, emulating oracle) <= 5e-3 (stages, L2) / 1.5e-2 (gradients, L2): decorrelation bound;
-  G4   logits vs the fp32 golden logits produced by the imported reference: <= 1e-2 max-norm (reported; the
-       reference's own CPU bf16 autocast sits at 0.9-1.3e-2).
+  G4   logits vs the fp32 golden logits produced by the imported reference, max-norm relative, gated PER CASE at 1.5 x the
+       value measured on MI355X (the path is run-to-run deterministic): micro 1.92e-3 -> 3.0e-3, tiny 1.49e-3 -> 2.4e-3,
+       base (one volume) 1.70e-3 -> 2.6e-3.  The north-star "1e-3" is out of reach of bf16 MFMA operands:
+       profiles/r02_cast_point_ablation.txt switches the forward cast points off one at a time in the emulating oracle -
+       no single point dominates, and bf16 WEIGHTS ALONE (every activation kept fp32) already cost 1.0e-3 (micro, tiny),
+       4.6e-3 (d1024 L6) and 5.9e-3 (base); the reference's own CPU bf16 autocast sits at 0.9-1.3e-2.
 Measured errors are appended to gpurun_out/parity_report.txt when that directory exists.
 """
 import os
@@ -111,10 +115,13 @@ def run_case(engine, tag, cfgdict, seeds, B=2, dropout=(0.0, 0.0, 0)):
     return logits, rt, errs
 
 
+G4_GATE = {"micro": 3.0e-3, "tiny": 2.4e-3}     # 1.5 x measured (1.92e-3, 1.49e-3): see the module docstring
+
+
 def check_g4(tag, logits, golden_logits):
     e = rel_err(logits, golden_logits)
     report(f"{tag} G4 logits vs fp32 reference golden: rel {e:.3e}")
-    assert e < 1e-2
+    assert e < G4_GATE[tag.split()[0]], (tag, e)
 
 
 def test_micro_vs_emulating_oracle(eng, golden):
@@ -186,7 +193,46 @@ def test_large_geometry_properties(eng):
         ref32 = ref_cpu.vit_forward(sd, ocfg, ref_cpu.fmri_to_video(fmri[:1]))
     e, e32 = rel_err(a[:1], ref), rel_err(a[:1], ref32)
     report(f"large-geometry(L2) fwd logits vs emulating oracle: rel {e:.3e}; vs fp32 oracle: rel {e32:.3e}")
-    assert e <= MAXREL and e32 < 1e-2
+    assert e <= MAXREL and e32 < 2.6e-3      # 1.5 x the measured 1.68e-3
+
+
+def test_large_full_depth_batch4_properties(eng):
+    """BASELINE.json configs[4] at FULL size (128^3, patch 8 -> n = 4097, dim 1024, depth 24, heads 16, mlp 4096), batch 4,
+    bf16 engine: run-to-run determinism of a training forward + backward, batch independence (volume 3 alone == volume 3
+    in the batch, bit for bit), finite non-zero gradients, and the logits of one volume against the bf16-emulating oracle
+    (three-way against fp32, as everywhere in this file)."""
+    cfgdict = dict(image_size=128, image_patch_size=8, frames=128, frame_patch_size=8, num_classes=2, dim=1024,
+                   depth=24, heads=16, mlp_dim=4096, channels=1, dim_head=64, pool="cls")
+    sd = W.make_tensors(W.vit_param_spec(**cfgdict), 41)
+    cfg, off, num, arena = load_arena(eng, cfgdict, sd)
+    params = arena.cuda()
+    p16 = params.bfloat16()
+    rt = eng.VitRuntime(cfg)
+    fmri = W.make_volume((4, 128, 128, 128), 42)
+    video = ref_cpu.fmri_to_video(fmri.cuda())
+    dlogits = torch.tensor([[1.0, -1.0], [0.5, 0.25], [-0.75, 0.5], [0.1, -0.2]], device="cuda")
+    a = rt.forward(video, params, p16, training=True).clone()
+    grads = torch.zeros_like(params)
+    rt.backward(dlogits, params, p16, grads, False)
+    g1 = grads.clone()
+    b = rt.forward(video, params, p16, training=True).clone()
+    grads.zero_()
+    rt.backward(dlogits, params, p16, grads, False)
+    assert torch.equal(a, b) and torch.equal(g1, grads)
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    nz = [float(g1[o:o + n].abs().max()) > 0 for o, n in zip(off, num)]
+    assert all(nz), "a parameter tensor received no gradient"
+    single = rt.forward(ref_cpu.fmri_to_video(fmri[3:4].cuda()), params, p16, training=False)
+    assert torch.equal(single[0], a[3])
+    with torch.no_grad():
+        ocfg = ref_cpu.ViTCfg(**cfgdict)
+        v0 = ref_cpu.fmri_to_video(fmri[:1])
+        emu = ref_cpu.vit_forward(sd, ocfg, v0, emulate_bf16=True)
+        ref32 = ref_cpu.vit_forward(sd, ocfg, v0)
+    e, e32, ee = rel_err(a[:1], emu), rel_err(a[:1], ref32), rel_err(emu, ref32)
+    report(f"large full depth (L24, B4) logits: vs emulating oracle {e:.3e}; vs fp32 oracle {e32:.3e}; emulation vs fp32 {ee:.3e}")
+    assert e32 <= RATIO * ee + 5e-4, (e32, ee)
+    assert e <= 2e-2           # decorrelation bound after 24 blocks (two numbers)
 
 
 def test_base_config_forward_and_gradients_one_volume(eng):
@@ -233,4 +279,4 @@ def test_base_config_properties(eng):
     e, e32 = rel_err(a[:1], ref), rel_err(a[:1], ref32)
     report(f"base fwd logits vs emulating oracle: rel {e:.3e}; vs fp32 oracle (G4): rel {e32:.3e}")
     assert e <= MAXREL          # two numbers: L2 and max-norm coincide
-    assert e32 < 1e-2
+    assert e32 < 2.6e-3         # G4 at base size: 1.5 x the measured 1.70e-3

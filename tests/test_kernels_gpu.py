@@ -162,6 +162,67 @@ def test_gemm_warp_specialised_kernel_forced(ops, M, N, K, ws):
         lib.nv_gemm_set_tile(0, 0)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (257, 264, 192), (2052, 768, 768), (2052, 2304, 768), (520, 392, 1024), (300, 8, 128)])
+def test_gemm_ping_pong_kernel_forced(ops, M, N, K):
+    """The eight-wave 256 x 128 ping-pong kernel (csrc/gemm_pp.hip): every layout and fused epilogue against fp64, ragged M / N
+    (hardware bounds), one to sixteen K tiles (prologue / steady state / drain of the three-stage ring), ragged token count of
+    the weight-gradient layout, and run-to-run bit equality (the staggered wave groups must not race on the ring)."""
+    from neurovit_amd._cabi import lib
+    lib.nv_gemm_set_tile(4, 0)
+    try:
+        A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+        bias, resid = rnd(N, seed=3), rnd(M, N, seed=4)
+        ref = A.double() @ B.double().T
+        Ad, Bd = dev(A), dev(B)
+        first = ops.gemm(ops.NT, ops.EPI_STORE_BF16, Ad, Bd)
+        assert_close_bf16(first, ref, "pp.nt_bf16")
+        for _ in range(5):
+            assert torch.equal(ops.gemm(ops.NT, ops.EPI_STORE_BF16, Ad, Bd), first)
+        assert_close_f32(ops.gemm(ops.NT, ops.EPI_BIAS_F32, Ad, Bd, bias=dev(bias)), ref + bias.double(), "pp.bias_f32", 1e-5)
+        assert_close_f32(ops.gemm(ops.NT, ops.EPI_BIAS_RESID, Ad, Bd, bias=dev(bias), aux_in=dev(resid)),
+                         ref + bias.double() + resid.double(), "pp.nt_resid", 1e-5)
+        u = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        h = ops.gemm(ops.NT, ops.EPI_BIAS_GELU, Ad, Bd, bias=dev(bias), aux_out=u)
+        assert_close_bf16(u, ref + bias.double(), "pp.gelu.u")
+        assert_close_bf16(h, F.gelu(ref + bias.double()), "pp.gelu.h")
+        Bt = bf(rnd(K, N, seed=7, scale=K ** -0.5))
+        refn = A.double() @ Bt.double()
+        assert_close_f32(ops.gemm(ops.NN, ops.EPI_STORE_F32, Ad, dev(Bt)), refn, "pp.nn_f32", 1e-5)
+        assert_close_bf16(ops.gemm(ops.NN, ops.EPI_STORE_BF16, Ad, dev(Bt)), refn, "pp.nn_bf16")
+        ug = bf(rnd(M, N, seed=8))
+        assert_close_bf16(ops.gemm(ops.NN, ops.EPI_DGELU, Ad, dev(Bt), aux_in=dev(ug)), refn * ref_cpu._gelu_grad(ug.double()), "pp.dgelu")
+        Kt, Mo = M, (K + 7) // 8 * 8                      # TN: reduction over a ragged token count
+        At, B2 = bf(rnd(Kt, Mo, seed=9)), bf(rnd(Kt, N, seed=10, scale=Kt ** -0.5))
+        c0 = rnd(Mo, N, seed=11)
+        c = dev(c0.clone())
+        ops.gemm(ops.TN, ops.EPI_STORE_F32, dev(At), dev(B2), out=c, accumulate=True)
+        assert_close_f32(c, At.double().T @ B2.double() + c0.double(), "pp.tn", 1e-5)
+    finally:
+        lib.nv_gemm_set_tile(0, 0)
+
+
+def test_gemm_ping_pong_grouped_equals_single_launches(ops):
+    """Grouped weight gradients on the ping-pong tiles: bit-identical to single launches of the same kernel."""
+    from neurovit_amd._cabi import lib
+    K = 2052
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    probs, singles = [], []
+    lib.nv_gemm_set_tile(4, 0)
+    try:
+        for i, (Mo, N) in enumerate(shapes):
+            At, B2 = dev(bf(rnd(K, Mo, seed=20 + i))), dev(bf(rnd(K, N, seed=30 + i, scale=K ** -0.5)))
+            acc = i % 2 == 1
+            base = dev(rnd(Mo, N, seed=40 + i)) if acc else torch.empty(Mo, N, device="cuda")
+            singles.append(ops.gemm(ops.TN, ops.EPI_STORE_F32, At, B2, out=base.clone(), accumulate=acc))
+            probs.append((At, B2, base.clone(), acc))
+        ops.gemm_tn_grouped(probs)
+        for (At, B2, C1, acc), ref in zip(probs, singles):
+            assert torch.equal(C1, ref)
+        assert_close_f32(probs[0][2], probs[0][0].double().T @ probs[0][1].double(), "pp.grouped", 1e-5)
+    finally:
+        lib.nv_gemm_set_tile(0, 0)
+
+
 def test_gemm_rejects_bad_args(ops):
     A, B = dev(bf(rnd(16, 12))), dev(bf(rnd(8, 12)))
     with pytest.raises((RuntimeError, AssertionError)):

@@ -2,7 +2,10 @@
 native engine, checked against fixtures produced by the imported reference and against the CPU oracle.
 
 Tolerances: the reference fixtures are fp32; the HIP path uses bf16 MFMA operands, so comparisons against them are
-G4-style (<= 1e-2 max-norm, measured ~1.5e-3; see tests/test_engine_gpu.py for the rationale).  Integer results
+G4-style gates set at 1.5 x the value measured on MI355X (run-to-run deterministic; see tests/test_engine_gpu.py and
+profiles/r02_cast_point_ablation.txt for why bf16 operands cannot reach 1e-3).  The d1024 / depth 6 model at 32^3
+(n = 65 tokens) is the noisiest case: its two logits are small against the residual stream they are read from
+(measured 5.7e-3; the emulating oracle's own spread over seeds at this size is 2.2e-3 .. 9.1e-3).  Integer results
 (argmax class, key lists) are exact.
 """
 import os
@@ -17,7 +20,8 @@ from conftest import rel_err, rel_l2, report
 from oracle import ref_cpu, train_step
 
 pytestmark = pytest.mark.gpu
-G4 = 1e-2
+G4_NEURO32 = 8.6e-3       # logits of the d1024 L6 fixture model: 1.5 x the measured 5.73e-3
+G4_NEURO16 = 9.4e-3       # per-volume logits of the 4D fixture (16^3 volumes): 1.5 x 6.23e-3
 
 
 @pytest.fixture(scope="module")
@@ -46,13 +50,13 @@ def test_neuro3d_forward_hooks_gradcam_vs_reference_fixture(nv, golden):
     logits = model(x)
     assert logits.shape == (2, 2) and logits.dtype == torch.float32 and logits.requires_grad
     report(f"neuro3d (d1024 L6, 32^3) G4 logits vs reference fixture: rel {rel_err(logits, g['logits']):.3e}")
-    assert rel_err(logits, g["logits"]) < G4
+    assert rel_err(logits, g["logits"]) < G4_NEURO32
     loss = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(g["labels"]).long().cuda())     # stock torch criterion works too
     loss.backward()
-    assert abs(loss.item() - g["loss"][0]) < 1e-2
+    assert abs(loss.item() - g["loss"][0]) < 3.5e-3           # measured 2.3e-3
     report(f"neuro3d hook activations vs fixture: rel L2 {rel_l2(model.activations, g['activations']):.3e}; gradients {rel_l2(model.gradients, g['gradients']):.3e}; loss diff {abs(loss.item() - g['loss'][0]):.3e}")
-    assert rel_l2(model.activations, g["activations"]) < G4
-    assert rel_l2(model.gradients, g["gradients"]) < 2e-2
+    assert rel_l2(model.activations, g["activations"]) < 6e-3   # measured 3.9e-3 (a bf16 tensor after five blocks)
+    assert rel_l2(model.gradients, g["gradients"]) < 1.4e-2     # measured 9.2e-3
     assert model.activations.device.type == "cpu" and model.gradients.shape == g["gradients"].shape
     # Grad-CAM (NeuroEncoder.py:84-133) end to end
     model.zero_grad()
@@ -82,11 +86,11 @@ def test_neuro4d_vs_reference_fixture(nv, golden):
     x = W.make_volume((2, S, S, S, T), 23).cuda()
     logits = model(x)
     report(f"neuro4d G4 logits vs reference fixture: rel {rel_err(logits, g['logits']):.3e}")
-    assert rel_err(logits, g["logits"]) < G4
+    assert rel_err(logits, g["logits"]) < 1e-5                  # measured 3e-7: the post-norm temporal head forgets the encoder's noise
     with torch.no_grad():
         vols = x.permute(0, 4, 1, 2, 3).reshape(2 * T, S, S, S)
         report(f"neuro4d per-volume logits vs fixture: rel {rel_err(model.volume_encoder(vols), g['volume_logits']):.3e}")
-        assert rel_err(model.volume_encoder(vols), g["volume_logits"]) < G4
+        assert rel_err(model.volume_encoder(vols), g["volume_logits"]) < G4_NEURO16
     loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(g["labels"]).long().cuda())
     loss.backward()
     assert all(q.grad is None for q in model.volume_encoder.parameters())           # frozen encoder
@@ -427,7 +431,8 @@ def test_standalone_blocks_forward_backward_vs_oracle(nv):
     _three_way(y, y_emu, y_ref)
     _three_way(xg.grad, dx_emu, dx_ref)
     for k, p in tr.named_parameters():
-        _three_way(p.grad, g_emu["transformer." + k], g_ref["transformer." + k], slack=2.0, floor=1e-3)
+        # bias gradients are column sums of bf16(dy) here (exact in the oracle): allow one bf16 rounding of slack
+        _three_way(p.grad, g_emu["transformer." + k], g_ref["transformer." + k], slack=2.0, floor=4e-3 if k.endswith("bias") else 1e-3)
 
     # each module on its own: Attention / FeedForward outputs WITHOUT the residual (vit_3d.py:60,26)
     attn0, ff0 = tr.layers[0]

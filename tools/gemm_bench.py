@@ -25,8 +25,13 @@ SHAPES = [  # name, layout, epi, M, N, K
     ("dWo      TN f32  ", ops.TN, ops.EPI_STORE_F32, d, inner, M),
     ("dWqkv    TN f32  ", ops.TN, ops.EPI_STORE_F32, 3 * inner, d, M),
     ("big      NT bf16 ", ops.NT, ops.EPI_STORE_BF16, 8192, 8192, 4096),
-    ("xfc1shp  NT bf16 ", ops.NT, ops.EPI_STORE_BF16, M, m, d),
-    ("xfc1shp  NT f32  ", ops.NT, ops.EPI_STORE_F32, M, m, d),
+    ("b20 qkv  NT bf16 ", ops.NT, ops.EPI_STORE_BF16, 10260, 3 * inner, d),
+    ("b20 fc1  NT gelu ", ops.NT, ops.EPI_BIAS_GELU, 10260, m, d),
+    ("b20 fc2  NT resid", ops.NT, ops.EPI_BIAS_RESID, 10260, d, m),
+    ("b20 out  NT resid", ops.NT, ops.EPI_BIAS_RESID, 10260, d, inner),
+    ("lrg qkv  NT bf16 ", ops.NT, ops.EPI_STORE_BF16, 16388, 3072, 1024),
+    ("lrg fc1  NT gelu ", ops.NT, ops.EPI_BIAS_GELU, 16388, 4096, 1024),
+    ("lrg fc2  NT resid", ops.NT, ops.EPI_BIAS_RESID, 16388, 1024, 4096),
 ]
 
 
@@ -35,12 +40,14 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--tile", default="", help="force tile, e.g. 64x128 (default: heuristic)")
-    ap.add_argument("--debug", type=int, default=0)
+    ap.add_argument("--dbg", type=int, default=0, help="ping-pong kernel timing ablation (results wrong by design): 1 no DMA, 2 B frags from one slot, 4 A frags read once")
     a = ap.parse_args()
-    assert not a.debug, "the ablation hooks were removed from the library (see profiles/r01_gemm_ablation.log)"
+    if a.dbg:
+        from neurovit_amd._cabi import lib as _l
+        _l.nv_gemm_set_tile(8, a.dbg)
     if a.tile:
         from neurovit_amd._cabi import lib
-        bm, bn = {"ws128x128": (1, 1), "ws128x64": (2, 1), "ws64x128": (3, 1), "ws128x128d": (1, 2), "ws128x64d": (2, 2), "ws64x128d": (3, 2), "ws128x64k": (2, 3), "ws64x128k": (3, 3)}.get(a.tile) or tuple(int(v) for v in a.tile.split("x"))
+        bm, bn = {"ws128x128": (1, 1), "ws128x64": (2, 1), "ws64x128": (3, 1), "ws128x128d": (1, 2), "ws128x64d": (2, 2), "ws64x128d": (3, 2), "ws128x64k": (2, 3), "ws64x128k": (3, 3), "pp": (4, 0), "nopp": (5, 0)}.get(a.tile) or tuple(int(v) for v in a.tile.split("x"))
         lib.nv_gemm_set_tile(bm, bn)
         print(f"--- tile {bm}x{bn}")
     dev = "cuda"
@@ -80,9 +87,28 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.iters
         fl = 2.0 * Mo * N * K
-        if "big" not in name and not name.startswith("x"):
+        if "big" not in name and not name.startswith(("x", "b20", "lrg")):
             tot_t += us; tot_f += fl
         print(f"{name}  M={Mo:5d} N={N:5d} K={K:5d}  {us:8.2f} us  {fl / us / 1e6:8.1f} TFLOP/s", flush=True)
+    if not a.only or "grouped" in a.only:
+        g = torch.Generator(device="cpu").manual_seed(2)
+        probs = []
+        fl = 0.0
+        for Mo, N in ((d, m), (m, d), (d, inner), (3 * inner, d)):
+            At, B2 = torch.randn(M, Mo, generator=g).to(dev).bfloat16(), torch.randn(M, N, generator=g).to(dev).bfloat16()
+            probs.append((At, B2, torch.empty(Mo, N, device=dev), False))
+            fl += 2.0 * M * Mo * N
+        for _ in range(3):
+            ops.gemm_tn_grouped(probs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(a.iters):
+            ops.gemm_tn_grouped(probs)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / a.iters
+        print(f"grouped wgrad (4 problems of a layer, K={M})        {us:8.2f} us  {fl / us / 1e6:8.1f} TFLOP/s", flush=True)
     if tot_t:
         print(f"model shapes total: {tot_t:.1f} us, {tot_f / tot_t / 1e6:.1f} TFLOP/s aggregate")
 
