@@ -43,13 +43,17 @@ int nv_prof_summary(int kind, double* ms, double* work, long* count);
  * layout 2 (TN): C[M,N] = A[K,M]^T . B[K,N]      wgrad    dW = dy^T x
  * epi 0 STORE_BF16, 1 STORE_F32 (+= if accumulate), 2 BIAS_F32, 3 BIAS_GELU (aux_out = pre-activation bf16,
  * C = exact-erf GELU bf16; vit_3d.py:19-20), 4 BIAS_RESID (C f32 = aux_in f32 + acc + bias; vit_3d.py:73-74),
- * 5 DGELU (C bf16 = acc * gelu'(aux_in bf16)).  A, B bf16.
+ * 5 DGELU (C bf16 = acc * gelu'(aux_in bf16)), 6 DGELU_COLSUM (5, and aux_out f32 [ceil(M / tile rows), ld_aux_out] receives the
+ * per-tile column sums of the stored values: the bias gradient of the Linear in front of the GELU without a second pass over C;
+ * sum its rows with nv_reduce_multi; tile rows from nv_gemm_tile_rows).  A, B bf16.
  * Dropout (nn.Dropout of vit_3d.py:21,23,45; drop_p = 0 disables): applied by epilogue 3 to the GELU output, by 4 to
  * (acc + bias) before the residual add, by 5 to acc; element (m, n) is kept iff hash(drop_seed, m*N + n) >= p*2^32 and
  * scaled by 1/(1-p) - the same mask is recomputed wherever the backward pass needs it. */
 int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C,
                  long ldc, const float* bias, const void* aux_in, long ld_aux_in, void* aux_out, long ld_aux_out,
                  int accumulate, float alpha, unsigned long drop_seed, float drop_p, void* stream);
+
+int nv_gemm_tile_rows(int layout, int M, int N, int K, long lda, long ldb);   /* 0: epilogue 6 not available for this shape */
 
 /* Up to four independent problems of one layout / epilogue in ONE launch (provided for layout 2 / TN with epilogue 1: the
  * four weight-gradient GEMMs of a transformer layer, vit_3d.py:19,22,41,44 backward).  Same arithmetic per tile as
@@ -84,6 +88,19 @@ int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float*
  * ordered after this call - lets several reductions share one cross-stream event. */
 #define NV_LN_NO_REDUCE ((void*)(-1L))
 int nv_ln_bwd_reduce(const void* workspace, int M, int d, float* dgamma, float* dbeta, float* dcolsum, int accumulate, void* stream);
+
+/* Several reductions of per-workgroup partial sums in ONE launch: out[s][c] (+)= sum_r partials[r][s * width + c].  A layer's bias
+ * and LayerNorm-affine gradients (nv_ln_bwd with NV_LN_NO_REDUCE: rows = nv_ln_bwd_partial_rows(M), nseg = 3, width = d;
+ * nv_gemm_bf16 epilogue 6: rows = ceil(M / nv_gemm_tile_rows), nseg = 1, width = N) all become final at the same point of the
+ * backward pass; one launch instead of one per tensor.  count <= 8.  Deterministic (fixed summation order). */
+typedef struct nv_reduce_job {
+  const float* partials;
+  int rows, width, nseg;
+  float* out[3];           /* NULL = segment skipped */
+  int accumulate;
+} nv_reduce_job;
+int nv_reduce_multi(const nv_reduce_job* jobs, int count, void* stream);
+int nv_ln_bwd_partial_rows(int M);
 
 /* ---- input contract (src/data/DatasetADNI.py:212-213, DatasetADNI_4D.py:86-87): crop of the raw volume + z-score
  * (x - mean) / (std + eps), population std over the whole cropped sample, statistics accumulated in double.

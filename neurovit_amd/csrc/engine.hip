@@ -71,8 +71,8 @@ struct WS {
   long xp, pst, t, est, x0, xh, hst, wpe16;
   std::vector<LayerW> layer;
   // backward scratch
-  long g, g16, g16b, dxn, hookg, du, dao, dqkv, delta, dt, dt16, dxp, dwpe, red, red2, red3;
-  long alt[7];   // second copy (odd layers) of g16, g16b, du, dqkv, red, red2, red3: the auxiliary stream works one layer behind
+  long g, g16, g16b, dxn, hookg, du, dao, dqkv, delta, dt, dt16, dxp, dwpe, red, red2, red3, cs1;
+  long alt[8];   // second copy (odd layers) of g16, g16b, du, dqkv, red, red2, red3, cs1: the auxiliary stream works one layer behind
   long red_bytes, red2_bytes, total;
 };
 
@@ -107,9 +107,11 @@ void make_ws(const Dims& D, int training, WS& W) {
     W.red3 = add(nv_ln_bwd_workspace_bytes(D.M, D.d));   // LN1-backward partials (reduced on the auxiliary stream one layer late)
     W.alt[0] = add(M * d * 2); W.alt[1] = add(M * d * 2); W.alt[2] = add(M * D.m * 2); W.alt[3] = add(M * 3 * D.inner * 2);
     W.alt[4] = add(W.red_bytes); W.alt[5] = add(W.red2_bytes); W.alt[6] = add(nv_ln_bwd_workspace_bytes(D.M, D.d));
+    const long cs1_bytes = (long)((M + 63) / 64) * D.m * 4;          // per-tile column sums of dU (bias gradient of FC1), <= M / 64 tile rows
+    W.cs1 = add(cs1_bytes); W.alt[7] = add(cs1_bytes);
   } else {
-    W.g = W.g16 = W.dxn = W.hookg = W.du = W.dao = W.dqkv = W.delta = W.dt = W.dt16 = W.dxp = W.dwpe = W.red = W.g16b = W.red2 = W.red3 = -1;
-    for (int i = 0; i < 7; ++i) W.alt[i] = -1;
+    W.g = W.g16 = W.dxn = W.hookg = W.du = W.dao = W.dqkv = W.delta = W.dt = W.dt16 = W.dxp = W.dwpe = W.red = W.g16b = W.red2 = W.red3 = W.cs1 = -1;
+    for (int i = 0; i < 8; ++i) W.alt[i] = -1;
     W.red_bytes = W.red2_bytes = 0;
   }
   W.total = cur;
@@ -275,6 +277,10 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   auto RED = [&](int l) -> void* { return ws + ((l & 1) ? W.alt[4] : W.red); };
   auto RED2 = [&](int l) -> void* { return ws + ((l & 1) ? W.alt[5] : W.red2); };
   auto RED3 = [&](int l) -> void* { return ws + ((l & 1) ? W.alt[6] : W.red3); };
+  auto CS1 = [&](int l) -> float* { return (float*)(ws + ((l & 1) ? W.alt[7] : W.cs1)); };
+  // rows of the GEMM tile that will compute dU: > 0 when the fused column-sum epilogue (bias gradient of FC1) is available
+  const int du_tile_rows = nv_gemm_tile_rows(1, M, D.m, d, d, D.m);
+  const int ln_rows = nv_ln_bwd_partial_rows(M);
   void* red = ws + W.red;
   const float scale = 1.0f / sqrtf((float)D.dh);
   hipStream_t S = (hipStream_t)stream;
@@ -303,7 +309,7 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     const LayerP& qp = T.layer[lp];
     return nv_ln_bwd_reduce(RED3(lp), M, d, gr + qp.n1g, gr + qp.n1b, (lp > 0) ? gr + T.layer[lp - 1].b2 : nullptr, acc, sA);
   };
-  void* const ln_reduce = forked ? NV_LN_NO_REDUCE : nullptr;
+  void* const ln_reduce = NV_LN_NO_REDUCE;   // every parameter-gradient reduction of a layer goes into ONE nv_reduce_multi launch
   for (int l = D.L - 1; l >= 0; --l) {
     const int stage = D.L - l;
     if (stage < first_stage || stage > last_stage) continue;
@@ -318,7 +324,8 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     void* du = DU(l);
     void* dqkv = DQKV(l);
     // ---- FeedForward backward (vit_3d.py:16-26)
-    RUN(nv_gemm_bf16(1, 5, M, D.m, d, g16, d, p16 + q.w2, D.m, du, D.m, nullptr, ws + w.u, D.m, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 2), drop_p, stream));   // dU = (g W2 * mask) * gelu'(u)
+    RUN(nv_gemm_bf16(1, du_tile_rows ? 6 : 5, M, D.m, d, g16, d, p16 + q.w2, D.m, du, D.m, nullptr, ws + w.u, D.m, du_tile_rows ? CS1(l) : nullptr, D.m, 0, 1.f,
+                     site_seed(drop_seed, 4 * l + 2), drop_p, stream));   // dU = (g W2 * mask) * gelu'(u)  [+ per-tile column sums -> db1]
     RUN(nv_gemm_bf16(1, 1, M, d, D.m, du, D.m, p16 + q.w1, d, dxn, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));                        // dxn2 = dU W1
     RUN(nv_ln_bwd(dxn, d, (float*)(ws + w.x1), d, st2, st2 + M, p + q.n2g, M, d, g, g, d, g16b, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, RED(l),
                   W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream, ln_reduce));                                   // g += dLN2 -> g16b
@@ -328,9 +335,21 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
                     (float*)(ws + W.delta), dqkv, 3 * D.inner, site_seed(drop_seed, 4 * l + 0), drop_p, stream));
     // ---- [A] everything of this layer that only finishes parameter gradients
     if (forked) RUN(stream_sync(S, A));                                                                                        // dU, g16b, dqkv (and the LN partials) ready
-    RUN(nv_colsum_bf16(du, D.m, M, D.m, gr + q.b1, acc, RED2(l), W.red2_bytes, sA));                                           // [A] db1
-    if (forked) RUN(nv_ln_bwd_reduce(RED(l), M, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, sA));                               // [A] dLN2 affine, dbo = colsum(g)
-    if (forked && pending_ln1 >= 0) { RUN(reduce_ln1(pending_ln1)); pending_ln1 = -1; }                                        // [A] dLN1 affine + db2 of the layer above
+    {
+      // [A] ONE launch for every small parameter gradient that is final by now: db1 (column sums of dU), dLN2 affine + dbo
+      // (= colsum(g)), and dLN1 affine + db2 of the layer above (whose partials were written after that layer's block ran)
+      nv_reduce_job jobs[3];
+      int nj = 0;
+      if (du_tile_rows) jobs[nj++] = {CS1(l), (M + du_tile_rows - 1) / du_tile_rows, D.m, 1, {gr + q.b1, nullptr, nullptr}, acc};
+      else RUN(nv_colsum_bf16(du, D.m, M, D.m, gr + q.b1, acc, RED2(l), W.red2_bytes, sA));
+      jobs[nj++] = {(const float*)RED(l), ln_rows, d, 3, {gr + q.n2g, gr + q.n2b, gr + q.bo}, acc};
+      if (pending_ln1 >= 0) {
+        const LayerP& qp = T.layer[pending_ln1];
+        jobs[nj++] = {(const float*)RED3(pending_ln1), ln_rows, d, 3, {gr + qp.n1g, gr + qp.n1b, (pending_ln1 > 0) ? gr + T.layer[pending_ln1 - 1].b2 : nullptr}, acc};
+        pending_ln1 = -1;
+      }
+      RUN(nv_reduce_multi(jobs, nj, sA));
+    }
     {
       // the four weight gradients of the layer in ONE grouped launch (864 tiles keep two workgroups resident on every CU;
       // launched one by one their 72-288 tiles leave the CUs half empty and latency bound)
@@ -350,13 +369,13 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     if (forked && prev_done && hipStreamWaitEvent(S, prev_done, 0) != hipSuccess) { nv_set_error("nv_vit_backward: event wait failed"); return NV_ERR_HIP; }
     RUN(nv_ln_bwd(dxn1, d, xin, d, st1, st1 + M, p + q.n1g, M, d, g, g, d, G16(l - 1), d, gr + q.n1g, gr + q.n1b, (l > 0) ? gr + T.layer[l - 1].b2 : nullptr,
                   acc, RED3(l), nv_ln_bwd_workspace_bytes(M, d), site_seed(drop_seed, 4 * (l - 1) + 3), (l > 0) ? drop_p : 0.f, stream, ln_reduce));
-    if (forked) pending_ln1 = l;
+    pending_ln1 = l;
     prev_done = done;
     layers_here = true;
   }
   if (last_stage < D.L + 1) {
+    if (pending_ln1 >= 0) { if (forked) RUN(stream_sync(S, A)); RUN(reduce_ln1(pending_ln1)); }
     if (forked) {
-      if (pending_ln1 >= 0) { RUN(stream_sync(S, A)); RUN(reduce_ln1(pending_ln1)); }
       if (join_aux) {
         RUN(stream_sync(A, S));   // every gradient written on [A] (weight GEMMs, reductions) is ordered before what follows on the main stream
       } else {                    // the caller orders the consumer of this range after BOTH streams; the next call inherits the dependency
@@ -384,7 +403,7 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   // [A] gradient of the patch LayerNorm's affine parameters (needs dxp = dt Wpe and a second gather of the volume);
   // the main stream meanwhile produces the patch-embedding weight gradient
   if (forked) RUN(stream_sync(S, A));                                                                                          // dt16 and layer 0's LN1 partials ready
-  if (forked && pending_ln1 >= 0) RUN(reduce_ln1(pending_ln1));
+  if (pending_ln1 >= 0) RUN(reduce_ln1(pending_ln1));
   RUN(nv_gemm_bf16(1, 1, D.T, D.Ppad, d, ws + W.dt16, d, wpe, D.Ppad, ws + W.dxp, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, sA));              // [A] dxp = dt Wpe
   RUN(nv_patch_ln_bwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
                       cfg->image_patch_size, cfg->frame_patch_size, (float*)(ws + W.dxp), D.Ppad, pst, pst + D.T, gr + T.pe_g, gr + T.pe_b, acc, redA,

@@ -295,7 +295,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, const int bid) {
 #undef WS_MFMA
 #undef SB
 #undef WS_ADVANCE
-  static_assert(BM * cpitch<BN>() <= S * STAGE, "C tile must fit in the ring");
+  static_assert(BM * cpitch<BN>() + colsum_scratch_bytes<BM, BN, WS_THREADS>() <= S * STAGE, "C tile (+ column-sum scratch) must fit in the ring");
   park_acc<MI, NI, BN>(acc, smem, wm * TM, wn * TN, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw barrier carries no wait: the parked tile must be written first
   __builtin_amdgcn_s_barrier();                         // barrier E
@@ -365,17 +365,23 @@ static int launch_ws(const GemmArgs& a, hipStream_t s) {
   return NV_OK;
 }
 
-template <bool A_T, bool B_T, int EPI>
-static int launch(const GemmArgs& a, hipStream_t s) {
-  // warp-specialised kernel: needs whole K tiles for K-contiguous operands (buffer bounds zero-fill a ragged K only
-  // when K is the row index, i.e. for "T" operands) and 31-bit byte offsets; tiny problems keep the small-tile kernel.
-  const bool k_ok = (a.K % BK == 0) || (A_T && B_T);
-  const long rowsA = A_T ? a.K : a.M, rowsB = B_T ? a.K : a.N;
-  const bool fits = rowsA * a.lda < (1L << 30) && rowsB * a.ldb < (1L << 30);
-  const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  const long tpp = (long)((a.M + PP_BM - 1) / PP_BM) * ((a.N + PP_BN - 1) / PP_BN);
-  if (k_ok && fits && (g_tile_override == 4 || (g_tile_override == 0 && tpp >= g_pp_min_tiles)))
-    return launch_pp(A_T ? 2 : (B_T ? 1 : 0), EPI, a, s);
+// Kernel choice for one problem (shared by the launcher and by nv_gemm_tile_rows, which tells the caller how many partial rows a
+// fused column-sum epilogue produces).  family: 0 small-tile register-epilogue kernel, 1 warp-specialised (ws = 1: 128x128,
+// 2: 128x64, 3: 64x128; ring as below), 2 eight-wave ping-pong 256 x 128.
+struct GemmPlan { int family, ws, ring, sel, bm; };
+static GemmPlan plan_gemm(bool A_T, bool B_T, int M, int N, int K, long lda, long ldb) {
+  GemmPlan p{0, 0, 0, 0, 0};
+  // large-tile kernels: need whole K tiles for K-contiguous operands (buffer bounds zero-fill a ragged K only when K is the row
+  // index, i.e. for "T" operands) and 31-bit byte offsets; tiny problems keep the small-tile kernel.
+  const bool k_ok = (K % BK == 0) || (A_T && B_T);
+  const long rowsA = A_T ? K : M, rowsB = B_T ? K : N;
+  const bool fits = rowsA * lda < (1L << 30) && rowsB * ldb < (1L << 30);
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const long tpp = (long)((M + PP_BM - 1) / PP_BM) * ((N + PP_BN - 1) / PP_BN);
+  if (k_ok && fits && (g_tile_override == 4 || (g_tile_override == 0 && tpp >= g_pp_min_tiles))) {
+    p.family = 2; p.bm = PP_BM;
+    return p;
+  }
   if (k_ok && fits && g_tile_override < 1000) {
     int ws = (g_tile_override >= 4) ? 0 : g_tile_override;                 // 1: 128x128, 2: 128x64, 3: 64x128 (forced); 0: heuristic
     // measured on the ViT3D-base shapes (M = 2052): the 64x128 tile wins or ties everywhere (two workgroups per CU, so
@@ -384,30 +390,56 @@ static int launch(const GemmArgs& a, hipStream_t s) {
     // ring geometry: 1 = 3 stages x 64-deep, 2 = deep ring (6 / 4 stages x 64), 3 = 3 stages x 128-deep (one barrier per 128 of K;
     // needs whole 128-deep steps unless both operands are K-strided, where the buffer bounds zero-fill)
     int ring = g_ring_override;
-    const bool k128_ok = ((a.K % (2 * BK)) == 0) || (A_T && B_T);
+    const bool k128_ok = ((K % (2 * BK)) == 0) || (A_T && B_T);
     // measured (profiles/r01_gemm_shapes_tiles.log): 128-deep steps win when the grid leaves one workgroup per CU anyway and
     // K is long; otherwise two co-resident 3 x 64 workgroups per CU (72 KiB each) overlap each other's epilogue and waits
-    const long t64x128 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
-    if (ring == 0) ring = (k128_ok && t64x128 <= 256 && a.K >= 1536) ? 3 : 1;
+    const long t64x128 = (long)((M + 63) / 64) * ((N + 127) / 128);
+    if (ring == 0) ring = (k128_ok && t64x128 <= 256 && K >= 1536) ? 3 : 1;
     if (ring == 3 && !k128_ok) ring = 1;
-    if (ws == 1) return ring == 2 ? launch_ws<128, 128, 4, 1, A_T, B_T, EPI>(a, s) : launch_ws<128, 128, 3, 1, A_T, B_T, EPI>(a, s);
-    if (ws == 2) return ring == 3 ? launch_ws<128, 64, 3, 2, A_T, B_T, EPI>(a, s) : (ring == 2 ? launch_ws<128, 64, 6, 1, A_T, B_T, EPI>(a, s) : launch_ws<128, 64, 3, 1, A_T, B_T, EPI>(a, s));
-    if (ws == 3) return ring == 3 ? launch_ws<64, 128, 3, 2, A_T, B_T, EPI>(a, s) : (ring == 2 ? launch_ws<64, 128, 6, 1, A_T, B_T, EPI>(a, s) : launch_ws<64, 128, 3, 1, A_T, B_T, EPI>(a, s));
+    if (ws >= 1 && ws <= 3) {
+      p.family = 1; p.ws = ws; p.ring = ring; p.bm = (ws == 3) ? 64 : 128;
+      return p;
+    }
   }
-  int sel = g_tile_override >= 1000 ? g_tile_override : 0;
-  if (!sel) {
+  p.sel = g_tile_override >= 1000 ? g_tile_override : 0;
+  if (!p.sel) {
     // enough workgroups to give every one of the 256 CUs several co-resident blocks; prefer the larger tile
     // (less LDS traffic per MFMA) when the problem is big enough.
-    const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    const long t64x128 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
-    sel = (t128 >= 1024) ? 128128 : (t64x128 >= 768 ? 64128 : 64064);
+    const long t64x128 = (long)((M + 63) / 64) * ((N + 127) / 128);
+    p.sel = (t128 >= 1024) ? 128128 : (t64x128 >= 768 ? 64128 : 64064);
   }
-  switch (sel) {
-    case 128128: return launch_tile<128, 128, A_T, B_T, EPI>(a, s);
-    case 64128: return launch_tile<64, 128, A_T, B_T, EPI>(a, s);
-    case 128064: return launch_tile<128, 64, A_T, B_T, EPI>(a, s);
-    default: return launch_tile<64, 64, A_T, B_T, EPI>(a, s);
+  return p;
+}
+
+template <bool A_T, bool B_T, int EPI>
+static int launch(const GemmArgs& a, hipStream_t s) {
+  const GemmPlan p = plan_gemm(A_T, B_T, a.M, a.N, a.K, a.lda, a.ldb);
+  if (p.family == 2) return launch_pp(A_T ? 2 : (B_T ? 1 : 0), EPI, a, s);
+  if (p.family == 1) {
+    const int ws = p.ws, ring = p.ring;
+    if (ws == 1) return ring == 2 ? launch_ws<128, 128, 4, 1, A_T, B_T, EPI>(a, s) : launch_ws<128, 128, 3, 1, A_T, B_T, EPI>(a, s);
+    if (ws == 2) return ring == 3 ? launch_ws<128, 64, 3, 2, A_T, B_T, EPI>(a, s) : (ring == 2 ? launch_ws<128, 64, 6, 1, A_T, B_T, EPI>(a, s) : launch_ws<128, 64, 3, 1, A_T, B_T, EPI>(a, s));
+    return ring == 3 ? launch_ws<64, 128, 3, 2, A_T, B_T, EPI>(a, s) : (ring == 2 ? launch_ws<64, 128, 6, 1, A_T, B_T, EPI>(a, s) : launch_ws<64, 128, 3, 1, A_T, B_T, EPI>(a, s));
   }
+  if constexpr (EPI == EPI_DGELU_COLSUM) {
+    nv_set_error("nv_gemm_bf16: the fused column-sum epilogue needs a large-tile kernel for this shape (ask nv_gemm_tile_rows first)");
+    return NV_ERR_ARG;
+  } else {
+    switch (p.sel) {
+      case 128128: return launch_tile<128, 128, A_T, B_T, EPI>(a, s);
+      case 64128: return launch_tile<64, 128, A_T, B_T, EPI>(a, s);
+      case 128064: return launch_tile<128, 64, A_T, B_T, EPI>(a, s);
+      default: return launch_tile<64, 64, A_T, B_T, EPI>(a, s);
+    }
+  }
+}
+
+// Rows of the workgroup tile nv_gemm_bf16 will use for this problem when asked for the fused column-sum epilogue (6): the
+// epilogue writes ceil(M / rows) partial rows.  0 = that epilogue is not available for the shape (use epilogue 5 + nv_colsum_bf16).
+extern "C" int nv_gemm_tile_rows(int layout, int M, int N, int K, long lda, long ldb) {
+  if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0) return 0;
+  const GemmPlan p = plan_gemm(layout == 2, layout >= 1, M, N, K, lda, ldb);
+  return p.family == 0 ? 0 : p.bm;
 }
 
 extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
@@ -433,7 +465,8 @@ extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void
   hipStream_t s = (hipStream_t)stream;
   const bool need_bias = (epi == EPI_BIAS_F32 || epi == EPI_BIAS_GELU || epi == EPI_BIAS_RESID);
   NV_CHECK_ARG(!need_bias || (bias && nv_aligned16(bias)), "nv_gemm_bf16: epilogue %d needs a 16-byte aligned bias", epi);
-  NV_CHECK_ARG(!(epi == EPI_BIAS_RESID || epi == EPI_DGELU) || (aux_in && nv_aligned16(aux_in) && (ld_aux_in % 4) == 0),
+  NV_CHECK_ARG(epi != EPI_DGELU_COLSUM || (aux_out && ld_aux_out >= N), "nv_gemm_bf16: epilogue 6 needs aux_out = f32 [ceil(M / tile rows), ld_aux_out >= N]");
+  NV_CHECK_ARG(!(epi == EPI_BIAS_RESID || epi == EPI_DGELU || epi == EPI_DGELU_COLSUM) || (aux_in && nv_aligned16(aux_in) && (ld_aux_in % 4) == 0),
                "nv_gemm_bf16: epilogue %d needs aux_in", epi);
   NV_CHECK_ARG(epi != EPI_BIAS_GELU || !aux_out || (nv_aligned16(aux_out) && (ld_aux_out % 4) == 0),
                "nv_gemm_bf16: EPI_BIAS_GELU: aux_out must be 16-byte aligned (or null: the pre-activation is not stored)");
@@ -446,6 +479,7 @@ extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void
     case 1 * 16 + EPI_STORE_BF16: return launch<false, true, EPI_STORE_BF16>(a, s);
     case 1 * 16 + EPI_STORE_F32: return launch<false, true, EPI_STORE_F32>(a, s);
     case 1 * 16 + EPI_DGELU: return launch<false, true, EPI_DGELU>(a, s);
+    case 1 * 16 + EPI_DGELU_COLSUM: return launch<false, true, EPI_DGELU_COLSUM>(a, s);
     case 2 * 16 + EPI_STORE_F32: return launch<true, true, EPI_STORE_F32>(a, s);
     default: break;
   }

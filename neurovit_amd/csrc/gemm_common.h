@@ -10,6 +10,8 @@ enum {
   EPI_BIAS_GELU = 3,    // aux_out(bf16) = u = acc + bias[n];  C(bf16) = gelu(u)
   EPI_BIAS_RESID = 4,   // C(f32)  = aux_in(f32)[m,n] + acc + bias[n]
   EPI_DGELU = 5,        // C(bf16) = acc * gelu'(aux_in(bf16)[m,n])
+  EPI_DGELU_COLSUM = 6, // EPI_DGELU + aux_out(f32)[tile_row, n] = column sums of the stored bf16 values over the tile's rows: the bias
+                        // gradient of the Linear in front of the GELU, produced where the tile already is (large-tile kernels only)
 };
 
 struct GemmArgs {
@@ -157,10 +159,10 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int rc0, int ks, in
 
 // ---- epilogue core: four consecutive output columns (m, n .. n+3) ----------------------------------------------------
 template <int EPI>
-__device__ __forceinline__ void epilogue4(f32x4 v, const GemmArgs& g, int m, int n) {
+__device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, int n) {
   if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.bias + n);
   f32x4 keep = f32x4{1.f, 1.f, 1.f, 1.f};
-  if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_DGELU) {
+  if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_DGELU || EPI == EPI_DGELU_COLSUM) {
     if (g.drop.thresh) {
       keep = drop_factor4(g.drop, (unsigned long long)m * g.N + n);      // N % 8 == 0, n % 4 == 0
     }
@@ -182,17 +184,20 @@ __device__ __forceinline__ void epilogue4(f32x4 v, const GemmArgs& g, int m, int
   } else if constexpr (EPI == EPI_BIAS_RESID) {
     v = v * keep + *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
     *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
-  } else if constexpr (EPI == EPI_DGELU) {
+  } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DGELU_COLSUM) {
     const bf16x4 u = *reinterpret_cast<const bf16x4*>((const bf16*)g.aux_in + (long)m * g.ld_aux_in + n);
-    *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
-        cvt4(v[0] * keep[0] * gelu_grad_f((float)u[0]), v[1] * keep[1] * gelu_grad_f((float)u[1]),
-             v[2] * keep[2] * gelu_grad_f((float)u[2]), v[3] * keep[3] * gelu_grad_f((float)u[3]));
+    const bf16x4 o = cvt4(v[0] * keep[0] * gelu_grad_f((float)u[0]), v[1] * keep[1] * gelu_grad_f((float)u[1]),
+                          v[2] * keep[2] * gelu_grad_f((float)u[2]), v[3] * keep[3] * gelu_grad_f((float)u[3]));
+    *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) = o;
+    v = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};     // what the weight-gradient GEMM will read: summed as stored
   }
+  return v;
 }
 
 // ---- register epilogue: lane holds C[m = mb + 16i + (lane&15)][n = nb + 16j + 4*(lane>>4) + 0..3] -----------------
 template <int EPI, int MI, int NI>
 __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmArgs& g, int mb, int nb, int lane) {
+  static_assert(EPI != EPI_DGELU_COLSUM, "fused column sums need the LDS epilogue");
   const int lr = lane & 15, lg = lane >> 4;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -220,14 +225,39 @@ __device__ __forceinline__ void park_acc(const f32x4 (&acc)[MI][NI], char* ctile
     for (int j = 0; j < NI; ++j)
       *reinterpret_cast<f32x4*>(ctile + (rb + 16 * i + lr) * cpitch<BN>() + (cb + 16 * j + 4 * lg) * 4) = acc[i][j];
 }
+template <int BM, int BN, int NT> constexpr int colsum_scratch_bytes() { return (NT / 64) * BN * 4; }   // behind the parked C tile
 template <int EPI, int BM, int BN, int NT>
-__device__ __forceinline__ void epilogue_lds(const char* ctile, const GemmArgs& g, int m0, int n0, int tid) {
+__device__ __forceinline__ void epilogue_lds(char* ctile, const GemmArgs& g, int m0, int n0, int tid) {
   constexpr int CPR = BN / 4;                 // 16-byte chunks per row
+  static_assert(NT % CPR == 0 && 64 % CPR == 0, "every thread keeps one column group");
+  f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
   for (int c = tid; c < BM * CPR; c += NT) {
     const int row = c / CPR, col = (c % CPR) * 4;
     const int m = m0 + row, n = n0 + col;
-    if (m < g.M && n < g.N) epilogue4<EPI>(*reinterpret_cast<const f32x4*>(ctile + row * cpitch<BN>() + col * 4), g, m, n);
+    if (m < g.M && n < g.N) {
+      const f32x4 r = epilogue4<EPI>(*reinterpret_cast<const f32x4*>(ctile + row * cpitch<BN>() + col * 4), g, m, n);
+      if constexpr (EPI == EPI_DGELU_COLSUM) csum += r;
+    }
+  }
+  if constexpr (EPI == EPI_DGELU_COLSUM) {
+    // deterministic column sums of this tile: lanes of a wave that share a column group, then the waves in a fixed order
+    // through a small LDS array behind the parked tile, one partial row per tile row of the grid
+#pragma unroll
+    for (int o = 32; o >= CPR; o >>= 1) {
+      csum[0] += __shfl_xor(csum[0], o, 64); csum[1] += __shfl_xor(csum[1], o, 64);
+      csum[2] += __shfl_xor(csum[2], o, 64); csum[3] += __shfl_xor(csum[3], o, 64);
+    }
+    float* scr = reinterpret_cast<float*>(ctile + BM * cpitch<BN>());
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < CPR) *reinterpret_cast<f32x4*>(scr + wave * BN + lane * 4) = csum;
+    __syncthreads();
+    if (tid < BN && n0 + tid < g.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) s += scr[w * BN + tid];
+      ((float*)g.aux_out)[(long)(m0 / BM) * g.ld_aux_out + n0 + tid] = s;
+    }
   }
 }
 

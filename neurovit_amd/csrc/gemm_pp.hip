@@ -76,7 +76,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
   constexpr int MH = MI / 2;                  // m-tiles per half
   constexpr int NP = 4 * NSUB;                // DMA pieces per loader wave per K tile
   static_assert(2 * NP <= 63, "vmcnt range");
-  static_assert(PP_S * STAGE <= 160 * 1024 && BM * cpitch<BN>() <= PP_S * STAGE, "LDS budget");
+  static_assert(PP_S * STAGE <= 160 * 1024 && BM * cpitch<BN>() + colsum_scratch_bytes<BM, BN, PP_THREADS>() <= PP_S * STAGE, "LDS budget");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Tile order: each XCD (private 4 MiB L2) owns a contiguous run of logical ids (xcd_remap) and its 32 CUs hold 32 consecutive
@@ -290,6 +290,7 @@ int launch_pp(int layout, int epi, const GemmArgs& a, hipStream_t s) {
     case 1 * 16 + EPI_STORE_BF16: return launch_pp_t<false, true, EPI_STORE_BF16>(a, s);
     case 1 * 16 + EPI_STORE_F32: return launch_pp_t<false, true, EPI_STORE_F32>(a, s);
     case 1 * 16 + EPI_DGELU: return launch_pp_t<false, true, EPI_DGELU>(a, s);
+    case 1 * 16 + EPI_DGELU_COLSUM: return launch_pp_t<false, true, EPI_DGELU_COLSUM>(a, s);
     case 2 * 16 + EPI_STORE_F32: return launch_pp_t<true, true, EPI_STORE_F32>(a, s);
     default: break;
   }

@@ -194,6 +194,68 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// Several partial-sum reductions in ONE launch (a transformer layer's bias / LayerNorm-affine gradients all wait for the same
+// point of the backward pass): job j owns blocks [block_end[j-1], block_end[j]), each block = 32 columns x 8 row groups as above.
+constexpr int REDUCE_MAX_JOBS = 8;
+struct ReduceJobs {
+  nv_reduce_job job[REDUCE_MAX_JOBS];
+  int block_end[REDUCE_MAX_JOBS];
+  int count;
+};
+__global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceJobs J) {
+  __shared__ float sh[8][33];
+  int j = 0;
+  while (j + 1 < J.count && (int)blockIdx.x >= J.block_end[j]) ++j;          // workgroup-uniform
+  const nv_reduce_job& q = J.job[j];
+  const int blk = blockIdx.x - (j ? J.block_end[j - 1] : 0);
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int i = blk * 32 + cl, R = q.rows, tot = q.nseg * q.width;
+  const long stride = tot;
+  const float* __restrict__ part = q.partials;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < tot) {
+    int r = rg;
+    for (; r + 24 < R; r += 32) {
+      s0 += part[(long)r * stride + i];
+      s1 += part[(long)(r + 8) * stride + i];
+      s2 += part[(long)(r + 16) * stride + i];
+      s3 += part[(long)(r + 24) * stride + i];
+    }
+    for (; r < R; r += 8) s0 += part[(long)r * stride + i];
+  }
+  sh[rg][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && i < tot) {
+    const float s = ((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl])) + ((sh[4][cl] + sh[5][cl]) + (sh[6][cl] + sh[7][cl]));
+    const int seg = i / q.width, c = i - seg * q.width;
+    float* o = q.out[seg];
+    if (o) o[c] = q.accumulate ? o[c] + s : s;
+  }
+}
+
+extern "C" int nv_reduce_multi(const nv_reduce_job* jobs, int count, void* stream) {
+  NV_CHECK_ARG(jobs && count >= 1 && count <= REDUCE_MAX_JOBS, "nv_reduce_multi: 1..%d jobs", REDUCE_MAX_JOBS);
+  ReduceJobs J;
+  int blocks = 0;
+  for (int j = 0; j < count; ++j) {
+    const nv_reduce_job& q = jobs[j];
+    NV_CHECK_ARG(q.partials && q.rows > 0 && q.width > 0 && q.nseg >= 1 && q.nseg <= 3, "nv_reduce_multi: job %d: bad shape", j);
+    J.job[j] = q;
+    blocks += (q.nseg * q.width + 31) / 32;
+    J.block_end[j] = blocks;
+  }
+  for (int j = count; j < REDUCE_MAX_JOBS; ++j) { J.job[j] = jobs[0]; J.block_end[j] = blocks; }
+  J.count = count;
+  hipLaunchKernelGGL(reduce_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
+  NV_CHECK_LAUNCH("nv_reduce_multi");
+  return NV_OK;
+}
+
+extern "C" int nv_ln_bwd_partial_rows(int M) {
+  int b = (M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  return b < 256 ? b : 256;
+}
+
 static int ln_bwd_blocks(int M) {
   int b = (M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   return b < 256 ? b : 256;

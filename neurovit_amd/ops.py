@@ -13,7 +13,7 @@ import torch
 from ._cabi import check, lib
 
 NT, NN, TN = 0, 1, 2
-EPI_STORE_BF16, EPI_STORE_F32, EPI_BIAS_F32, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_DGELU = 0, 1, 2, 3, 4, 5
+EPI_STORE_BF16, EPI_STORE_F32, EPI_BIAS_F32, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_DGELU, EPI_DGELU_COLSUM = 0, 1, 2, 3, 4, 5, 6
 
 
 def _stream() -> int:
@@ -51,7 +51,7 @@ def gemm(layout: int, epi: int, A: torch.Tensor, B: torch.Tensor, *, out: Option
         M, K = A.shape; N = B.shape[1]; assert B.shape[0] == K
     else:
         K, M = A.shape; N = B.shape[1]; assert B.shape[0] == K
-    odt = torch.bfloat16 if epi in (EPI_STORE_BF16, EPI_BIAS_GELU, EPI_DGELU) else torch.float32
+    odt = torch.bfloat16 if epi in (EPI_STORE_BF16, EPI_BIAS_GELU, EPI_DGELU, EPI_DGELU_COLSUM) else torch.float32
     if out is None:
         out = torch.empty((M, N), dtype=odt, device=A.device)
     assert out.dtype == odt and out.shape == (M, N) and out.stride(1) == 1
@@ -251,3 +251,34 @@ def dropout_apply(x: torch.Tensor, drop_seed: int = 0, drop_p: float = 0.0, want
     o32 = torch.empty((M, N), dtype=torch.float32, device=x.device) if want32 else None
     check(lib.nv_dropout_apply(_p(x), x.stride(0), M, N, drop_seed, drop_p, _p(o16), N, _p(o32), N, _stream()), "nv_dropout_apply")
     return o16, o32
+
+
+class ReduceJob(ctypes.Structure):            # include/neurovit_hip.h::nv_reduce_job
+    _fields_ = [("partials", ctypes.c_void_p), ("rows", ctypes.c_int), ("width", ctypes.c_int), ("nseg", ctypes.c_int),
+                ("out", ctypes.c_void_p * 3), ("accumulate", ctypes.c_int)]
+
+
+def reduce_multi(jobs) -> None:
+    """jobs: [(partials f32 [rows, nseg*width], width, [out tensors or None] (nseg of them), accumulate)] - one launch."""
+    arr = (ReduceJob * len(jobs))()
+    for i, (part, width, outs, acc) in enumerate(jobs):
+        _need_cuda(part)
+        rows, tot = part.shape
+        nseg = tot // width
+        assert nseg * width == tot and len(outs) == nseg and part.is_contiguous()
+        o = (ctypes.c_void_p * 3)(*[(_p(t) if t is not None else None) for t in list(outs) + [None] * (3 - nseg)])
+        arr[i] = ReduceJob(part.data_ptr(), rows, width, nseg, o, int(acc))
+    check(lib.nv_reduce_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), _stream()), "nv_reduce_multi")
+
+
+def gemm_dgelu_colsum(A: torch.Tensor, B: torch.Tensor, u: torch.Tensor, drop_seed: int = 0, drop_p: float = 0.0):
+    """dU = (A B) * gelu'(u) (bf16) with the fused column-sum epilogue -> (dU, partial column sums f32 [tile rows, N]);
+    raises when the shape has no large-tile kernel (use EPI_DGELU + colsum_bf16 then)."""
+    M, K = A.shape
+    N = B.shape[1]
+    rows = lib.nv_gemm_tile_rows(NN, M, N, K, A.stride(0), B.stride(0))
+    if rows == 0:
+        raise RuntimeError("neurovit_amd: fused column-sum epilogue not available for this shape")
+    part = torch.empty(((M + rows - 1) // rows, N), dtype=torch.float32, device=A.device)
+    out = gemm(NN, EPI_DGELU_COLSUM, A, B, aux_in=u, aux_out=part, drop_seed=drop_seed, drop_p=drop_p)
+    return out, part

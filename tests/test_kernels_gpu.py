@@ -223,6 +223,34 @@ def test_gemm_ping_pong_grouped_equals_single_launches(ops):
         lib.nv_gemm_set_tile(0, 0)
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_gemm_dgelu_fused_colsum_and_reduce_multi(ops, tile):
+    """Epilogue 6: dU as epilogue 5 (bit-identical) plus per-tile column sums of the stored bf16 values; nv_reduce_multi sums the
+    partial rows (and other jobs in the same launch) deterministically.  Every large-tile kernel family."""
+    from neurovit_amd._cabi import lib
+    M, N, K = 2052, 3072 if tile in (0, 4) else 392, 768
+    A, Bt = bf(rnd(M, K, seed=6)), bf(rnd(K, N, seed=7, scale=K ** -0.5))
+    u = bf(rnd(M, N, seed=8))
+    lib.nv_gemm_set_tile(tile, 0)
+    try:
+        plain = ops.gemm(ops.NN, ops.EPI_DGELU, dev(A), dev(Bt), aux_in=dev(u))
+        fused, part = ops.gemm_dgelu_colsum(dev(A), dev(Bt), dev(u))
+        fused2, part2 = ops.gemm_dgelu_colsum(dev(A), dev(Bt), dev(u))
+    finally:
+        lib.nv_gemm_set_tile(0, 0)
+    assert torch.equal(plain, fused) and torch.equal(fused, fused2) and torch.equal(part, part2)
+    want = fused.double().sum(0)
+    db = torch.full((N,), 7.0, device="cuda")
+    other = dev(rnd(40, 3 * 64, seed=9))
+    o0, o2 = torch.zeros(64, device="cuda"), torch.ones(64, device="cuda")
+    ops.reduce_multi([(part, N, [db], False), (other, 64, [o0, None, o2], True)])
+    assert_close_f32(db, want, "colsum", 1e-5)
+    assert_close_f32(o0, other[:, :64].double().sum(0), "seg0", 1e-5)
+    assert_close_f32(o2, other[:, 128:].double().sum(0) + 1.0, "seg2 accumulate", 1e-5)
+    ops.reduce_multi([(part, N, [db], True)])
+    assert_close_f32(db, 2 * want, "colsum accumulate", 1e-5)
+
+
 def test_gemm_rejects_bad_args(ops):
     A, B = dev(bf(rnd(16, 12))), dev(bf(rnd(8, 12)))
     with pytest.raises((RuntimeError, AssertionError)):

@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace --stats CSV: per-kernel calls, total / average time per step.
+usage: tools/kstats.py <kernel_stats.csv> <steps>"""
+import csv
+import sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = float(sys.argv[2])
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print(f"total kernel time per step: {tot / steps / 1e6:.3f} ms; launches per step: {sum(int(r['Calls']) for r in rows) / steps:.1f}")
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:40]:
+    print(f"{float(r['TotalDurationNs']) / steps / 1e3:9.1f} us/step  {int(r['Calls']) / steps:6.1f} x {float(r['AverageNs']) / 1e3:8.2f} us  {r['Name'][:110]}")
