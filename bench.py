@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--same-data", action="store_true", help="rehearsal: every rank gets rank 0's batch (with --grad-comm fp32 the "
                                                               "averaged gradients, hence the loss curve, must equal the 1-GPU run bit for bit)")
+    ap.add_argument("--forward-only", action="store_true", help="time inference forwards (validate path, Trainer.py:101-118) instead of train steps")
+    ap.add_argument("--fp8", action="store_true", help="with --forward-only: the fp8 (OCP e4m3) inference path (BASELINE.json configs[4]), "
+                                                       "activation scales calibrated on the bench batch")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous rehearsal without a GPU: every rank joins the process group, "
                                                             "runs the barrier + max-over-ranks timing plumbing around an empty step and rank 0 "
                                                             "prints the JSON line with value null (tests/test_bench_launcher_cpu.py)")
@@ -169,6 +172,55 @@ def dry_run(a, world, rank):
         dist.destroy_process_group()
 
 
+def forward_only_bench(a, model, x, size, S, p, B, world, rank, device, dist):
+    """--forward-only: inference forwards of the preset (bf16, or fp8 with --fp8) at batch B per GPU, same timing contract."""
+    from neurovit_amd.engine import flops_forward, make_config
+    model.eval()
+    vit = model.volume_encoder.vit3d
+    if a.fp8:
+        with torch.no_grad():
+            vit.enable_fp8(x.permute(0, 3, 1, 2).unsqueeze(1))
+
+    def fwd():
+        with torch.no_grad():
+            return model(x)
+
+    for _ in range(max(a.warmup, 2)):
+        fwd()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = fwd()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    vcfg = dict(image_size=S, image_patch_size=p, frames=S, frame_patch_size=p, num_classes=2, dim=size["TRAINING_VIT_DIM"],
+                depth=size["TRAINING_VIT_DEPTH"], heads=size["TRAINING_VIT_HEADS"], mlp_dim=size["TRAINING_VIT_MLP_DIM"], channels=1, dim_head=64)
+    f_fwd = flops_forward(make_config(**vcfg))
+    value = B * world * a.steps / elapsed
+    # fp8 runs are priced against the dense fp8 peak for the linears they run in fp8 and the bf16 peak for the rest: reported as
+    # the fraction of the bf16 peak (conservative, one number) and, separately, of the fp8 peak
+    out_line = {"metric": f"fMRI volumes/sec (forward only) ViT3D {S}^3 p{p} d{size['TRAINING_VIT_DIM']} L{size['TRAINING_VIT_DEPTH']}",
+                "value": round(value, 2), "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "fp8 (e4m3 qkv/FC1/FC2 operands, bf16 elsewhere, fp32 accumulate)" if a.fp8 else "bf16", "data": "synthetic",
+                "config": {"workload": f"ViT3D-{a.preset} {S}^3 patch {p}, inference forward, batch {B}/GPU", "global_batch": B * world, "parallelism": f"dp{world}"},
+                "mfma_frac_bf16_peak": round(value / world * f_fwd / (PEAK_BF16_TFLOPS * 1e12), 4),
+                "mfma_frac_fp8_peak": round(value / world * f_fwd / (2 * PEAK_BF16_TFLOPS * 1e12), 4) if a.fp8 else None,
+                "logits_finite": bool(torch.isfinite(out).all())}
+    if rank == 0:
+        print(json.dumps(out_line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     global torch
     a = parse()
@@ -221,6 +273,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.forward_only:
+        return forward_only_bench(a, model, x, size, S, p, B, world, rank, device, dist)
     log(f"model built on {device}, warm-up {a.warmup} steps")
     for _ in range(a.warmup):
         step(x, y)

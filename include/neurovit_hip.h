@@ -55,6 +55,18 @@ int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void* A, long l
 
 int nv_gemm_tile_rows(int layout, int M, int N, int K, long lda, long ldb);   /* 0: epilogue 6 not available for this shape */
 
+/* ---- fp8 inference path (BASELINE.json configs[4]: ViT3D-large, "fp8 MFMA"): OCP e4m3 operands, fp32 accumulate on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), dequantisation per output column in the epilogue.
+ * nv_quant_rows_f8: out8[r, :] = sat(W[r, :] * sw[r]) with sw[r] = 448 / max|W[r, :]|; colscale[r] = 1 / (act_scale * sw[r]).
+ * nv_ln_fwd_f8: LayerNorm(d) (vit_3d.py:18,37) -> sat(y * out_scale) as e4m3 (inference: no statistics saved).
+ * nv_gemm_f8 (NT): C = epi((A8 . B8^T) * colscale[n]); epi 0 bf16 store, 1 f32 store, 4 f32 = aux_in + acc + bias,
+ * 7 e4m3 = sat(gelu(acc + bias) * out_scale) (FC1 feeding FC2).  K % 128 == 0. */
+int nv_quant_rows_f8(const float* W, long ldw, int rows, int cols, void* out8, long ld8, float act_scale, float* colscale, void* stream);
+int nv_ln_fwd_f8(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, float out_scale, void* y8,
+                 long ldy, void* stream);
+int nv_gemm_f8(int epi, int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc,
+               const float* colscale, const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* stream);
+
 /* Up to four independent problems of one layout / epilogue in ONE launch (provided for layout 2 / TN with epilogue 1: the
  * four weight-gradient GEMMs of a transformer layer, vit_3d.py:19,22,41,44 backward).  Same arithmetic per tile as
  * nv_gemm_bf16; the point is occupancy: 864 tiles together instead of 72-288 at a time. */
@@ -200,6 +212,14 @@ long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int training, cons
 int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
                    const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
                    unsigned long drop_seed, float* logits, void* stream);
+/* fp8 inference forward (BASELINE.json configs[4] "ViT3D-large ... fp8 MFMA"): qkv / FC1 / FC2 of every block on e4m3 operands.
+ * act_scales: HOST array [depth][3] (LN1 output, LN2 output, GELU output; calibrated: 448 / (headroom * amax)); params8: byte arena
+ * with the element offsets of the parameter arena; colscales: f32 [nv_vit_fp8_scale_count].  Workspace: training = 0 layout. */
+long nv_vit_fp8_scale_count(const nv_vit_config* cfg);
+int nv_vit_quantize_fp8(const nv_vit_config* cfg, const float* params, const float* act_scales, void* params8, float* colscales, void* stream);
+int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
+                       const float* params, const void* params16, const void* params8, const float* colscales,
+                       const float* act_scales, void* workspace, long ws_bytes, float* logits, void* stream);
 int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                     const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
                     int accumulate, float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream, void* aux_stream);

@@ -248,6 +248,89 @@ extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* vide
   return NV_OK;
 }
 
+// ---- fp8 inference path (BASELINE.json configs[4]): qkv, FC1 and FC2 of every block on OCP e4m3 operands (92 % of the linear
+// FLOPs; the output projection, whose input comes head by head out of the attention kernel, stays bf16, as do the patch embedding,
+// attention and the head).  Weights: per-output-row scales; activations (LN outputs, GELU output): one calibrated scale per
+// tensor, applied by the kernel that produces them.  Layout of the scale arena: layer l at l * (3*inner + m + d):
+// [colscale qkv (3*inner) | colscale FC1 (m) | colscale FC2 (d)].  act_scales: HOST array [depth][3] = xn1, xn2, h.
+extern "C" long nv_vit_fp8_scale_count(const nv_vit_config* cfg) {
+  Dims D; if (make_dims(cfg, 1, D)) return -1;
+  return (long)D.L * (3L * D.inner + D.m + D.d);
+}
+
+extern "C" int nv_vit_quantize_fp8(const nv_vit_config* cfg, const float* params, const float* act_scales, void* params8, float* colscales, void* stream) {
+  Dims D; RUN(make_dims(cfg, 1, D));
+  ParamTab T; make_params(D, T);
+  NV_CHECK_ARG(params && act_scales && params8 && colscales, "nv_vit_quantize_fp8: null pointer");
+  NV_CHECK_ARG(D.d % 128 == 0 && D.m % 128 == 0, "nv_vit_quantize_fp8: the fp8 GEMM needs dim and mlp_dim to be multiples of 128 (got %d, %d)", D.d, D.m);
+  char* p8 = (char*)params8;
+  const long per = 3L * D.inner + D.m + D.d;
+  for (int l = 0; l < D.L; ++l) {
+    const LayerP& q = T.layer[l];
+    float* cs = colscales + l * per;
+    RUN(nv_quant_rows_f8(params + q.wqkv, D.d, 3 * D.inner, D.d, p8 + q.wqkv, D.d, act_scales[3 * l + 0], cs, stream));
+    RUN(nv_quant_rows_f8(params + q.w1, D.d, D.m, D.d, p8 + q.w1, D.d, act_scales[3 * l + 1], cs + 3L * D.inner, stream));
+    RUN(nv_quant_rows_f8(params + q.w2, D.m, D.d, D.m, p8 + q.w2, D.m, act_scales[3 * l + 2], cs + 3L * D.inner + D.m, stream));
+  }
+  return NV_OK;
+}
+
+extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const float* params,
+                                  const void* params16, const void* params8, const float* colscales, const float* act_scales, void* workspace,
+                                  long ws_bytes, float* logits, void* stream) {
+  Dims D; RUN(make_dims(cfg, B, D));
+  ParamTab T; make_params(D, T);
+  WS W; make_ws(D, 0, W);
+  NV_CHECK_ARG(video && shape5 && strides5 && params && params16 && params8 && colscales && act_scales && workspace && logits, "nv_vit_forward_fp8: null pointer");
+  NV_CHECK_ARG(shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == cfg->image_size,
+               "nv_vit_forward_fp8: video is [%ld,%ld,%ld,%ld,%ld], the model was built for [%d,%d,%d,%d,%d] (B, channels, frames, height, width)",
+               shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size);
+  NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_forward_fp8: workspace too small (%ld < %ld)", ws_bytes, W.total);
+  NV_CHECK_ARG(D.d % 128 == 0 && D.m % 128 == 0, "nv_vit_forward_fp8: dim and mlp_dim must be multiples of 128");
+  NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params) && nv_aligned16(params16) && nv_aligned16(params8), "nv_vit_forward_fp8: alignment");
+  char* ws = (char*)workspace;
+  const float* p = params;
+  const bf16* p16 = (const bf16*)params16;
+  const char* p8 = (const char*)params8;
+  const float eps = cfg->ln_eps;
+  const int M = D.M, d = D.d;
+  const long per = 3L * D.inner + D.m + D.d;
+
+  float* pst = (float*)(ws + W.pst);
+  RUN(nv_patch_ln_fwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
+                      cfg->image_patch_size, cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, ws + W.xp, D.Ppad, pst, pst + D.T, stream));
+  const void* wpe = p16 + T.pe_w;
+  if (D.P != D.Ppad) {
+    RUN(nv_cast_bf16_2d(p + T.pe_w, D.P, d, D.P, ws + W.wpe16, D.Ppad, stream));
+    wpe = ws + W.wpe16;
+  }
+  RUN(nv_gemm_bf16(0, 2, D.T, d, D.Ppad, ws + W.xp, D.Ppad, wpe, D.Ppad, ws + W.t, d, p + T.pe_bias, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+  float* est = (float*)(ws + W.est);
+  RUN(nv_embed_finish_fwd((float*)(ws + W.t), d, B, D.N, d, p + T.pe_g2, p + T.pe_b2, eps, p + T.pos, p + T.cls, (float*)(ws + W.x0), d, est,
+                          est + D.T, 0, 0.f, stream));
+  const float scale = 1.0f / sqrtf((float)D.dh);
+  const float* xin = (float*)(ws + W.x0);
+  for (int l = 0; l < D.L; ++l) {
+    const LayerP& q = T.layer[l];
+    const LayerW& w = W.layer[l];
+    const float* cs = colscales + l * per;
+    const float s_xn1 = act_scales[3 * l], s_xn2 = act_scales[3 * l + 1], s_h = act_scales[3 * l + 2];
+    float* x1 = (float*)(ws + w.x1);
+    float* x2 = (float*)(ws + ((l & 1) ? W.x0 : w.x2));
+    RUN(nv_ln_fwd_f8(xin, d, M, d, p + q.n1g, p + q.n1b, eps, s_xn1, ws + w.xn1, d, stream));
+    RUN(nv_gemm_f8(0, M, 3 * D.inner, d, ws + w.xn1, d, p8 + q.wqkv, d, ws + w.qkv, 3 * D.inner, cs, nullptr, nullptr, 0, 1.f, stream));
+    RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), 0, 0.f, stream));
+    RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+    RUN(nv_ln_fwd_f8(x1, d, M, d, p + q.n2g, p + q.n2b, eps, s_xn2, ws + w.xn2, d, stream));
+    RUN(nv_gemm_f8(7, M, D.m, d, ws + w.xn2, d, p8 + q.w1, d, ws + w.h, D.m, cs + 3L * D.inner, p + q.b1, nullptr, 0, s_h, stream));
+    RUN(nv_gemm_f8(4, M, d, D.m, ws + w.h, D.m, p8 + q.w2, D.m, x2, d, cs + 3L * D.inner + D.m, p + q.b2, x1, d, 1.f, stream));
+    xin = x2;
+  }
+  RUN(nv_head_fwd(xin, (long)D.n * d, B, d, p + T.hg, p + T.hb, eps, p + T.hw, p + T.hbias, D.C, (float*)(ws + W.xh), (float*)(ws + W.hst),
+                  logits, stream));
+  return NV_OK;
+}
+
 // Backward in stages so the caller can overlap the data-parallel gradient all-reduce with it:
 //   stage 0 = classification head, stage 1+k = transformer layer (depth-1-k), stage depth+1 = patch embedding.
 // Stages must be run in increasing order over [0, depth+1]; the running residual gradient lives in the workspace.

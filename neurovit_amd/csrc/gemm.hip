@@ -459,6 +459,7 @@ extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ld_aux_in = ld_aux_in; a.ld_aux_out = ld_aux_out;
   a.M = M; a.N = N; a.K = K; a.accumulate = accumulate; a.alpha = alpha;
   a.drop = make_drop(drop_seed, drop_p);
+  a.colscale = nullptr;
   // each XCD (private 4 MiB L2) gets a contiguous run of tiles: run along the dimension of the SMALLER operand so the
   // larger operand's panel is the one that stays resident
   a.col_order = (N > M) ? 1 : 0;
@@ -487,6 +488,28 @@ extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void
   return NV_ERR_ARG;
 }
 
+// fp8 (OCP e4m3) operands, NT layout: C = epilogue((A8 . B8^T) * colscale[n]).  Eight-wave 256 x 128 kernel only (the path exists for
+// the large-M inference shapes of ViT3D-large); K % 128 == 0.
+extern "C" int nv_gemm_f8(int epi, int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc, const float* colscale,
+                          const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* stream) {
+  NV_CHECK_ARG(M > 0 && N > 0 && K > 0 && A8 && B8 && C && colscale, "nv_gemm_f8: null operand / empty problem");
+  NV_CHECK_ARG((K % 128) == 0 && (N % 8) == 0 && (lda % 16) == 0 && (ldb % 16) == 0 && lda >= K && ldb >= K && ldc >= N && (ldc % 4) == 0,
+               "nv_gemm_f8: K must be a multiple of 128, N of 8, lda / ldb of 16, ldc of 4");
+  NV_CHECK_ARG(nv_aligned16(A8) && nv_aligned16(B8) && nv_aligned16(C) && nv_aligned16(colscale), "nv_gemm_f8: 16-byte alignment");
+  NV_CHECK_ARG((long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31), "nv_gemm_f8: operand too large for 32-bit offsets");
+  const bool need_bias = (epi == EPI_BIAS_RESID || epi == EPI_BIAS_GELU_F8);
+  NV_CHECK_ARG(!need_bias || (bias && nv_aligned16(bias)), "nv_gemm_f8: epilogue %d needs a bias", epi);
+  NV_CHECK_ARG(epi != EPI_BIAS_RESID || (aux_in && nv_aligned16(aux_in) && (ld_aux_in % 4) == 0), "nv_gemm_f8: epilogue 4 needs aux_in");
+  GemmArgs a;
+  a.A = (const bf16*)A8; a.B = (const bf16*)B8; a.C = C; a.bias = bias; a.aux_in = aux_in; a.aux_out = nullptr;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ld_aux_in = ld_aux_in; a.ld_aux_out = 0;
+  a.M = M; a.N = N; a.K = K; a.accumulate = 0; a.alpha = out_scale;
+  a.drop = make_drop(0, 0.f);
+  a.colscale = colscale;
+  a.col_order = 0;
+  return launch_pp_f8(epi, a, (hipStream_t)stream);
+}
+
 // Grouped weight-gradient GEMMs (layout 2 / TN, fp32 store or accumulate): see gemm_ws_grouped_kernel.
 extern "C" int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gemm_problem* pr, void* stream) {
   NV_CHECK_ARG(layout == 2 && epi == EPI_STORE_F32, "nv_gemm_bf16_grouped: only layout 2 (TN) with epilogue 1 (fp32 store) is provided");
@@ -508,6 +531,7 @@ extern "C" int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gem
     a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ld_aux_in = 0; a.ld_aux_out = 0;
     a.M = q.M; a.N = q.N; a.K = q.K; a.accumulate = q.accumulate; a.alpha = 1.f;
     a.drop = make_drop(0, 0.f);
+    a.colscale = nullptr;
     a.col_order = (q.N > q.M) ? 1 : 0;
     tiles += ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN);
     G.tile_end[i] = tiles;

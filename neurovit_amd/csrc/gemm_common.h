@@ -10,6 +10,7 @@ enum {
   EPI_BIAS_GELU = 3,    // aux_out(bf16) = u = acc + bias[n];  C(bf16) = gelu(u)
   EPI_BIAS_RESID = 4,   // C(f32)  = aux_in(f32)[m,n] + acc + bias[n]
   EPI_DGELU = 5,        // C(bf16) = acc * gelu'(aux_in(bf16)[m,n])
+  EPI_BIAS_GELU_F8 = 7, // C(fp8 e4m3) = sat(gelu(acc * colscale[n] + bias[n]) * alpha): FC1 of the fp8 inference path, feeding FC2 directly
   EPI_DGELU_COLSUM = 6, // EPI_DGELU + aux_out(f32)[tile_row, n] = column sums of the stored bf16 values over the tile's rows: the bias
                         // gradient of the Linear in front of the GELU, produced where the tile already is (large-tile kernels only)
 };
@@ -27,7 +28,17 @@ struct GemmArgs {
   DropCfg drop;    // EPI_BIAS_RESID: on (acc + bias); EPI_BIAS_GELU: on gelu(u); EPI_DGELU: on acc (the incoming dH)
   int col_order;   // 1: consecutive workgroups walk DOWN a tile column (keeps the B panel in the XCD's L2), 0: along a tile row
   float alpha;
+  const float* colscale;   // fp8 operands: acc *= colscale[n] (1 / (activation scale * weight-row scale)) before the epilogue; null otherwise
 };
+
+// OCP e4m3 (gfx950's fp8: v_cvt_pk_fp8_f32), saturating: four floats -> four bytes
+__device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = fminf(fmaxf(v[i], -448.f), 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+  return (unsigned)w;
+}
 
 constexpr int BK = 64;
 constexpr int NTHREADS = 256;
@@ -160,7 +171,8 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int rc0, int ks, in
 // ---- epilogue core: four consecutive output columns (m, n .. n+3) ----------------------------------------------------
 template <int EPI>
 __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, int n) {
-  if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+  if (g.colscale) v *= *reinterpret_cast<const f32x4*>(g.colscale + n);
+  if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_GELU_F8) v += *reinterpret_cast<const f32x4*>(g.bias + n);
   f32x4 keep = f32x4{1.f, 1.f, 1.f, 1.f};
   if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_DGELU || EPI == EPI_DGELU_COLSUM) {
     if (g.drop.thresh) {
@@ -181,6 +193,9 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, in
     if (g.aux_out) __builtin_nontemporal_store(cvt4(v[0], v[1], v[2], v[3]), reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n));
     *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
         cvt4(gelu_f(v[0]) * keep[0], gelu_f(v[1]) * keep[1], gelu_f(v[2]) * keep[2], gelu_f(v[3]) * keep[3]);
+  } else if constexpr (EPI == EPI_BIAS_GELU_F8) {
+    const f32x4 h = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])} * g.alpha;
+    *reinterpret_cast<unsigned*>((char*)g.C + (long)m * g.ldc + n) = pack_fp8x4(h);
   } else if constexpr (EPI == EPI_BIAS_RESID) {
     v = v * keep + *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
     *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;

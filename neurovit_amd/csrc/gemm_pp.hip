@@ -35,20 +35,28 @@ constexpr int PP_GM = 4;        // tile rows per group of the tile order (4 x 25
 
 // per-lane DMA source offsets (bytes) of pieces I = lw, lw + 4, lw + 8, lw + 12 of one 128-wide sub-image (four loader waves);
 // rc0 = first matrix row (K-contiguous operand) / first matrix column (K-strided operand) of the sub-image
-template <bool T>
+template <bool T, int ESZ = 2>
 __device__ __forceinline__ void pp_offsets(long ld, int rc0, int lw, int lane, int (&voff)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int I = lw + 4 * i;
     if constexpr (!T) {
       const int row = I * 8 + (lane >> 3), ch = (lane & 7) ^ ((lane >> 3) & 7);            // img128_off inverse
-      voff[i] = (int)((((long)(rc0 + row)) * ld + (ch << 3)) * 2);
+      voff[i] = (int)(((long)(rc0 + row)) * ld * ESZ + (ch << 4));
     } else {
+      static_assert(ESZ == 2, "K-strided operands are bf16 only");
       const int krow = I * 4 + (lane >> 4);
       const int ch = (lane & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3));                // img256_off inverse
       voff[i] = (int)(((long)krow * ld + rc0 + (ch << 3)) * 2);
     }
   }
+}
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x8 f8cat(bf16x8 lo, bf16x8 hi) {      // 2 x 16 bytes -> the 32-byte fp8 operand of one lane
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 a = __builtin_bit_cast(i32x4, lo), b = __builtin_bit_cast(i32x4, hi);
+  return i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -65,7 +73,11 @@ __device__ __forceinline__ void pp_offsets(long ld, int rc0, int lw, int lane, i
 // while group 0's reads are in flight, and group 1 reads while group 0 computes - the matrix pipe never waits for LDS, with a
 // quarter of the barriers of a phase-by-phase ping-pong (measured: the barrier-per-phase form lost 25 % of the MFMA-only rate
 // to barrier overhead and to loaders that arrive late at a 256-cycle barrier interval).
-template <int BM, int BN, int WM, int WN, bool A_T, bool B_T, int EPI, int DBG = 0>
+// F8: both operands are OCP e4m3 bytes, K-contiguous; a ring stage is 128 elements deep (the same 128-byte rows, images, DMA pieces
+// and fragment reads as bf16) and each 16 x 16 output block takes ONE v_mfma_scale_f32_16x16x128_f8f6f4 per stage (unit block
+// scales; 32 cycles, i.e. the cycles of the two bf16 MFMAs it replaces at twice their K: double the FLOPs per byte and per cycle).
+// The k order inside a lane's 32 bytes is [chunk g | chunk 4 + g] of the row for BOTH operands - a dot product does not care.
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_T, int EPI, int DBG = 0, bool F8 = false>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the declaration (it rejects the TN instantiation of this body)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -89,21 +101,23 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
   const int gsz = (tiles_m - first_m < PP_GM) ? tiles_m - first_m : PP_GM;
   const int rin = bid - gid * per_group;
   const int m0 = (first_m + rin % gsz) * BM, n0 = (rin / gsz) * BN;
-  const int nk = (g.K + BK - 1) / BK;
+  constexpr int ESZ = F8 ? 1 : 2, KT = F8 ? 2 * BK : BK;      // element bytes, elements per ring stage
+  static_assert(!F8 || (!A_T && !B_T), "fp8 operands are K-contiguous");
+  const int nk = (g.K + KT - 1) / KT;
 
   if (wid >= PP_CWAVES) {
     // ------------------------------------------------------------------ loader waves: LDS-DMA only
     const int lw = wid - PP_CWAVES;
-    const unsigned bytesA = (unsigned)((((long)(A_T ? g.K : g.M) - 1) * g.lda + (A_T ? g.M : g.K)) * 2);
-    const unsigned bytesB = (unsigned)((((long)(B_T ? g.K : g.N) - 1) * g.ldb + (B_T ? g.N : g.K)) * 2);
+    const unsigned bytesA = (unsigned)((((long)(A_T ? g.K : g.M) - 1) * g.lda + (A_T ? g.M : g.K)) * ESZ);
+    const unsigned bytesB = (unsigned)((((long)(B_T ? g.K : g.N) - 1) * g.ldb + (B_T ? g.N : g.K)) * ESZ);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, bytesB, 0x00020000);
     int voA[NSA][4], voB[NSB][4];
 #pragma unroll
-    for (int s = 0; s < NSA; ++s) pp_offsets<A_T>(g.lda, ((DBG & 2) ? 0 : m0) + 128 * s, lw, lane, voA[s]);
+    for (int s = 0; s < NSA; ++s) pp_offsets<A_T, ESZ>(g.lda, ((DBG & 2) ? 0 : m0) + 128 * s, lw, lane, voA[s]);
 #pragma unroll
-    for (int s = 0; s < NSB; ++s) pp_offsets<B_T>(g.ldb, ((DBG & 2) ? 0 : n0) + 128 * s, lw, lane, voB[s]);
-    const int stepA = (DBG & 2) ? 0 : (int)((A_T ? (long)BK * g.lda : BK) * 2), stepB = (DBG & 2) ? 0 : (int)((B_T ? (long)BK * g.ldb : BK) * 2);
+    for (int s = 0; s < NSB; ++s) pp_offsets<B_T, ESZ>(g.ldb, ((DBG & 2) ? 0 : n0) + 128 * s, lw, lane, voB[s]);
+    const int stepA = (DBG & 2) ? 0 : (int)((A_T ? (long)BK * g.lda : KT) * ESZ), stepB = (DBG & 2) ? 0 : (int)((B_T ? (long)BK * g.ldb : KT) * ESZ);
     auto issue_tile = [&](int t, char* dst) {
 #pragma unroll
       for (int s = 0; s < NSA; ++s)
@@ -162,10 +176,17 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
     fa[i][1] = read_frag<A_T, 128>((img) + a_off, a_rc + 16 * i, 1, lane);     \
   }
 #define PP_MFMA(I0)                                                             \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                             \
+  if constexpr (!F8) {                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                           \
+      _Pragma("unroll") for (int i = (I0); i < (I0) + MH; ++i)                 \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j)                         \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);  \
+  } else {                                                                      \
     _Pragma("unroll") for (int i = (I0); i < (I0) + MH; ++i)                   \
       _Pragma("unroll") for (int j = 0; j < NI; ++j)                           \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(f8cat(fb[j][0], fb[j][1]), f8cat(fa[i][0], fa[i][1]), acc[i][j], \
+                                                                     0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);                         \
+  }
 
   int slot = 0;
   if (grp == 0) {
@@ -222,6 +243,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
 template <int BM, int BN, int WM, int WN, bool A_T, bool B_T, int EPI>
 __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_kernel(const GemmArgs g) {
   gemm_pp_body<BM, BN, WM, WN, A_T, B_T, EPI>(g, xcd_remap(blockIdx.x, gridDim.x));
+}
+template <int EPI>
+__global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_f8_kernel(const GemmArgs g) {
+  gemm_pp_body<PP_BM, PP_BN, 4, 2, false, false, EPI, 0, true>(g, xcd_remap(blockIdx.x, gridDim.x));
 }
 template <int DBG>
 __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_dbg_kernel(const GemmArgs g) {
@@ -295,6 +320,36 @@ int launch_pp(int layout, int epi, const GemmArgs& a, hipStream_t s) {
     default: break;
   }
   nv_set_error("nv_gemm_bf16/pp: unsupported layout/epilogue combination (%d, %d)", layout, epi);
+  return NV_ERR_ARG;
+}
+
+template <int EPI>
+static int launch_pp_f8_t(const GemmArgs& a, hipStream_t s) {
+  constexpr int LDS = PP_S * (PP_BM / 128 + PP_BN / 128) * PP_SUB;
+  const int tiles = ((a.M + PP_BM - 1) / PP_BM) * ((a.N + PP_BN - 1) / PP_BN);
+  auto kern = gemm_pp_f8_kernel<EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int slot = nv_prof_begin(5, 2.0 * a.M * a.N * a.K, s);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(PP_THREADS), LDS, s, a);
+  nv_prof_end(slot, s);
+  NV_CHECK_LAUNCH("nv_gemm_f8");
+  return NV_OK;
+}
+
+// fp8 (OCP e4m3) x fp8, NT layout, fp32 accumulate, per-column dequantisation in the epilogue
+int launch_pp_f8(int epi, const GemmArgs& a, hipStream_t s) {
+  switch (epi) {
+    case EPI_STORE_BF16: return launch_pp_f8_t<EPI_STORE_BF16>(a, s);
+    case EPI_STORE_F32: return launch_pp_f8_t<EPI_STORE_F32>(a, s);
+    case EPI_BIAS_RESID: return launch_pp_f8_t<EPI_BIAS_RESID>(a, s);
+    case EPI_BIAS_GELU_F8: return launch_pp_f8_t<EPI_BIAS_GELU_F8>(a, s);
+    default: break;
+  }
+  nv_set_error("nv_gemm_f8: unsupported epilogue %d (0 bf16 store, 1 f32 store, 4 bias + residual, 7 bias + GELU -> fp8)", epi);
   return NV_ERR_ARG;
 }
 

@@ -102,6 +102,52 @@ class VitRuntime:
         self._dropout = dropout
         return logits
 
+    # ------------------------------------------------------------------ fp8 inference (BASELINE.json configs[4])
+    def calibrate_fp8(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, headroom: float = 2.0):
+        """One bf16 forward of `video` with every layer's activations kept; returns the per-layer activation scales
+        [depth][3] = 448 / (headroom * amax) of the LN1 output, the LN2 output and the GELU output.  e4m3 is a floating
+        format: headroom costs no relative precision, it only moves the subnormal floor."""
+        self.forward(video, params, params16, training=True)
+        B = video.shape[0]
+        n = (self.cfg.frames // self.cfg.frame_patch_size) * (self.cfg.image_size // self.cfg.image_patch_size) ** 2 + 1
+        scales = []
+        for l in range(self.cfg.depth):
+            row = []
+            for name, width in (("xn1", self.cfg.dim), ("xn2", self.cfg.dim), ("h", self.cfg.mlp_dim)):
+                amax = float(self.tap(name, l, (B * n, width), torch.bfloat16).abs().max())     # calibration only: off the hot path
+                row.append(448.0 / (headroom * max(amax, 1e-6)))
+            scales.append(row)
+        return scales
+
+    def quantize_fp8(self, params: torch.Tensor, act_scales):
+        """fp8 weight arena (bytes at the parameter arena's element offsets) + column scales for the given activation scales."""
+        cnt = lib.nv_vit_fp8_scale_count(ctypes.byref(self.cfg))
+        if cnt < 0:
+            check(-1, "nv_vit_fp8_scale_count")
+        flat = [float(v) for row in act_scales for v in row]
+        host = (ctypes.c_float * len(flat))(*flat)
+        p8 = torch.zeros(params.numel(), dtype=torch.uint8, device=params.device)
+        cs = torch.empty(cnt, dtype=torch.float32, device=params.device)
+        check(lib.nv_vit_quantize_fp8(ctypes.byref(self.cfg), params.data_ptr(), ctypes.cast(host, ctypes.c_void_p), p8.data_ptr(), cs.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream), "nv_vit_quantize_fp8")
+        return dict(params8=p8, colscales=cs, act_scales=host, act_list=act_scales)
+
+    def forward_fp8(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, f8) -> torch.Tensor:
+        if not video.is_cuda:
+            raise RuntimeError("neurovit_amd: ViT forward needs a CUDA/HIP tensor on MI355X - there is no CPU fallback")
+        assert video.dtype == torch.float32 and video.dim() == 5
+        B = video.shape[0]
+        ws = self.workspace(B, False, video.device)
+        logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
+        check(lib.nv_vit_forward_fp8(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video), params.data_ptr(),
+                                     params16.data_ptr(), f8["params8"].data_ptr(), f8["colscales"].data_ptr(),
+                                     ctypes.cast(f8["act_scales"], ctypes.c_void_p), ws.data_ptr(), ws.numel(), logits.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream), "nv_vit_forward_fp8")
+        self._last = (B, False, ws, video)
+        self.generation += 1
+        self.backward_done = False
+        return logits
+
     def backward(self, dlogits: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, grads: torch.Tensor,
                  accumulate: bool, stages: Optional[Tuple[int, int]] = None, join_aux: bool = True) -> None:
         """Whole backward, or only stages [first, last] (0 = head, 1+k = layer depth-1-k, depth+1 = embedding).

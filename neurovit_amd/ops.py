@@ -282,3 +282,38 @@ def gemm_dgelu_colsum(A: torch.Tensor, B: torch.Tensor, u: torch.Tensor, drop_se
     part = torch.empty(((M + rows - 1) // rows, N), dtype=torch.float32, device=A.device)
     out = gemm(NN, EPI_DGELU_COLSUM, A, B, aux_in=u, aux_out=part, drop_seed=drop_seed, drop_p=drop_p)
     return out, part
+
+
+EPI_BIAS_GELU_F8 = 7
+
+
+def quant_rows_f8(W: torch.Tensor, act_scale: float):
+    """fp32 [rows, cols] -> (e4m3 bytes uint8 [rows, cols], colscale f32 [rows] = 1 / (act_scale * row scale))."""
+    _need_cuda(W)
+    rows, cols = W.shape
+    out = torch.empty((rows, cols), dtype=torch.uint8, device=W.device)
+    cs = torch.empty(rows, dtype=torch.float32, device=W.device)
+    check(lib.nv_quant_rows_f8(_p(W), W.stride(0), rows, cols, _p(out), cols, float(act_scale), _p(cs), _stream()), "nv_quant_rows_f8")
+    return out, cs
+
+
+def ln_fwd_f8(x: torch.Tensor, gamma, beta, out_scale: float, eps: float = 1e-5) -> torch.Tensor:
+    _need_cuda(x)
+    M, d = x.shape
+    y = torch.empty((M, d), dtype=torch.uint8, device=x.device)
+    check(lib.nv_ln_fwd_f8(_p(x), x.stride(0), M, d, _p(gamma), _p(beta), eps, float(out_scale), _p(y), d, _stream()), "nv_ln_fwd_f8")
+    return y
+
+
+def gemm_f8(epi: int, A8: torch.Tensor, B8: torch.Tensor, colscale: torch.Tensor, *, bias=None, aux_in=None, out_scale: float = 1.0, out=None):
+    """C = epi((A8 B8^T) * colscale[n]); A8 [M, K], B8 [N, K] e4m3 bytes (uint8 tensors)."""
+    _need_cuda(A8, B8)
+    assert A8.dtype == torch.uint8 and B8.dtype == torch.uint8
+    M, K = A8.shape
+    N = B8.shape[0]
+    odt = {EPI_STORE_BF16: torch.bfloat16, EPI_STORE_F32: torch.float32, EPI_BIAS_RESID: torch.float32, EPI_BIAS_GELU_F8: torch.uint8}[epi]
+    if out is None:
+        out = torch.empty((M, N), dtype=odt, device=A8.device)
+    check(lib.nv_gemm_f8(epi, M, N, K, _p(A8), A8.stride(0), _p(B8), B8.stride(0), _p(out), out.stride(0), _p(colscale), _p(bias), _p(aux_in),
+                         0 if aux_in is None else aux_in.stride(0), float(out_scale), _stream()), "nv_gemm_f8")
+    return out

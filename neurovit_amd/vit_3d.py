@@ -206,9 +206,9 @@ class _ViTFunction(torch.autograd.Function):
     arena (which `param.grad` views), so backward returns None for them (no per-tensor accumulate copies)."""
 
     @staticmethod
-    def forward(ctx, module, video, *params):
-        # grad mode is always off inside Function.forward: needs_input_grad tells whether a graph is being built
-        need_grad = any(ctx.needs_input_grad[2:])
+    def forward(ctx, module, video, need_grad, *params):
+        # need_grad is decided by the caller: grad mode is always off inside Function.forward, and ctx.needs_input_grad
+        # reflects requires_grad alone (it stays True under torch.no_grad()), so neither tells whether a graph is being built
         ctx.module = module
         out = module._run_forward(video, need_grad)
         ctx.generation = module._rt.generation     # the workspace holds THIS forward's activations until the next forward
@@ -224,7 +224,7 @@ class _ViTFunction(torch.autograd.Function):
                 "before the next forward of the same module (siamese / two-forward losses need one module instance per branch).")
         ctx.module._run_backward(dlogits)
         rt.backward_done = True
-        return (None, None) + (None,) * len(ctx.module._plist)
+        return (None, None, None) + (None,) * len(ctx.module._plist)
 
 
 class ViT(nn.Module):
@@ -287,6 +287,7 @@ class ViT(nn.Module):
         self._shadow_key = None
         self._last_logits = None   # most recent forward's logits (the Trainer shell reads them without a second forward)
         self._grad_sync = None     # parallel.GradSync: all-reduce gradient buckets while backward still runs
+        self._fp8 = None           # enable_fp8(): e4m3 weights + scales for inference forwards
 
     # ------------------------------------------------------------------ arena management
     def _build_arena(self):
@@ -349,6 +350,21 @@ class ViT(nn.Module):
             ops.cast_bf16(self._arena.view(1, -1), out=self._shadow.view(1, -1))
             self._shadow_key = key
 
+    # ------------------------------------------------------------------ fp8 inference (BASELINE.json configs[4])
+    def enable_fp8(self, calibration_video: torch.Tensor, headroom: float = 2.0):
+        """Switch inference forwards (no grad being recorded) to the fp8 path: qkv / FC1 / FC2 of every block on OCP e4m3 MFMA
+        operands.  `calibration_video` ([B, C, F, H, W] on the device) fixes the per-tensor activation scales; weights are
+        re-quantised from the fp32 master parameters (call again after training steps).  Training forwards keep using bf16."""
+        self.flat_parameters()
+        self._refresh_shadow()
+        scales = self._rt.calibrate_fp8(calibration_video.float(), self._arena, self._shadow, headroom)
+        self._fp8 = self._rt.quantize_fp8(self._arena, scales)
+        self._fp8["key"] = tuple(p._version for p in self._plist)
+        return scales
+
+    def disable_fp8(self):
+        self._fp8 = None
+
     # ------------------------------------------------------------------ execution
     def _run_forward(self, video, need_grad):
         drop = (0.0, 0.0, 0)
@@ -358,6 +374,11 @@ class ViT(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             drop = (self._dropout_p[0], self._dropout_p[1], seed)
         self._refresh_shadow()
+        if self._fp8 is not None and not need_grad and not self.training:
+            if self._fp8["key"] != tuple(p._version for p in self._plist):      # parameters changed since quantisation
+                self._fp8 = dict(self._rt.quantize_fp8(self._arena, self._fp8["act_list"]), key=tuple(p._version for p in self._plist))
+            self._last_logits = self._rt.forward_fp8(video, self._arena, self._shadow, self._fp8)
+            return self._last_logits
         self._last_logits = self._rt.forward(video, self._arena, self._shadow, training=need_grad, dropout=drop)
         return self._last_logits
 
@@ -410,7 +431,8 @@ class ViT(nn.Module):
             self._build_arena()
         if self._arena.device != video.device:
             raise RuntimeError(f"neurovit_amd.ViT: parameters on {self._arena.device}, input on {video.device}")
-        return _ViTFunction.apply(self, video.float(), *self._plist)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)
+        return _ViTFunction.apply(self, video.float(), need_grad, *self._plist)
 
     # activations / gradients of the last block's attention LayerNorm output (Grad-CAM contract, NeuroEncoder.py:70-82)
     def last_attn_norm_output_raw(self) -> torch.Tensor:

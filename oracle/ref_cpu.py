@@ -85,6 +85,18 @@ def strip_prefix(sd: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Te
 CAST_OFF = set()
 
 
+def _q8(x: torch.Tensor, scale) -> torch.Tensor:
+    """OCP e4m3 quantise-dequantise (round to nearest even, saturating at +-448), fp32 storage: the fp8 path's cast points."""
+    return (x * scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) / scale
+
+
+def _q8_rows(w: torch.Tensor) -> torch.Tensor:
+    """Per-output-row weight quantisation of csrc/quant.hip::quant_rows_f8_kernel."""
+    amax = w.abs().amax(dim=1, keepdim=True)
+    sw = torch.where(amax > 0, 448.0 / amax, torch.ones_like(amax))
+    return _q8(w, sw)
+
+
 def _r(x: torch.Tensor, point: Optional[str] = None) -> torch.Tensor:
     """Round-to-nearest-even to bf16, keep fp32 storage.  Autograd: identity."""
     if point is not None and point in CAST_OFF:
@@ -286,7 +298,7 @@ def _linear(x, w, b, emulate, xpoint=None):
     return F.linear(x, w, b)
 
 
-def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None, drop=None):
+def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None, drop=None, f8=None):
     """Attention.forward (vit_3d.py:48-60).  `pre` = 'transformer.layers.{i}.0.'.
     drop = (p, seed_attn, seed_out) applies the HIP path's dropout masks (train mode, p > 0)."""
     B, n, d = x.shape
@@ -294,7 +306,9 @@ def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None, drop=None):
     xn = F.layer_norm(x, (d,), sd[pre + "norm.weight"], sd[pre + "norm.bias"], LN_EPS)
     if taps is not None:
         taps[pre + "norm.out"] = xn
-    if emulate:
+    if f8 is not None:          # fp8 path: LN output and to_qkv weight in e4m3, fp32 accumulate, bf16 qkv (f8 = scale of the LN output)
+        qkv = _r(F.linear(_q8(xn, f8), _q8_rows(sd[pre + "to_qkv.weight"])), "qkv")
+    elif emulate:
         xn = _r(xn, "xn1")
         qkv = _r(_linear(xn, sd[pre + "to_qkv.weight"], None, True, "xn1"), "qkv")
     else:
@@ -324,13 +338,17 @@ def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None, drop=None):
     return out
 
 
-def feed_forward(sd, pre, x, emulate=False, drop=None):
+def feed_forward(sd, pre, x, emulate=False, drop=None, f8=None):
     """FeedForward.forward (vit_3d.py:16-26).  `pre` = 'transformer.layers.{i}.1.'.  drop = (p, seed_hidden, seed_out)."""
     d = x.shape[-1]
     rows = x.shape[0] * x.shape[1]
     hmask = drop_mask(drop[1], drop[0], (rows, sd[pre + "net.1.weight"].shape[0])).reshape(x.shape[0], x.shape[1], -1) if drop else None
     omask = drop_mask(drop[2], drop[0], (rows, d)).reshape(x.shape) if drop else None
     xn = F.layer_norm(x, (d,), sd[pre + "net.0.weight"], sd[pre + "net.0.bias"], LN_EPS)
+    if f8 is not None:          # fp8 path: f8 = (scale of the LN output, scale of the GELU output)
+        u = F.linear(_q8(xn, f8[0]), _q8_rows(sd[pre + "net.1.weight"])) + sd[pre + "net.1.bias"]
+        h = _q8(F.gelu(u), f8[1])
+        return F.linear(h, _q8_rows(sd[pre + "net.4.weight"])) + sd[pre + "net.4.bias"]
     if emulate:
         u = _linear(_r(xn, "xn2"), sd[pre + "net.1.weight"], sd[pre + "net.1.bias"], True, "xn2")
         h = _GeluEmu.apply(u, torch.ones(()) if hmask is None else hmask)
@@ -363,7 +381,7 @@ def patch_embed(sd, cfg: ViTCfg, video, emulate=False, taps=None, drop=None):
 
 def vit_forward(sd: Dict[str, torch.Tensor], cfg: ViTCfg, video: torch.Tensor,
                 emulate_bf16: bool = False, taps: Optional[dict] = None,
-                dropout: Optional[Tuple[float, float, int]] = None) -> torch.Tensor:
+                dropout: Optional[Tuple[float, float, int]] = None, fp8_scales=None) -> torch.Tensor:
     """ViT.forward (vit_3d.py:112-126).  video: [B, C, F, H, W].
     dropout = None (eval / p = 0) or (p_blocks, p_embedding, seed): train-mode dropout with the HIP path's masks."""
     dp = dropout if dropout and (dropout[0] > 0 or dropout[1] > 0) else None
@@ -372,8 +390,10 @@ def vit_forward(sd: Dict[str, torch.Tensor], cfg: ViTCfg, video: torch.Tensor,
         pa, pf = f"transformer.layers.{i}.0.", f"transformer.layers.{i}.1."
         da = (dp[0], site_seed(dp[2], 4 * i + 0), site_seed(dp[2], 4 * i + 1)) if dp and dp[0] > 0 else None
         df = (dp[0], site_seed(dp[2], 4 * i + 2), site_seed(dp[2], 4 * i + 3)) if dp and dp[0] > 0 else None
-        x = attention(sd, pa, x, cfg.heads, cfg.dim_head, emulate_bf16, taps, da) + x
-        x = feed_forward(sd, pf, x, emulate_bf16, df) + x
+        f8a = fp8_scales[i][0] if fp8_scales is not None else None      # fp8 inference path (csrc/engine.hip::nv_vit_forward_fp8)
+        f8f = (fp8_scales[i][1], fp8_scales[i][2]) if fp8_scales is not None else None
+        x = attention(sd, pa, x, cfg.heads, cfg.dim_head, emulate_bf16, taps, da, f8a) + x
+        x = feed_forward(sd, pf, x, emulate_bf16, df, f8f) + x
         if taps is not None:
             taps[f"block{i}"] = x
     x = x.mean(dim=1) if cfg.pool == "mean" else x[:, 0]

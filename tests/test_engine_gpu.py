@@ -280,3 +280,34 @@ def test_base_config_properties(eng):
     report(f"base fwd logits vs emulating oracle: rel {e:.3e}; vs fp32 oracle (G4): rel {e32:.3e}")
     assert e <= MAXREL          # two numbers: L2 and max-norm coincide
     assert e32 < 2.6e-3         # G4 at base size: 1.5 x the measured 1.70e-3
+
+
+def test_fp8_inference_forward_vs_fp8_emulating_oracle(eng):
+    """BASELINE.json configs[4] asks for fp8 MFMA on the large model.  The fp8 inference path (qkv / FC1 / FC2 on OCP e4m3
+    operands, per-row weight scales, calibrated per-tensor activation scales) against an oracle with the same cast points
+    (oracle/ref_cpu.py: fp8_scales=...), three-way against fp32.  Tolerance, stated: e4m3 carries 3 mantissa bits (2^-4 relative
+    per element), so logits sit at a few 1e-2 of the fp32 result - ten times the bf16 path; the gate is that the HIP path is no
+    further from fp32 than the emulation of its own arithmetic (x 1.5 + 5e-3), and within 6e-2 of fp32 outright."""
+    cfgdict = dict(W.MICRO, depth=3)
+    sd = W.make_tensors(W.vit_param_spec(**cfgdict), 51)
+    cfg, off, num, arena = load_arena(eng, cfgdict, sd)
+    params = arena.cuda()
+    p16 = params.bfloat16()
+    rt = eng.VitRuntime(cfg)
+    fmri = W.make_volume((3, 32, 32, 32), 52)
+    video = ref_cpu.fmri_to_video(fmri.cuda())
+    scales = rt.calibrate_fp8(video, params, p16)
+    f8 = rt.quantize_fp8(params, scales)
+    a = rt.forward_fp8(video, params, p16, f8).clone()
+    b = rt.forward_fp8(video, params, p16, f8)
+    assert torch.equal(a, b)
+    bf = rt.forward(video, params, p16, training=False)
+    with torch.no_grad():
+        ocfg = ref_cpu.ViTCfg(**cfgdict)
+        v = ref_cpu.fmri_to_video(fmri)
+        ref32 = ref_cpu.vit_forward(sd, ocfg, v)
+        emu8 = ref_cpu.vit_forward(sd, ocfg, v, emulate_bf16=True, fp8_scales=scales)
+    e_hip, e_emu, e_pair, e_bf = rel_err(a, ref32), rel_err(emu8, ref32), rel_err(a, emu8), rel_err(bf, ref32)
+    report(f"fp8 forward (micro, depth 3): HIP vs fp32 {e_hip:.3e}; fp8 emulation vs fp32 {e_emu:.3e}; HIP vs emulation {e_pair:.3e}; bf16 path vs fp32 {e_bf:.3e}")
+    assert e_hip <= RATIO * e_emu + 5e-3 and e_hip < 6e-2
+    assert e_pair < 6e-2

@@ -251,6 +251,56 @@ def test_gemm_dgelu_fused_colsum_and_reduce_multi(ops, tile):
     assert_close_f32(db, 2 * want, "colsum accumulate", 1e-5)
 
 
+def _e4m3(t):
+    """fp32 -> OCP e4m3 (round to nearest even, saturating) on the CPU: (bytes, dequantised fp32)."""
+    q = t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), q.float()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (2052, 2304, 768), (520, 392, 1024), (300, 8, 256)])
+def test_gemm_fp8_kernel(ops, M, N, K):
+    """fp8 (OCP e4m3) GEMM on v_mfma_scale_f32_16x16x128_f8f6f4: exact integer-free check - the operands are exactly representable,
+    products are accumulated in fp32, so the result must match the fp64 product of the DEQUANTISED operands to fp32 rounding;
+    row quantisation and the LayerNorm -> fp8 kernel are checked byte for byte against torch's e4m3 conversion."""
+    W = rnd(N, K, seed=2, scale=K ** -0.5)
+    x = rnd(M, K, seed=1)
+    sa = 448.0 / float(x.abs().max()) * 0.5
+    w8, cs = ops.quant_rows_f8(dev(W), sa)
+    sw = 448.0 / W.abs().amax(dim=1, keepdim=True)
+    ref8, wdq = _e4m3(W * sw)
+    assert (w8.cpu().to(torch.int16) - ref8.to(torch.int16)).abs().max().item() <= 1          # reciprocal rounding may move a tie
+    assert (w8.cpu() != ref8).float().mean().item() < 1e-3
+    assert_close_f32(cs, (1.0 / (sa * sw)).reshape(-1).double(), "colscale", 1e-6)
+    a8, adq = _e4m3(x * sa)
+    wdq_dev = w8.cpu().view(torch.float8_e4m3fn).float()                                     # what the device actually multiplies
+    ref = (adq.double() @ wdq_dev.double().T) * cs.cpu().double()
+    bias, resid = rnd(N, seed=3), rnd(M, N, seed=4)
+    A8 = dev(a8)
+    assert_close_f32(ops.gemm_f8(ops.EPI_STORE_F32, A8, w8, cs), ref, "f8.store_f32", 1e-4)   # the K = 128 MFMA sums its 128 products with fewer guard bits than an fp32 fma chain: 2e-5 measured
+    assert_close_bf16(ops.gemm_f8(ops.EPI_STORE_BF16, A8, w8, cs), ref, "f8.store_bf16")
+    assert_close_f32(ops.gemm_f8(ops.EPI_BIAS_RESID, A8, w8, cs, bias=dev(bias), aux_in=dev(resid)), ref + bias.double() + resid.double(), "f8.resid", 1e-4)
+    h8 = ops.gemm_f8(ops.EPI_BIAS_GELU_F8, A8, w8, cs, bias=dev(bias), out_scale=16.0)
+    _, want = _e4m3((F.gelu(ref + bias.double()) * 16.0).float())
+    got = h8.cpu().view(torch.float8_e4m3fn).float()
+    step = torch.maximum(want.abs(), torch.tensor(2.0 ** -6)) * 0.126 + 2.0 ** -9            # one e4m3 code step (3 mantissa bits)
+    assert ((got - want).abs() <= step).all()                                                # -0 == +0; at most one step at rounding ties
+    assert (got != want).float().mean().item() < 2e-2
+    first = ops.gemm_f8(ops.EPI_STORE_F32, A8, w8, cs)
+    for _ in range(3):
+        assert torch.equal(ops.gemm_f8(ops.EPI_STORE_F32, A8, w8, cs), first)
+
+
+def test_ln_fwd_fp8(ops):
+    M, d = 2052, 1024
+    x, gamma, beta = rnd(M, d, seed=1) * 2 + 0.3, 1 + 0.1 * rnd(d, seed=2), 0.1 * rnd(d, seed=3)
+    y8 = ops.ln_fwd_f8(dev(x), dev(gamma), dev(beta), 32.0)
+    ref = F.layer_norm(x.double(), (d,), gamma.double(), beta.double(), 1e-5) * 32.0
+    _, want = _e4m3(ref.float())
+    got = y8.cpu().view(torch.float8_e4m3fn).float()
+    step = torch.maximum(want.abs(), torch.tensor(2.0 ** -6)) * 0.126 + 2.0 ** -9
+    assert ((got - want).abs() <= step).all() and (got != want).float().mean().item() < 1e-2
+
+
 def test_gemm_rejects_bad_args(ops):
     A, B = dev(bf(rnd(16, 12))), dev(bf(rnd(8, 12)))
     with pytest.raises((RuntimeError, AssertionError)):

@@ -90,6 +90,30 @@ def main():
         if "big" not in name and not name.startswith(("x", "b20", "lrg")):
             tot_t += us; tot_f += fl
         print(f"{name}  M={Mo:5d} N={N:5d} K={K:5d}  {us:8.2f} us  {fl / us / 1e6:8.1f} TFLOP/s", flush=True)
+    if not a.only or "f8" in a.only:
+        for name, Mo, N, K in (("f8 big ", 8192, 8192, 4096), ("f8 lrg qkv", 16388, 3072, 1024), ("f8 lrg fc1 gelu->f8", 16388, 4096, 1024), ("f8 lrg fc2 resid", 16388, 1024, 4096),
+                               ("f8 b20 qkv", 10260, 2304, 768)):
+            A8 = torch.randint(0, 120, (Mo, K), dtype=torch.uint8, device=dev)
+            B8 = torch.randint(0, 120, (N, K), dtype=torch.uint8, device=dev)
+            cs = torch.rand(N, device=dev) * 1e-3
+            bias = torch.randn(N, device=dev)
+            resid = torch.randn(Mo, N, device=dev)
+            epi = ops.EPI_BIAS_GELU_F8 if "gelu" in name else (ops.EPI_BIAS_RESID if "resid" in name else ops.EPI_STORE_BF16)
+            kw = dict(bias=bias) if epi != ops.EPI_STORE_BF16 else {}
+            if epi == ops.EPI_BIAS_RESID:
+                kw["aux_in"] = resid
+            out = ops.gemm_f8(epi, A8, B8, cs, **kw)
+            for _ in range(3):
+                ops.gemm_f8(epi, A8, B8, cs, out=out, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(a.iters):
+                ops.gemm_f8(epi, A8, B8, cs, out=out, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / a.iters
+            print(f"{name:22s} M={Mo:5d} N={N:5d} K={K:5d}  {us:8.2f} us  {2.0 * Mo * N * K / us / 1e6:8.1f} TFLOP/s", flush=True)
     if not a.only or "grouped" in a.only:
         g = torch.Generator(device="cpu").manual_seed(2)
         probs = []
