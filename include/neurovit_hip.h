@@ -144,7 +144,7 @@ int nv_embed_finish_bwd(const float* g, long ldg, const float* t, long ldt, cons
                         unsigned long drop_seed, float drop_p, void* stream);
 
 /* ---- multi-head attention core (vit_3d.py:51-59): qkv bf16 [B,n,3*inner] -> out bf16 [B,n,inner], lse f32 [B,heads,n] */
-int nv_attn_set_mode(int mode);   /* testing aid: 0 = heuristic, 1 = streaming kernels, 2 = LDS-resident kernels (n <= 576);
+int nv_attn_set_mode(int mode);   /* testing aid: 0 = heuristic, 1 = streaming kernels, 2 = LDS-resident kernels (n <= 576), 3 = wide streaming forward;
                                     + 20: resident forward with two partner waves per row group (key range split, merged through LDS) */
 int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
                 float* lse, unsigned long drop_seed, float drop_p, void* stream);

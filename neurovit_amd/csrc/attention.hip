@@ -376,6 +376,110 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
   }
 }
 
+// ================================================================================================ wide streaming forward
+// Long sequences / large batches (ViT3D-large: n = 4097; the 4D path: B*T = 20 volumes).  Against attn_fwd_kernel:
+//   * every wave owns TWO 16-row groups (32 query rows): one set of K / V fragment reads from LDS (8 ds_read_b128 +
+//     16 ds_read_b64_tr_b16 per 64-key tile) now feeds 32 MFMAs instead of 16 - the fragment reads were the streaming
+//     kernel's largest per-tile cost after the softmax;
+//   * K / V tiles arrive by LDS-DMA into a two-stage ring (no staging registers, no ds_write pass), ONE barrier per tile:
+//     the DMA of tile kt+1 is in flight while tile kt is computed.
+// Same tile order, same two-state online softmax, same per-group arithmetic as the other forward kernels: bit-identical.
+constexpr int WIDE_ROWS = 128;     // query rows per workgroup (4 waves x 32)
+__global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
+                                                               bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop) {
+  __shared__ __attribute__((aligned(16))) char wsmem[2 * 2 * IMG];      // [stage][K image | V image]
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const int q0 = blockIdx.x * WIDE_ROWS + 32 * wid;
+
+  bf16x8 qf[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int qrow = min(q0 + 16 * u + r, n - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[u][ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+  }
+
+  // LDS-DMA of one K and one V tile: 8 + 8 pieces of 1 KiB (8 rows x 128 B), pieces wid and wid + 4 of each per wave
+  const unsigned bytes = (unsigned)((((long)n - 1) * ld + DH) * 2);
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + inner), 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + 2 * inner), 0, bytes, 0x00020000);
+  int voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wid + 4 * i) * 8 + (lane >> 3);
+    voff[i] = (int)(((long)row * ld + (((lane & 7) ^ (row & 7)) << 3)) * 2);            // img128_off inverse
+  }
+  const int step = (int)(64 * ld * 2);
+  auto issue = [&](int t, char* stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_void_t*)(stage + (wid + 4 * i) * 1024), 16, voff[i], t * step, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_void_t*)(stage + IMG + (wid + 4 * i) * 1024), 16, voff[i], t * step, 0, 0);
+    }
+  };
+
+  f32x4 o[2][4], o0[2][4];
+  float m[2], l[2], m0[2], l0[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    m[u] = m0[u] = -INFINITY; l[u] = l0[u] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[u][t] = o0[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nkt = (n + TK - 1) / TK;
+  const int nh = attn_half_tiles(nkt);
+  issue(0, wsmem);
+  for (int kt = 0; kt < nkt; ++kt) {
+    char* cur = wsmem + (kt & 1) * 2 * IMG;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
+    __builtin_amdgcn_s_barrier();                         // ... everybody's; and every read of the other stage (tile kt-1) is done
+    if (kt + 1 < nkt) issue(kt + 1, wsmem + ((kt + 1) & 1) * 2 * IMG);
+    if (kt == nh) {                                       // second half of the key range: park the first state
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        m0[u] = m[u]; l0[u] = l[u]; m[u] = -INFINITY; l[u] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { o0[u][t] = o[u][t]; o[u][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
+    }
+    RowFrags F;
+    f32x4 s[2][4];
+    load_row_frags(cur, r, g, F);
+    mfma_rows(F, qf[0], s[0], true);
+    mfma_rows(F, qf[1], s[1], true);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tr_frags(cur + IMG, r, g, F);                    // V fragments requested before the softmax arithmetic
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_softmax(s[0], kt, kt == nkt - 1, n, o[0], m[0], l[0], scale_log2e, drop, blockIdx.y, q0 + r, g);
+    fwd_softmax(s[1], kt, kt == nkt - 1, n, o[1], m[1], l[1], scale_log2e, drop, blockIdx.y, q0 + 16 + r, g);
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_pv(F, s[0], o[0]);
+    fwd_pv(F, s[1], o[1]);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (nkt <= nh) {                                      // single tile: the (empty) second state is merged all the same
+      m0[u] = m[u]; l0[u] = l[u]; m[u] = -INFINITY; l[u] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { o0[u][t] = o[u][t]; o[u][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    softmax_merge(m0[u], l0[u], o0[u], m[u], l[u], o[u]);
+    const float ltot = group_sum(l0[u]);
+    const float inv = 1.0f / ltot;
+    const int q = q0 + 16 * u + r;
+    if (q < n) {
+      bf16* orow = out + ((long)b * n + q) * ldo + h * DH;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        *reinterpret_cast<bf16x4*>(orow + 16 * t + 4 * g) = cvt4(o0[u][t][0] * inv, o0[u][t][1] * inv, o0[u][t][2] * inv, o0[u][t][3] * inv);
+      if (g == 0 && lse) lse[((long)b * heads + h) * n + q] = (m0[u] + log2f(ltot)) * 0.69314718055994530942f;
+    }
+  }
+}
+
 static int g_attn_mode = 0;    // 0 = heuristic, 1 = streaming kernels, 2 = resident kernels (tests compare the two bit for bit)
 static int g_attn_split = 1;   // resident forward: waves per row group.  Two (partner waves split the key range, four waves per
                                // SIMD) measured the same 13.5 us as one at n = 513: the kernel is VALU/MFMA-issue bound, not latency bound
@@ -401,7 +505,11 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
                "nv_attn_fwd: bad dims");
   NV_CHECK_ARG(nv_aligned16(qkv) && nv_aligned16(out), "nv_attn_fwd: alignment");
   const int slot = nv_prof_begin(3, 4.0 * B * heads * (double)n * n * DH, stream);
-  if (attn_resident(n)) {
+  // LDS-resident K / V (one 144 KiB workgroup per CU) pays when there are few row groups (ViT3D-base at batch 4: 240 workgroups);
+  // with thousands of row groups the wide streaming kernel keeps several workgroups per CU and reads half the fragments
+  const long wide_groups = (long)B * heads * ((n + WIDE_ROWS - 1) / WIDE_ROWS);
+  const bool use_res = g_attn_mode != 3 && attn_resident(n) && (g_attn_mode == 2 || wide_groups < 768);
+  if (use_res) {
     NV_CHECK_ARG((long)n * ld_qkv < (1L << 30), "nv_attn_fwd: operand too large for 32-bit buffer offsets");
     const int lds = 2 * ((n + TK - 1) / TK) * IMG;
     static bool attr = false;
@@ -416,6 +524,9 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
     else
       hipLaunchKernelGGL(attn_fwd_res_kernel<1>, dim3(attn_res_blocks(n), B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
                          (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
+  } else if (g_attn_mode != 1 && (long)n * ld_qkv < (1L << 30)) {
+    hipLaunchKernelGGL(attn_fwd_wide_kernel, dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv,
+                       n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
   } else
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((n + TQ - 1) / TQ, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
                      heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));

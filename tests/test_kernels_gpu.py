@@ -465,6 +465,26 @@ def test_attention_resident_equals_streaming(ops, B, n, heads, drop):
     assert torch.isfinite(res[2][2].float()).all()
 
 
+@pytest.mark.parametrize("B,n,heads,drop", [(2, 1001, 2, 0.0), (1, 4097, 1, 0.0), (20, 513, 12, 0.0), (3, 700, 2, 0.1), (1, 129, 1, 0.0), (2, 65, 3, 0.2)])
+def test_attention_wide_forward_equals_streaming(ops, B, n, heads, drop):
+    """The wide streaming forward (32 query rows per wave, K / V tiles by LDS-DMA into a two-stage ring, one barrier per tile)
+    must reproduce the reference streaming kernel bit for bit (output; log-sum-exp to one ulp) on long sequences (n = 1001 of the
+    reference default, n = 4097 of ViT3D-large), the 4D batch (20 x 12 heads at n = 513), ragged last tiles and dropout."""
+    from neurovit_amd._cabi import lib
+    inner = heads * 64
+    qkv = dev(bf(rnd(B * n, 3 * inner, seed=n + heads)))
+    try:
+        lib.nv_attn_set_mode(1)
+        out1, lse1 = ops.attn_fwd(qkv, B, n, heads, drop_seed=7, drop_p=drop)
+        lib.nv_attn_set_mode(3)                   # force the wide kernel
+        out3, lse3 = ops.attn_fwd(qkv, B, n, heads, drop_seed=7, drop_p=drop)
+        out3b, _ = ops.attn_fwd(qkv, B, n, heads, drop_seed=7, drop_p=drop)
+    finally:
+        lib.nv_attn_set_mode(0)
+    assert torch.equal(out1, out3) and torch.equal(out3, out3b)
+    assert (lse1 - lse3).abs().max().item() <= 2e-6          # the final (m + log2 l) * ln 2 may contract differently: one ulp
+
+
 def test_attention_rescale_branch(ops):
     """Force the online-softmax rescale: one key in the LAST tile dominates one query row."""
     B, n, heads, dh = 1, 200, 1, 64
