@@ -27,8 +27,12 @@ sys.path.insert(0, ROOT)
 torch = None
 
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
-KIND_NAMES = {0: "gemm_ws_kernel NT (forward linears)", 1: "gemm_ws_kernel NN (data gradients)",
-              2: "gemm_ws_kernel TN (weight gradients, auxiliary stream)", 3: "attn_fwd_res_kernel", 4: "attn_bwd_dq_res + attn_bwd_dkv_res kernels"}
+# nv_prof kinds -> the rocprofv3 kernel names of the same launches (profiles/r02_*kernel_stats.csv)
+KIND_NAMES = {0: "gemm_ws_kernel<64,128,...,false,false,*> (NT: out-proj, FC2, patch embed)", 1: "gemm_ws_kernel<64,128,...,false,true,*> (NN: dxn1, dxn2, dAO)",
+              2: "gemm_ws_kernel<...,true,true,1> (TN: patch-embed weight gradient)", 3: "attn_fwd_res_kernel", 4: "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
+              10: "gemm_pp_kernel<256,128,4,2,false,false,*> (NT: qkv, FC1)", 11: "gemm_pp_kernel<256,128,4,2,false,true,*> (NN: dU with fused GELU' and bias column sums)",
+              12: "gemm_pp_kernel<256,128,4,2,true,true,1> (TN)", 13: "gemm_pp_grouped_tn_kernel (four weight gradients of a layer, auxiliary stream)"}
+GEMM_KINDS = (0, 1, 2, 10, 11, 12, 13)
 
 
 def parse():
@@ -364,7 +368,7 @@ def main():
             if ck.value:
                 kinds[k] = dict(ms=msk.value, flops=wk.value, launches=ck.value)
         lib.nv_prof_enable(0)
-        gemm = [kinds[k] for k in (0, 1, 2) if k in kinds]
+        gemm = [kinds[k] for k in GEMM_KINDS if k in kinds]
         g_ms, g_fl, g_n = sum(k["ms"] for k in gemm), sum(k["flops"] for k in gemm), sum(k["launches"] for k in gemm)
         return kinds, g_ms, g_fl, g_n
 
@@ -381,11 +385,13 @@ def main():
     rt.use_aux_stream = was
     achieved_serial = s_fl / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(tfile):
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tfile):      # PMC counters cannot be read in-process: measured with rocprofv3 --pmc on this same command
         tj = json.load(open(tfile))
         traffic, traffic_src = tj["traffic_MB_per_launch"] * 1e6, tj["source"]
-    roofline = {"bound": "mfma", "kernel": "gemm_ws_kernel (NT/NN/TN instantiations, all fused epilogues)",
+    roofline = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family: gemm_pp_kernel / gemm_pp_grouped_tn_kernel (256x128 tiles) + gemm_ws_kernel (64x128 tiles), all fused epilogues",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "bytes/launch (fabric fetch + write, PMC)", "traffic_source": traffic_src,
                 "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches_per_step": g_n // prof_steps,

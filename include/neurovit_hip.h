@@ -32,8 +32,8 @@ int nv_version(void);
 int nv_arch_ok(void);                 /* 1 iff the current HIP device is gfx950 */
 const char* nv_last_error(void);
 
-/* ---- optional per-launch hipEvent profiler (bench.py roofline leg).  kind: 0 gemm NT, 1 gemm NN, 2 gemm TN,
- * 3 attention fwd, 4 attention bwd.  nv_prof_summary synchronises; call it outside timed regions. */
+/* ---- optional per-launch hipEvent profiler (bench.py roofline leg).  kind: warp-specialised GEMM kernels 0 NT, 1 NN, 2 TN;
+ * 3 attention fwd, 4 attention bwd; 5 fp8 GEMM; eight-wave 256 x 128 GEMM kernel 10 NT, 11 NN, 12 TN, 13 grouped TN.  nv_prof_summary synchronises; call it outside timed regions. */
 int nv_prof_enable(int on);
 int nv_prof_summary(int kind, double* ms, double* work, long* count);
 

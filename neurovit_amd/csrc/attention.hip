@@ -132,7 +132,7 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4], int kt, bool last, in
       }
     const float psum = ps[0] + ps[1];
     if (__any(moved)) {
-      l = l * alpha + psum;
+      l = __builtin_fmaf(l, alpha, psum);      // explicit shape: the same rounding in every kernel that inlines this
 #pragma unroll
       for (int t = 0; t < 4; ++t) o[t] *= alpha;
     } else {

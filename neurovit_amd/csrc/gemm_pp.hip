@@ -272,7 +272,7 @@ int launch_pp_t(const GemmArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  const int slot = nv_prof_begin((A_T ? 2 : (B_T ? 1 : 0)), 2.0 * a.M * a.N * a.K, s);
+  const int slot = nv_prof_begin(10 + (A_T ? 2 : (B_T ? 1 : 0)), 2.0 * a.M * a.N * a.K, s);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(PP_THREADS), LDS, s, a);
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_bf16/pp");
@@ -363,7 +363,7 @@ int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  const int slot = nv_prof_begin(2, flops, s);
+  const int slot = nv_prof_begin(13, flops, s);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(PP_THREADS), LDS, s, G);
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_bf16_grouped/pp");
