@@ -858,6 +858,238 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf1
   }
 }
 
+// ------------------------------------------------------------------------------------------------ wide streaming backward
+// Long sequences (ViT3D-large, n = 4097): the same restructuring as attn_fwd_wide_kernel.  Every wave owns two 16-row groups
+// (query rows in the dQ pass, keys in the dK / dV pass), so one set of LDS fragment reads feeds twice the MFMAs; the streamed
+// operand tiles arrive by LDS-DMA into a two-stage ring with one barrier per tile.  Per-group arithmetic is that of the
+// streaming kernels (shared __device__ pieces).
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
+                                                                  const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse, int n,
+                                                                  int heads, float scale, float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                                  long ldd, DropCfg drop) {
+  __shared__ __attribute__((aligned(16))) char wsmem[2 * 2 * IMG];      // [stage][K image | V image]
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const int q0 = blockIdx.x * WIDE_ROWS + 32 * wid;
+  const float scale_log2e = scale * 1.44269504088896340736f;
+
+  bf16x8 qf[2][2], dof[2][2];
+  float dl[2], lse2[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int qrow = min(q0 + 16 * u + r, n - 1);
+    float d = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[u][ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+      const long off = ((long)b * n + qrow) * ldo + h * DH + 32 * ks + 8 * g;
+      dof[u][ks] = *reinterpret_cast<const bf16x8*>(dout + off);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(out + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += (float)dof[u][ks][j] * (float)of[j];
+    }
+    dl[u] = group_sum(d);
+    lse2[u] = lse[((long)b * heads + h) * n + qrow] * 1.44269504088896340736f;
+    if (g == 0 && q0 + 16 * u + r < n) delta[((long)b * heads + h) * n + q0 + 16 * u + r] = dl[u];
+  }
+
+  const unsigned bytes = (unsigned)((((long)n - 1) * ld + DH) * 2);
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + inner), 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + 2 * inner), 0, bytes, 0x00020000);
+  int voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wid + 4 * i) * 8 + (lane >> 3);
+    voff[i] = (int)(((long)row * ld + (((lane & 7) ^ (row & 7)) << 3)) * 2);            // img128_off inverse
+  }
+  const int step = (int)(64 * ld * 2);
+  auto issue = [&](int t, char* stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_void_t*)(stage + (wid + 4 * i) * 1024), 16, voff[i], t * step, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_void_t*)(stage + IMG + (wid + 4 * i) * 1024), 16, voff[i], t * step, 0, 0);
+    }
+  };
+
+  f32x4 dq[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dq[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nkt = (n + TK - 1) / TK;
+  issue(0, wsmem);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* cur = wsmem + (kt & 1) * 2 * IMG;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nkt) issue(kt + 1, wsmem + ((kt + 1) & 1) * 2 * IMG);
+    RowFrags F;
+    f32x4 sc[2][4], dp[2][4], ds[2][4];
+    load_row_frags(cur, r, g, F);
+    mfma_rows(F, qf[0], sc[0], true);
+    mfma_rows(F, qf[1], sc[1], true);
+    load_row_frags(cur + IMG, r, g, F);
+    mfma_rows(F, dof[0], dp[0], true);
+    mfma_rows(F, dof[1], dp[1], true);
+    dq_softmax_grad(sc[0], dp[0], ds[0], kt, n, dl[0], lse2[0], scale_log2e, drop, blockIdx.y, q0 + r, g);
+    dq_softmax_grad(sc[1], dp[1], ds[1], kt, n, dl[1], lse2[1], scale_log2e, drop, blockIdx.y, q0 + 16 + r, g);
+    load_tr_frags(cur, r, g, F);                          // (after the exponentials: requesting them earlier spills registers)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const bf16x8 dsf[2] = {cvt8(ds[u][0], ds[u][1]), cvt8(ds[u][2], ds[u][3])};
+      mfma_rows(F, dsf, dq[u], false);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int q = q0 + 16 * u + r;
+    if (q < n) {
+      bf16* drow = dqkv + ((long)b * n + q) * ldd + h * DH;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        *reinterpret_cast<bf16x4*>(drow + 16 * t + 4 * g) = cvt4(dq[u][t][0] * scale, dq[u][t][1] * scale, dq[u][t][2] * scale, dq[u][t][3] * scale);
+    }
+  }
+}
+
+// in-place form of dkv_softmax_grad for the wide kernel (p overwrites sc, ds overwrites dp: identical arithmetic, fewer live
+// registers); sLraw holds the raw natural-log lse of this query tile (converted to the log2 domain here: the same one rounding)
+__device__ __forceinline__ void dkv_softmax_grad_inplace(f32x4 (&sc)[4], f32x4 (&dp)[4], const float* sLraw, const float* sDl, int qt, int n,
+                                                         float scale_log2e, const DropCfg& drop, int bh, int keyabs, int g) {
+    const f32x2 c2 = {scale_log2e, scale_log2e};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLraw + 16 * t + 4 * g) * 1.44269504088896340736f;
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + 16 * t + 4 * g);
+      f32x4 f = {1.f, 1.f, 1.f, 1.f};
+      if (drop.thresh) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          f[j] = drop_factor(drop, (((unsigned long long)bh * n + (qt * TQ + 16 * t + 4 * g + j)) * ((n + 3) & ~3)) + keyabs);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x2 x = {sc[t][2 * hh], sc[t][2 * hh + 1]};
+        const f32x2 lv = {-l4[2 * hh], -l4[2 * hh + 1]}, dlv = {d4[2 * hh], d4[2 * hh + 1]};
+        const f32x2 fv = {f[2 * hh], f[2 * hh + 1]}, dpv = {dp[t][2 * hh], dp[t][2 * hh + 1]};
+        x = __builtin_elementwise_fma(x, c2, lv);
+        const f32x2 pv = {fast_exp2(x[0]), fast_exp2(x[1])};
+        const f32x2 pd = pv * fv;
+        const f32x2 dsv = pv * (dpv * fv - dlv);
+        sc[t][2 * hh] = pd[0]; sc[t][2 * hh + 1] = pd[1];
+        dp[t][2 * hh] = dsv[0]; dp[t][2 * hh + 1] = dsv[1];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout, long ldo,
+                                                                   const float* __restrict__ lse, const float* __restrict__ delta, int n,
+                                                                   int heads, float scale, bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
+  // [stage][Q image | dO image | 64 lse | 64 delta].  Query rows beyond n arrive as zeros everywhere (buffer bounds): Q = dO = 0 makes
+  // their scores, dP and delta zero, so their (unmasked) probabilities multiply zeros - the same exact zeros the streaming kernel adds
+  constexpr int STG = 2 * IMG + 2 * TQ * 4;
+  __shared__ __attribute__((aligned(16))) char wsmem[2 * STG];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const bf16* K = Q + inner;
+  const bf16* V = Q + 2 * inner;
+  const bf16* dO = dout + (long)b * n * ldo + h * DH;
+  const int key0 = blockIdx.x * WIDE_ROWS + 32 * wid;
+  const float scale_log2e = scale * 1.44269504088896340736f;
+
+  bf16x8 kf[2][2], vf[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int krow = min(key0 + 16 * u + r, n - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[u][ks] = *reinterpret_cast<const bf16x8*>(K + (long)krow * ld + 32 * ks + 8 * g);
+      vf[u][ks] = *reinterpret_cast<const bf16x8*>(V + (long)krow * ld + 32 * ks + 8 * g);
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Q, 0, (unsigned)((((long)n - 1) * ld + DH) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)dO, 0, (unsigned)((((long)n - 1) * ldo + DH) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(lse + ((long)b * heads + h) * n), 0, (unsigned)(n * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsDl = __builtin_amdgcn_make_buffer_rsrc((void*)(delta + ((long)b * heads + h) * n), 0, (unsigned)(n * 4), 0x00020000);
+  int voq[2], vod[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wid + 4 * i) * 8 + (lane >> 3);
+    const int ch = ((lane & 7) ^ (row & 7)) << 3;                                        // img128_off inverse
+    voq[i] = (int)(((long)row * ld + ch) * 2);
+    vod[i] = (int)(((long)row * ldo + ch) * 2);
+  }
+  const int stepq = (int)(64 * ld * 2), stepd = (int)(64 * ldo * 2);
+  auto issue = [&](int t, char* stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t*)(stage + (wid + 4 * i) * 1024), 16, voq[i], t * stepq, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t*)(stage + IMG + (wid + 4 * i) * 1024), 16, vod[i], t * stepd, 0, 0);
+    }
+    if (wid == 0) {                                       // 64 lse and 64 delta values of the tile: one dword per lane
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (lds_void_t*)(stage + 2 * IMG), 4, lane * 4, t * TQ * 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsDl, (lds_void_t*)(stage + 2 * IMG + TQ * 4), 4, lane * 4, t * TQ * 4, 0, 0);
+    }
+  };
+
+  f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dk[u][t] = dv[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nqt = (n + TQ - 1) / TQ;
+  issue(0, wsmem);
+  for (int qt = 0; qt < nqt; ++qt) {
+    const char* cur = wsmem + (qt & 1) * STG;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (qt + 1 < nqt) issue(qt + 1, wsmem + ((qt + 1) & 1) * STG);
+    const float* sL = reinterpret_cast<const float*>(cur + 2 * IMG);
+    const float* sDl = sL + TQ;
+    RowFrags F;
+    f32x4 sc[2][4], dp[2][4];
+    load_row_frags(cur, r, g, F);
+    mfma_rows(F, kf[0], sc[0], true);
+    mfma_rows(F, kf[1], sc[1], true);
+    __builtin_amdgcn_sched_barrier(0);                    // (keeps one fragment set live at a time: the kernel is at the register limit)
+    load_row_frags(cur + IMG, r, g, F);
+    mfma_rows(F, vf[0], dp[0], true);
+    mfma_rows(F, vf[1], dp[1], true);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 pf[2][2], dsf[2][2];                           // rounded at once: 16 registers per group instead of 32
+    dkv_softmax_grad_inplace(sc[0], dp[0], sL, sDl, qt, n, scale_log2e, drop, blockIdx.y, key0 + r, g);
+    pf[0][0] = cvt8(sc[0][0], sc[0][1]); pf[0][1] = cvt8(sc[0][2], sc[0][3]);
+    dsf[0][0] = cvt8(dp[0][0], dp[0][1]); dsf[0][1] = cvt8(dp[0][2], dp[0][3]);
+    dkv_softmax_grad_inplace(sc[1], dp[1], sL, sDl, qt, n, scale_log2e, drop, blockIdx.y, key0 + 16 + r, g);
+    pf[1][0] = cvt8(sc[1][0], sc[1][1]); pf[1][1] = cvt8(sc[1][2], sc[1][3]);
+    dsf[1][0] = cvt8(dp[1][0], dp[1][1]); dsf[1][1] = cvt8(dp[1][2], dp[1][3]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tr_frags(cur + IMG, r, g, F);
+    mfma_rows(F, pf[0], dv[0], false);
+    mfma_rows(F, pf[1], dv[1], false);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tr_frags(cur, r, g, F);
+    mfma_rows(F, dsf[0], dk[0], false);
+    mfma_rows(F, dsf[1], dk[1], false);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int key = key0 + 16 * u + r;
+    if (key < n) {
+      bf16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        *reinterpret_cast<bf16x4*>(drow + inner + 16 * t + 4 * g) = cvt4(dk[u][t][0] * scale, dk[u][t][1] * scale, dk[u][t][2] * scale, dk[u][t][3] * scale);
+        *reinterpret_cast<bf16x4*>(drow + 2 * inner + 16 * t + 4 * g) = cvt4(dv[u][t][0], dv[u][t][1], dv[u][t][2], dv[u][t][3]);
+      }
+    }
+  }
+}
+
 // delta: [B, heads, n] fp32 scratch (written by the dQ kernel, read by the dK/dV kernel).
 extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const void* dout, long ld_out, const float* lse, int B, int n,
                            int heads, int dim_head, float scale, float* delta, void* dqkv, long ld_dqkv, unsigned long drop_seed, float drop_p,
@@ -870,7 +1102,7 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((n + TQ - 1) / TQ, B * heads);
   const int slot = nv_prof_begin(4, 10.0 * B * heads * (double)n * n * DH, stream);   // algorithmic: 5 products
-  if (attn_resident(n)) {
+  if (attn_resident(n) && g_attn_mode != 3) {
     NV_CHECK_ARG((long)n * ld_qkv < (1L << 30) && (long)n * ld_out < (1L << 30), "nv_attn_bwd: operand too large for 32-bit buffer offsets");
     const int nt = (n + TK - 1) / TK;
     static bool attr = false;
@@ -889,9 +1121,20 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
     NV_CHECK_LAUNCH("nv_attn_bwd/dkv(resident)");
     return NV_OK;
   }
+  // wide kernels (32 rows / keys per wave) once the grid is large enough to fill the chip with them; small grids keep 16
+  const bool wide = g_attn_mode != 1 && (long)n * ld_qkv < (1L << 30) && (long)n * ld_out < (1L << 30) &&
+                    (g_attn_mode >= 3 || (long)B * heads * ((n + WIDE_ROWS - 1) / WIDE_ROWS) >= 512);
+  if (wide)
+    hipLaunchKernelGGL(attn_bwd_dq_wide_kernel, dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
+                       (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+  else
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out, lse, n,
                      heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
   NV_CHECK_LAUNCH("nv_attn_bwd/dq");
+  if (wide)
+    hipLaunchKernelGGL(attn_bwd_dkv_wide_kernel, dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
+                       (const bf16*)dout, ld_out, lse, delta, n, heads, scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+  else
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)dout, ld_out, lse, delta, n, heads,
                      scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
   nv_prof_end(slot, stream);

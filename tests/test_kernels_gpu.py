@@ -489,6 +489,26 @@ def test_attention_wide_forward_equals_streaming(ops, B, n, heads, drop):
     assert (diff > 0).float().mean().item() <= 2e-5 and (diff <= out1.float().abs() * 2 ** -7 + 1e-30).all()
 
 
+@pytest.mark.parametrize("B,n,heads,drop", [(2, 1001, 2, 0.0), (1, 4097, 1, 0.0), (3, 700, 2, 0.1), (1, 129, 1, 0.0), (2, 65, 3, 0.2)])
+def test_attention_wide_backward_equals_streaming(ops, B, n, heads, drop):
+    """Wide streaming backward kernels (32 query rows / keys per wave, LDS-DMA ring; lse and delta tiles by dword LDS-DMA, padded
+    query rows as zeros instead of +inf): dQ, dK, dV and delta bit for bit equal to the reference streaming kernels."""
+    from neurovit_amd._cabi import lib
+    inner = heads * 64
+    qkv = dev(bf(rnd(B * n, 3 * inner, seed=n + heads)))
+    do = dev(bf(rnd(B * n, inner, seed=3)))
+    try:
+        lib.nv_attn_set_mode(1)
+        out, lse = ops.attn_fwd(qkv, B, n, heads, drop_seed=11, drop_p=drop)
+        d1, delta1 = ops.attn_bwd(qkv, out, do, lse, B, n, heads, drop_seed=11, drop_p=drop)
+        lib.nv_attn_set_mode(3)
+        d3, delta3 = ops.attn_bwd(qkv, out, do, lse, B, n, heads, drop_seed=11, drop_p=drop)
+    finally:
+        lib.nv_attn_set_mode(0)
+    assert torch.equal(d1, d3) and torch.equal(delta1, delta3)
+    assert torch.isfinite(d3.float()).all()
+
+
 def test_attention_rescale_branch(ops):
     """Force the online-softmax rescale: one key in the LAST tile dominates one query row."""
     B, n, heads, dh = 1, 200, 1, 64
