@@ -320,12 +320,15 @@ static int g_ring_override = 0;   // 0 heuristic, 1 = 3 x 64, 2 = deep x 64, 3 =
 static int g_tile_override = 0;   // 0 = heuristic; 1..3 = warp-specialised 128x128 / 128x64 / 64x128; 4 = ping-pong 256x128; 5 = never ping-pong;
                                   // else BM*1000 + BN (small-tile kernel)
 static int g_pp_grouped = 1;      // grouped weight-gradient launch on ping-pong tiles
-static int g_pp_min_tiles = 128;   // heuristic: problems with at least this many 256 x 128 tiles go to the ping-pong kernel
+static int g_pp_min_tiles = 128;
+static int g_pq_min_tiles = 768;       // problems with at least this many 256 x 256 tiles go to gemm_pq.hip: measured +5-8 % on 8192^2 x 4096
+                                       // (1.14 vs 1.05-1.10 PFLOP/s), equal on ViT3D-large's FC1, worse below (tile quantisation on 256 CUs)   // heuristic: problems with at least this many 256 x 128 tiles go to the ping-pong kernel
 extern "C" int nv_gemm_set_tile(int bm, int bn) {   // tuning aid (tools/gemm_bench.py)
   if (bm == 6) { g_pp_min_tiles = bn; return 0; }
   if (bm == 7) { g_pp_grouped = bn; return 0; }
   if (bm == 8) { g_pp_dbg = bn; return 0; }
-  g_tile_override = (bm == 0) ? 0 : (bm <= 5 ? bm : bm * 1000 + bn);
+  if (bm == 10) { g_pq_min_tiles = bn; return 0; }
+  g_tile_override = (bm == 0) ? 0 : ((bm <= 5 || bm == 9) ? bm : bm * 1000 + bn);
   g_ring_override = (bm >= 1 && bm <= 3) ? bn : 0;      // for the warp-specialised tiles bn selects the ring: 1 shallow, 2 deep
   return 0;
 }
@@ -378,6 +381,11 @@ static GemmPlan plan_gemm(bool A_T, bool B_T, int M, int N, int K, long lda, lon
   const bool fits = rowsA * lda < (1L << 30) && rowsB * ldb < (1L << 30);
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   const long tpp = (long)((M + PP_BM - 1) / PP_BM) * ((N + PP_BN - 1) / PP_BN);
+  const long tpq = (long)((M + PQ_BM - 1) / PQ_BM) * ((N + PQ_BN - 1) / PQ_BN);
+  if (k_ok && fits && (g_tile_override == 9 || (g_tile_override == 0 && tpq >= g_pq_min_tiles))) {
+    p.family = 3; p.bm = 128;              // 256 x 256 tiles whose epilogue runs in two passes of 128 rows
+    return p;
+  }
   if (k_ok && fits && (g_tile_override == 4 || (g_tile_override == 0 && tpp >= g_pp_min_tiles))) {
     p.family = 2; p.bm = PP_BM;
     return p;
@@ -414,6 +422,7 @@ static GemmPlan plan_gemm(bool A_T, bool B_T, int M, int N, int K, long lda, lon
 template <bool A_T, bool B_T, int EPI>
 static int launch(const GemmArgs& a, hipStream_t s) {
   const GemmPlan p = plan_gemm(A_T, B_T, a.M, a.N, a.K, a.lda, a.ldb);
+  if (p.family == 3) return launch_pq(A_T ? 2 : (B_T ? 1 : 0), EPI, a, s);
   if (p.family == 2) return launch_pp(A_T ? 2 : (B_T ? 1 : 0), EPI, a, s);
   if (p.family == 1) {
     const int ws = p.ws, ring = p.ring;
@@ -507,6 +516,8 @@ extern "C" int nv_gemm_f8(int epi, int M, int N, int K, const void* A8, long lda
   a.drop = make_drop(0, 0.f);
   a.colscale = colscale;
   a.col_order = 0;
+  const long tpq = (long)((M + PQ_BM - 1) / PQ_BM) * ((N + PQ_BN - 1) / PQ_BN);
+  if (g_tile_override == 9 || (g_tile_override == 0 && tpq >= g_pq_min_tiles)) return launch_pq_f8(epi, a, (hipStream_t)stream);
   return launch_pp_f8(epi, a, (hipStream_t)stream);
 }
 

@@ -3,6 +3,9 @@
 #include "gemm_common.h"
 
 constexpr int PP_BM = 256, PP_BN = 128;
+constexpr int PQ_BM = 256, PQ_BN = 256;     // gemm_pq.hip
+int launch_pq(int layout, int epi, const GemmArgs& a, hipStream_t s);
+int launch_pq_f8(int epi, const GemmArgs& a, hipStream_t s);
 int launch_pp(int layout, int epi, const GemmArgs& a, hipStream_t s);
 int launch_pp_f8(int epi, const GemmArgs& a, hipStream_t s);
 int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_t s);

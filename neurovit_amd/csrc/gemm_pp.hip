@@ -1,26 +1,28 @@
-// Eight-wave "ping-pong" bf16 MFMA GEMM for large tiles (256 x 128 x 64) on gfx950.
+// 256 x 128 x 64 tiles: eight compute waves + four LDS-DMA loader waves per workgroup - bf16 and fp8 MFMA GEMM for gfx950.
 //
-// Why a second kernel family.  The warp-specialised 128 x 128 / 64 x 128 kernels of gemm.hip spend four of their eight waves
-// on LDS-DMA and give each consumer wave a 64 x 64 tile: per 64-deep K step a workgroup pulls 32 KiB through the CU's
-// L2 -> LDS path (~64 B/clk) for 512 MFMA cycles per SIMD - exactly the path's limit - and its four consumer waves read
-// 128 B/clk of fragments.  It tops out at ~0.86 PFLOP/s (profiles/r01_gemm_vs_vendor_blas.log).  A 256 x 128 tile needs 48 KiB
-// per 1024 MFMA cycles (47 B/clk) and, with ALL eight waves computing 64 x 64 sub-tiles, the same fragment bytes per MFMA.
+// Why a second kernel family.  The warp-specialised 128 x 128 / 64 x 128 kernels of gemm.hip give each of FOUR consumer waves a
+// 64 x 64 tile: per 64-deep K step a workgroup pulls 32 KiB through the CU's L2 -> LDS path (~64 B/clk) for 512 MFMA cycles per
+// SIMD - the path's limit - and they top out at ~0.86 PFLOP/s (profiles/r01_gemm_vs_vendor_blas.log).  A 256 x 128 tile needs
+// 48 KiB per 1024 MFMA cycles and, with EIGHT waves computing 64 x 64 sub-tiles, the same fragment bytes per MFMA.
 //
-// Structure (after the 8-phase template of the CDNA4 guide, re-derived for this tile):
-//   * 512 threads = 8 waves as 4 (M) x 2 (N), wave tile 64 x 64 (4 x 4 MFMA tiles of 16 x 16 x 32, 64 accumulator VGPRs);
-//   * every wave both issues LDS-DMA (buffer_load ... lds, 6 x 1 KiB pieces per K tile) and computes; the two waves that
-//     share a SIMD (wave w and w + 4) run HALF A PHASE APART: while one is in its MFMA segment (16 MFMAs, s_setprio 1) the
-//     other is in its load segment (ds_read_b128 fragment reads + DMA issue), separated by raw s_barriers - matrix pipe and
-//     LDS / DMA work of one SIMD overlap by construction instead of by luck;
-//   * a K tile is two phases (the wave's upper / lower 32 rows); the B fragments of a K tile are read once, in phase 0;
-//   * three-stage LDS ring (3 x 48 KiB), DMA runs two K tiles ahead and stays in flight across barriers behind COUNTED
-//     s_waitcnt vmcnt (never 0 inside the loop); the wait that retires K tile j sits before the barrier that precedes the
-//     first read of tile j by the EARLIER half of the waves, for both halves (RAW), and the DMA that overwrites the slot of
-//     tile j-1 is issued two barriers after the last fragment read of that slot has been waited for (WAR);
+// Structure:
+//   * 768 threads: waves 0-7 compute (4 (M) x 2 (N), wave tile 64 x 64 = 4 x 4 MFMA tiles of 16 x 16 x 32, 64 accumulator VGPRs,
+//     <= 168 VGPRs in all: three waves per SIMD); waves 8-11, one per SIMD, only issue LDS-DMA (buffer_load ... lds, 12 x 1 KiB
+//     pieces per K tile each) behind counted s_waitcnt vmcnt;
+//   * three-stage LDS ring (3 x 48 KiB), ONE raw s_barrier per K tile executed by all twelve waves: after barrier k tile k is
+//     complete (the loaders waited for it) and the slot of tile k-1 is free; the loaders then issue tile k+2 and wait for k+1;
+//   * the two compute waves of a SIMD (w and w + 4) run HALF A TILE out of step: right after the barrier group 1 still has 16 MFMAs
+//     of tile k-1 (fragments held in registers) while group 0's fragment reads are in flight, and group 1 reads while group 0
+//     computes - the matrix pipe never waits for LDS.  (First built as the CDNA4 guide's phase-by-phase ping-pong - two barriers
+//     per 16 MFMAs, DMA issued by the compute waves: 0.93-1.05 PFLOP/s.  Timing ablations showed the loop running at 1.43-1.48
+//     without DMA and 1.46-1.51 MFMA-only, the fragment reads free, and the DMA's cost on the CU independent of where the data
+//     comes from or how far ahead it is issued; what paid was fewer barriers and DMA off the compute waves: 1.05-1.10.);
+//   * L2-aware tile order (groups of four tile rows, column by column: a 4 x 8 block of tiles per XCD wave, 82 % L2 hits);
 //   * operand images, swizzles, transposed reads (ds_read_b64_tr_b16) and the fused epilogues are those of gemm.hip
 //     (gemm_common.h); 128-wide sub-images make every layout (NT / NN / TN) a composition of the same 16 KiB pieces;
-//   * epilogue: accumulators parked as an fp32 [256][128] tile in the (now idle) ring, then all eight waves run the
-//     row-wise fused epilogue (gemm_common.h::epilogue_lds).
+//   * epilogue: accumulators parked as an fp32 [256][128] tile in the (now idle) ring, then all twelve waves run the row-wise
+//     fused epilogue (gemm_common.h::epilogue_lds);
+//   * F8: OCP e4m3 operands on v_mfma_scale_f32_16x16x128_f8f6f4 (see gemm_pp_body).
 #include "gemm_common.h"
 #include "gemm_pp.h"
 

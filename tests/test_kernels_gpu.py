@@ -201,6 +201,52 @@ def test_gemm_ping_pong_kernel_forced(ops, M, N, K):
         lib.nv_gemm_set_tile(0, 0)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (257, 264, 192), (2052, 768, 768), (520, 776, 1024), (300, 8, 128)])
+def test_gemm_256x256_kernel_forced(ops, M, N, K):
+    """gemm_pq.hip (256 x 256 tiles, DMA issued by the compute waves, two-stage ring, two-pass epilogue): every layout and fused
+    epilogue against fp64, ragged M / N, one to sixteen K tiles, the fused column sums, run-to-run bit equality."""
+    from neurovit_amd._cabi import lib
+    lib.nv_gemm_set_tile(9, 0)
+    try:
+        A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+        bias, resid = rnd(N, seed=3), rnd(M, N, seed=4)
+        ref = A.double() @ B.double().T
+        Ad, Bd = dev(A), dev(B)
+        first = ops.gemm(ops.NT, ops.EPI_STORE_BF16, Ad, Bd)
+        assert_close_bf16(first, ref, "pq.nt_bf16")
+        for _ in range(5):
+            assert torch.equal(ops.gemm(ops.NT, ops.EPI_STORE_BF16, Ad, Bd), first)
+        assert_close_f32(ops.gemm(ops.NT, ops.EPI_BIAS_RESID, Ad, Bd, bias=dev(bias), aux_in=dev(resid)), ref + bias.double() + resid.double(), "pq.nt_resid", 1e-5)
+        u = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        h = ops.gemm(ops.NT, ops.EPI_BIAS_GELU, Ad, Bd, bias=dev(bias), aux_out=u)
+        assert_close_bf16(u, ref + bias.double(), "pq.gelu.u")
+        assert_close_bf16(h, F.gelu(ref + bias.double()), "pq.gelu.h")
+        Bt = bf(rnd(K, N, seed=7, scale=K ** -0.5))
+        refn = A.double() @ Bt.double()
+        assert_close_f32(ops.gemm(ops.NN, ops.EPI_STORE_F32, Ad, dev(Bt)), refn, "pq.nn_f32", 1e-5)
+        ug = bf(rnd(M, N, seed=8))
+        plain = ops.gemm(ops.NN, ops.EPI_DGELU, Ad, dev(Bt), aux_in=dev(ug))
+        assert_close_bf16(plain, refn * ref_cpu._gelu_grad(ug.double()), "pq.dgelu")
+        fused, part = ops.gemm_dgelu_colsum(Ad, dev(Bt), dev(ug))
+        assert torch.equal(plain, fused) and part.shape[0] == (M + 127) // 128
+        assert_close_f32(part.sum(0), fused.double().sum(0), "pq.colsum", 1e-5)
+        Kt, Mo = M, (K + 7) // 8 * 8                      # TN: reduction over a ragged token count
+        At, B2 = bf(rnd(Kt, Mo, seed=9)), bf(rnd(Kt, N, seed=10, scale=Kt ** -0.5))
+        c0 = rnd(Mo, N, seed=11)
+        c = dev(c0.clone())
+        ops.gemm(ops.TN, ops.EPI_STORE_F32, dev(At), dev(B2), out=c, accumulate=True)
+        assert_close_f32(c, At.double().T @ B2.double() + c0.double(), "pq.tn", 1e-5)
+        if K % 128 == 0 and N % 8 == 0:                   # fp8 operands through the same tile
+            x = rnd(M, K, seed=21)
+            sa = 448.0 / float(x.abs().max()) * 0.5
+            w8, cs = ops.quant_rows_f8(dev(rnd(N, K, seed=22, scale=K ** -0.5)), sa)
+            a8 = dev((x * sa).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+            ref8 = (a8.cpu().view(torch.float8_e4m3fn).float().double() @ w8.cpu().view(torch.float8_e4m3fn).float().double().T) * cs.cpu().double()
+            assert_close_f32(ops.gemm_f8(ops.EPI_STORE_F32, a8, w8, cs), ref8, "pq.f8", 1e-4)
+    finally:
+        lib.nv_gemm_set_tile(0, 0)
+
+
 def test_gemm_ping_pong_grouped_equals_single_launches(ops):
     """Grouped weight gradients on the ping-pong tiles: bit-identical to single launches of the same kernel."""
     from neurovit_amd._cabi import lib
