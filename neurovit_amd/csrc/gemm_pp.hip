@@ -283,8 +283,8 @@ int launch_pp_t(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int g_pp_dbg = 0;   // timing-only ablations of the NT / bf16-store kernel (tools/gemm_bench.py --dbg): 1 no DMA, 2 B fragments from
-                    // one slot, 4 A fragments read once; results are wrong by design
+int g_pp_dbg = 0;   // timing-only ablations of the NT / bf16-store kernel (tools/gemm_bench.py --dbg; results are wrong by design):
+                    // 1 no DMA after the prologue, 2 every DMA from one L2-hot 48 KiB region, 4 fragments read once (5 = 1 + 4: MFMA only)
 template <int DBG>
 static int launch_pp_dbg(const GemmArgs& a, hipStream_t s) {
   constexpr int LDS = PP_S * (PP_BM / 128 + PP_BN / 128) * PP_SUB;
@@ -302,9 +302,6 @@ int launch_pp(int layout, int epi, const GemmArgs& a, hipStream_t s) {
       case 2: return launch_pp_dbg<2>(a, s);
       case 4: return launch_pp_dbg<4>(a, s);
       case 5: return launch_pp_dbg<5>(a, s);
-      case 8: return launch_pp_dbg<8>(a, s);
-      case 12: return launch_pp_dbg<12>(a, s);
-      case 9: return launch_pp_dbg<9>(a, s);
       default: break;
     }
   }

@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--tile", default="", help="force tile, e.g. 64x128 (default: heuristic)")
-    ap.add_argument("--dbg", type=int, default=0, help="ping-pong kernel timing ablation (results wrong by design): 1 no DMA, 2 B frags from one slot, 4 A frags read once")
+    ap.add_argument("--dbg", type=int, default=0, help="256x128 kernel timing ablation (results wrong by design): 1 no DMA, 2 DMA from one L2-hot region, 4 fragments read once, 5 MFMA only")
     a = ap.parse_args()
     if a.dbg:
         from neurovit_amd._cabi import lib as _l
