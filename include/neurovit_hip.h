@@ -119,6 +119,9 @@ int nv_ln_bwd_partial_rows(int M);
  * raw [B,X,Y,Z,T] with element strides (T = 1 for 3D), dtype 0 = float32 / 1 = int16; crop8 = {x0,y0,z0,t0,Sx,Sy,Sz,St};
  * out dense float32 [B,Sx,Sy,Sz,St]; stats (optional) [B,2] = mean, std. */
 long nv_zscore_crop_workspace_bytes(int B);
+/* statistics only: sigma[b] = population std of cropped volume b + eps, mean[b] optional (workspace as nv_zscore_crop) */
+int nv_volume_sigma(const void* raw, int dtype, const long* strides5, int B, const int* crop8, float eps, float* sigma, float* mean,
+                    void* workspace, long ws_bytes, void* stream);
 int nv_zscore_crop(const void* raw, int dtype, const long* strides5, int B, const int* crop8, float eps, float* out,
                    float* stats, void* workspace, long ws_bytes, void* stream);
 
@@ -127,7 +130,15 @@ int nv_zscore_crop(const void* raw, int dtype, const long* strides5, int B, cons
  * [B,H,W,D] dataset tensor - no copy); out bf16 [B*N, ldo] = LayerNorm(patch_dim)(patches). */
 int nv_patch_ln_fwd(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
                     const float* gamma, const float* beta, float eps, void* out, long ldo, float* mean, float* rstd,
-                    void* stream);
+                    const float* vol_sigma, void* stream);
+/* vol_sigma (may be NULL): [B] = std + 1e-8 of each RAW volume (nv_volume_sigma).  `video` is then the un-normalised (cropped
+ * view of the) scanner volume: LayerNorm over a patch of (x - mu) / sigma equals LayerNorm over the patch of x with eps * sigma^2,
+ * so the dataset's z-score (src/data/DatasetADNI.py:213) is folded into this kernel's epsilon - no normalised copy is written.
+ * nv_patch_ln_fwd_4d: all T timepoints of a 4D sample x [Bo, H, W, D, T] (contiguous, T % 4 == 0; src/data/DatasetADNI_4D.py:86-96)
+ * in one pass - replaces the strided regroup copy of NeuroEncoder.py:54-56; token rows (bo*T + t)*N + n. */
+int nv_patch_ln_fwd_4d(const float* x, int Bo, int H, int W, int D, int T, int p1, int p2, int pf, const float* gamma,
+                       const float* beta, float eps, void* out, long ldo, float* mean, float* rstd, const float* vol_sigma,
+                       void* stream);
 long nv_patch_ln_bwd_workspace_bytes(int tokens, int P);
 int nv_patch_ln_bwd(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
                     const float* dxp, long ldd, const float* mean, const float* rstd, float* dgamma, float* dbeta,
@@ -209,6 +220,18 @@ long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int training, cons
  * bounds, so it is rejected with NV_ERR_ARG).
  * drop_p / emb_drop_p / drop_seed: nn.Dropout of the blocks (vit_3d.py:21,23,39,45) and of the embedding (:100); both 0
  * in eval mode.  backward must be given the forward's values. */
+/* Optional input forms, nv_vit_forward_in / nv_vit_forward_fp8:
+ *   vol_sigma   != NULL: `video` holds RAW volumes; [B] (or [B / time_points]) = std + 1e-8 per sample (nv_volume_sigma): the z-score
+ *                        is folded into the patch LayerNorm (see nv_patch_ln_fwd); crop = the strides / base pointer of the view;
+ *   time_points  > 0   : `video` is a contiguous 4D batch [B / T, H, W, D, T] (shape5 = that shape) and volume b*T + t is timepoint t
+ *                        of sample b - no regroup copy (nv_patch_ln_fwd_4d; T % 4 == 0, channels = 1); strides5 is ignored. */
+typedef struct nv_vit_input {
+  const float* vol_sigma;
+  int time_points;
+} nv_vit_input;
+int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
+                      const nv_vit_input* in, const float* params, const void* params16, void* workspace, long ws_bytes,
+                      int training, float drop_p, float emb_drop_p, unsigned long drop_seed, float* logits, void* stream);
 int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
                    const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
                    unsigned long drop_seed, float* logits, void* stream);
@@ -218,7 +241,7 @@ int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const lo
 long nv_vit_fp8_scale_count(const nv_vit_config* cfg);
 int nv_vit_quantize_fp8(const nv_vit_config* cfg, const float* params, const float* act_scales, void* params8, float* colscales, void* stream);
 int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
-                       const float* params, const void* params16, const void* params8, const float* colscales,
+                       const nv_vit_input* in, const float* params, const void* params16, const void* params8, const float* colscales,
                        const float* act_scales, void* workspace, long ws_bytes, float* logits, void* stream);
 int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                     const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,

@@ -60,10 +60,23 @@ class NeuroEncoder(nn.Module):
         # folded into the batch; the B*T logit pairs then form a length-T sequence for the temporal transformer.
         series = fmri.to(self.device)
         n_samples, n_time = series.shape[0], series.shape[-1]
-        as_volumes = series.movedim(-1, 1).flatten(0, 1)              # [B, H, W, D, T] -> [B*T, H, W, D]
-        per_volume = self.volume_encoder(as_volumes).unflatten(0, (n_samples, n_time))
+        vit = self.volume_encoder.vit3d
+        frozen = not (torch.is_grad_enabled() and any(p.requires_grad for p in vit.parameters()))
+        if frozen and n_time % 4 == 0 and n_time <= 64 and series.dtype == torch.float32 and series.is_contiguous():
+            # fused 4D gather (csrc/norm.hip::patch_ln_fwd_t_kernel): the B*T volumes are read in place, no regroup copy
+            per_volume = vit(series, time_points=n_time).unflatten(0, (n_samples, n_time))
+        else:
+            as_volumes = series.movedim(-1, 1).flatten(0, 1)          # [B, H, W, D, T] -> [B*T, H, W, D]  (strided copy)
+            per_volume = self.volume_encoder(as_volumes).unflatten(0, (n_samples, n_time))
         pooled = self.temporal_transformer(per_volume).mean(dim=1)
         return self.projection_head(pooled)
+
+    def forward_raw(self, raw, crop=None):
+        """3D model fed RAW scanner volumes [B, X, Y, Z] float32 on the device: the dataset's crop (DatasetADNI.py:212) is a strided
+        view and its z-score (:213) is folded into the patch LayerNorm - one statistics pass, no normalised copy."""
+        if self.config['TRAINING_DIM'] != 3:
+            raise NotImplementedError("forward_raw: 3D model only (4D samples are normalised over all timepoints: DatasetADNI_4D.py:86-87)")
+        return self.volume_encoder.forward_raw(raw, crop)
 
     # ---- Grad-CAM contract (NeuroEncoder.py:70-82): activation / gradient of the last block's attention-LN output.
     # The reference copies both to the CPU on EVERY forward / backward (a blocking D2H sync per step); here they stay
@@ -175,6 +188,17 @@ class ViT3DEncoder(nn.Module):
             emb_dropout=self.dropout,
             pool='cls'
         ).to(self.device)
+
+    def forward_raw(self, raw, crop=None):
+        from .preprocess import ADNI_CROP, crop_view, volume_sigma
+        crop = ADNI_CROP if crop is None else crop
+        raw = raw.to(self.device)
+        if raw.dtype != torch.float32:                                 # int16 scanner data: the gather kernel reads float32 -> separate pass
+            from .preprocess import zscore_crop
+            return self.forward(zscore_crop(raw, crop))
+        sigma = volume_sigma(raw, crop)                                # std + 1e-8 per cropped volume (statistics in double)
+        view = crop_view(raw, crop)                                    # [B, Sx, Sy, Sz] strided view of the raw tensor
+        return self.vit3d(view.permute(0, 3, 1, 2).unsqueeze(1), vol_sigma=sigma)
 
     def forward(self, x):
         # x: (batch, H, W, D).  The permuted tensor is only a VIEW: the patch-gather kernel reads the original

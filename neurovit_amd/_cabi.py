@@ -25,6 +25,11 @@ class VitConfig(ctypes.Structure):
                 ("mlp_dim", ctypes.c_int), ("ln_eps", ctypes.c_float)]
 
 
+class VitInput(ctypes.Structure):
+    """struct nv_vit_input (neurovit_hip.h): optional input forms of nv_vit_forward_in / nv_vit_forward_fp8."""
+    _fields_ = [("vol_sigma", ctypes.c_void_p), ("time_points", ctypes.c_int)]
+
+
 def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
     """{symbol: (restype, [argtypes])} for every `nv_*` prototype declared in the header."""
     src = open(path).read()

@@ -189,13 +189,38 @@ extern "C" long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int tra
   return -1;
 }
 
+// Patch front end shared by the bf16 and fp8 forwards: the three input forms of nv_vit_input (see the header).
+static int patch_front(const nv_vit_config* cfg, const Dims& D, const ParamTab& T, int B, const float* video, const long* strides5, const nv_vit_input* in,
+                       const float* p, float eps, void* xp, float* pst, void* stream) {
+  const float* sigma = in ? in->vol_sigma : nullptr;
+  if (in && in->time_points > 0) {
+    NV_CHECK_ARG(B % in->time_points == 0 && cfg->channels == 1, "nv_vit_forward: time_points=%d must divide B=%d (channels = 1)", in->time_points, B);
+    // video = contiguous [B / T, H, W, D, T]: (H, W, D) of the dataset = (image, image, frames) of the ViT (NeuroEncoder.py:200-202)
+    return nv_patch_ln_fwd_4d(video, B / in->time_points, cfg->image_size, cfg->image_size, cfg->frames, in->time_points, cfg->image_patch_size,
+                              cfg->image_patch_size, cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, xp, D.Ppad, pst, pst + D.T, sigma, stream);
+  }
+  return nv_patch_ln_fwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
+                         cfg->image_patch_size, cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, xp, D.Ppad, pst, pst + D.T, sigma, stream);
+}
+
 extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
                               const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
                               unsigned long drop_seed, float* logits, void* stream) {
+  return nv_vit_forward_in(cfg, B, video, shape5, strides5, nullptr, params, params16, workspace, ws_bytes, training, drop_p, emb_drop_p, drop_seed, logits, stream);
+}
+
+extern "C" int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
+                                 const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
+                                 unsigned long drop_seed, float* logits, void* stream) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, training, W);
   NV_CHECK_ARG(video && shape5 && strides5 && params && params16 && workspace && logits, "nv_vit_forward: null pointer");
+  if (in && in->time_points > 0)
+    NV_CHECK_ARG(shape5[0] * shape5[4] == B && shape5[4] == in->time_points && shape5[1] == cfg->image_size && shape5[2] == cfg->image_size && shape5[3] == cfg->frames,
+                 "nv_vit_forward: 4D input is [%ld,%ld,%ld,%ld,%ld], expected [B/T, %d, %d, %d, T=%d] with B = %d", shape5[0], shape5[1], shape5[2], shape5[3],
+                 shape5[4], cfg->image_size, cfg->image_size, cfg->frames, in->time_points, B);
+  else
   NV_CHECK_ARG(shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == cfg->image_size,
                "nv_vit_forward: video is [%ld,%ld,%ld,%ld,%ld], the model was built for [%d,%d,%d,%d,%d] (B, channels, frames, height, width)",
                shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size);
@@ -209,8 +234,7 @@ extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* vide
 
   // A1+A2: gather + LayerNorm(patch_dim) -> bf16
   float* pst = (float*)(ws + W.pst);
-  RUN(nv_patch_ln_fwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
-                      cfg->image_patch_size, cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, ws + W.xp, D.Ppad, pst, pst + D.T, stream));
+  RUN(patch_front(cfg, D, T, B, video, strides5, in, p, eps, ws + W.xp, pst, stream));
   // A3: Linear(patch_dim, dim)
   const void* wpe = p16 + T.pe_w;
   if (D.P != D.Ppad) {
@@ -275,14 +299,14 @@ extern "C" int nv_vit_quantize_fp8(const nv_vit_config* cfg, const float* params
   return NV_OK;
 }
 
-extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const float* params,
-                                  const void* params16, const void* params8, const float* colscales, const float* act_scales, void* workspace,
+extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
+                                  const float* params, const void* params16, const void* params8, const float* colscales, const float* act_scales, void* workspace,
                                   long ws_bytes, float* logits, void* stream) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 0, W);
   NV_CHECK_ARG(video && shape5 && strides5 && params && params16 && params8 && colscales && act_scales && workspace && logits, "nv_vit_forward_fp8: null pointer");
-  NV_CHECK_ARG(shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == cfg->image_size,
+  NV_CHECK_ARG((in && in->time_points > 0) || (shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == cfg->image_size),
                "nv_vit_forward_fp8: video is [%ld,%ld,%ld,%ld,%ld], the model was built for [%d,%d,%d,%d,%d] (B, channels, frames, height, width)",
                shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size);
   NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_forward_fp8: workspace too small (%ld < %ld)", ws_bytes, W.total);
@@ -297,8 +321,7 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
   const long per = 3L * D.inner + D.m + D.d;
 
   float* pst = (float*)(ws + W.pst);
-  RUN(nv_patch_ln_fwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
-                      cfg->image_patch_size, cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, ws + W.xp, D.Ppad, pst, pst + D.T, stream));
+  RUN(patch_front(cfg, D, T, B, video, strides5, in, p, eps, ws + W.xp, pst, stream));
   const void* wpe = p16 + T.pe_w;
   if (D.P != D.Ppad) {
     RUN(nv_cast_bf16_2d(p + T.pe_w, D.P, d, D.P, ws + W.wpe16, D.Ppad, stream));

@@ -334,11 +334,16 @@ __device__ __forceinline__ long patch_elem_offset(const PatchGeom& g, int b, int
 template <bool VEC>
 __global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const float* __restrict__ video, PatchGeom g, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, bf16* __restrict__ out, long ldo,
-                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                           const float* __restrict__ vol_sigma) {
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (tok >= g.B * g.N) return;
   const int b = tok / g.N, n = tok - b * g.N;
+  // RAW (un-normalised) volumes: LayerNorm over a patch of z = (x - mu) / sigma equals LayerNorm over the patch of x with
+  // eps * sigma^2 in place of eps (mu drops out, sigma scales numerator and denominator): the dataset's per-volume z-score
+  // (DatasetADNI.py:213) costs one multiply here instead of a pass over the volume
+  if (vol_sigma) { const float sg = vol_sigma[b]; eps *= sg * sg; }
   bf16* orow = out + (long)tok * ldo;
   float mean, rstd;
   if constexpr (VEC) {
@@ -396,7 +401,7 @@ static int make_geom(PatchGeom& g, const long* strides, int B, int C, int F, int
 // out: [B*N, ldo] bf16 with ldo >= P (columns P..ldo-1 are written as zero), mean/rstd: [B*N].
 extern "C" int nv_patch_ln_fwd(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
                                const float* gamma, const float* beta, float eps, void* out, long ldo, float* mean, float* rstd,
-                               void* stream) {
+                               const float* vol_sigma, void* stream) {
   PatchGeom g;
   int rc = make_geom(g, strides5, B, C, F, H, W, p1, p2, pf);
   if (rc) return rc;
@@ -404,10 +409,132 @@ extern "C" int nv_patch_ln_fwd(const float* video, const long* strides5, int B, 
   const dim3 grid((g.B * g.N + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (patch_vec_ok(video, g, ldo) && nv_aligned16(gamma) && nv_aligned16(beta) && nv_aligned16(out))
-    hipLaunchKernelGGL(patch_ln_fwd_kernel<true>, grid, block, 0, s, video, g, gamma, beta, eps, (bf16*)out, ldo, mean, rstd);
+    hipLaunchKernelGGL(patch_ln_fwd_kernel<true>, grid, block, 0, s, video, g, gamma, beta, eps, (bf16*)out, ldo, mean, rstd, vol_sigma);
   else
-    hipLaunchKernelGGL(patch_ln_fwd_kernel<false>, grid, block, 0, s, video, g, gamma, beta, eps, (bf16*)out, ldo, mean, rstd);
+    hipLaunchKernelGGL(patch_ln_fwd_kernel<false>, grid, block, 0, s, video, g, gamma, beta, eps, (bf16*)out, ldo, mean, rstd, vol_sigma);
   NV_CHECK_LAUNCH("nv_patch_ln_fwd");
+  return NV_OK;
+}
+
+// ---- 4D samples: patch gather + LayerNorm(patch_dim) of ALL timepoints of one patch position, straight from [Bo, H, W, D, T]
+// (T innermost, as DatasetADNI_4D returns it).  The reference regroups the sample into T volumes with a strided copy
+// (NeuroEncoder.py:54-56: 168 MB per sample); a T-strided gather per volume would touch every cache line of the sample once per
+// timepoint.  Here one workgroup owns a patch position for all T: its p1*p2 runs of pf*T contiguous floats are read coalesced
+// (float4 = four timepoints of one voxel), the per-timepoint statistics are reduced deterministically through LDS, a second
+// sweep (L2 / Infinity-Cache hits) normalises, and an LDS transpose turns the [voxel][t] order into T token rows written in
+// 8-byte pieces.  Token (bo*T + t)*N + n is bit-for-bit what a volume-by-volume call would address.  Needs C = 1, T % 4 == 0.
+struct PatchTGeom {
+  int Bo, H, W, D, T, p1, p2, pf, gf, gh, gw, N, P;
+};
+__global__ __launch_bounds__(256) void patch_ln_fwd_t_kernel(const float* __restrict__ x, PatchTGeom g, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, bf16* __restrict__ out, long ldo,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                             const float* __restrict__ vol_sigma, int nact) {
+  extern __shared__ __attribute__((aligned(16))) char tsm[];
+  const int TG = g.T >> 2;                               // float4 groups per voxel
+  const int KR = nact / TG;                              // voxels (features) per round
+  float* red = reinterpret_cast<float*>(tsm);            // [nact][8] partial sums, then [T] mean | [T] rstd
+  bf16* tile = reinterpret_cast<bf16*>(tsm + (size_t)nact * 8 * sizeof(float));   // [T][KR] transposed round
+  const int tid = threadIdx.x;
+  const int bo = blockIdx.x / g.N, n = blockIdx.x - bo * g.N;
+  const int wt = n % g.gw, ht = (n / g.gw) % g.gh, ft = n / (g.gw * g.gh);
+  const bool act = tid < nact;
+  const int tg = tid % TG, kk = tid / TG;                // this thread's timepoint group and voxel slot inside a round
+  const int run_len = g.pf * g.T;                        // contiguous floats of one (i1, i2) run
+  auto item_ptr = [&](int k) -> const float* {           // first of the four timepoints of voxel k (feature index k) for this tg
+    const int run = k / g.pf, ifr = k - run * g.pf;
+    const int i1 = run / g.p2, i2 = run - i1 * g.p2;
+    const long base = ((((long)bo * g.H + ht * g.p1 + i1) * g.W + wt * g.p2 + i2) * g.D + (long)ft * g.pf) * g.T;
+    return x + base + (long)ifr * g.T + 4 * tg;
+  };
+  // ---- sweep 1: shifted sums (pivot = voxel 0) per timepoint
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+  if (act) {
+    pv = *reinterpret_cast<const f32x4*>(item_ptr(0));
+    for (int k = kk; k < g.P; k += KR) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(item_ptr(k)) - pv;
+      s1 += v;
+      s2 += v * v;
+    }
+    *reinterpret_cast<f32x4*>(red + tid * 8) = s1;
+    *reinterpret_cast<f32x4*>(red + tid * 8 + 4) = s2;
+  }
+  __syncthreads();
+  float mean_t = 0.f, rstd_t = 0.f;
+  if (tid < g.T) {                                       // fixed summation order: deterministic
+    const int mytg = tid >> 2, c = tid & 3;
+    float a = 0.f, q = 0.f;
+    for (int j = 0; j < KR; ++j) {
+      a += red[(j * TG + mytg) * 8 + c];
+      q += red[(j * TG + mytg) * 8 + 4 + c];
+    }
+    const float pivot = x[(item_ptr(0) - 4 * tg - x) + tid];            // voxel 0, timepoint tid
+    const float ms = a / (float)g.P;
+    float var = q / (float)g.P - ms * ms;
+    var = var < 0.f ? 0.f : var;
+    float e = eps;
+    if (vol_sigma) { const float sg = vol_sigma[bo]; e *= sg * sg; }
+    mean_t = pivot + ms;
+    rstd_t = 1.0f / sqrtf(var + e);
+  }
+  __syncthreads();                                       // partial sums consumed
+  if (tid < g.T) {
+    red[tid] = mean_t;
+    red[g.T + tid] = rstd_t;
+    const long tok = ((long)bo * g.T + tid) * g.N + n;
+    mean_out[tok] = mean_t;
+    rstd_out[tok] = rstd_t;
+  }
+  __syncthreads();
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+  if (act) {
+    mu = *reinterpret_cast<const f32x4*>(red + 4 * tg);
+    rs = *reinterpret_cast<const f32x4*>(red + g.T + 4 * tg);
+  }
+  // ---- sweep 2: normalise, transpose [voxel][t] -> [t][voxel] through LDS, write 8-byte pieces of the T token rows
+  const int pieces = (KR + 3) >> 2;                      // 4-feature pieces per timepoint per round
+  for (int k0 = 0; k0 < g.P; k0 += KR) {
+    const int k = k0 + kk;
+    if (act && k < g.P) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(item_ptr(k));
+      const float gm = gamma[k], bt = beta[k];
+      const f32x4 y = (v - mu) * rs * gm + bt;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) tile[(4 * tg + c) * KR + kk] = (bf16)y[c];
+    }
+    __syncthreads();
+    for (int e = tid; e < g.T * pieces; e += 256) {
+      const int t = e / pieces, pc = e - t * pieces;
+      const int kf = k0 + 4 * pc;
+      if (kf < g.P) {                                    // P % 4 == 0 and KR % 4 == 0: whole pieces
+        const long tok = ((long)bo * g.T + t) * g.N + n;
+        *reinterpret_cast<bf16x4*>(out + tok * ldo + kf) = *reinterpret_cast<const bf16x4*>(tile + t * KR + 4 * pc);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// x: contiguous [Bo, H, W, D, T] float32; tokens of volume (bo, t) are rows (bo*T + t)*N + n of `out` (bf16 [Bo*T*N, ldo]).
+extern "C" int nv_patch_ln_fwd_4d(const float* x, int Bo, int H, int W, int D, int T, int p1, int p2, int pf, const float* gamma,
+                                  const float* beta, float eps, void* out, long ldo, float* mean, float* rstd, const float* vol_sigma,
+                                  void* stream) {
+  NV_CHECK_ARG(x && gamma && beta && out && mean && rstd, "nv_patch_ln_fwd_4d: null pointer");
+  NV_CHECK_ARG(Bo > 0 && T > 0 && (T % 4) == 0 && T <= 64 && p1 > 0 && p2 > 0 && pf > 0 && H % p1 == 0 && W % p2 == 0 && D % pf == 0,
+               "nv_patch_ln_fwd_4d: T=%d must be a multiple of 4 (<= 64) and the extents divisible by the patch", T);
+  PatchTGeom g;
+  g.Bo = Bo; g.H = H; g.W = W; g.D = D; g.T = T; g.p1 = p1; g.p2 = p2; g.pf = pf;
+  g.gf = D / pf; g.gh = H / p1; g.gw = W / p2; g.N = g.gf * g.gh * g.gw; g.P = p1 * p2 * pf;
+  NV_CHECK_ARG((g.P % 4) == 0 && ldo >= g.P && (ldo % 4) == 0 && nv_aligned16(x) && nv_aligned16(out), "nv_patch_ln_fwd_4d: patch_dim %% 4, ldo, alignment");
+  const int TG = T / 4;
+  int nact = (256 / TG) * TG;                            // active threads: a multiple of the float4 groups per voxel ...
+  nact -= (nact / TG % 4) * TG;                          // ... with a multiple of four voxels per round (whole 8-byte output pieces)
+  NV_CHECK_ARG(nact >= TG * 4, "nv_patch_ln_fwd_4d: T too large for one workgroup");
+  const size_t lds = (size_t)nact * 8 * sizeof(float) + (size_t)T * (nact / TG) * sizeof(bf16);
+  hipLaunchKernelGGL(patch_ln_fwd_t_kernel, dim3((unsigned)(Bo * g.N)), dim3(256), lds, (hipStream_t)stream, x, g, gamma, beta, eps, (bf16*)out, ldo,
+                     mean, rstd, vol_sigma, nact);
+  NV_CHECK_LAUNCH("nv_patch_ln_fwd_4d");
   return NV_OK;
 }
 

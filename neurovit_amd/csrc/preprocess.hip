@@ -77,6 +77,24 @@ __global__ __launch_bounds__(256) void zscore_apply_kernel(const T* __restrict__
     o[i] = (crop_load(raw, g, b, i) - mean) * inv;
 }
 
+// sigma[b] = population std of cropped volume b + eps, mean[b] optional: the statistics alone (for the fused raw-volume path:
+// nv_vit_forward(..., vol_sigma) folds the z-score into the patch LayerNorm's epsilon, so no normalised copy is written)
+__global__ __launch_bounds__(64) void zscore_finish_kernel(const double* __restrict__ partial, int nparts, double cnt, float eps, float* __restrict__ sigma,
+                                                          float* __restrict__ mean_out) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < nparts; ++i) {
+    s += partial[((long)b * nparts + i) * 2];
+    q += partial[((long)b * nparts + i) * 2 + 1];
+  }
+  const double mean = s / cnt;
+  double var = q / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  sigma[b] = (float)(sqrt(var) + (double)eps);
+  if (mean_out) mean_out[b] = (float)mean;
+}
+
 extern "C" long nv_zscore_crop_workspace_bytes(int B) { return (long)B * 256 * 2 * sizeof(double); }
 
 // raw: [B, X, Y, Z, T] with element strides `strides5` (T = 1 for 3D input), dtype 0 = float32, 1 = int16.
@@ -110,5 +128,28 @@ extern "C" int nv_zscore_crop(const void* raw, int dtype, const long* strides5, 
     hipLaunchKernelGGL(zscore_apply_kernel<short>, grid2, dim3(256), 0, s, (const short*)raw, g, (const double*)workspace, nparts, eps, out, stats);
   }
   NV_CHECK_LAUNCH("nv_zscore_crop");
+  return NV_OK;
+}
+
+// Statistics only: sigma[b] = std(cropped volume b) + eps (and mean[b] when asked).  Same crop / dtype conventions as nv_zscore_crop.
+extern "C" int nv_volume_sigma(const void* raw, int dtype, const long* strides5, int B, const int* crop8, float eps, float* sigma, float* mean,
+                               void* workspace, long ws_bytes, void* stream) {
+  NV_CHECK_ARG(raw && sigma && strides5 && crop8 && B > 0, "nv_volume_sigma: null argument");
+  NV_CHECK_ARG(dtype == 0 || dtype == 1, "nv_volume_sigma: dtype %d unsupported (0 = float32, 1 = int16)", dtype);
+  NV_CHECK_ARG(ws_bytes >= nv_zscore_crop_workspace_bytes(B), "nv_volume_sigma: workspace too small");
+  CropGeom g;
+  for (int i = 0; i < 5; ++i) g.s[i] = strides5[i];
+  g.n[0] = B;
+  for (int i = 0; i < 4; ++i) { g.o[i] = crop8[i]; g.n[1 + i] = crop8[4 + i]; }
+  NV_CHECK_ARG(g.n[1] > 0 && g.n[2] > 0 && g.n[3] > 0 && g.n[4] > 0 && g.o[0] >= 0 && g.o[1] >= 0 && g.o[2] >= 0 && g.o[3] >= 0, "nv_volume_sigma: bad crop");
+  g.per_volume = (long)g.n[1] * g.n[2] * g.n[3] * g.n[4];
+  int nparts = (int)((g.per_volume + 256 * 16 - 1) / (256 * 16));
+  if (nparts > 256) nparts = 256;
+  if (nparts < 1) nparts = 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(zscore_stats_kernel<float>, dim3(nparts, B), dim3(256), 0, s, (const float*)raw, g, (double*)workspace);
+  else hipLaunchKernelGGL(zscore_stats_kernel<short>, dim3(nparts, B), dim3(256), 0, s, (const short*)raw, g, (double*)workspace);
+  hipLaunchKernelGGL(zscore_finish_kernel, dim3(B), dim3(64), 0, s, (const double*)workspace, nparts, (double)g.per_volume, eps, sigma, mean);
+  NV_CHECK_LAUNCH("nv_volume_sigma");
   return NV_OK;
 }

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from ._cabi import VitConfig, check, lib
+from ._cabi import VitConfig, VitInput, check, lib
 
 _BYTES = {torch.float32: 4, torch.bfloat16: 2}
 
@@ -78,24 +78,45 @@ class VitRuntime:
             self._ws[key] = ws
         return ws
 
-    def forward(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, training: bool,
-                dropout: Tuple[float, float, int] = (0.0, 0.0, 0)) -> torch.Tensor:
-        """video: [B, C, F, H, W] fp32 view (any strides).  Returns logits [B, num_classes] fp32.
-        dropout = (p of the blocks, p of the embedding, seed) - (0, 0, *) in eval mode."""
+    def _input_form(self, video: torch.Tensor, vol_sigma, time_points: int):
+        """(B, nv_vit_input or None) after checking the extents: plain [B, C, F, H, W] view, or (time_points > 0) a contiguous
+        4D batch [B / T, H, W, D, T]; vol_sigma marks RAW volumes (z-score folded into the patch LayerNorm)."""
         if not video.is_cuda:
             raise RuntimeError("neurovit_amd: ViT forward needs a CUDA/HIP tensor on MI355X - there is no CPU fallback")
         assert video.dtype == torch.float32 and video.dim() == 5
-        B = video.shape[0]
-        want = (self.cfg.channels, self.cfg.frames, self.cfg.image_size, self.cfg.image_size)
-        if tuple(video.shape[1:]) != want:
-            raise ValueError(f"neurovit_amd: video of shape {tuple(video.shape)} does not match the model's "
-                             f"[B, channels, frames, height, width] = [B, {', '.join(map(str, want))}]")
+        c = self.cfg
+        if time_points:
+            want = (c.image_size, c.image_size, c.frames, time_points)
+            if tuple(video.shape[1:]) != want or not video.is_contiguous() or time_points % 4 or c.channels != 1:
+                raise ValueError(f"neurovit_amd: 4D batch of shape {tuple(video.shape)} (contiguous: {video.is_contiguous()}) does not match "
+                                 f"[B, H, W, D, T] = [B, {', '.join(map(str, want))}] with T % 4 == 0")
+            B = video.shape[0] * time_points
+        else:
+            want = (c.channels, c.frames, c.image_size, c.image_size)
+            if tuple(video.shape[1:]) != want:
+                raise ValueError(f"neurovit_amd: video of shape {tuple(video.shape)} does not match the model's "
+                                 f"[B, channels, frames, height, width] = [B, {', '.join(map(str, want))}]")
+            B = video.shape[0]
+        if vol_sigma is None and not time_points:
+            return B, None
+        if vol_sigma is not None:
+            assert vol_sigma.is_cuda and vol_sigma.dtype == torch.float32 and vol_sigma.numel() == video.shape[0] and vol_sigma.is_contiguous()
+        return B, VitInput(None if vol_sigma is None else vol_sigma.data_ptr(), int(time_points))
+
+    def forward(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, training: bool,
+                dropout: Tuple[float, float, int] = (0.0, 0.0, 0), vol_sigma=None, time_points: int = 0) -> torch.Tensor:
+        """video: [B, C, F, H, W] fp32 view (any strides).  Returns logits [B, num_classes] fp32.
+        dropout = (p of the blocks, p of the embedding, seed) - (0, 0, *) in eval mode.
+        vol_sigma / time_points: the optional input forms of nv_vit_forward_in (raw volumes; contiguous 4D batch)."""
+        B, inp = self._input_form(video, vol_sigma, time_points)
         ws = self.workspace(B, training, video.device)
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
-        check(lib.nv_vit_forward(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
-                                 params.data_ptr(), params16.data_ptr(), ws.data_ptr(), ws.numel(), int(training), float(dropout[0]),
+        check(lib.nv_vit_forward_in(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
+                                    None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p),
+                                    params.data_ptr(), params16.data_ptr(), ws.data_ptr(), ws.numel(), int(training), float(dropout[0]),
                                  float(dropout[1]), int(dropout[2]), logits.data_ptr(),
-                                 torch.cuda.current_stream().cuda_stream), "nv_vit_forward")
+                                 torch.cuda.current_stream().cuda_stream), "nv_vit_forward_in")
+        self._keep = (vol_sigma, inp)                    # the backward re-gathers the same (raw) input
         self._last = (B, training, ws, video)
         self.generation += 1
         self.backward_done = False
@@ -132,14 +153,12 @@ class VitRuntime:
                                       torch.cuda.current_stream().cuda_stream), "nv_vit_quantize_fp8")
         return dict(params8=p8, colscales=cs, act_scales=host, act_list=act_scales)
 
-    def forward_fp8(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, f8) -> torch.Tensor:
-        if not video.is_cuda:
-            raise RuntimeError("neurovit_amd: ViT forward needs a CUDA/HIP tensor on MI355X - there is no CPU fallback")
-        assert video.dtype == torch.float32 and video.dim() == 5
-        B = video.shape[0]
+    def forward_fp8(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, f8, vol_sigma=None, time_points: int = 0) -> torch.Tensor:
+        B, inp = self._input_form(video, vol_sigma, time_points)
         ws = self.workspace(B, False, video.device)
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
-        check(lib.nv_vit_forward_fp8(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video), params.data_ptr(),
+        check(lib.nv_vit_forward_fp8(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
+                                     None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p), params.data_ptr(),
                                      params16.data_ptr(), f8["params8"].data_ptr(), f8["colscales"].data_ptr(),
                                      ctypes.cast(f8["act_scales"], ctypes.c_void_p), ws.data_ptr(), ws.numel(), logits.data_ptr(),
                                      torch.cuda.current_stream().cuda_stream), "nv_vit_forward_fp8")
@@ -155,6 +174,8 @@ class VitRuntime:
         stream - order the consumer of the range's gradients after `aux_stream_object()` as well."""
         assert self._last is not None and self._last[1], "backward needs a preceding forward(training=True)"
         B, _, ws, video = self._last
+        if getattr(self, "_keep", (None, None))[1] is not None and self._keep[1].time_points:
+            raise NotImplementedError("neurovit_amd: the fused 4D input form is forward-only (the 4D model's encoder is frozen, NeuroEncoder.py:34-36)")
         first, last = (0, self.cfg.depth + 1) if stages is None else stages
         if first == 0:
             self._dlogits = dlogits.contiguous().float()

@@ -102,7 +102,7 @@ def ln_bwd(dy, x, st, gamma, g_in=None, want_g16=True, accumulate=False, dgamma=
     return g_out, g16, dgamma, dbeta, dcolsum
 
 
-def patch_ln_fwd(video: torch.Tensor, p1: int, p2: int, pf: int, gamma, beta, eps: float = 1e-5, ldo: Optional[int] = None):
+def patch_ln_fwd(video: torch.Tensor, p1: int, p2: int, pf: int, gamma, beta, eps: float = 1e-5, ldo: Optional[int] = None, vol_sigma=None):
     """video [B,C,F,H,W] (any strides, e.g. the permuted view of a [B,H,W,D] volume)."""
     _need_cuda(video)
     B, C, F, H, W = video.shape
@@ -112,7 +112,7 @@ def patch_ln_fwd(video: torch.Tensor, p1: int, p2: int, pf: int, gamma, beta, ep
     out = torch.empty((B * N, ldo), dtype=torch.bfloat16, device=video.device)
     st = torch.empty((2, B * N), dtype=torch.float32, device=video.device)
     check(lib.nv_patch_ln_fwd(_p(video), strides5(video), B, C, F, H, W, p1, p2, pf, _p(gamma), _p(beta), eps, _p(out), ldo, _p(st[0]),
-                              _p(st[1]), _stream()), "nv_patch_ln_fwd")
+                              _p(st[1]), _p(vol_sigma), _stream()), "nv_patch_ln_fwd")
     return out, st
 
 
@@ -317,3 +317,17 @@ def gemm_f8(epi: int, A8: torch.Tensor, B8: torch.Tensor, colscale: torch.Tensor
     check(lib.nv_gemm_f8(epi, M, N, K, _p(A8), A8.stride(0), _p(B8), B8.stride(0), _p(out), out.stride(0), _p(colscale), _p(bias), _p(aux_in),
                          0 if aux_in is None else aux_in.stride(0), float(out_scale), _stream()), "nv_gemm_f8")
     return out
+
+
+def patch_ln_fwd_4d(x: torch.Tensor, p1: int, p2: int, pf: int, gamma, beta, eps: float = 1e-5, vol_sigma=None):
+    """x f32 contiguous [Bo, H, W, D, T] -> tokens bf16 [Bo*T*N, P] of the T volumes of every sample (row (bo*T + t)*N + n)."""
+    _need_cuda(x)
+    assert x.dim() == 5 and x.is_contiguous() and x.dtype == torch.float32
+    Bo, H, W, D, T = x.shape
+    P = p1 * p2 * pf
+    N = (D // pf) * (H // p1) * (W // p2)
+    out = torch.empty((Bo * T * N, P), dtype=torch.bfloat16, device=x.device)
+    st = torch.empty((2, Bo * T * N), dtype=torch.float32, device=x.device)
+    check(lib.nv_patch_ln_fwd_4d(_p(x), Bo, H, W, D, T, p1, p2, pf, _p(gamma), _p(beta), eps, _p(out), P, _p(st[0]), _p(st[1]), _p(vol_sigma),
+                                 _stream()), "nv_patch_ln_fwd_4d")
+    return out, st

@@ -52,3 +52,28 @@ def zscore_crop(raw: torch.Tensor, crop: Sequence[Tuple[Optional[int], Optional[
                              torch.cuda.current_stream().cuda_stream), "nv_zscore_crop")
     out = out if four_d else out.squeeze(-1)
     return (out, stats) if return_stats else out
+
+
+def crop_view(raw: torch.Tensor, crop: Sequence[Tuple[Optional[int], Optional[int]]] = ADNI_CROP) -> torch.Tensor:
+    """The cropped volume as a strided VIEW of raw [B, X, Y, Z] (no copy)."""
+    (x0, sx), (y0, sy), (z0, sz) = (_span(c, s) for c, s in zip(crop, raw.shape[1:4]))
+    return raw[:, x0:x0 + sx, y0:y0 + sy, z0:z0 + sz]
+
+
+def volume_sigma(raw: torch.Tensor, crop: Sequence[Tuple[Optional[int], Optional[int]]] = ADNI_CROP, eps: float = 1e-8) -> torch.Tensor:
+    """[B] = population std of each cropped volume + eps (statistics in double; one pass over the raw volumes, nothing written back)."""
+    if not raw.is_cuda:
+        raise RuntimeError("neurovit_amd.preprocess.volume_sigma: input must live on the MI355X (cuda) device - there is no CPU fallback")
+    if raw.dim() != 4 or raw.dtype not in (torch.float32, torch.int16):
+        raise ValueError("volume_sigma: expected raw [B, X, Y, Z] float32 or int16")
+    B, X, Y, Z = raw.shape
+    (x0, sx), (y0, sy), (z0, sz) = (_span(c, s) for c, s in zip(crop, (X, Y, Z)))
+    sigma = torch.empty(B, dtype=torch.float32, device=raw.device)
+    nb = lib.nv_zscore_crop_workspace_bytes(B)
+    ws = torch.empty(nb, dtype=torch.uint8, device=raw.device)
+    strides = (ctypes.c_long * 5)(*raw.stride(), 0)
+    crop8 = (ctypes.c_int * 8)(x0, y0, z0, 0, sx, sy, sz, 1)
+    check(lib.nv_volume_sigma(raw.data_ptr(), 0 if raw.dtype == torch.float32 else 1, ctypes.cast(strides, ctypes.c_void_p), B,
+                              ctypes.cast(crop8, ctypes.c_void_p), eps, sigma.data_ptr(), None, ws.data_ptr(), nb,
+                              torch.cuda.current_stream().cuda_stream), "nv_volume_sigma")
+    return sigma

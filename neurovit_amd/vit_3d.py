@@ -206,11 +206,11 @@ class _ViTFunction(torch.autograd.Function):
     arena (which `param.grad` views), so backward returns None for them (no per-tensor accumulate copies)."""
 
     @staticmethod
-    def forward(ctx, module, video, need_grad, *params):
+    def forward(ctx, module, video, need_grad, extra, *params):
         # need_grad is decided by the caller: grad mode is always off inside Function.forward, and ctx.needs_input_grad
         # reflects requires_grad alone (it stays True under torch.no_grad()), so neither tells whether a graph is being built
         ctx.module = module
-        out = module._run_forward(video, need_grad)
+        out = module._run_forward(video, need_grad, extra)
         ctx.generation = module._rt.generation     # the workspace holds THIS forward's activations until the next forward
         return out
 
@@ -224,7 +224,7 @@ class _ViTFunction(torch.autograd.Function):
                 "before the next forward of the same module (siamese / two-forward losses need one module instance per branch).")
         ctx.module._run_backward(dlogits)
         rt.backward_done = True
-        return (None, None, None) + (None,) * len(ctx.module._plist)
+        return (None, None, None, None) + (None,) * len(ctx.module._plist)
 
 
 class ViT(nn.Module):
@@ -366,7 +366,8 @@ class ViT(nn.Module):
         self._fp8 = None
 
     # ------------------------------------------------------------------ execution
-    def _run_forward(self, video, need_grad):
+    def _run_forward(self, video, need_grad, extra=(None, 0)):
+        vol_sigma, time_points = extra
         drop = (0.0, 0.0, 0)
         if self.training and (self._dropout_p[0] > 0 or self._dropout_p[1] > 0):
             # nn.Dropout semantics (vit_3d.py:21,23,39,45,100) with a counter-based mask: a fresh seed per forward from
@@ -377,9 +378,10 @@ class ViT(nn.Module):
         if self._fp8 is not None and not need_grad and not self.training:
             if self._fp8["key"] != tuple(p._version for p in self._plist):      # parameters changed since quantisation
                 self._fp8 = dict(self._rt.quantize_fp8(self._arena, self._fp8["act_list"]), key=tuple(p._version for p in self._plist))
-            self._last_logits = self._rt.forward_fp8(video, self._arena, self._shadow, self._fp8)
+            self._last_logits = self._rt.forward_fp8(video, self._arena, self._shadow, self._fp8, vol_sigma=vol_sigma, time_points=time_points)
             return self._last_logits
-        self._last_logits = self._rt.forward(video, self._arena, self._shadow, training=need_grad, dropout=drop)
+        self._last_logits = self._rt.forward(video, self._arena, self._shadow, training=need_grad, dropout=drop, vol_sigma=vol_sigma,
+                                             time_points=time_points)
         return self._last_logits
 
     def _run_backward(self, dlogits):
@@ -418,11 +420,17 @@ class ViT(nn.Module):
             sync.bucket_ready(grads, begin, end, also_after=None if last == last_stage else self._rt.aux_stream_object(grads.device))
         sync.finish()
 
-    def forward(self, video):
+    def forward(self, video, vol_sigma=None, time_points=0):
+        """video [B, C, F, H, W] -> [B, num_classes] (vit_3d.py:112-126).  Beyond the reference (both optional):
+        vol_sigma [B] marks `video` as RAW volumes whose per-volume z-score (std + 1e-8) is folded into the patch LayerNorm;
+        time_points = T > 0 takes a contiguous 4D batch [B, H, W, D, T] and encodes its B*T volumes without the regroup copy."""
         if not video.is_cuda:
             raise RuntimeError("neurovit_amd.ViT: input must live on the MI355X (cuda) device - there is no CPU fallback")
         c = self._cfg
-        if video.dim() != 5 or tuple(video.shape[1:]) != (c.channels, c.frames, c.image_size, c.image_size):
+        if time_points:
+            if video.dim() != 5 or tuple(video.shape[1:]) != (c.image_size, c.image_size, c.frames, time_points):
+                raise ValueError(f"neurovit_amd.ViT: expected a 4D batch [B, {c.image_size}, {c.image_size}, {c.frames}, {time_points}], got {tuple(video.shape)}")
+        elif video.dim() != 5 or tuple(video.shape[1:]) != (c.channels, c.frames, c.image_size, c.image_size):
             # the reference fails here too (einops Rearrange / the pos_embedding add, vit_3d.py:92,118); the gather kernel
             # takes its extents from the config, so a wrong-sized volume must never reach it
             raise ValueError(f"neurovit_amd.ViT: expected video [B, {c.channels}, {c.frames}, {c.image_size}, {c.image_size}] "
@@ -432,7 +440,9 @@ class ViT(nn.Module):
         if self._arena.device != video.device:
             raise RuntimeError(f"neurovit_amd.ViT: parameters on {self._arena.device}, input on {video.device}")
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)
-        return _ViTFunction.apply(self, video.float(), need_grad, *self._plist)
+        if time_points and need_grad:
+            raise NotImplementedError("neurovit_amd.ViT: the fused 4D input form is forward-only (frozen encoder of the 4D model)")
+        return _ViTFunction.apply(self, video.float(), need_grad, (vol_sigma, int(time_points)), *self._plist)
 
     # activations / gradients of the last block's attention LayerNorm output (Grad-CAM contract, NeuroEncoder.py:70-82)
     def last_attn_norm_output_raw(self) -> torch.Tensor:

@@ -535,3 +535,78 @@ def test_ce_loss_out_of_range_label_poisons_loss_without_oob_read(nv):
     assert abs(good.item() - torch.nn.functional.cross_entropy(logits, torch.tensor([0, 1, 1, 0], device="cuda")).item()) < 1e-5
     bad, dl = ops.ce_loss(logits, torch.tensor([0, 7, 1, -3], device="cuda"))
     assert torch.isnan(bad).all() and torch.isfinite(dl).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# input fusions.  (a) 4D samples [B, H, W, D, T] are encoded without the regroup copy of NeuroEncoder.py:54-56;
+# (b) raw volumes: the dataset's crop is a strided view and its z-score is folded into the patch LayerNorm's epsilon.
+@pytest.mark.parametrize("S,p,T", [(16, 8, 4), (32, 8, 8), (32, 16, 20)])
+def test_patch_gather_4d_equals_per_volume_gather(nv, S, p, T):
+    from neurovit_amd import ops
+    rs = np.random.RandomState(S + T)
+    x = torch.from_numpy(rs.randn(2, S, S, S, T).astype(np.float32) * 1.5 + 0.3).cuda()
+    P = p ** 3
+    gamma = torch.from_numpy(1 + 0.1 * rs.randn(P).astype(np.float32)).cuda()
+    beta = torch.from_numpy(0.1 * rs.randn(P).astype(np.float32)).cuda()
+    sigma = torch.tensor([0.7, 1.9], device="cuda")
+    for vs in (None, sigma):
+        tok4, st4 = ops.patch_ln_fwd_4d(x, p, p, p, gamma, beta, vol_sigma=vs)
+        vols = x.permute(0, 4, 1, 2, 3).reshape(2 * T, S, S, S)                          # the reference's regroup (a copy)
+        video = vols.permute(0, 3, 1, 2).unsqueeze(1)
+        tok, st = ops.patch_ln_fwd(video, p, p, p, gamma, beta, vol_sigma=None if vs is None else vs.repeat_interleave(T))
+        assert tok4.shape == tok.shape
+        assert rel_err(st4[0], st[0]) < 1e-5 and rel_err(st4[1], st[1]) < 1e-4
+        d = (tok4.float() - tok.float()).abs()
+        assert (d <= tok.float().abs() * 2 ** -7 + 1e-6).all() and (d > 0).float().mean().item() < 2e-3     # one bf16 ulp at most, rarely
+        tok4b, _ = ops.patch_ln_fwd_4d(x, p, p, p, gamma, beta, vol_sigma=vs)
+        assert torch.equal(tok4, tok4b)                                                  # deterministic
+
+
+def test_raw_volume_forward_equals_zscored_forward(nv):
+    """forward_raw(raw) == forward(zscore_crop(raw)) up to bf16 noise; gradients too (the backward re-gathers the raw volume)."""
+    from neurovit_amd.preprocess import ADNI_CROP, zscore_crop
+    S, p = 32, 8
+    size = dict(TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
+    model = nv.NeuroEncoder(W.neuro_config(S, p, DEVICE="cuda", **size))
+    model.load_state_dict(W.make_tensors(W.vit_param_spec(**W.MICRO), 1, prefix="volume_encoder.vit3d."), strict=True)
+    model.train()
+    rs = np.random.RandomState(3)
+    raw = torch.from_numpy((rs.randn(3, S + 1, S + 19, S + 1) * 40 + 300).astype(np.float32)).cuda()     # scanner-like values, 33 x 51 x 33
+    ref_in = zscore_crop(raw, ADNI_CROP)
+    assert ref_in.shape == (3, S, S, S)
+    a = model(ref_in)
+    a.sum().backward()
+    ga = {k: v.grad.clone() for k, v in model.named_parameters()}
+    model.zero_grad()
+    b = model.forward_raw(raw)
+    b.sum().backward()
+    assert rel_err(b, a) < 3e-3, rel_err(b, a)
+    for k, v in model.named_parameters():
+        assert rel_l2(v.grad, ga[k]) < 1e-2, k
+    model.eval()
+    with torch.no_grad():
+        assert rel_err(model.forward_raw(raw), model(ref_in)) < 3e-3
+
+
+def test_neuro4d_fused_gather_equals_copy_path(nv):
+    S, p, T = 16, 8, 8
+    sd3 = _neuro_sd(S, p, 21)
+    with tempfile.TemporaryDirectory() as td:
+        torch.save(dict(sd3), os.path.join(td, "ckpt3d.pth"))
+        model = nv.NeuroEncoder(W.neuro_config(S, p, dim=4, DEVICE="cuda", GLOBAL_BASE_PATH=td, BEST_MODEL_PATH="ckpt3d.pth"))
+    model.load_state_dict(W.make_tensors(W.temporal_param_spec(), 22), strict=False)
+    model.eval()
+    x = W.make_volume((2, S, S, S, T), 23).cuda()
+    with torch.no_grad():
+        fused = model(x)                                                                 # T % 4 == 0, contiguous -> fused gather
+        vols = x.permute(0, 4, 1, 2, 3).reshape(2 * T, S, S, S)
+        enc_copy = model.volume_encoder(vols)
+        enc_fused = model.volume_encoder.vit3d(x, time_points=T)
+        assert rel_err(enc_fused, enc_copy) < 3e-3
+        copy = model.projection_head(model.temporal_transformer(enc_copy.reshape(2, T, -1)).mean(dim=1))
+        assert rel_err(fused, copy) < 1e-3
+    model.train()                                                                        # 4D training: frozen encoder, trainable temporal head
+    out = model(x)
+    out.sum().backward()
+    assert all(q.grad is None for q in model.volume_encoder.parameters())
+    assert all(q.grad is not None for q in model.temporal_transformer.parameters())
