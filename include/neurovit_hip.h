@@ -171,7 +171,10 @@ long nv_head_bwd_workspace_bytes(int B, int d);
 int nv_head_bwd(const float* dlogits, int B, int C, const float* W, const float* x, long row_stride, const float* stats,
                 const float* xh, const float* gamma, int d, int n, float* g, long ldg, void* g16, long ldg16, float* dgamma,
                 float* dbeta, float* dW, float* dbias, float* dcolsum, int accumulate, void* workspace, long ws_bytes,
-                unsigned long drop_seed, float drop_p, void* stream);
+                unsigned long drop_seed, float drop_p, int pool_mean, void* stream);
+/* pool='mean' (vit_3d.py:127): out[b,:] = mean_t x[b,t,:]; feed it to nv_head_fwd / nv_head_bwd with row_stride = d
+   and pool_mean = 1 (every row of g then receives dx / n) */
+int nv_token_mean(const float* x, int B, int n, int d, float* out, void* stream);
 
 /* ---- bias gradients: out[c] (+)= sum_r X[r,c], X bf16 */
 long nv_colsum_workspace_bytes(int M, int N);
@@ -208,6 +211,7 @@ typedef struct nv_vit_config {
   int image_size, image_patch_size, frames, frame_patch_size;
   int channels, num_classes, dim, depth, heads, dim_head, mlp_dim;
   float ln_eps;
+  int pool_mean;   /* 0: pool='cls' (NeuroEncoder.py:194), 1: pool='mean' (vit_3d.py:127) */
 } nv_vit_config;
 
 long nv_vit_param_count(const nv_vit_config* cfg);

@@ -17,6 +17,7 @@ inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
 struct Dims {
   int B, N, n, P, Ppad, d, inner, m, L, C, heads, dh, M, T;   // M = B*n rows of the stream, T = B*N tokens
   int gf, gh, gw;
+  int pool_mean;
 };
 
 int make_dims(const nv_vit_config* c, int B, Dims& D) {
@@ -39,6 +40,7 @@ int make_dims(const nv_vit_config* c, int B, Dims& D) {
   D.d = c->dim; D.heads = c->heads; D.dh = c->dim_head; D.inner = c->heads * c->dim_head; D.m = c->mlp_dim;
   D.L = c->depth; D.C = c->num_classes;
   D.M = B * D.n; D.T = B * D.N;
+  D.pool_mean = c->pool_mean != 0;
   return NV_OK;
 }
 
@@ -68,7 +70,7 @@ void make_params(const Dims& D, ParamTab& T) {
 // ---- workspace layout -------------------------------------------------------------------------------
 struct LayerW { long xn1, st1, qkv, lse, ao, x1, xn2, st2, u, h, x2; };
 struct WS {
-  long xp, pst, t, est, x0, xh, hst, wpe16;
+  long xp, pst, t, est, x0, xh, hst, wpe16, xm;
   std::vector<LayerW> layer;
   // backward scratch
   long g, g16, g16b, dxn, hookg, du, dao, dqkv, delta, dt, dt16, dxp, dwpe, red, red2, red3, cs1;
@@ -82,6 +84,7 @@ void make_ws(const Dims& D, int training, WS& W) {
   const long M = D.M, T = D.T, d = D.d;
   W.xp = add(T * D.Ppad * 2); W.pst = add(T * 2 * 4); W.t = add(T * d * 4); W.est = add(T * 2 * 4); W.x0 = add(M * d * 4);
   W.xh = add((long)D.B * d * 4); W.hst = add((long)D.B * 2 * 4);
+  W.xm = D.pool_mean ? add((long)D.B * d * 4) : -1;      // pool='mean': token mean of the last block's output
   W.wpe16 = (D.P != D.Ppad) ? add(d * D.Ppad * 2) : -1;
   const int nl = training ? D.L : 1;     // inference: every layer reuses one set of buffers (x ping-pongs x1 <-> x2/x0)
   W.layer.resize(D.L);
@@ -267,7 +270,13 @@ extern "C" int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* v
     xin = x2;
   }
   // A9: cls pooling + LayerNorm + Linear(dim, C)
-  RUN(nv_head_fwd(xin, (long)D.n * d, B, d, p + T.hg, p + T.hb, eps, p + T.hw, p + T.hbias, D.C, (float*)(ws + W.xh), (float*)(ws + W.hst),
+  const float* pooled = xin;
+  long pooled_stride = (long)D.n * d;
+  if (D.pool_mean) {
+    RUN(nv_token_mean(xin, B, D.n, d, (float*)(ws + W.xm), stream));
+    pooled = (float*)(ws + W.xm); pooled_stride = d;
+  }
+  RUN(nv_head_fwd(pooled, pooled_stride, B, d, p + T.hg, p + T.hb, eps, p + T.hw, p + T.hbias, D.C, (float*)(ws + W.xh), (float*)(ws + W.hst),
                   logits, stream));
   return NV_OK;
 }
@@ -349,7 +358,13 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
     RUN(nv_gemm_f8(4, M, d, D.m, ws + w.h, D.m, p8 + q.w2, D.m, x2, d, cs + 3L * D.inner + D.m, p + q.b2, x1, d, 1.f, stream));
     xin = x2;
   }
-  RUN(nv_head_fwd(xin, (long)D.n * d, B, d, p + T.hg, p + T.hb, eps, p + T.hw, p + T.hbias, D.C, (float*)(ws + W.xh), (float*)(ws + W.hst),
+  const float* pooled = xin;
+  long pooled_stride = (long)D.n * d;
+  if (D.pool_mean) {
+    RUN(nv_token_mean(xin, B, D.n, d, (float*)(ws + W.xm), stream));
+    pooled = (float*)(ws + W.xm); pooled_stride = d;
+  }
+  RUN(nv_head_fwd(pooled, pooled_stride, B, d, p + T.hg, p + T.hb, eps, p + T.hw, p + T.hbias, D.C, (float*)(ws + W.xh), (float*)(ws + W.hst),
                   logits, stream));
   return NV_OK;
 }
@@ -399,9 +414,10 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
   // head: writes g (zeros + cls rows) and the last layer's FC2 bias gradient (colsum of g)
   const float* xlast = (float*)(ws + W.layer[D.L - 1].x2);
   if (first_stage == 0)
-  RUN(nv_head_bwd(dlogits, B, D.C, p + T.hw, xlast, (long)D.n * d, (float*)(ws + W.hst), (float*)(ws + W.xh), p + T.hg, d, D.n, g, d, G16(D.L - 1), d,
+  RUN(nv_head_bwd(dlogits, B, D.C, p + T.hw, D.pool_mean ? (const float*)(ws + W.xm) : xlast, D.pool_mean ? (long)d : (long)D.n * d,
+                  (float*)(ws + W.hst), (float*)(ws + W.xh), p + T.hg, d, D.n, g, d, G16(D.L - 1), d,
                   gr + T.hg, gr + T.hb, gr + T.hw, gr + T.hbias, gr + T.layer[D.L - 1].b2, acc, red, W.red_bytes,
-                  site_seed(drop_seed, 4 * (D.L - 1) + 3), drop_p, stream));
+                  site_seed(drop_seed, 4 * (D.L - 1) + 3), drop_p, D.pool_mean, stream));
 
   // One cross-stream event per layer in each direction (an event record costs several microseconds of queue time): the main
   // stream signals once, after the attention backward; the auxiliary stream then runs, one layer behind the main stream,

@@ -755,13 +755,15 @@ extern "C" int nv_head_fwd(const float* x, long row_stride, int B, int d, const 
   return NV_OK;
 }
 
-// Backward of the head for volume b (one workgroup): dxh = dlogits[b] . W; LN backward on the cls row;
+// Backward of the head for volume b (one workgroup): dxh = dlogits[b] . W; LN backward on the pooled row (cls row, or the
+// token mean when pool_mean: then x is the [B, d] pooled matrix and every row of g gets dx / n);
 // writes g[b, 0, :] = dx (fp32 + bf16; the other rows were zeroed by a memset node in front) and per-volume
 // partials [b][3][d] = (dgamma, dbeta, dx) reduced afterwards.
 __global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict__ dlogits, int C, const float* __restrict__ Wt,
                                                          const float* __restrict__ x, long row_stride, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, int d, int n, float* __restrict__ g, long ldg,
-                                                         bf16* __restrict__ g16, long ldg16, float* __restrict__ partials, DropCfg drop) {
+                                                         bf16* __restrict__ g16, long ldg16, float* __restrict__ partials, DropCfg drop,
+                                                         int pool_mean) {
   extern __shared__ __attribute__((aligned(16))) float sh[];   // dyh[d] + 8 scratch
   float* dys = sh;
   float* scratch = sh + d;
@@ -787,7 +789,20 @@ __global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict
   const float c2 = ((scratch[4] + scratch[5]) + (scratch[6] + scratch[7])) / (float)d;
   for (int c = tid; c < d; c += 256) {
     const float xh = (row[c] - mean) * rstd;
-    const float dx = (dys[c] - c1 - xh * c2) * rstd;
+    float dx = (dys[c] - c1 - xh * c2) * rstd;
+    if (pool_mean) {   // pool = 'mean' (vit_3d.py:127): every token row receives dx / n
+      dx /= (float)n;
+      float cs = 0.f;
+      for (int t = 0; t < n; ++t) {
+        const long r = (long)b * n + t;
+        g[r * ldg + c] = dx;
+        const float dxm = drop.thresh ? dx * drop_factor(drop, (unsigned long long)r * d + c) : dx;
+        if (g16) g16[r * ldg16 + c] = (bf16)dxm;
+        cs += dxm;
+      }
+      partials[((long)b * 3 + 2) * d + c] = cs;
+      continue;
+    }
     g[(long)b * n * ldg + c] = dx;
     const float dxm = drop.thresh ? dx * drop_factor(drop, (unsigned long long)b * n * d + c) : dx;   // last block's FF output dropout
     if (g16) g16[(long)b * n * ldg16 + c] = (bf16)dxm;
@@ -812,23 +827,42 @@ __global__ void head_bwd_w_kernel(const float* __restrict__ dlogits, const float
   }
 }
 
+// pool = 'mean' (vit_3d.py:127): out[b, c] = mean over the n token rows of x[b, :, c]. 64 columns x 4 row groups per workgroup.
+__global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ x, int n, int d, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < d)
+    for (int t = rg; t < n; t += 4) s += x[((long)b * n + t) * d + c];
+  part[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < d) out[(long)b * d + c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x])) / (float)n;
+}
+
+extern "C" int nv_token_mean(const float* x, int B, int n, int d, float* out, void* stream) {
+  NV_CHECK_ARG(B > 0 && n > 0 && d > 0, "nv_token_mean: bad shape B=%d n=%d d=%d", B, n, d);
+  hipLaunchKernelGGL(token_mean_kernel, dim3((d + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, n, d, out);
+  NV_CHECK_LAUNCH("nv_token_mean");
+  return NV_OK;
+}
+
 extern "C" long nv_head_bwd_workspace_bytes(int B, int d) { return (long)B * 3 * d * sizeof(float); }
 
 extern "C" int nv_head_bwd(const float* dlogits, int B, int C, const float* W, const float* x, long row_stride, const float* stats,
                            const float* xh, const float* gamma, int d, int n, float* g, long ldg, void* g16, long ldg16,
                            float* dgamma, float* dbeta, float* dW, float* dbias, float* dcolsum, int accumulate, void* workspace,
-                           long ws_bytes, unsigned long drop_seed, float drop_p, void* stream) {
+                           long ws_bytes, unsigned long drop_seed, float drop_p, int pool_mean, void* stream) {
   NV_CHECK_ARG(ws_bytes >= nv_head_bwd_workspace_bytes(B, d), "nv_head_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   NV_CHECK_ARG(ldg == d && (!g16 || ldg16 == d), "nv_head_bwd: g / g16 must be dense [B*n, d]");
   // the residual gradient is zero except for the cls rows (pool = 'cls'): wide memsets, then the cls rows
-  if (hipMemsetAsync(g, 0, (size_t)B * n * d * sizeof(float), s) != hipSuccess ||
-      (g16 && hipMemsetAsync(g16, 0, (size_t)B * n * d * 2, s) != hipSuccess)) {
+  if (!pool_mean && (hipMemsetAsync(g, 0, (size_t)B * n * d * sizeof(float), s) != hipSuccess ||
+      (g16 && hipMemsetAsync(g16, 0, (size_t)B * n * d * 2, s) != hipSuccess))) {
     nv_set_error("nv_head_bwd: hipMemsetAsync failed");
     return NV_ERR_HIP;
   }
   hipLaunchKernelGGL(head_bwd_x_kernel, dim3(B), dim3(256), (d + 8) * sizeof(float), s, dlogits, C, W, x, row_stride, stats, gamma, d, n,
-                     g, ldg, (bf16*)g16, ldg16, (float*)workspace, make_drop(drop_seed, drop_p));
+                     g, ldg, (bf16*)g16, ldg16, (float*)workspace, make_drop(drop_seed, drop_p), pool_mean);
   NV_CHECK_LAUNCH("nv_head_bwd/x");
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 31) / 32), dim3(256), 0, s, (const float*)workspace, B, d, 3, dgamma, dbeta,
                      dcolsum, accumulate);

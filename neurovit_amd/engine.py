@@ -21,9 +21,11 @@ _BYTES = {torch.float32: 4, torch.bfloat16: 2}
 
 
 def make_config(*, image_size, image_patch_size, frames, frame_patch_size, num_classes, dim, depth, heads, mlp_dim,
-                channels=3, dim_head=64, ln_eps=1e-5, **_) -> VitConfig:
+                channels=3, dim_head=64, ln_eps=1e-5, pool='cls', **_) -> VitConfig:
+    if pool not in ('cls', 'mean'):
+        raise ValueError("pool type must be either cls (cls token) or mean (mean pooling)")
     return VitConfig(image_size, image_patch_size, frames, frame_patch_size, channels, num_classes, dim, depth, heads,
-                     dim_head, mlp_dim, ln_eps)
+                     dim_head, mlp_dim, ln_eps, int(pool == 'mean'))
 
 
 def param_layout(cfg: VitConfig) -> Tuple[List[int], List[int], int]:

@@ -190,7 +190,7 @@ def head_bwd(dlogits, W, x, st, xh, gamma, drop_seed=0, drop_p=0.0):
     nb = lib.nv_head_bwd_workspace_bytes(B, d)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     check(lib.nv_head_bwd(_p(dlogits), B, C, _p(W), _p(x), n * d, _p(st), _p(xh), _p(gamma), d, n, _p(g), d, _p(g16), d, _p(dgamma), _p(dbeta),
-                          _p(dW), _p(db), _p(dcol), 0, _p(ws), nb, drop_seed, drop_p, _stream()), "nv_head_bwd")
+                          _p(dW), _p(db), _p(dcol), 0, _p(ws), nb, drop_seed, drop_p, 0, _stream()), "nv_head_bwd")
     return g, g16, dgamma, dbeta, dW, db, dcol
 
 

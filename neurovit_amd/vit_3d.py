@@ -269,15 +269,14 @@ class ViT(nn.Module):
         if image_height != image_width or patch_height != patch_width:
             raise NotImplementedError("neurovit_amd: the gfx950 engine supports square images / patches (the NeuroEncoder "
                                       "path is cubic: NeuroEncoder.py:183-186)")
-        if pool != 'cls':
-            raise NotImplementedError("neurovit_amd: pool='mean' is not on the hot path (NeuroEncoder.py:194 uses 'cls')")
         if heads == 1 and dim_head == dim:
             raise NotImplementedError("neurovit_amd: heads == 1 with dim_head == dim drops to_out (vit_3d.py:32,43-46); the "
                                       "engine's parameter table always carries to_out - not on the NeuroEncoder path")
         self._dropout_p = (float(dropout), float(emb_dropout))
         self._cfg = engine.make_config(image_size=image_height, image_patch_size=patch_height, frames=frames,
                                        frame_patch_size=frame_patch_size, num_classes=num_classes, dim=dim, depth=depth,
-                                       heads=heads, mlp_dim=mlp_dim, channels=channels, dim_head=dim_head)
+                                       heads=heads, mlp_dim=mlp_dim, channels=channels, dim_head=dim_head,
+                                       pool=pool)
         self._rt = engine.VitRuntime(self._cfg)
         self._arena: Optional[torch.Tensor] = None      # flat fp32 master parameters
         self._shadow: Optional[torch.Tensor] = None     # flat bf16 copy read by the MFMA kernels

@@ -151,8 +151,7 @@ def test_unsupported_constructions_raise():
     from neurovit_amd.vit_3d import ViT
     with pytest.raises(NotImplementedError):
         ViT(**dict(W.MICRO, dim=64, heads=1))            # to_out becomes Identity in the reference (vit_3d.py:32)
-    with pytest.raises(NotImplementedError):
-        ViT(**dict(W.MICRO, pool="mean"))
+    assert ViT(**dict(W.MICRO, pool="mean"))._cfg.pool_mean == 1 and ViT(**W.MICRO)._cfg.pool_mean == 0
     with pytest.raises(AssertionError):
         ViT(**dict(W.MICRO, image_size=30))              # vit_3d.py:83 divisibility assert
 

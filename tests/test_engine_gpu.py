@@ -142,6 +142,15 @@ def test_micro_train_mode_dropout_same_masks(eng):
     run_case(eng, "micro+dropout", dict(W.MICRO), (1, 2), dropout=(0.1, 0.2, 123456789))
 
 
+def test_pool_mean(eng):
+    """pool='mean' (vit_3d.py:127: x.mean(dim=1) instead of the cls row): token-mean kernel in front of the head, and a
+    head backward that gives every token row dx / n - with and without dropout (the last FF dropout mask then applies to
+    every row of the incoming gradient)."""
+    run_case(eng, "micro+mean", dict(W.MICRO, pool="mean"), (11, 12))
+    run_case(eng, "micro+mean+dropout", dict(W.MICRO, pool="mean"), (11, 12), dropout=(0.1, 0.2, 987654321))
+    run_case(eng, "p9+mean", dict(W.MICRO, pool="mean", image_size=27, image_patch_size=9, frames=27, frame_patch_size=9), (13, 14), B=3)
+
+
 def test_odd_patch_size_like_reference_default(eng):
     """The reference's default geometry is 90^3 / patch 9 (configs/config.yaml:39-40): patch_dim = 729 is not a multiple
     of 8 (scalar gather path, zero-padded GEMM operands, padded weight-gradient scratch) and n = N+1 is odd."""

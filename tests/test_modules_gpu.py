@@ -444,6 +444,39 @@ def test_standalone_blocks_forward_backward_vs_oracle(nv):
         assert ff0(x.cuda().reshape(-1, dim)).shape == (B * n, dim)          # FeedForward takes any [..., dim]
 
 
+def test_vit_module_pool_mean_autograd_vs_oracle(nv):
+    """ViT(pool='mean') as an nn.Module under stock autograd (vit_3d.py:127): logits and gradients, including the cls token's
+    (non-zero only through attention under pool='cls', directly averaged under 'mean'), against the fp32 oracle."""
+    from neurovit_amd.vit_3d import ViT
+    cfgdict = dict(W.MICRO, pool="mean")
+    sd = W.make_tensors(W.vit_param_spec(**cfgdict), 61)
+    vit = ViT(**cfgdict).cuda()
+    vit.load_state_dict(sd, strict=True)
+    vit.train()
+    x = W.make_volume((3, 32, 32, 32), 62)
+    video = ref_cpu.fmri_to_video(x)
+    logits = vit(video.cuda())
+    wl = torch.tensor([[1.0, -2.0], [0.5, 0.25], [-1.0, 3.0]])
+    (logits * wl.cuda()).sum().backward()
+
+    def oracle(emulate):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        lg = ref_cpu.vit_forward(leaves, ref_cpu.ViTCfg(**cfgdict), video, emulate_bf16=emulate)
+        (lg * wl).sum().backward()
+        return lg.detach(), {k: v.grad for k, v in leaves.items()}
+
+    lg32, g32 = oracle(False)
+    lge, ge = oracle(True)
+    _three_way(logits, lge, lg32, floor=4e-3)
+    for k, p in vit.named_parameters():
+        _three_way(p.grad, ge[k], g32[k], slack=2.0, floor=4e-3 if k.endswith("bias") else 2e-3)
+    # the 'cls' model on the same weights gives different logits (the pooling really changed)
+    cls = ViT(**W.MICRO).cuda()
+    cls.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        assert rel_l2(cls(video.cuda()), lg32) > 0.05
+
+
 def test_standalone_blocks_dropout_train_vs_eval(nv):
     from neurovit_amd.vit_3d import Attention, FeedForward
     torch.manual_seed(3)
