@@ -53,13 +53,40 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* img, int t, int ks, int r,
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // bare v_exp_f32: arguments here are <= 0 and results in [0, 1]; results below 2^-126 flush to zero (they vanish in the sums)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// Exchange with the lanes l ^ 16 and l ^ 32 (the four lane groups that share a score row) on the VALU: v_permlane16_swap /
+// v_permlane32_swap (gfx950) swap the odd 16- / 32-lane rows of one register with the even rows of another, so two copies of v
+// come back as (v[l & ~16], v[l | 16]) - their max / sum is the pair's in every lane.  __shfl_xor compiles to ds_bpermute_b32:
+// an LDS-crossbar round trip the wave waits for (lgkmcnt(0)) twice per key tile, in a loop with two waves per SIMD to hide it.
+// (asm: the builtin form lost the combining fmaxf at -O3.)
+__device__ __forceinline__ void lane_pair16(float v, float& a, float& b) {
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_pair32(float v, float& a, float& b) {
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+// single-instruction maxima: fmaxf on MFMA results / asm outputs gets a canonicalising v_max_f32 x, x, x in front of every operand
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+// single-instruction f32 arithmetic: beside MFMAs the packed forms (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32, which the compiler
+// also builds by itself from adjacent scalar operations) cost more issue time than the two scalar instructions they replace
+__device__ __forceinline__ float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float vmul(float a, float b) { return a * b; }
 __device__ __forceinline__ float group_max(float v) {   // over the 4 lane groups sharing r
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+  float a, b;
+  lane_pair16(v, a, b);
+  v = vmax(a, b);
+  lane_pair32(v, a, b);
+  return vmax(a, b);
 }
 __device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  float a, b;
+  lane_pair16(v, a, b);
+  v = a + b;
+  lane_pair32(v, a, b);
+  return a + b;
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -104,15 +131,15 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4], int kt, bool last, in
         for (int j = 0; j < 4; ++j)
           if (kt * TK + 16 * t + 4 * g + j >= n) s[t][j] = -INFINITY;
     }
-    float mloc = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
-    mloc = fmaxf(fmaxf(mloc, s[0][3]), s[1][0]);
+    float mloc = vmax3(s[0][0], s[0][1], s[0][2]);
+    mloc = vmax3(mloc, s[0][3], s[1][0]);
 #pragma unroll
     for (int t = 1; t < 4; ++t) {
-      if (t > 1) mloc = fmaxf(fmaxf(mloc, s[t - 1][3]), s[t][0]);
-      mloc = fmaxf(fmaxf(mloc, s[t][1]), s[t][2]);
+      if (t > 1) mloc = vmax3(mloc, s[t - 1][3], s[t][0]);
+      mloc = vmax3(mloc, s[t][1], s[t][2]);
     }
-    mloc = fmaxf(mloc, s[3][3]);
-    const float mnew = fmaxf(m, group_max(mloc) * scale_log2e);
+    mloc = vmax(mloc, s[3][3]);
+    const float mnew = vmax(m, group_max(mloc) * scale_log2e);
     const bool moved = mnew != m;                 // running max unchanged for every row of this wave -> skip the rescale
     const float alpha = fast_exp2(m - mnew);
     m = mnew;
@@ -253,10 +280,20 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr int RES_THREADS = 512;
 constexpr int RES_MAX_TILES = 9;
 
+// Buffer resource for LDS-DMA from a workgroup-uniform base.  The bases here come out of 64-bit VALU address arithmetic on
+// blockIdx, so the compiler treats them as divergent and wraps EVERY buffer_load ... lds in a waterfall loop (four
+// v_readfirstlane + compares + saveexec + branch per DMA instruction); reading the words back through v_readfirstlane puts the
+// descriptor in SGPRs once.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 // all eight waves: DMA rows 0 .. 64*nt-1 of X (row stride ld elements, 64 bf16 per row) into nt swizzled 8 KiB images
 __device__ __forceinline__ void res_dma(const bf16* X, long ld, int n, int nt, char* img, int wid, int lane) {
   const unsigned bytes = (unsigned)((((long)n - 1) * ld + DH) * 2);
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(X, bytes);
   const int row = lane >> 3;                                          // 8 rows x 8 chunks per wave-instruction
   const int voff = (int)((((long)(wid * 8 + row)) * ld + ((((lane & 7) ^ (row & 7))) << 3)) * 2);   // img128_off inverse
   const int step = (int)(64 * ld * 2);
@@ -404,8 +441,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __res
 
   // LDS-DMA of one K and one V tile: 8 + 8 pieces of 1 KiB (8 rows x 128 B), pieces wid and wid + 4 of each per wave
   const unsigned bytes = (unsigned)((((long)n - 1) * ld + DH) * 2);
-  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + inner), 0, bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + 2 * inner), 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsK = uniform_rsrc((Q + inner), bytes);
+  const __amdgpu_buffer_rsrc_t rsV = uniform_rsrc((Q + 2 * inner), bytes);
   int voff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -896,8 +933,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const bf16* __
   }
 
   const unsigned bytes = (unsigned)((((long)n - 1) * ld + DH) * 2);
-  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + inner), 0, bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + 2 * inner), 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsK = uniform_rsrc((Q + inner), bytes);
+  const __amdgpu_buffer_rsrc_t rsV = uniform_rsrc((Q + 2 * inner), bytes);
   int voff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -1011,10 +1048,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* _
       vf[u][ks] = *reinterpret_cast<const bf16x8*>(V + (long)krow * ld + 32 * ks + 8 * g);
     }
   }
-  const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Q, 0, (unsigned)((((long)n - 1) * ld + DH) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)dO, 0, (unsigned)((((long)n - 1) * ldo + DH) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(lse + ((long)b * heads + h) * n), 0, (unsigned)(n * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsDl = __builtin_amdgcn_make_buffer_rsrc((void*)(delta + ((long)b * heads + h) * n), 0, (unsigned)(n * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsQ = uniform_rsrc(Q, (unsigned)((((long)n - 1) * ld + DH) * 2));
+  const __amdgpu_buffer_rsrc_t rsD = uniform_rsrc(dO, (unsigned)((((long)n - 1) * ldo + DH) * 2));
+  const __amdgpu_buffer_rsrc_t rsL = uniform_rsrc((lse + ((long)b * heads + h) * n), (unsigned)(n * 4));
+  const __amdgpu_buffer_rsrc_t rsDl = uniform_rsrc((delta + ((long)b * heads + h) * n), (unsigned)(n * 4));
   int voq[2], vod[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {

@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
-"""Backward attention kernels side by side (nv_attn_set_mode: 1 streaming, 0 heuristic, 4 wide dQ + wide dK/dV).  Tuning aid."""
+"""Backward attention kernels side by side (nv_attn_set_mode: 1 streaming, 0 heuristic, 2 LDS-resident, 4 wide dQ + wide dK/dV).  Tuning aid."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neurovit_amd import ops
 from neurovit_amd._cabi import lib
-for (B, n, heads) in ((4, 4097, 16), (16, 1001, 8), (2, 1001, 2)):
+for (B, n, heads) in ((4, 513, 12), (20, 513, 12), (4, 4097, 16), (16, 1001, 8), (2, 1001, 2)):
     qkv = torch.randn(B * n, 3 * heads * 64, device="cuda").bfloat16()
     do = torch.randn(B * n, heads * 64, device="cuda").bfloat16()
     lib.nv_attn_set_mode(1)
     out, lse = ops.attn_fwd(qkv, B, n, heads)
     ref, dref = ops.attn_bwd(qkv, out, do, lse, B, n, heads)
-    for mode in (1, 0, 4):
+    for mode in (1, 0, 2, 4):
+        if mode == 2 and n > 576:
+            continue
         lib.nv_attn_set_mode(mode)
         for _ in range(2):
             dqkv, delta = ops.attn_bwd(qkv, out, do, lse, B, n, heads)
