@@ -140,8 +140,7 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4], int kt, bool last, in
     }
     mloc = vmax(mloc, s[3][3]);
     const float mnew = vmax(m, group_max(mloc) * scale_log2e);
-    const bool moved = mnew != m;                 // running max unchanged for every row of this wave -> skip the rescale
-    const float alpha = fast_exp2(m - mnew);
+    const float alpha = (mnew != m) ? fast_exp2(m - mnew) : 1.0f;      // m = mnew = -inf cannot make a NaN this way
     m = mnew;
     const f32x2 c2 = {scale_log2e, scale_log2e}, m2 = {-mnew, -mnew};
     f32x2 ps = {0.f, 0.f};
@@ -158,13 +157,11 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4], int kt, bool last, in
         s[t][2 * hh + 1] = x[1];
       }
     const float psum = ps[0] + ps[1];
-    if (__any(moved)) {
-      l = __builtin_fmaf(l, alpha, psum);      // explicit shape: the same rounding in every kernel that inlines this
+    // branch-free: a factor of exactly 1 where the maximum stood still (bit-identical to skipping the multiply; the skipping
+    // form made the compiler copy all sixteen accumulators on the not-taken side to rejoin the two paths)
+    l = __builtin_fmaf(l, alpha, psum);        // explicit shape: the same rounding in every kernel that inlines this
 #pragma unroll
-      for (int t = 0; t < 4; ++t) o[t] *= alpha;
-    } else {
-      l += psum;
-    }
+    for (int t = 0; t < 4; ++t) o[t] *= alpha;
     if (drop.thresh) {      // attention dropout (vit_3d.py:56): mask the probabilities that enter P.V, not the normaliser
       // element (bh, q, key) has index (bh * n + q) * npad + key with npad = n rounded up to 4: every lane's four keys share one hash
       const unsigned long long base = (((unsigned long long)bh * n + qabs) * ((n + 3) & ~3)) + (unsigned long long)kt * TK;
@@ -280,25 +277,41 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr int RES_THREADS = 512;
 constexpr int RES_MAX_TILES = 9;
 
-// Buffer resource for LDS-DMA from a workgroup-uniform base.  The bases here come out of 64-bit VALU address arithmetic on
-// blockIdx, so the compiler treats them as divergent and wraps EVERY buffer_load ... lds in a waterfall loop (four
-// v_readfirstlane + compares + saveexec + branch per DMA instruction); reading the words back through v_readfirstlane puts the
-// descriptor in SGPRs once.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, unsigned bytes) {
+// LDS-DMA issued by the waves that also read the tiles.  Two things the builtin form costs here:
+//   * descriptor: the bases come out of 64-bit VALU address arithmetic on blockIdx, the compiler treats them as divergent and wraps
+//     EVERY buffer_load ... lds in a waterfall loop (four v_readfirstlane + compares + saveexec + branch per DMA instruction) -
+//     the words go through v_readfirstlane once instead;
+//   * waits: the compiler knows a builtin DMA writes LDS and, unable to tell the ring stages apart, puts s_waitcnt vmcnt(0) in
+//     front of the next transposed LDS read of the same wave - the transfer of tile k+1, just issued, is drained before tile k is
+//     read, and every tile costs a full L2 / HBM round trip.  Issued from inline asm the DMA is invisible to that bookkeeping;
+//     completion is tracked by hand (counted s_waitcnt vmcnt + workgroup barrier, as the kernels already did).
+typedef int dma_desc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_desc uniform_rsrc(const void* base, unsigned bytes) {
   const unsigned long long a = (unsigned long long)base;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+  return dma_desc{(int)__builtin_amdgcn_readfirstlane((unsigned)a), (int)(__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffff),
+                  (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000};
+}
+// one wave-instruction: lane l copies BYTES (16 or 4) from base + voff(l) + soff to LDS at dst + l * BYTES (dst, soff wave-uniform)
+template <int BYTES>
+__device__ __forceinline__ void lds_dma(dma_desc rsrc, const char* dst, int voff, int soff) {
+  typedef __attribute__((address_space(3))) const char lds_cchar;
+  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_cchar*)dst);
+  const int so = __builtin_amdgcn_readfirstlane(soff);
+  if constexpr (BYTES == 16)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(a), "v"(voff), "s"(rsrc), "s"(so) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(a), "v"(voff), "s"(rsrc), "s"(so) : "memory");
 }
 
 // all eight waves: DMA rows 0 .. 64*nt-1 of X (row stride ld elements, 64 bf16 per row) into nt swizzled 8 KiB images
 __device__ __forceinline__ void res_dma(const bf16* X, long ld, int n, int nt, char* img, int wid, int lane) {
   const unsigned bytes = (unsigned)((((long)n - 1) * ld + DH) * 2);
-  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(X, bytes);
+  const dma_desc rs = uniform_rsrc(X, bytes);
   const int row = lane >> 3;                                          // 8 rows x 8 chunks per wave-instruction
   const int voff = (int)((((long)(wid * 8 + row)) * ld + ((((lane & 7) ^ (row & 7))) << 3)) * 2);   // img128_off inverse
   const int step = (int)(64 * ld * 2);
   for (int t = 0; t < nt; ++t)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(img + t * IMG + wid * 1024), 16, voff, t * step, 0, 0);
+    lds_dma<16>(rs, img + t * IMG + wid * 1024, voff, t * step);
 }
 // this wave's 16-row group, or -1
 __device__ __forceinline__ int res_group(int n, int wid) {
@@ -322,17 +335,19 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
   const int nkt = (n + TK - 1) / TK;
   char* sK = rsmem;
   char* sV = rsmem + nkt * IMG;
-  if (SPLIT == 1 || half == 0) res_dma(Q + inner, ld, n, nkt, sK, slot, lane);
-  if (SPLIT == 1 || half == 1) res_dma(Q + 2 * inner, ld, n, nkt, sV, slot, lane);
   const int grp = res_group(n, slot);
   const int q0 = (grp < 0 ? 0 : grp) * 16;
   const int qrow = min(q0 + r, n - 1);
   bf16x8 qf[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
-  __syncthreads();                                   // drains the DMA (vmcnt(0)) of every wave
+  if (SPLIT == 1 || half == 0) res_dma(Q + inner, ld, n, nkt, sK, slot, lane);
+  if (SPLIT == 1 || half == 1) res_dma(Q + 2 * inner, ld, n, nkt, sV, slot, lane);
+  // (taking the tiles one by one as they land - a counted wait and a barrier per tile - measured 16.1 us against 14.5: the
+  // per-tile barriers keep the two waves of a SIMD in step, and in step their MFMA and softmax phases collide instead of overlapping)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                   // the DMA of every wave has landed
   if (SPLIT == 1 && grp < 0) return;
-
   f32x4 o[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -441,8 +456,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __res
 
   // LDS-DMA of one K and one V tile: 8 + 8 pieces of 1 KiB (8 rows x 128 B), pieces wid and wid + 4 of each per wave
   const unsigned bytes = (unsigned)((((long)n - 1) * ld + DH) * 2);
-  const __amdgpu_buffer_rsrc_t rsK = uniform_rsrc((Q + inner), bytes);
-  const __amdgpu_buffer_rsrc_t rsV = uniform_rsrc((Q + 2 * inner), bytes);
+  const dma_desc rsK = uniform_rsrc((Q + inner), bytes);
+  const dma_desc rsV = uniform_rsrc((Q + 2 * inner), bytes);
   int voff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -453,8 +468,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __res
   auto issue = [&](int t, char* stage) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_void_t*)(stage + (wid + 4 * i) * 1024), 16, voff[i], t * step, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_void_t*)(stage + IMG + (wid + 4 * i) * 1024), 16, voff[i], t * step, 0, 0);
+      lds_dma<16>(rsK, stage + (wid + 4 * i) * 1024, voff[i], t * step);
+      lds_dma<16>(rsV, stage + IMG + (wid + 4 * i) * 1024, voff[i], t * step);
     }
   };
 
@@ -469,19 +484,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __res
   const int nkt = (n + TK - 1) / TK;
   const int nh = attn_half_tiles(nkt);
   issue(0, wsmem);
-  for (int kt = 0; kt < nkt; ++kt) {
+  // the Q fragments' loads retire HERE as far as the compiler's wait bookkeeping goes: left to their first use inside the loop it
+  // would wait for them there, on every pass, with counts that ignore the DMA issued in between (vmcnt(3..0): a full drain)
+  asm volatile("" ::"v"(qf[0][0]), "v"(qf[0][1]), "v"(qf[1][0]), "v"(qf[1][1]));
+  auto tile = [&](int kt) {
     char* cur = wsmem + (kt & 1) * 2 * IMG;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
     __builtin_amdgcn_s_barrier();                         // ... everybody's; and every read of the other stage (tile kt-1) is done
     if (kt + 1 < nkt) issue(kt + 1, wsmem + ((kt + 1) & 1) * 2 * IMG);
-    if (kt == nh) {                                       // second half of the key range: park the first state
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        m0[u] = m[u]; l0[u] = l[u]; m[u] = -INFINITY; l[u] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { o0[u][t] = o[u][t]; o[u][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      }
-    }
     RowFrags F;
     f32x4 s[2][4];
     load_row_frags(cur, r, g, F);
@@ -495,15 +505,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __res
     __builtin_amdgcn_sched_barrier(0);
     fwd_pv(F, s[0], o[0]);
     fwd_pv(F, s[1], o[1]);
-  }
+  };
+  // two loops, one per half of the key range (the split point every forward kernel uses), the first state parked in between:
+  // as ONE loop with the parking under `if (kt == nh)` the compiler copied all 34 state registers on every pass
+  const int nfirst = nh < nkt ? nh : nkt;
+  for (int kt = 0; kt < nfirst; ++kt) tile(kt);
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    if (nkt <= nh) {                                      // single tile: the (empty) second state is merged all the same
-      m0[u] = m[u]; l0[u] = l[u]; m[u] = -INFINITY; l[u] = 0.f;
+    m0[u] = m[u]; l0[u] = l[u]; m[u] = -INFINITY; l[u] = 0.f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { o0[u][t] = o[u][t]; o[u][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    }
-    softmax_merge(m0[u], l0[u], o0[u], m[u], l[u], o[u]);
+    for (int t = 0; t < 4; ++t) { o0[u][t] = o[u][t]; o[u][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  for (int kt = nfirst; kt < nkt; ++kt) tile(kt);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    softmax_merge(m0[u], l0[u], o0[u], m[u], l[u], o[u]);      // a single tile leaves the second state empty: merged all the same
     const float ltot = group_sum(l0[u]);
     const float inv = 1.0f / ltot;
     const int q = q0 + 16 * u + r;
@@ -933,8 +949,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const bf16* __
   }
 
   const unsigned bytes = (unsigned)((((long)n - 1) * ld + DH) * 2);
-  const __amdgpu_buffer_rsrc_t rsK = uniform_rsrc((Q + inner), bytes);
-  const __amdgpu_buffer_rsrc_t rsV = uniform_rsrc((Q + 2 * inner), bytes);
+  const dma_desc rsK = uniform_rsrc((Q + inner), bytes);
+  const dma_desc rsV = uniform_rsrc((Q + 2 * inner), bytes);
   int voff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -945,8 +961,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const bf16* __
   auto issue = [&](int t, char* stage) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_void_t*)(stage + (wid + 4 * i) * 1024), 16, voff[i], t * step, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_void_t*)(stage + IMG + (wid + 4 * i) * 1024), 16, voff[i], t * step, 0, 0);
+      lds_dma<16>(rsK, stage + (wid + 4 * i) * 1024, voff[i], t * step);
+      lds_dma<16>(rsV, stage + IMG + (wid + 4 * i) * 1024, voff[i], t * step);
     }
   };
 
@@ -1048,10 +1064,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* _
       vf[u][ks] = *reinterpret_cast<const bf16x8*>(V + (long)krow * ld + 32 * ks + 8 * g);
     }
   }
-  const __amdgpu_buffer_rsrc_t rsQ = uniform_rsrc(Q, (unsigned)((((long)n - 1) * ld + DH) * 2));
-  const __amdgpu_buffer_rsrc_t rsD = uniform_rsrc(dO, (unsigned)((((long)n - 1) * ldo + DH) * 2));
-  const __amdgpu_buffer_rsrc_t rsL = uniform_rsrc((lse + ((long)b * heads + h) * n), (unsigned)(n * 4));
-  const __amdgpu_buffer_rsrc_t rsDl = uniform_rsrc((delta + ((long)b * heads + h) * n), (unsigned)(n * 4));
+  const dma_desc rsQ = uniform_rsrc(Q, (unsigned)((((long)n - 1) * ld + DH) * 2));
+  const dma_desc rsD = uniform_rsrc(dO, (unsigned)((((long)n - 1) * ldo + DH) * 2));
+  const dma_desc rsL = uniform_rsrc((lse + ((long)b * heads + h) * n), (unsigned)(n * 4));
+  const dma_desc rsDl = uniform_rsrc((delta + ((long)b * heads + h) * n), (unsigned)(n * 4));
   int voq[2], vod[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -1064,12 +1080,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* _
   auto issue = [&](int t, char* stage) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t*)(stage + (wid + 4 * i) * 1024), 16, voq[i], t * stepq, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t*)(stage + IMG + (wid + 4 * i) * 1024), 16, vod[i], t * stepd, 0, 0);
+      lds_dma<16>(rsQ, stage + (wid + 4 * i) * 1024, voq[i], t * stepq);
+      lds_dma<16>(rsD, stage + IMG + (wid + 4 * i) * 1024, vod[i], t * stepd);
     }
     if (wid == 0) {                                       // 64 lse and 64 delta values of the tile: one dword per lane
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (lds_void_t*)(stage + 2 * IMG), 4, lane * 4, t * TQ * 4, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsDl, (lds_void_t*)(stage + 2 * IMG + TQ * 4), 4, lane * 4, t * TQ * 4, 0, 0);
+      lds_dma<4>(rsL, stage + 2 * IMG, lane * 4, t * TQ * 4);
+      lds_dma<4>(rsDl, stage + 2 * IMG + TQ * 4, lane * 4, t * TQ * 4);
     }
   };
 
