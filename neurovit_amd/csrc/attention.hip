@@ -16,6 +16,13 @@
 // recomputing P from the saved log-sum-exp.
 #include "common.h"
 
+// attention_generic.hip: any other head dim (multiples of 8 up to 128), scalar kernels
+bool attn_generic_supported(int dim_head);
+int launch_attn_generic_fwd(const void* qkv, long ld, int B, int n, int heads, int dh, float scale, void* out, long ldo, float* lse, DropCfg drop,
+                            hipStream_t s);
+int launch_attn_generic_bwd(const void* qkv, long ld, const void* out, const void* dout, long ldo, const float* lse, int B, int n, int heads, int dh,
+                            float scale, float* delta, void* dqkv, long ldd, DropCfg drop, hipStream_t s);
+
 constexpr int DH = 64;            // dim_head (reference default, vit_3d.py:29)
 constexpr int TQ = 64;            // rows per workgroup (4 waves x 16)
 constexpr int TK = 64;            // keys per LDS tile
@@ -553,10 +560,12 @@ static void attn_res_attr(Kern kern, int lds) {
 
 extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
                            float* lse, unsigned long drop_seed, float drop_p, void* stream) {
-  NV_CHECK_ARG(dim_head == DH, "nv_attn_fwd: dim_head=%d unsupported (only 64)", dim_head);
-  NV_CHECK_ARG(B > 0 && n > 0 && heads > 0 && ld_qkv >= 3 * heads * DH && ld_out >= heads * DH && (ld_qkv % 8) == 0 && (ld_out % 4) == 0,
+  NV_CHECK_ARG(attn_generic_supported(dim_head), "nv_attn_fwd: dim_head=%d unsupported (multiples of 8 up to 128)", dim_head);
+  NV_CHECK_ARG(B > 0 && n > 0 && heads > 0 && ld_qkv >= 3 * heads * dim_head && ld_out >= heads * dim_head && (ld_qkv % 8) == 0 && (ld_out % 4) == 0,
                "nv_attn_fwd: bad dims");
   NV_CHECK_ARG(nv_aligned16(qkv) && nv_aligned16(out), "nv_attn_fwd: alignment");
+  if (dim_head != DH)      // the MFMA kernels below are built for the reference's default head dim (vit_3d.py:29); any other one: attention_generic.hip
+    return launch_attn_generic_fwd(qkv, ld_qkv, B, n, heads, dim_head, scale, out, ld_out, lse, make_drop(drop_seed, drop_p), (hipStream_t)stream);
   const int slot = nv_prof_begin(3, 4.0 * B * heads * (double)n * n * DH, stream);
   // LDS-resident K / V (one 144 KiB workgroup per CU) pays when there are few row groups (ViT3D-base at batch 4: 240 workgroups);
   // with thousands of row groups the wide streaming kernel keeps several workgroups per CU and reads half the fragments
@@ -1147,12 +1156,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* _
 extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const void* dout, long ld_out, const float* lse, int B, int n,
                            int heads, int dim_head, float scale, float* delta, void* dqkv, long ld_dqkv, unsigned long drop_seed, float drop_p,
                            void* stream) {
-  NV_CHECK_ARG(dim_head == DH, "nv_attn_bwd: dim_head=%d unsupported (only 64)", dim_head);
-  NV_CHECK_ARG(B > 0 && n > 0 && heads > 0 && ld_qkv >= 3 * heads * DH && ld_dqkv >= 3 * heads * DH && ld_out >= heads * DH &&
+  NV_CHECK_ARG(attn_generic_supported(dim_head), "nv_attn_bwd: dim_head=%d unsupported (multiples of 8 up to 128)", dim_head);
+  NV_CHECK_ARG(B > 0 && n > 0 && heads > 0 && ld_qkv >= 3 * heads * dim_head && ld_dqkv >= 3 * heads * dim_head && ld_out >= heads * dim_head &&
                    (ld_qkv % 8) == 0 && (ld_out % 8) == 0 && (ld_dqkv % 4) == 0,
                "nv_attn_bwd: bad dims");
   NV_CHECK_ARG(nv_aligned16(qkv) && nv_aligned16(out) && nv_aligned16(dout) && nv_aligned16(dqkv), "nv_attn_bwd: alignment");
   hipStream_t s = (hipStream_t)stream;
+  if (dim_head != DH)
+    return launch_attn_generic_bwd(qkv, ld_qkv, out, dout, ld_out, lse, B, n, heads, dim_head, scale, delta, dqkv, ld_dqkv, make_drop(drop_seed, drop_p), s);
   const dim3 grid((n + TQ - 1) / TQ, B * heads);
   const int slot = nv_prof_begin(4, 10.0 * B * heads * (double)n * n * DH, stream);   // algorithmic: 5 products
   if (attn_resident(n) && g_attn_mode != 3) {

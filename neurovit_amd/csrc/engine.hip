@@ -26,7 +26,8 @@ int make_dims(const nv_vit_config* c, int B, Dims& D) {
                    c->image_size % c->image_patch_size == 0,
                "Image dimensions must be divisible by the patch size.");
   NV_CHECK_ARG(c->frames % c->frame_patch_size == 0, "Frames must be divisible by frame patch size");
-  NV_CHECK_ARG(c->dim_head == 64, "nv_vit: dim_head=%d unsupported by the gfx950 attention kernel (64 only)", c->dim_head);
+  NV_CHECK_ARG(c->dim_head >= 8 && c->dim_head <= 128 && c->dim_head % 8 == 0,
+               "nv_vit: dim_head=%d unsupported (multiples of 8 up to 128; 64 runs the MFMA attention kernels, the others scalar ones)", c->dim_head);
   NV_CHECK_ARG(c->dim % 8 == 0 && c->dim <= 2048 && c->mlp_dim % 8 == 0, "nv_vit: dim must be a multiple of 8 and <= 2048, mlp_dim a multiple of 8");
   NV_CHECK_ARG(!(c->heads == 1 && c->dim_head == c->dim), "nv_vit: heads==1 && dim_head==dim (no output projection) is not supported");
   NV_CHECK_ARG(c->depth >= 1 && c->num_classes >= 1 && c->channels >= 1, "nv_vit: bad depth/classes/channels");

@@ -158,9 +158,9 @@ class Attention(nn.Module):
         """Standalone use (vit_3d.py:48-60): x [batch, tokens, dim] fp32 on the device -> to_out(attention(norm(x)))."""
         if isinstance(self.to_out, nn.Identity):
             raise NotImplementedError("neurovit_amd: heads == 1 with dim_head == dim (no output projection) is not provided")
-        if self.dim_head != 64:
-            raise NotImplementedError("neurovit_amd: the gfx950 attention kernels are written for dim_head = 64 "
-                                      "(the only value the NeuroEncoder path uses: vit_3d.py:78 default)")
+        if self.dim_head % 8 or not 8 <= self.dim_head <= 128:
+            raise NotImplementedError("neurovit_amd: dim_head must be a multiple of 8 up to 128 (64, the vit_3d.py:78 default and "
+                                      "the only value the NeuroEncoder path uses, runs the MFMA attention kernels; the others scalar ones)")
         p = float(self.dropout.p)
         seeds = (_new_seed(p, self.training), _new_seed(p, self.training))
         return _AttentionFn.apply(x, self.norm.weight, self.norm.bias, self.to_qkv.weight, self.to_out[0].weight, self.to_out[0].bias,

@@ -43,7 +43,7 @@ def test_workspace_and_error_paths():
     cfg = engine.make_config(**W.BASE)
     inf, trn = (lib.nv_vit_workspace_bytes(ctypes.byref(cfg), 4, t) for t in (0, 1))
     assert 0 < inf < trn
-    bad = engine.make_config(**dict(W.BASE, dim_head=32))
+    bad = engine.make_config(**dict(W.BASE, dim_head=36))
     assert lib.nv_vit_workspace_bytes(ctypes.byref(bad), 4, 1) < 0 and "dim_head" in last_error()
     bad = engine.make_config(**dict(W.BASE, image_size=100))
     assert lib.nv_vit_param_count(ctypes.byref(bad)) < 0 and "divisible" in last_error()

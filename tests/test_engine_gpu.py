@@ -151,6 +151,13 @@ def test_pool_mean(eng):
     run_case(eng, "p9+mean", dict(W.MICRO, pool="mean", image_size=27, image_patch_size=9, frames=27, frame_patch_size=9), (13, 14), B=3)
 
 
+def test_other_head_dims(eng):
+    """dim_head 32 and 128 through the whole encoder (forward stages, logits, every gradient, with dropout for one of them): the
+    attention of these runs on attention_generic.hip, everything else on the same kernels as dim_head 64."""
+    run_case(eng, "dh32", dict(W.MICRO, dim_head=32, heads=4), (21, 22))
+    run_case(eng, "dh128+dropout", dict(W.MICRO, dim_head=128, heads=2), (23, 24), dropout=(0.1, 0.1, 5150))
+
+
 def test_odd_patch_size_like_reference_default(eng):
     """The reference's default geometry is 90^3 / patch 9 (configs/config.yaml:39-40): patch_dim = 729 is not a multiple
     of 8 (scalar gather path, zero-padded GEMM operands, padded weight-gradient scratch) and n = N+1 is odd."""

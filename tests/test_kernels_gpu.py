@@ -488,6 +488,36 @@ def test_attention_fwd_bwd(ops, B, n, heads):
     assert_close_stat(dqkv, dref, "attn.dqkv")
 
 
+@pytest.mark.parametrize("B,n,heads,dh,drop", [(2, 65, 3, 32, 0.0), (1, 200, 2, 128, 0.0), (2, 37, 2, 48, 0.0), (1, 130, 2, 32, 0.2), (1, 70, 1, 128, 0.1),
+                                                 (1, 513, 2, 8, 0.0)])
+def test_attention_other_head_dims(ops, B, n, heads, dh, drop):
+    """dim_head != 64 (vit_3d.py:29 takes any; attention_generic.hip: scalar kernels, exact row maximum): forward, LSE and the three
+    gradients against an fp64 attention on the same bf16 inputs, with the product's dropout mask regenerated by the oracle.
+    Tolerance 4e-3 rel l2: outputs and the P / dS operands are rounded to bf16 (2^-9 each) as in the MFMA kernels."""
+    inner, seed = heads * dh, 4242
+    qkv = bf(rnd(B * n, 3 * inner, seed=n + dh)).float()
+    q, k, v = (t.reshape(B, n, heads, dh).permute(0, 2, 1, 3).double().clone().requires_grad_(True) for t in qkv.chunk(3, dim=-1))
+    mask = ref_cpu.attn_drop_mask(seed, drop, B, heads, n).double() if drop else None
+    s = torch.matmul(q, k.transpose(-1, -2)) * dh ** -0.5
+    p = torch.softmax(s, dim=-1)
+    ref = torch.matmul(p if mask is None else p * mask, v)
+    out, lse = ops.attn_fwd(dev(bf(qkv)), B, n, heads, dh, drop_seed=seed if drop else 0, drop_p=drop)
+    ref2 = ref.permute(0, 2, 1, 3).reshape(B * n, inner)
+    assert rel_l2(out.float(), ref2.detach()) < 4e-3
+    assert_close_f32(lse, torch.logsumexp(s, dim=-1).detach(), "gen.lse", 1e-4)
+    do = bf(rnd(B * n, inner, seed=7)).float()
+    ref.backward(do.double().reshape(B, n, heads, dh).permute(0, 2, 1, 3))
+    dqkv, delta = ops.attn_bwd(dev(bf(qkv)), out, dev(bf(do)), lse, B, n, heads, dh, drop_seed=seed if drop else 0, drop_p=drop)
+    for name, t, lo in (("dq", q, 0), ("dk", k, inner), ("dv", v, 2 * inner)):
+        g = t.grad.permute(0, 2, 1, 3).reshape(B * n, inner)
+        assert rel_l2(dqkv[:, lo:lo + inner].float(), g) < 6e-3, name       # + the bf16 forward output inside delta
+    assert_close_f32(delta.reshape(B, heads, n), (do.reshape(B, n, heads, dh).permute(0, 2, 1, 3).double() * out.float().cpu().reshape(B, n, heads, dh).permute(0, 2, 1, 3).double()).sum(-1),
+                     "gen.delta", 1e-4)
+    # run-to-run bit equality (fixed reduction order)
+    out2, _ = ops.attn_fwd(dev(bf(qkv)), B, n, heads, dh, drop_seed=seed if drop else 0, drop_p=drop)
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("B,n,heads,drop", [(2, 513, 3, 0.0), (1, 576, 2, 0.0), (3, 65, 2, 0.1), (2, 9, 1, 0.0), (1, 500, 1, 0.2)])
 def test_attention_resident_equals_streaming(ops, B, n, heads, drop):
     """n <= 576: the LDS-resident kernels (K/V - or Q/dO - of one head loaded once) must reproduce the streaming kernels
