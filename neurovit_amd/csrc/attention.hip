@@ -284,32 +284,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr int RES_THREADS = 512;
 constexpr int RES_MAX_TILES = 9;
 
-// LDS-DMA issued by the waves that also read the tiles.  Two things the builtin form costs here:
-//   * descriptor: the bases come out of 64-bit VALU address arithmetic on blockIdx, the compiler treats them as divergent and wraps
-//     EVERY buffer_load ... lds in a waterfall loop (four v_readfirstlane + compares + saveexec + branch per DMA instruction) -
-//     the words go through v_readfirstlane once instead;
-//   * waits: the compiler knows a builtin DMA writes LDS and, unable to tell the ring stages apart, puts s_waitcnt vmcnt(0) in
-//     front of the next transposed LDS read of the same wave - the transfer of tile k+1, just issued, is drained before tile k is
-//     read, and every tile costs a full L2 / HBM round trip.  Issued from inline asm the DMA is invisible to that bookkeeping;
-//     completion is tracked by hand (counted s_waitcnt vmcnt + workgroup barrier, as the kernels already did).
-typedef int dma_desc __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ dma_desc uniform_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)base;
-  return dma_desc{(int)__builtin_amdgcn_readfirstlane((unsigned)a), (int)(__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffff),
-                  (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000};
-}
-// one wave-instruction: lane l copies BYTES (16 or 4) from base + voff(l) + soff to LDS at dst + l * BYTES (dst, soff wave-uniform)
-template <int BYTES>
-__device__ __forceinline__ void lds_dma(dma_desc rsrc, const char* dst, int voff, int soff) {
-  typedef __attribute__((address_space(3))) const char lds_cchar;
-  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_cchar*)dst);
-  const int so = __builtin_amdgcn_readfirstlane(soff);
-  if constexpr (BYTES == 16)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(a), "v"(voff), "s"(rsrc), "s"(so) : "memory");
-  else
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(a), "v"(voff), "s"(rsrc), "s"(so) : "memory");
-}
-
+// (LDS-DMA helpers - uniform_rsrc / lds_dma, issued from inline asm - are in common.h)
 // all eight waves: DMA rows 0 .. 64*nt-1 of X (row stride ld elements, 64 bf16 per row) into nt swizzled 8 KiB images
 __device__ __forceinline__ void res_dma(const bf16* X, long ld, int n, int nt, char* img, int wid, int lane) {
   const unsigned bytes = (unsigned)((((long)n - 1) * ld + DH) * 2);
@@ -1077,24 +1052,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* _
   const dma_desc rsD = uniform_rsrc(dO, (unsigned)((((long)n - 1) * ldo + DH) * 2));
   const dma_desc rsL = uniform_rsrc((lse + ((long)b * heads + h) * n), (unsigned)(n * 4));
   const dma_desc rsDl = uniform_rsrc((delta + ((long)b * heads + h) * n), (unsigned)(n * 4));
-  int voq[2], vod[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wid + 4 * i) * 8 + (lane >> 3);
-    const int ch = ((lane & 7) ^ (row & 7)) << 3;                                        // img128_off inverse
-    voq[i] = (int)(((long)row * ld + ch) * 2);
-    vod[i] = (int)(((long)row * ldo + ch) * 2);
-  }
   const int stepq = (int)(64 * ld * 2), stepd = (int)(64 * ldo * 2);
   auto issue = [&](int t, char* stage) {
+    // piece (wid + 4 i) = rows 8 (wid + 4 i) .. + 7: the piece's first row goes into the scalar offset, the lane's row inside the
+    // piece and its swizzled chunk (img128_off inverse) are recomputed here from a fresh lane id - this kernel is at the register
+    // limit, and offsets held across the loop were spilled (their reload drains the DMA in flight: see fresh_lane)
+    const int ln = fresh_lane(), lrow = ln >> 3, ch = ((ln & 7) ^ lrow) << 3;
+    const int vq = (lrow * (int)ld + ch) * 2, vd = (lrow * (int)ldo + ch) * 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      lds_dma<16>(rsQ, stage + (wid + 4 * i) * 1024, voq[i], t * stepq);
-      lds_dma<16>(rsD, stage + IMG + (wid + 4 * i) * 1024, vod[i], t * stepd);
+      lds_dma<16>(rsQ, stage + (wid + 4 * i) * 1024, vq, t * stepq + (wid + 4 * i) * 8 * (int)ld * 2);
+      lds_dma<16>(rsD, stage + IMG + (wid + 4 * i) * 1024, vd, t * stepd + (wid + 4 * i) * 8 * (int)ldo * 2);
     }
     if (wid == 0) {                                       // 64 lse and 64 delta values of the tile: one dword per lane
-      lds_dma<4>(rsL, stage + 2 * IMG, lane * 4, t * TQ * 4);
-      lds_dma<4>(rsDl, stage + 2 * IMG + TQ * 4, lane * 4, t * TQ * 4);
+      lds_dma<4>(rsL, stage + 2 * IMG, ln * 4, t * TQ * 4);
+      lds_dma<4>(rsDl, stage + 2 * IMG + TQ * 4, ln * 4, t * TQ * 4);
     }
   };
 

@@ -143,6 +143,40 @@ __device__ __forceinline__ float drop_factor(const DropCfg& d, unsigned long lon
   return (field >= d.thresh) ? d.scale : 0.f;
 }
 
+// LDS-DMA issued by the waves that also read the tiles.  Two things the builtin form costs here:
+//   * descriptor: the bases come out of 64-bit VALU address arithmetic on blockIdx, the compiler treats them as divergent and wraps
+//     EVERY buffer_load ... lds in a waterfall loop (four v_readfirstlane + compares + saveexec + branch per DMA instruction) -
+//     the words go through v_readfirstlane once instead;
+//   * waits: the compiler knows a builtin DMA writes LDS and, unable to tell the ring stages apart, puts s_waitcnt vmcnt(0) in
+//     front of the next transposed LDS read of the same wave - the transfer of tile k+1, just issued, is drained before tile k is
+//     read, and every tile costs a full L2 / HBM round trip.  Issued from inline asm the DMA is invisible to that bookkeeping;
+//     completion is tracked by hand (counted s_waitcnt vmcnt + workgroup barrier, as the kernels already did).
+typedef int dma_desc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_desc uniform_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return dma_desc{(int)__builtin_amdgcn_readfirstlane((unsigned)a), (int)(__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffff),
+                  (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000};
+}
+// one wave-instruction: lane l copies BYTES (16 or 4) from base + voff(l) + soff to LDS at dst + l * BYTES (dst, soff wave-uniform)
+template <int BYTES>
+__device__ __forceinline__ void lds_dma(dma_desc rsrc, const char* dst, int voff, int soff) {
+  typedef __attribute__((address_space(3))) const char lds_cchar;
+  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_cchar*)dst);
+  const int so = __builtin_amdgcn_readfirstlane(soff);
+  if constexpr (BYTES == 16)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(a), "v"(voff), "s"(rsrc), "s"(so) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(a), "v"(voff), "s"(rsrc), "s"(so) : "memory");
+}
+
+// Lane id the compiler cannot hoist: per-lane DMA offsets computed from it INSIDE a tile loop are not kept in (or spilled from)
+// registers across the loop - a spilled offset comes back through scratch_load + s_waitcnt vmcnt(0), which drains the DMA in flight.
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // XCD-aware bijective remap of a 1-D block id: blocks b, b+8, ... share an XCD (round-robin dispatch),
 // so give each XCD a contiguous range of logical tiles (L2 locality of shared operand panels).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

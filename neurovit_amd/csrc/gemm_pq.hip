@@ -76,8 +76,8 @@ __device__ __forceinline__ void gemm_pq_body(const GemmArgs& g, const int bid) {
 
   const unsigned bytesA = (unsigned)((((long)(A_T ? g.K : g.M) - 1) * g.lda + (A_T ? g.M : g.K)) * ESZ);
   const unsigned bytesB = (unsigned)((((long)(B_T ? g.K : g.N) - 1) * g.ldb + (B_T ? g.N : g.K)) * ESZ);
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, bytesA, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, bytesB, 0x00020000);
+  const dma_desc rA = uniform_rsrc(g.A, bytesA);
+  const dma_desc rB = uniform_rsrc(g.B, bytesB);
   int voA[2][2], voB[2][2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -90,8 +90,8 @@ __device__ __forceinline__ void gemm_pq_body(const GemmArgs& g, const int bid) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(dst + s * PQ_SUB + (wid + 8 * i) * 1024), 16, voA[s][i], t * stepA, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(dst + (2 + s) * PQ_SUB + (wid + 8 * i) * 1024), 16, voB[s][i], t * stepB, 0, 0);
+        lds_dma<16>(rA, dst + s * PQ_SUB + (wid + 8 * i) * 1024, voA[s][i], t * stepA);
+        lds_dma<16>(rB, dst + (2 + s) * PQ_SUB + (wid + 8 * i) * 1024, voB[s][i], t * stepB);
       }
   };
 

@@ -32,6 +32,10 @@ SHAPES = [  # name, layout, epi, M, N, K
     ("lrg qkv  NT bf16 ", ops.NT, ops.EPI_STORE_BF16, 16388, 3072, 1024),
     ("lrg fc1  NT gelu ", ops.NT, ops.EPI_BIAS_GELU, 16388, 4096, 1024),
     ("lrg fc2  NT resid", ops.NT, ops.EPI_BIAS_RESID, 16388, 1024, 4096),
+    ("lrg dU   NN dgelu", ops.NN, ops.EPI_DGELU, 16388, 4096, 1024),
+    ("lrg dxn1 NN f32  ", ops.NN, ops.EPI_STORE_F32, 16388, 1024, 4096),
+    ("lrg dxnq NN f32  ", ops.NN, ops.EPI_STORE_F32, 16388, 1024, 3072),
+    ("lrg dW1  TN f32  ", ops.TN, ops.EPI_STORE_F32, 4096, 1024, 16388),
 ]
 
 
