@@ -287,8 +287,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step(x, y)
+    enqueued = time.perf_counter() - t0          # host time to enqueue the K steps: far below `elapsed` = the GPU is the limiter
     barrier()
     elapsed = time.perf_counter() - t0
+    log(f"host enqueue {enqueued / a.steps * 1e3:.3f} ms/step of {elapsed / a.steps * 1e3:.3f} ms/step")
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
