@@ -127,6 +127,7 @@ __device__ __forceinline__ void mfma_rows(const RowFrags& F, const bf16x8 (&y)[2
     for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.f[ks][t], y[ks], acc[t], 0, 0, 0);
 }
 // online softmax of one tile's raw scores s (in place -> probabilities, dropout applied), running max m / sum l, rescale of o
+template <bool DROP>
 __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4], int kt, bool last, int n, f32x4 (&o)[4], float& m, float& l, float scale_log2e,
                                             const DropCfg& drop, int bh, int qabs, int g) {
     // bookkeeping on the RAW scores (scale_log2e > 0, so max commutes with the scaling); the scaling itself is
@@ -169,7 +170,7 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4], int kt, bool last, in
     l = __builtin_fmaf(l, alpha, psum);        // explicit shape: the same rounding in every kernel that inlines this
 #pragma unroll
     for (int t = 0; t < 4; ++t) o[t] *= alpha;
-    if (drop.thresh) {      // attention dropout (vit_3d.py:56): mask the probabilities that enter P.V, not the normaliser
+    if constexpr (DROP) {      // attention dropout (vit_3d.py:56): mask the probabilities that enter P.V, not the normaliser
       // element (bh, q, key) has index (bh * n + q) * npad + key with npad = n rounded up to 4: every lane's four keys share one hash
       const unsigned long long base = (((unsigned long long)bh * n + qabs) * ((n + 3) & ~3)) + (unsigned long long)kt * TK;
 #pragma unroll
@@ -181,13 +182,14 @@ __device__ __forceinline__ void fwd_pv(const RowFrags& V, const f32x4 (&s)[4], f
   const bf16x8 pf[2] = {cvt8(s[0], s[1]), cvt8(s[2], s[3])};
   mfma_rows(V, pf, o, false);
 }
+template <bool DROP>
 __device__ __forceinline__ void fwd_tile(const char* sK, const char* sV, int kt, bool last, int n, const bf16x8 (&qf)[2], f32x4 (&o)[4],
                                          float& m, float& l, float scale_log2e, const DropCfg& drop, int bh, int qabs, int r, int g) {
   RowFrags F;
   f32x4 s[4];
   load_row_frags(sK, r, g, F);
   mfma_rows(F, qf, s, true);
-  fwd_softmax(s, kt, last, n, o, m, l, scale_log2e, drop, bh, qabs, g);
+  fwd_softmax<DROP>(s, kt, last, n, o, m, l, scale_log2e, drop, bh, qabs, g);
   load_tr_frags(sV, r, g, F);
   fwd_pv(F, s, o);
 }
@@ -207,6 +209,7 @@ __device__ __forceinline__ void softmax_merge(float& m, float& l, f32x4 (&o)[4],
 // first key tile of the second half of the key range
 __device__ __forceinline__ int attn_half_tiles(int nkt) { return (nkt + 1) >> 1; }
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
                                                        bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
       for (int t = 0; t < 4; ++t) { o0[t] = o[t]; o[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
-    fwd_tile(sK, sV, kt, kt == nkt - 1, n, qf, o, m, l, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
+    fwd_tile<DROP>(sK, sV, kt, kt == nkt - 1, n, qf, o, m, l, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
   }
   if (nkt <= nh) {                       // single tile: the (empty) second state is merged all the same
     m0 = m; l0 = l; m = -INFINITY; l = 0.f;
@@ -304,7 +307,7 @@ __device__ __forceinline__ int res_group(int n, int wid) {
 
 // SPLIT = 2: sixteen waves; waves w and w + 8 share a row group and take one half of the key tiles each (four waves per
 // SIMD instead of two hide the softmax's dependent-instruction latency), then merge (m, l, o) through LDS.
-template <int SPLIT>
+template <int SPLIT, bool DROP>
 __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads,
                                                                            float scale_log2e, bf16* __restrict__ out, long ldo,
                                                                            float* __restrict__ lse, DropCfg drop) {
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
       // four waves per SIMD hide the LDS latency by themselves; the plain tile step keeps the kernel within 128 VGPRs
       if (grp >= 0)
         for (int kt = k0; kt < k1; ++kt)
-          fwd_tile(sK + kt * IMG, sV + kt * IMG, kt, kt == nkt - 1, n, qf, o1, m1, l1, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
+          fwd_tile<DROP>(sK + kt * IMG, sV + kt * IMG, kt, kt == nkt - 1, n, qf, o1, m1, l1, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
     } else if (grp >= 0 && k0 < k1) {
       // software pipeline: the V fragments of this tile and the K fragments of the next one are requested from LDS before the
       // softmax arithmetic, so the ds_read latency sits under ~130 VALU instructions instead of in front of the MFMAs
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
         load_tr_frags(sV + kt * IMG, r, g, VF);
         load_row_frags(sK + (kt + 1 < k1 ? kt + 1 : kt) * IMG, r, g, KF);
         __builtin_amdgcn_sched_barrier(0);
-        fwd_softmax(sc, kt, kt == nkt - 1, n, o1, m1, l1, scale_log2e, drop, blockIdx.y, q0 + r, g);
+        fwd_softmax<DROP>(sc, kt, kt == nkt - 1, n, o1, m1, l1, scale_log2e, drop, blockIdx.y, q0 + r, g);
         __builtin_amdgcn_sched_barrier(0);
         fwd_pv(VF, sc, o1);
       }
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
 //     the DMA of tile kt+1 is in flight while tile kt is computed.
 // Same tile order, same two-state online softmax, same per-group arithmetic as the other forward kernels: bit-identical.
 constexpr int WIDE_ROWS = 128;     // query rows per workgroup (4 waves x 32)
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
                                                                bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) char wsmem[2 * 2 * IMG];      // [stage][K image | V image]
@@ -482,8 +486,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __res
     __builtin_amdgcn_sched_barrier(0);
     load_tr_frags(cur + IMG, r, g, F);                    // V fragments requested before the softmax arithmetic
     __builtin_amdgcn_sched_barrier(0);
-    fwd_softmax(s[0], kt, kt == nkt - 1, n, o[0], m[0], l[0], scale_log2e, drop, blockIdx.y, q0 + r, g);
-    fwd_softmax(s[1], kt, kt == nkt - 1, n, o[1], m[1], l[1], scale_log2e, drop, blockIdx.y, q0 + 16 + r, g);
+    fwd_softmax<DROP>(s[0], kt, kt == nkt - 1, n, o[0], m[0], l[0], scale_log2e, drop, blockIdx.y, q0 + r, g);
+    fwd_softmax<DROP>(s[1], kt, kt == nkt - 1, n, o[1], m[1], l[1], scale_log2e, drop, blockIdx.y, q0 + 16 + r, g);
     __builtin_amdgcn_sched_barrier(0);
     fwd_pv(F, s[0], o[0]);
     fwd_pv(F, s[1], o[1]);
@@ -541,6 +545,8 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
   NV_CHECK_ARG(nv_aligned16(qkv) && nv_aligned16(out), "nv_attn_fwd: alignment");
   if (dim_head != DH)      // the MFMA kernels below are built for the reference's default head dim (vit_3d.py:29); any other one: attention_generic.hip
     return launch_attn_generic_fwd(qkv, ld_qkv, B, n, heads, dim_head, scale, out, ld_out, lse, make_drop(drop_seed, drop_p), (hipStream_t)stream);
+  const bool dropping = make_drop(drop_seed, drop_p).thresh != 0;      // two instantiations of every kernel: the dropout code under a runtime
+                                                                         // branch cost register copies (and, in one kernel, spills) on the path without it
   const int slot = nv_prof_begin(3, 4.0 * B * heads * (double)n * n * DH, stream);
   // LDS-resident K / V (one 144 KiB workgroup per CU) pays when there are few row groups (ViT3D-base at batch 4: 240 workgroups);
   // with thousands of row groups the wide streaming kernel keeps several workgroups per CU and reads half the fragments
@@ -551,22 +557,32 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
     const int lds = 2 * ((n + TK - 1) / TK) * IMG;
     static bool attr = false;
     if (!attr) {
-      attn_res_attr(attn_fwd_res_kernel<1>, 2 * RES_MAX_TILES * IMG);
-      attn_res_attr(attn_fwd_res_kernel<2>, 2 * RES_MAX_TILES * IMG);
+      attn_res_attr(attn_fwd_res_kernel<1, false>, 2 * RES_MAX_TILES * IMG);
+      attn_res_attr(attn_fwd_res_kernel<1, true>, 2 * RES_MAX_TILES * IMG);
+      attn_res_attr(attn_fwd_res_kernel<2, false>, 2 * RES_MAX_TILES * IMG);
+      attn_res_attr(attn_fwd_res_kernel<2, true>, 2 * RES_MAX_TILES * IMG);
       attr = true;
     }
     if (g_attn_split == 2)
-      hipLaunchKernelGGL(attn_fwd_res_kernel<2>, dim3(attn_res_blocks(n), B * heads), dim3(2 * RES_THREADS), lds, (hipStream_t)stream,
+      { if (dropping) hipLaunchKernelGGL((attn_fwd_res_kernel<2, true>), dim3(attn_res_blocks(n), B * heads), dim3(2 * RES_THREADS), lds, (hipStream_t)stream,
                          (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
+    else hipLaunchKernelGGL((attn_fwd_res_kernel<2, false>), dim3(attn_res_blocks(n), B * heads), dim3(2 * RES_THREADS), lds, (hipStream_t)stream,
+                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p)); }
     else
-      hipLaunchKernelGGL(attn_fwd_res_kernel<1>, dim3(attn_res_blocks(n), B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
+      { if (dropping) hipLaunchKernelGGL((attn_fwd_res_kernel<1, true>), dim3(attn_res_blocks(n), B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
                          (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
+    else hipLaunchKernelGGL((attn_fwd_res_kernel<1, false>), dim3(attn_res_blocks(n), B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
+                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p)); }
   } else if (g_attn_mode != 1 && (long)n * ld_qkv < (1L << 30)) {
-    hipLaunchKernelGGL(attn_fwd_wide_kernel, dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv,
+    { if (dropping) hipLaunchKernelGGL((attn_fwd_wide_kernel<true>), dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv,
                        n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
+    else hipLaunchKernelGGL((attn_fwd_wide_kernel<false>), dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv,
+                       n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p)); }
   } else
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((n + TQ - 1) / TQ, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
+  { if (dropping) hipLaunchKernelGGL((attn_fwd_kernel<true>), dim3((n + TQ - 1) / TQ, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
                      heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
+    else hipLaunchKernelGGL((attn_fwd_kernel<false>), dim3((n + TQ - 1) / TQ, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
+                     heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p)); }
   nv_prof_end(slot, stream);
   NV_CHECK_LAUNCH("nv_attn_fwd");
   return NV_OK;
@@ -574,13 +590,14 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
 // one 64-key tile of the dQ pass for one wave (16 query rows), in pieces (see fwd_tile)
+template <bool DROP>
 __device__ __forceinline__ void dq_softmax_grad(const f32x4 (&sc)[4], f32x4 (&dp)[4], f32x4 (&ds)[4], int kt, int n, float dl, float lse2,
                                                 float scale_log2e, const DropCfg& drop, int bh, int qabs, int g) {
     const f32x2 c2 = {scale_log2e, scale_log2e}, l2 = {-lse2, -lse2}, d2 = {-dl, -dl};
     const bool ragged = kt * TK + TK > n;         // only the last key tile can hold out-of-range (zero-filled) keys
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      if (drop.thresh) {
+      if constexpr (DROP) {
         dp[t] *= drop_factor4(drop, (((unsigned long long)bh * n + qabs) * ((n + 3) & ~3)) + (kt * TK + 16 * t + 4 * g));
       }
 #pragma unroll
@@ -600,6 +617,7 @@ __device__ __forceinline__ void dq_softmax_grad(const f32x4 (&sc)[4], f32x4 (&dp
       }
     }
 }
+template <bool DROP>
 __device__ __forceinline__ void dq_tile(const char* sK, const char* sV, int kt, int n, const bf16x8 (&qf)[2], const bf16x8 (&dof)[2],
                                         f32x4 (&dq)[4], float dl, float lse2, float scale_log2e, const DropCfg& drop, int bh, int qabs,
                                         int r, int g) {
@@ -609,12 +627,13 @@ __device__ __forceinline__ void dq_tile(const char* sK, const char* sV, int kt, 
   mfma_rows(F, qf, sc, true);
   load_row_frags(sV, r, g, F);
   mfma_rows(F, dof, dp, true);
-  dq_softmax_grad(sc, dp, ds, kt, n, dl, lse2, scale_log2e, drop, bh, qabs, g);
+  dq_softmax_grad<DROP>(sc, dp, ds, kt, n, dl, lse2, scale_log2e, drop, bh, qabs, g);
   load_tr_frags(sK, r, g, F);
   const bf16x8 dsf[2] = {cvt8(ds[0], ds[1]), cvt8(ds[2], ds[3])};
   mfma_rows(F, dsf, dq, false);
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
                                                           const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse, int n,
                                                           int heads, float scale, float* __restrict__ delta, bf16* __restrict__ dqkv,
@@ -663,7 +682,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       tile_gload(K, ld, (kt + 1) * TK, n, tid, rk);
       tile_gload(V, ld, (kt + 1) * TK, n, tid, rv);
     }
-    dq_tile(sK, sV, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
+    dq_tile<DROP>(sK, sV, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
   }
   const int q = q0 + r;
   if (q < n) {
@@ -676,6 +695,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // one 64-query tile of the dK/dV pass for one wave (16 keys); sL / sDl hold this tile's 64 log2-domain lse and delta values
+template <bool DROP>
 __device__ __forceinline__ void dkv_softmax_grad(const f32x4 (&sc)[4], const f32x4 (&dp)[4], f32x4 (&p)[4], f32x4 (&ds)[4], const float* sL,
                                                  const float* sDl, int qt, int n, float scale_log2e, const DropCfg& drop, int bh, int keyabs,
                                                  int g) {
@@ -685,7 +705,7 @@ __device__ __forceinline__ void dkv_softmax_grad(const f32x4 (&sc)[4], const f32
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 16 * t + 4 * g);
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + 16 * t + 4 * g);
       f32x4 f = {1.f, 1.f, 1.f, 1.f};
-      if (drop.thresh) {
+      if constexpr (DROP) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           f[j] = drop_factor(drop, (((unsigned long long)bh * n + (qt * TQ + 16 * t + 4 * g + j)) * ((n + 3) & ~3)) + keyabs);
@@ -704,6 +724,7 @@ __device__ __forceinline__ void dkv_softmax_grad(const f32x4 (&sc)[4], const f32
       }
     }
 }
+template <bool DROP>
 __device__ __forceinline__ void dkv_tile(const char* sQ, const char* sD, const float* sL, const float* sDl, int qt, int n,
                                          const bf16x8 (&kf)[2], const bf16x8 (&vf)[2], f32x4 (&dk)[4], f32x4 (&dv)[4], float scale_log2e,
                                          const DropCfg& drop, int bh, int keyabs, int r, int g) {
@@ -713,7 +734,7 @@ __device__ __forceinline__ void dkv_tile(const char* sQ, const char* sD, const f
   load_row_frags(sD, r, g, G);
   mfma_rows(F, kf, sc, true);
   mfma_rows(G, vf, dp, true);
-  dkv_softmax_grad(sc, dp, p, ds, sL, sDl, qt, n, scale_log2e, drop, bh, keyabs, g);
+  dkv_softmax_grad<DROP>(sc, dp, p, ds, sL, sDl, qt, n, scale_log2e, drop, bh, keyabs, g);
   load_tr_frags(sD, r, g, G);
   load_tr_frags(sQ, r, g, F);
   const bf16x8 pf[2] = {cvt8(p[0], p[1]), cvt8(p[2], p[3])};
@@ -722,6 +743,7 @@ __device__ __forceinline__ void dkv_tile(const char* sQ, const char* sD, const f
   mfma_rows(F, dsf, dk, false);
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout, long ldo,
                                                            const float* __restrict__ lse, const float* __restrict__ delta, int n,
                                                            int heads, float scale, bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
@@ -776,7 +798,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
       tile_gload(dO, ldo, (qt + 1) * TQ, n, tid, rd);
       stats_load(qt + 1);
     }
-    dkv_tile(sQ, sD, sL, sDl, qt, n, kf, vf, dk, dv, scale_log2e, drop, blockIdx.y, key0 + r, r, g);
+    dkv_tile<DROP>(sQ, sD, sL, sDl, qt, n, kf, vf, dk, dv, scale_log2e, drop, blockIdx.y, key0 + r, r, g);
   }
   const int key = key0 + r;
   if (key < n) {
@@ -790,6 +812,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ resident backward kernels
+template <bool DROP>
 __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
                                                                       const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse,
                                                                       int n, int heads, float scale, float* __restrict__ delta,
@@ -831,7 +854,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const bf16
   for (int t = 0; t < 4; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   // (software-pipelining the fragment reads as in the forward kernel measured slower inside the train step: 901 vs 923 volumes/s)
   for (int kt = 0; kt < nkt; ++kt)
-    dq_tile(sK + kt * IMG, sV + kt * IMG, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
+    dq_tile<DROP>(sK + kt * IMG, sV + kt * IMG, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
   const int q = q0 + r;
   if (q < n) {
     bf16* drow = dqkv + ((long)b * n + q) * ldd + h * DH;
@@ -841,6 +864,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const bf16
   }
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout,
                                                                        long ldo, const float* __restrict__ lse, const float* __restrict__ delta,
                                                                        int n, int heads, float scale, bf16* __restrict__ dqkv, long ldd,
@@ -883,7 +907,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf1
 #pragma unroll
   for (int t = 0; t < 4; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int qt = 0; qt < nqt; ++qt)
-    dkv_tile(sQ + qt * IMG, sD + qt * IMG, sL + qt * TQ, sDl + qt * TQ, qt, n, kf, vf, dk, dv, scale_log2e, drop, blockIdx.y, key0 + r, r, g);
+    dkv_tile<DROP>(sQ + qt * IMG, sD + qt * IMG, sL + qt * TQ, sDl + qt * TQ, qt, n, kf, vf, dk, dv, scale_log2e, drop, blockIdx.y, key0 + r, r, g);
   const int key = key0 + r;
   if (key < n) {
     bf16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
@@ -900,6 +924,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf1
 // (query rows in the dQ pass, keys in the dK / dV pass), so one set of LDS fragment reads feeds twice the MFMAs; the streamed
 // operand tiles arrive by LDS-DMA into a two-stage ring with one barrier per tile.  Per-group arithmetic is that of the
 // streaming kernels (shared __device__ pieces).
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
                                                                   const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse, int n,
                                                                   int heads, float scale, float* __restrict__ delta, bf16* __restrict__ dqkv,
@@ -970,8 +995,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const bf16* __
     load_row_frags(cur + IMG, r, g, F);
     mfma_rows(F, dof[0], dp[0], true);
     mfma_rows(F, dof[1], dp[1], true);
-    dq_softmax_grad(sc[0], dp[0], ds[0], kt, n, dl[0], lse2[0], scale_log2e, drop, blockIdx.y, q0 + r, g);
-    dq_softmax_grad(sc[1], dp[1], ds[1], kt, n, dl[1], lse2[1], scale_log2e, drop, blockIdx.y, q0 + 16 + r, g);
+    dq_softmax_grad<DROP>(sc[0], dp[0], ds[0], kt, n, dl[0], lse2[0], scale_log2e, drop, blockIdx.y, q0 + r, g);
+    dq_softmax_grad<DROP>(sc[1], dp[1], ds[1], kt, n, dl[1], lse2[1], scale_log2e, drop, blockIdx.y, q0 + 16 + r, g);
     load_tr_frags(cur, r, g, F);                          // (after the exponentials: requesting them earlier spills registers)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -993,6 +1018,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const bf16* __
 
 // in-place form of dkv_softmax_grad for the wide kernel (p overwrites sc, ds overwrites dp: identical arithmetic, fewer live
 // registers); sLraw holds the raw natural-log lse of this query tile (converted to the log2 domain here: the same one rounding)
+template <bool DROP>
 __device__ __forceinline__ void dkv_softmax_grad_inplace(f32x4 (&sc)[4], f32x4 (&dp)[4], const float* sLraw, const float* sDl, int qt, int n,
                                                          float scale_log2e, const DropCfg& drop, int bh, int keyabs, int g) {
     const f32x2 c2 = {scale_log2e, scale_log2e};
@@ -1001,7 +1027,7 @@ __device__ __forceinline__ void dkv_softmax_grad_inplace(f32x4 (&sc)[4], f32x4 (
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLraw + 16 * t + 4 * g) * 1.44269504088896340736f;
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + 16 * t + 4 * g);
       f32x4 f = {1.f, 1.f, 1.f, 1.f};
-      if (drop.thresh) {
+      if constexpr (DROP) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           f[j] = drop_factor(drop, (((unsigned long long)bh * n + (qt * TQ + 16 * t + 4 * g + j)) * ((n + 3) & ~3)) + keyabs);
@@ -1021,6 +1047,7 @@ __device__ __forceinline__ void dkv_softmax_grad_inplace(f32x4 (&sc)[4], f32x4 (
     }
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout, long ldo,
                                                                    const float* __restrict__ lse, const float* __restrict__ delta, int n,
                                                                    int heads, float scale, bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
@@ -1095,10 +1122,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* _
     mfma_rows(F, vf[1], dp[1], true);
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 pf[2][2], dsf[2][2];                           // rounded at once: 16 registers per group instead of 32
-    dkv_softmax_grad_inplace(sc[0], dp[0], sL, sDl, qt, n, scale_log2e, drop, blockIdx.y, key0 + r, g);
+    dkv_softmax_grad_inplace<DROP>(sc[0], dp[0], sL, sDl, qt, n, scale_log2e, drop, blockIdx.y, key0 + r, g);
     pf[0][0] = cvt8(sc[0][0], sc[0][1]); pf[0][1] = cvt8(sc[0][2], sc[0][3]);
     dsf[0][0] = cvt8(dp[0][0], dp[0][1]); dsf[0][1] = cvt8(dp[0][2], dp[0][3]);
-    dkv_softmax_grad_inplace(sc[1], dp[1], sL, sDl, qt, n, scale_log2e, drop, blockIdx.y, key0 + 16 + r, g);
+    dkv_softmax_grad_inplace<DROP>(sc[1], dp[1], sL, sDl, qt, n, scale_log2e, drop, blockIdx.y, key0 + 16 + r, g);
     pf[1][0] = cvt8(sc[1][0], sc[1][1]); pf[1][1] = cvt8(sc[1][2], sc[1][3]);
     dsf[1][0] = cvt8(dp[1][0], dp[1][1]); dsf[1][1] = cvt8(dp[1][2], dp[1][3]);
     __builtin_amdgcn_sched_barrier(0);
@@ -1137,22 +1164,29 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
   if (dim_head != DH)
     return launch_attn_generic_bwd(qkv, ld_qkv, out, dout, ld_out, lse, B, n, heads, dim_head, scale, delta, dqkv, ld_dqkv, make_drop(drop_seed, drop_p), s);
   const dim3 grid((n + TQ - 1) / TQ, B * heads);
+  const bool dropping = make_drop(drop_seed, drop_p).thresh != 0;
   const int slot = nv_prof_begin(4, 10.0 * B * heads * (double)n * n * DH, stream);   // algorithmic: 5 products
   if (attn_resident(n) && g_attn_mode != 3) {
     NV_CHECK_ARG((long)n * ld_qkv < (1L << 30) && (long)n * ld_out < (1L << 30), "nv_attn_bwd: operand too large for 32-bit buffer offsets");
     const int nt = (n + TK - 1) / TK;
     static bool attr = false;
     if (!attr) {
-      attn_res_attr(attn_bwd_dq_res_kernel, 2 * RES_MAX_TILES * IMG);
-      attn_res_attr(attn_bwd_dkv_res_kernel, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
+      attn_res_attr(attn_bwd_dq_res_kernel<false>, 2 * RES_MAX_TILES * IMG);
+      attn_res_attr(attn_bwd_dq_res_kernel<true>, 2 * RES_MAX_TILES * IMG);
+      attn_res_attr(attn_bwd_dkv_res_kernel<false>, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
+      attn_res_attr(attn_bwd_dkv_res_kernel<true>, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
       attr = true;
     }
     const dim3 rgrid(attn_res_blocks(n), B * heads);
-    hipLaunchKernelGGL(attn_bwd_dq_res_kernel, rgrid, dim3(RES_THREADS), 2 * nt * IMG, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
+    { if (dropping) hipLaunchKernelGGL((attn_bwd_dq_res_kernel<true>), rgrid, dim3(RES_THREADS), 2 * nt * IMG, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
                        (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+    else hipLaunchKernelGGL((attn_bwd_dq_res_kernel<false>), rgrid, dim3(RES_THREADS), 2 * nt * IMG, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
+                       (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
     NV_CHECK_LAUNCH("nv_attn_bwd/dq(resident)");
-    hipLaunchKernelGGL(attn_bwd_dkv_res_kernel, rgrid, dim3(RES_THREADS), 2 * nt * IMG + 2 * nt * TQ * 4, s, (const bf16*)qkv, ld_qkv,
+    { if (dropping) hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<true>), rgrid, dim3(RES_THREADS), 2 * nt * IMG + 2 * nt * TQ * 4, s, (const bf16*)qkv, ld_qkv,
                        (const bf16*)dout, ld_out, lse, delta, n, heads, scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+    else hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<false>), rgrid, dim3(RES_THREADS), 2 * nt * IMG + 2 * nt * TQ * 4, s, (const bf16*)qkv, ld_qkv,
+                       (const bf16*)dout, ld_out, lse, delta, n, heads, scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
     nv_prof_end(slot, stream);
     NV_CHECK_LAUNCH("nv_attn_bwd/dkv(resident)");
     return NV_OK;
@@ -1161,18 +1195,26 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
   const bool wide = g_attn_mode != 1 && (long)n * ld_qkv < (1L << 30) && (long)n * ld_out < (1L << 30) &&
                     (g_attn_mode >= 3 || (long)B * heads * ((n + WIDE_ROWS - 1) / WIDE_ROWS) >= 512);
   if (wide)
-    hipLaunchKernelGGL(attn_bwd_dq_wide_kernel, dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
+    { if (dropping) hipLaunchKernelGGL((attn_bwd_dq_wide_kernel<true>), dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
                        (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+    else hipLaunchKernelGGL((attn_bwd_dq_wide_kernel<false>), dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
+                       (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
   else
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out, lse, n,
+  { if (dropping) hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out, lse, n,
                      heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out, lse, n,
+                     heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
   NV_CHECK_LAUNCH("nv_attn_bwd/dq");
   if (wide)
-    hipLaunchKernelGGL(attn_bwd_dkv_wide_kernel, dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
+    { if (dropping) hipLaunchKernelGGL((attn_bwd_dkv_wide_kernel<true>), dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
                        (const bf16*)dout, ld_out, lse, delta, n, heads, scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+    else hipLaunchKernelGGL((attn_bwd_dkv_wide_kernel<false>), dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
+                       (const bf16*)dout, ld_out, lse, delta, n, heads, scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
   else
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)dout, ld_out, lse, delta, n, heads,
+  { if (dropping) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)dout, ld_out, lse, delta, n, heads,
                      scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)dout, ld_out, lse, delta, n, heads,
+                     scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
   nv_prof_end(slot, stream);
   NV_CHECK_LAUNCH("nv_attn_bwd/dkv");
   return NV_OK;
