@@ -372,7 +372,7 @@ static int launch_ws(const GemmArgs& a, hipStream_t s) {
 // fused column-sum epilogue produces).  family: 0 small-tile register-epilogue kernel, 1 warp-specialised (ws = 1: 128x128,
 // 2: 128x64, 3: 64x128; ring as below), 2 eight-wave ping-pong 256 x 128.
 struct GemmPlan { int family, ws, ring, sel, bm; };
-static GemmPlan plan_gemm(bool A_T, bool B_T, int M, int N, int K, long lda, long ldb) {
+static GemmPlan plan_gemm(bool A_T, bool B_T, int epi, int M, int N, int K, long lda, long ldb) {
   GemmPlan p{0, 0, 0, 0, 0};
   // large-tile kernels: need whole K tiles for K-contiguous operands (buffer bounds zero-fill a ragged K only when K is the row
   // index, i.e. for "T" operands) and 31-bit byte offsets; tiny problems keep the small-tile kernel.
@@ -382,7 +382,11 @@ static GemmPlan plan_gemm(bool A_T, bool B_T, int M, int N, int K, long lda, lon
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   const long tpp = (long)((M + PP_BM - 1) / PP_BM) * ((N + PP_BN - 1) / PP_BN);
   const long tpq = (long)((M + PQ_BM - 1) / PQ_BM) * ((N + PQ_BN - 1) / PQ_BN);
-  if (k_ok && fits && (g_tile_override == 9 || (g_tile_override == 0 && tpq >= g_pq_min_tiles))) {
+  // 256 x 256: by a same-box A/B it wins on square problems and on the large preset's qkv (126 vs 133 us), ties on FC1 + GELU and loses
+  // to 256 x 128 wherever the epilogue or a transposed operand weighs (dU + GELU' 283 vs 270 us, N = 1024 data gradients, TN): plain
+  // stores of NT problems only
+  const bool pq_shape = !A_T && !B_T && (epi == EPI_STORE_BF16 || epi == EPI_STORE_F32 || epi == EPI_BIAS_F32);
+  if (k_ok && fits && (g_tile_override == 9 || (g_tile_override == 0 && pq_shape && tpq >= g_pq_min_tiles))) {
     p.family = 3; p.bm = 128;              // 256 x 256 tiles whose epilogue runs in two passes of 128 rows
     return p;
   }
@@ -421,7 +425,7 @@ static GemmPlan plan_gemm(bool A_T, bool B_T, int M, int N, int K, long lda, lon
 
 template <bool A_T, bool B_T, int EPI>
 static int launch(const GemmArgs& a, hipStream_t s) {
-  const GemmPlan p = plan_gemm(A_T, B_T, a.M, a.N, a.K, a.lda, a.ldb);
+  const GemmPlan p = plan_gemm(A_T, B_T, EPI, a.M, a.N, a.K, a.lda, a.ldb);
   if (p.family == 3) return launch_pq(A_T ? 2 : (B_T ? 1 : 0), EPI, a, s);
   if (p.family == 2) return launch_pp(A_T ? 2 : (B_T ? 1 : 0), EPI, a, s);
   if (p.family == 1) {
@@ -447,7 +451,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 // epilogue writes ceil(M / rows) partial rows.  0 = that epilogue is not available for the shape (use epilogue 5 + nv_colsum_bf16).
 extern "C" int nv_gemm_tile_rows(int layout, int M, int N, int K, long lda, long ldb) {
   if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0) return 0;
-  const GemmPlan p = plan_gemm(layout == 2, layout >= 1, M, N, K, lda, ldb);
+  const GemmPlan p = plan_gemm(layout == 2, layout >= 1, EPI_DGELU_COLSUM, M, N, K, lda, ldb);
   return p.family == 0 ? 0 : p.bm;
 }
 
