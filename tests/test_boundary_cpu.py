@@ -209,3 +209,27 @@ def test_flops_formula_in_package_equals_survey_numbers():
         c = {k: v for k, v in cfgdict.items() if k != "pool"}
         assert engine.flops_forward(engine.make_config(**c)) == ref_cpu.flops_forward(ref_cpu.ViTCfg(**cfgdict))
     assert abs(engine.flops_forward(engine.make_config(**{k: v for k, v in W.BASE.items() if k != "pool"})) / 1e9 - 100.07) < 0.01
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The ctypes mirrors of the header's structs (nv_vit_config, nv_vit_input, nv_gemm_problem, nv_reduce_job) against what a C
+    compiler makes of include/neurovit_hip.h: same size, same offset for every field (the header is plain C: gcc compiles it)."""
+    import subprocess
+    from neurovit_amd import ops
+    from neurovit_amd._cabi import HEADER, VitConfig, VitInput
+    structs = {"nv_vit_config": VitConfig, "nv_vit_input": VitInput, "nv_gemm_problem": ops.GemmProblem, "nv_reduce_job": ops.ReduceJob}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.strip()}
+    for cname, cls in structs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
