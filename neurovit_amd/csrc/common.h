@@ -157,7 +157,10 @@ __device__ __forceinline__ dma_desc uniform_rsrc(const void* base, unsigned byte
   return dma_desc{(int)__builtin_amdgcn_readfirstlane((unsigned)a), (int)(__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffff),
                   (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000};
 }
-// one wave-instruction: lane l copies BYTES (16 or 4) from base + voff(l) + soff to LDS at dst + l * BYTES (dst, soff wave-uniform)
+// one wave-instruction: lane l copies BYTES (16 or 4) from base + voff(l) + soff to LDS at dst + l * BYTES (dst, soff wave-uniform).
+// M0 (the LDS base of the transfer) is written inside the statement and not declared as clobbered - the compiler rejects reserved
+// registers there; it keeps nothing in M0 itself on gfx950 unless the kernel also uses the builtin LDS-DMA / GWS / s_movrel forms:
+// do not mix the builtin and this helper in one kernel.
 template <int BYTES>
 __device__ __forceinline__ void lds_dma(dma_desc rsrc, const char* dst, int voff, int soff) {
   typedef __attribute__((address_space(3))) const char lds_cchar;
