@@ -49,6 +49,7 @@ int nv_prof_summary(int kind, double* ms, double* work, long* count);
  * Dropout (nn.Dropout of vit_3d.py:21,23,45; drop_p = 0 disables): applied by epilogue 3 to the GELU output, by 4 to
  * (acc + bias) before the residual add, by 5 to acc; element (m, n) is kept iff hash(drop_seed, m*N + n) >= p*2^32 and
  * scaled by 1/(1-p) - the same mask is recomputed wherever the backward pass needs it. */
+/* epilogue 1 (fp32 store / accumulate): aux_out, when given, receives a bf16 copy of the stored values (ld_aux_out elements per row) */
 int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C,
                  long ldc, const float* bias, const void* aux_in, long ld_aux_in, void* aux_out, long ld_aux_out,
                  int accumulate, float alpha, unsigned long drop_seed, float drop_p, void* stream);
@@ -76,6 +77,7 @@ typedef struct nv_gemm_problem {
   const void* B; long ldb;     /* B[K, N] bf16 */
   void* C; long ldc;           /* C[M, N] f32 */
   int accumulate;              /* C += instead of C = */
+  void* C16; long ldc16;       /* optional (NULL): bf16 mirror of the stored C (data-parallel gradient message) */
 } nv_gemm_problem;
 int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gemm_problem* problems, void* stream);
 
@@ -263,7 +265,17 @@ int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const float* video, 
                            const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
                            int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
                            unsigned long drop_seed, void* stream, void* aux_stream, int join_aux);
+/* as nv_vit_backward_stages; grads16 (may be NULL): bf16 arena with the element offsets of `grads` - the weight gradients of the
+ * Linear layers (to_qkv, to_out, FC1, FC2 of every block; the patch embedding's when patch_dim % 8 == 0) are ALSO written there,
+ * rounded, by the GEMMs that produce them: a data-parallel caller sends them without a cast pass and converts only the small
+ * remaining ranges (nv_cast_ranges_bf16). */
+int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
+                             const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads, void* grads16,
+                             int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
+                             unsigned long drop_seed, void* stream, void* aux_stream, int join_aux);
 int nv_vit_stage_param_range(const nv_vit_config* cfg, int stage, long* begin, long* end);
+/* dst[b .. b + len) = bf16(src[b .. b + len)) for `count` element ranges (HOST arrays begins / lens; any count) */
+int nv_cast_ranges_bf16(const float* src, void* dst, const long* begins, const long* lens, int count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -378,12 +378,22 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
                                       const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
                                       int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
                                       unsigned long drop_seed, void* stream, void* aux_stream, int join_aux) {
+  return nv_vit_backward_stages16(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, nullptr, accumulate, first_stage,
+                                  last_stage, drop_p, emb_drop_p, drop_seed, stream, aux_stream, join_aux);
+}
+
+extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
+                                        const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads, void* grads16,
+                                        int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
+                                        unsigned long drop_seed, void* stream, void* aux_stream, int join_aux) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 1, W);
   NV_CHECK_ARG(video && strides5 && params && params16 && workspace && dlogits && grads, "nv_vit_backward: null pointer");
   NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_backward: workspace too small (%ld < %ld) - forward must run with training=1", ws_bytes, W.total);
-  NV_CHECK_ARG(nv_aligned16(grads), "nv_vit_backward: grads must be 16-byte aligned");
+  NV_CHECK_ARG(nv_aligned16(grads) && nv_aligned16(grads16), "nv_vit_backward: grads / grads16 must be 16-byte aligned");
+  bf16* gr16 = (bf16*)grads16;                     // optional bf16 mirror of the Linear weight gradients (data-parallel messages)
+  auto M16 = [&](long off) -> void* { return gr16 ? (void*)(gr16 + off) : nullptr; };
   char* ws = (char*)workspace;
   const float* p = params;
   const bf16* p16 = (const bf16*)params16;
@@ -477,10 +487,10 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
       // the four weight gradients of the layer in ONE grouped launch (864 tiles keep two workgroups resident on every CU;
       // launched one by one their 72-288 tiles leave the CUs half empty and latency bound)
       nv_gemm_problem pr[4];
-      pr[0] = {d, D.m, M, g16, d, ws + w.h, D.m, gr + q.w2, D.m, acc};                     // dW2 = g^T h
-      pr[1] = {D.m, d, M, du, D.m, ws + w.xn2, d, gr + q.w1, d, acc};                      // dW1 = dU^T xn2
-      pr[2] = {d, D.inner, M, g16b, d, ws + w.ao, D.inner, gr + q.wo, D.inner, acc};       // dWo = g^T ao
-      pr[3] = {3 * D.inner, d, M, dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, acc};  // dWqkv = dqkv^T xn1
+      pr[0] = {d, D.m, M, g16, d, ws + w.h, D.m, gr + q.w2, D.m, acc, M16(q.w2), D.m};                     // dW2 = g^T h
+      pr[1] = {D.m, d, M, du, D.m, ws + w.xn2, d, gr + q.w1, d, acc, M16(q.w1), d};                        // dW1 = dU^T xn2
+      pr[2] = {d, D.inner, M, g16b, d, ws + w.ao, D.inner, gr + q.wo, D.inner, acc, M16(q.wo), D.inner};   // dWo = g^T ao
+      pr[3] = {3 * D.inner, d, M, dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, acc, M16(q.wqkv), d};  // dWqkv = dqkv^T xn1
       RUN(nv_gemm_bf16_grouped(2, 1, 4, pr, sA));
     }
     hipEvent_t done = nullptr;
@@ -535,7 +545,7 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
     RUN(nv_gemm_bf16(2, 1, d, D.Ppad, D.T, ws + W.dt16, d, ws + W.xp, D.Ppad, ws + W.dwpe, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
     RUN(nv_copy_2d_f32((float*)(ws + W.dwpe), D.Ppad, d, D.P, gr + T.pe_w, D.P, acc, stream));
   } else {
-    RUN(nv_gemm_bf16(2, 1, d, D.P, D.T, ws + W.dt16, d, ws + W.xp, D.Ppad, gr + T.pe_w, D.P, nullptr, nullptr, 0, nullptr, 0, acc, 1.f, 0, 0.f, stream));   // dWpe = dt^T xp
+    RUN(nv_gemm_bf16(2, 1, d, D.P, D.T, ws + W.dt16, d, ws + W.xp, D.Ppad, gr + T.pe_w, D.P, nullptr, nullptr, 0, M16(T.pe_w), D.P, acc, 1.f, 0, 0.f, stream));   // dWpe = dt^T xp
   }
   if (forked) RUN(stream_sync(A, S));
   return NV_OK;

@@ -482,6 +482,8 @@ extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void
   NV_CHECK_ARG(epi != EPI_DGELU_COLSUM || (aux_out && ld_aux_out >= N), "nv_gemm_bf16: epilogue 6 needs aux_out = f32 [ceil(M / tile rows), ld_aux_out >= N]");
   NV_CHECK_ARG(!(epi == EPI_BIAS_RESID || epi == EPI_DGELU || epi == EPI_DGELU_COLSUM) || (aux_in && nv_aligned16(aux_in) && (ld_aux_in % 4) == 0),
                "nv_gemm_bf16: epilogue %d needs aux_in", epi);
+  NV_CHECK_ARG(epi != EPI_STORE_F32 || !aux_out || (((uintptr_t)aux_out & 7) == 0 && (ld_aux_out % 4) == 0 && ld_aux_out >= N),
+               "nv_gemm_bf16: epilogue 1: the optional bf16 mirror (aux_out) must be 8-byte aligned with ld_aux_out >= N, a multiple of 4");
   NV_CHECK_ARG(epi != EPI_BIAS_GELU || !aux_out || (nv_aligned16(aux_out) && (ld_aux_out % 4) == 0),
                "nv_gemm_bf16: EPI_BIAS_GELU: aux_out must be 16-byte aligned (or null: the pre-activation is not stored)");
   switch (layout * 16 + epi) {
@@ -542,8 +544,9 @@ extern "C" int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gem
                  "nv_gemm_bf16_grouped: problem %d: alignment / leading dimensions", i);
     NV_CHECK_ARG((long)q.K * q.lda < (1L << 30) && (long)q.K * q.ldb < (1L << 30), "nv_gemm_bf16_grouped: problem %d too large for 32-bit offsets", i);
     GemmArgs& a = G.p[i];
-    a.A = (const bf16*)q.A; a.B = (const bf16*)q.B; a.C = q.C; a.bias = nullptr; a.aux_in = nullptr; a.aux_out = nullptr;
-    a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ld_aux_in = 0; a.ld_aux_out = 0;
+    NV_CHECK_ARG(!q.C16 || (((uintptr_t)q.C16 & 7) == 0 && (q.ldc16 % 4) == 0 && q.ldc16 >= q.N), "nv_gemm_bf16_grouped: problem %d: bf16 mirror alignment / leading dimension", i);
+    a.A = (const bf16*)q.A; a.B = (const bf16*)q.B; a.C = q.C; a.bias = nullptr; a.aux_in = nullptr; a.aux_out = q.C16;
+    a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ld_aux_in = 0; a.ld_aux_out = q.ldc16;
     a.M = q.M; a.N = q.N; a.K = q.K; a.accumulate = q.accumulate; a.alpha = 1.f;
     a.drop = make_drop(0, 0.f);
     a.colscale = nullptr;

@@ -5,7 +5,7 @@
 
 enum {
   EPI_STORE_BF16 = 0,   // C(bf16) = acc
-  EPI_STORE_F32 = 1,    // C(f32)  = acc (+ C if accumulate)
+  EPI_STORE_F32 = 1,    // C(f32)  = acc (+ C if accumulate); aux_out(bf16), when given, = the same values rounded
   EPI_BIAS_F32 = 2,     // C(f32)  = acc + bias[n]
   EPI_BIAS_GELU = 3,    // aux_out(bf16) = u = acc + bias[n];  C(bf16) = gelu(u)
   EPI_BIAS_RESID = 4,   // C(f32)  = aux_in(f32)[m,n] + acc + bias[n]
@@ -185,6 +185,9 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, in
     float* c = (float*)g.C + (long)m * g.ldc + n;
     if (g.accumulate) v += *reinterpret_cast<const f32x4*>(c);
     *reinterpret_cast<f32x4*>(c) = v;
+    // optional bf16 mirror of what was stored (data-parallel gradient messages: the weight gradient leaves its GEMM already in the
+    // wire format, no cast pass over the arena afterwards)
+    if (g.aux_out) *reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n) = cvt4(v[0], v[1], v[2], v[3]);
   } else if constexpr (EPI == EPI_BIAS_F32) {
     *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
   } else if constexpr (EPI == EPI_BIAS_GELU) {

@@ -92,6 +92,46 @@ extern "C" int nv_cast_bf16_2d(const float* src, long ld_src, int rows, int cols
   return NV_OK;
 }
 
+// dst[b .. b + len) = bf16(src[b .. b + len)) for up to CAST_MAX_RANGES element ranges per launch (arguments by value): the small
+// parameter gradients (biases, LayerNorm affine, embeddings) of a data-parallel bucket whose Linear weight gradients were already
+// written in bf16 by their GEMMs.  One workgroup walks one range at a time (ranges are a few hundred to a few hundred thousand
+// elements); ranges start 8-element aligned in the arena, so the body moves 16 bytes in / 8 bytes out per lane and the tail is scalar.
+constexpr int CAST_MAX_RANGES = 48;
+struct CastRanges { long begin[CAST_MAX_RANGES]; long len[CAST_MAX_RANGES]; int count; };
+__global__ __launch_bounds__(256) void cast_ranges_kernel(const float* __restrict__ src, bf16* __restrict__ dst, const CastRanges R) {
+  for (int r = blockIdx.y; r < R.count; r += gridDim.y) {
+    const long b = R.begin[r], n = R.len[r];
+    const bool vec = ((b & 3) == 0);
+    const long n4 = vec ? (n >> 2) : 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + b + 4 * i);
+      *reinterpret_cast<bf16x4*>(dst + b + 4 * i) = cvt4(v[0], v[1], v[2], v[3]);
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[b + i] = (bf16)src[b + i];
+  }
+}
+
+extern "C" int nv_cast_ranges_bf16(const float* src, void* dst, const long* begins, const long* lens, int count, void* stream) {
+  NV_CHECK_ARG(src && dst && (count == 0 || (begins && lens)) && count >= 0 && nv_aligned16(src) && ((uintptr_t)dst & 7) == 0, "nv_cast_ranges_bf16: bad arguments");
+  for (int first = 0; first < count; first += CAST_MAX_RANGES) {
+    CastRanges R;
+    R.count = (count - first < CAST_MAX_RANGES) ? count - first : CAST_MAX_RANGES;
+    long longest = 0;
+    for (int i = 0; i < R.count; ++i) {
+      NV_CHECK_ARG(begins[first + i] >= 0 && lens[first + i] >= 0, "nv_cast_ranges_bf16: negative range");
+      R.begin[i] = begins[first + i]; R.len[i] = lens[first + i];
+      if (R.len[i] > longest) longest = R.len[i];
+    }
+    if (longest == 0) continue;
+    long gx = (longest / 4 + 255) / 256;
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(cast_ranges_kernel, dim3((unsigned)gx, (unsigned)R.count), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, R);
+    NV_CHECK_LAUNCH("nv_cast_ranges_bf16");
+  }
+  return NV_OK;
+}
+
 // out16[m, n] = bf16(x[m, n] * mask(m, n)), out32 likewise (either may be null): the nn.Dropout mask of one site (same
 // counter-based mask the GEMM epilogues apply, element index m*N + n) - used by the standalone Attention / FeedForward
 // modules, whose last Dropout (vit_3d.py:23,45) has no residual epilogue to ride in.

@@ -170,7 +170,8 @@ class VitRuntime:
         return logits
 
     def backward(self, dlogits: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, grads: torch.Tensor,
-                 accumulate: bool, stages: Optional[Tuple[int, int]] = None, join_aux: bool = True) -> None:
+                 accumulate: bool, stages: Optional[Tuple[int, int]] = None, join_aux: bool = True,
+                 grads16: Optional[torch.Tensor] = None) -> None:
         """Whole backward, or only stages [first, last] (0 = head, 1+k = layer depth-1-k, depth+1 = embedding).
         join_aux=False (only for ranges before the last stage): the current stream is not made to wait for the auxiliary
         stream - order the consumer of the range's gradients after `aux_stream_object()` as well."""
@@ -181,12 +182,14 @@ class VitRuntime:
         first, last = (0, self.cfg.depth + 1) if stages is None else stages
         if first == 0:
             self._dlogits = dlogits.contiguous().float()
-        check(lib.nv_vit_backward_stages(ctypes.byref(self.cfg), B, video.data_ptr(), ops.strides5(video), params.data_ptr(),
-                                         params16.data_ptr(), ws.data_ptr(), ws.numel(), self._dlogits.data_ptr(),
-                                         grads.data_ptr(), int(accumulate), first, last, float(self._dropout[0]),
-                                         float(self._dropout[1]), int(self._dropout[2]),
-                                         torch.cuda.current_stream().cuda_stream, self._aux_stream(video.device), int(join_aux)),
-              "nv_vit_backward_stages")
+        # grads16: bf16 arena (element offsets of `grads`) that also receives the Linear weight gradients, rounded, straight from
+        # their GEMMs - the data-parallel message buffer (mirrored_ranges() lists what lands there)
+        check(lib.nv_vit_backward_stages16(ctypes.byref(self.cfg), B, video.data_ptr(), ops.strides5(video), params.data_ptr(),
+                                           params16.data_ptr(), ws.data_ptr(), ws.numel(), self._dlogits.data_ptr(),
+                                           grads.data_ptr(), None if grads16 is None else grads16.data_ptr(), int(accumulate), first, last,
+                                           float(self._dropout[0]), float(self._dropout[1]), int(self._dropout[2]),
+                                           torch.cuda.current_stream().cuda_stream, self._aux_stream(video.device), int(join_aux)),
+              "nv_vit_backward_stages16")
 
     def aux_stream_object(self, device) -> Optional[torch.cuda.Stream]:
         """The torch stream object behind the engine's auxiliary stream (None when the engine runs single-stream)."""
@@ -197,7 +200,8 @@ class VitRuntime:
             return None
         st = self._aux.get(str(device))
         if st is None:
-            st = self._aux[str(device)] = torch.cuda.Stream(device=device)
+            from .parallel import independent_stream     # a stream that does not share the current stream's hardware queue
+            st = self._aux[str(device)] = independent_stream(device, [torch.cuda.current_stream(device)])
         return st.cuda_stream
 
     def stage_range(self, first: int, last: int) -> Tuple[int, int]:

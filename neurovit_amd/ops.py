@@ -35,6 +35,18 @@ def shape5(video: torch.Tensor):
     return (ctypes.c_long * 5)(*video.shape)
 
 
+def cast_ranges_bf16(src: torch.Tensor, dst: torch.Tensor, ranges) -> None:
+    """dst[b:e] = bf16(src[b:e]) for the element ranges [(b, e), ...] of two flat arenas (fp32 -> bf16), one launch per 48 ranges."""
+    _need_cuda(src, dst)
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.dim() == 1 and dst.numel() >= src.numel()
+    ranges = [(int(b), int(e)) for b, e in ranges if e > b]
+    if not ranges:
+        return
+    begins = (ctypes.c_long * len(ranges))(*[b for b, _ in ranges])
+    lens = (ctypes.c_long * len(ranges))(*[e - b for b, e in ranges])
+    check(lib.nv_cast_ranges_bf16(_p(src), _p(dst), begins, lens, len(ranges), _stream()), "nv_cast_ranges_bf16")
+
+
 def strides5(video: torch.Tensor):
     assert video.dim() == 5
     return (ctypes.c_long * 5)(*video.stride())
@@ -63,18 +75,23 @@ def gemm(layout: int, epi: int, A: torch.Tensor, B: torch.Tensor, *, out: Option
 
 class GemmProblem(ctypes.Structure):          # include/neurovit_hip.h::nv_gemm_problem
     _fields_ = [("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("A", ctypes.c_void_p), ("lda", ctypes.c_long),
-                ("B", ctypes.c_void_p), ("ldb", ctypes.c_long), ("C", ctypes.c_void_p), ("ldc", ctypes.c_long), ("accumulate", ctypes.c_int)]
+                ("B", ctypes.c_void_p), ("ldb", ctypes.c_long), ("C", ctypes.c_void_p), ("ldc", ctypes.c_long), ("accumulate", ctypes.c_int),
+                ("C16", ctypes.c_void_p), ("ldc16", ctypes.c_long)]
 
 
 def gemm_tn_grouped(problems) -> None:
-    """problems: up to four (A[K, M] bf16, B[K, N] bf16, C[M, N] f32, accumulate) - C (+)= A^T B, one launch."""
+    """problems: up to four (A[K, M] bf16, B[K, N] bf16, C[M, N] f32, accumulate[, C16[M, N] bf16 mirror]) - C (+)= A^T B, one launch."""
     arr = (GemmProblem * len(problems))()
-    for i, (A, B, C, acc) in enumerate(problems):
+    for i, pr in enumerate(problems):
+        A, B, C, acc = pr[:4]
+        C16 = pr[4] if len(pr) > 4 else None
         _need_cuda(A)
         K, M = A.shape
         N = B.shape[1]
         assert B.shape[0] == K and C.shape == (M, N) and C.dtype == torch.float32
-        arr[i] = GemmProblem(M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0), int(acc))
+        assert C16 is None or (C16.shape == (M, N) and C16.dtype == torch.bfloat16)
+        arr[i] = GemmProblem(M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0), int(acc),
+                             _p(C16), 0 if C16 is None else C16.stride(0))
     check(lib.nv_gemm_bf16_grouped(TN, EPI_STORE_F32, len(problems), ctypes.cast(arr, ctypes.c_void_p), _stream()), "nv_gemm_bf16_grouped")
 
 

@@ -27,6 +27,43 @@ def bucket_stages(n_stages: int, n_buckets: int) -> List[Tuple[int, int]]:
     return out
 
 
+def _runs_beside(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
+    """True when work on stream a is not queued behind work on stream b.  HIP multiplexes its streams onto a few hardware queues
+    (four per priority by default); two streams that share one execute in submission order - a wait enqueued on one (a bucket's
+    all-reduce waiting for the weight-gradient stream) then stalls every later kernel of the other.  Probe: a spin kernel on b,
+    a small fill on a; a's fill finishing first means separate queues."""
+    x = torch.empty(64, device=a.device)
+    torch.cuda.synchronize(a.device)
+    with torch.cuda.stream(b):
+        torch.cuda._sleep(4_000_000)                 # ~2 ms
+        eb = torch.cuda.Event()
+        eb.record(b)
+    with torch.cuda.stream(a):
+        x.fill_(1.0)
+        ea = torch.cuda.Event()
+        ea.record(a)
+    ea.synchronize()
+    beside = not eb.query()
+    torch.cuda.synchronize(a.device)
+    return beside
+
+
+def independent_stream(device, others, tries: int = 12) -> "torch.cuda.Stream":
+    """A stream from torch's pool that shares its hardware queue with none of `others` (None entries ignored); the last candidate
+    if the probe never succeeds (correct either way - only the overlap is lost).  Priority streams are not an answer: a
+    high-priority queue that mostly waits on events slowed the whole step by 80 % (measured)."""
+    others = [o for o in others if o is not None]
+    cand = torch.cuda.Stream(device=device)
+    try:
+        for _ in range(tries):
+            if all(_runs_beside(cand, o) for o in others):
+                return cand
+            cand = torch.cuda.Stream(device=device)
+    except (AttributeError, RuntimeError):           # no torch.cuda._sleep on this build: keep the first stream
+        pass
+    return cand
+
+
 class GradSync:
     """All-reduce (SUM) of gradient-arena ranges as they become final, optionally followed by a per-range callback
     (the fused AdamW of that range) on the same side stream, so both overlap the rest of the backward pass.
@@ -43,6 +80,8 @@ class GradSync:
         self.write_back = True      # bf16 messages: cast the reduced values back into the fp32 gradients (False: the consumer
                                     # reads `reduced_buffer()` itself, e.g. the fused AdamW - saves a pass over the arena)
         self._comm_buf: Optional[torch.Tensor] = None
+        self.mirrored = None        # bf16 messages: sorted element ranges the producer already wrote (rounded) into message_buffer();
+                                    # only the rest of a bucket is converted here (ViT.mirrored_ranges, nv_vit_backward_stages16)
         self.pg = process_group
         self.n_buckets = n_buckets
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -72,7 +111,20 @@ class GradSync:
             dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg)
             return
         buf = self.message_buffer(flat_grads)[begin:end]
-        buf.copy_(chunk)
+        if self.mirrored is None:
+            buf.copy_(chunk)
+        else:                          # the large ranges are in the buffer already: convert what lies between them
+            from . import ops
+            rest, cur = [], begin
+            for b, e in self.mirrored:
+                if e <= begin or b >= end:
+                    continue
+                if b > cur:
+                    rest.append((cur, b))
+                cur = max(cur, e)
+            if cur < end:
+                rest.append((cur, end))
+            ops.cast_ranges_bf16(flat_grads, self.message_buffer(flat_grads), rest)
         self.bytes_reduced += buf.numel() * 2
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
         if self.write_back:
@@ -86,7 +138,7 @@ class GradSync:
         chunk = flat_grads[begin:end]
         if chunk.is_cuda:
             if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(device=chunk.device)
+                self._comm_stream = independent_stream(chunk.device, [torch.cuda.current_stream(chunk.device), also_after])
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self._comm_stream.wait_event(ev)

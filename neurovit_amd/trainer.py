@@ -62,6 +62,10 @@ class TrainStep:
             vit._shadow_key = None
         self._pg = process_group
         vit._grad_sync = None
+        # parameters outside the ViT's arena (the 4D temporal head), found once: the per-step straggler loop must not search
+        ids = {id(q) for q in vit.parameters()}
+        self._outside = [p for p in model.parameters() if id(p) not in ids]
+        self._inside = [p for p in model.parameters() if id(p) in ids]
 
     def _bucket_update(self, begin: int, end: int):
         self.optimizer.step_range(self._vit, begin, end, grad_scale=1.0 / self.world, max_blocks=self._opt_blocks)
@@ -87,9 +91,8 @@ class TrainStep:
                 # stragglers, reduced inline: parameters outside the arena (the 10 k-parameter temporal head), and - when the
                 # ViT is only PARTIALLY trainable, so that no bucket pipeline runs over the arena - its trainable parameters
                 arena_synced = self.sync is not None
-                for p in model.parameters():
-                    in_arena = any(p is q for q in vit._plist)
-                    if p.grad is not None and not (in_arena and arena_synced):
+                for p in (self._outside if arena_synced else self._outside + self._inside):
+                    if p.grad is not None:
                         dist.all_reduce(p.grad, group=self._pg)
                         p.grad.mul_(scale)
                 if not arena_synced:

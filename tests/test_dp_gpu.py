@@ -93,3 +93,42 @@ def test_dp2_bf16_messages_close_to_fp32_messages():
     assert torch.equal(a[0], a[1])
     start = _model().volume_encoder.vit3d.flat_parameters()[0].detach().cpu()
     assert float(((a[0] - start) - (b[0] - start)).norm() / (b[0] - start).norm()) < 0.05
+
+
+def _msg_worker(q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + (os.getpid() % 200)))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from neurovit_amd.parallel import GradSync
+        from neurovit_amd.trainer import TrainStep
+        torch.cuda.set_device(0)
+        model = _model()
+        vit = model.volume_encoder.vit3d
+        step = TrainStep(model)
+        step.sync = GradSync(None, n_buckets=3, comm_dtype=torch.bfloat16)
+        step.sync.world = 2                # force the bucket pipeline; the group has one rank, so the sum is the identity
+        step.sync.write_back = False
+        step.world = 1
+        step(*_data(7))
+        torch.cuda.synchronize()
+        msg, grads = step.sync.reduced_buffer(), vit.flat_gradients()
+        mirrored = vit.mirrored_ranges()
+        covered = sum(e - b for b, e in mirrored)
+        q.put((bool(torch.equal(msg, grads.to(torch.bfloat16))), covered, grads.numel(), len(mirrored)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_message_buffer_is_the_rounded_gradient_arena():
+    """bf16 messages are assembled without a cast pass over the arena: the Linear weight gradients arrive in the message buffer from
+    their GEMMs' epilogues (nv_vit_backward_stages16), the ranges in between through nv_cast_ranges_bf16.  Every element of the buffer
+    must equal the rounded fp32 gradient, and the mirrored ranges must be what the module says they are (4 per block + patch embed)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_msg_worker, args=(q,))
+    p.start()
+    same, covered, total, count = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert same
+    assert count == 4 * SIZE["TRAINING_VIT_DEPTH"] + 1 and covered / total > 0.8

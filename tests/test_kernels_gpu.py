@@ -247,6 +247,36 @@ def test_gemm_256x256_kernel_forced(ops, M, N, K):
         lib.nv_gemm_set_tile(0, 0)
 
 
+def test_weight_gradient_bf16_mirror_and_cast_ranges(ops):
+    """Data-parallel message path: the fp32-store epilogue also writes a bf16 copy of what it stored (single TN launch, grouped
+    launch, with accumulation: the mirror is the rounded SUM), bit-equal to casting the fp32 result; nv_cast_ranges_bf16 converts the
+    ranges in between (aligned and unaligned starts, tails, > 48 ranges)."""
+    K, specs = 2052, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    probs, outs = [], []
+    for i, (Mo, N) in enumerate(specs):
+        At, B2 = dev(bf(rnd(K, Mo, seed=30 + i))), dev(bf(rnd(K, N, seed=40 + i, scale=K ** -0.5)))
+        C = dev(rnd(Mo, N, seed=50 + i))
+        C16 = torch.zeros((Mo, N), dtype=torch.bfloat16, device="cuda")
+        probs.append((At, B2, C, True, C16))
+        outs.append((At, B2, C.clone(), C, C16))
+    ops.gemm_tn_grouped(probs)
+    for At, B2, C0, C, C16 in outs:
+        assert_close_f32(C, At.double().cpu().T @ B2.double().cpu() + C0.double().cpu(), "mirror.f32", 1e-5)
+        assert torch.equal(C16, C.to(torch.bfloat16))
+    At, B2 = dev(bf(rnd(520, 264, seed=61))), dev(bf(rnd(520, 136, seed=62)))
+    m16 = torch.zeros((264, 136), dtype=torch.bfloat16, device="cuda")
+    c = ops.gemm(ops.TN, ops.EPI_STORE_F32, At, B2, aux_out=m16)
+    assert torch.equal(m16, c.to(torch.bfloat16))
+    src = dev(rnd(200000, seed=63))
+    dst = torch.full((200000,), 7.0, dtype=torch.bfloat16, device="cuda")
+    ranges = [(0, 8), (16, 16), (24, 1000), (1003, 1010), (4096, 150001)] + [(160000 + 64 * i, 160000 + 64 * i + 1 + (i % 63)) for i in range(60)]
+    ops.cast_ranges_bf16(src, dst, ranges)
+    want = torch.full((200000,), 7.0, dtype=torch.bfloat16, device="cuda")
+    for b, e in ranges:
+        want[b:e] = src[b:e].to(torch.bfloat16)
+    assert torch.equal(dst, want)
+
+
 def test_gemm_ping_pong_grouped_equals_single_launches(ops):
     """Grouped weight gradients on the ping-pong tiles: bit-identical to single launches of the same kernel."""
     from neurovit_amd._cabi import lib

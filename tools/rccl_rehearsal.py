@@ -40,7 +40,7 @@ def main():
     for dtype in (torch.float32, torch.bfloat16):
         model = build()
         step = TrainStep(model)
-        step.sync = GradSync(None, n_buckets=7, comm_dtype=dtype)
+        step.sync = GradSync(None, n_buckets=int(os.environ.get("REHEARSAL_BUCKETS", "7")), comm_dtype=dtype)
         step.sync.world = 2                       # force the collective path; the group itself has one rank
         step.sync.write_back = dtype != torch.bfloat16     # as TrainStep sets it: bf16 -> the fused AdamW reads the reduced buffer
         step.world = 1                            # keep the 1/world scaling of the optimizer at 1
@@ -52,10 +52,11 @@ def main():
         t = time.perf_counter()
         for _ in range(20):
             step(x, y)
+        host_ms = (time.perf_counter() - t) / 20 * 1e3
         dist.barrier()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t) / 20 * 1e3
-        print(f"{dtype}: losses {['%.5f' % v for v in losses]} (reference {['%.5f' % v for v in losses_ref]}), {ms:.3f} ms/step, "
+        print(f"{dtype}: host enqueue {host_ms:.3f} ms/step; losses {['%.5f' % v for v in losses]} (reference {['%.5f' % v for v in losses_ref]}), {ms:.3f} ms/step, "
               f"{step.sync.bytes_reduced / 24 / 1e6:.0f} MB reduced per step")
         tol = 0 if dtype == torch.float32 else 5e-2
         assert all(abs(a - b) <= tol * max(1.0, abs(b)) for a, b in zip(losses, losses_ref)), "loss curve differs from the single-process run"
