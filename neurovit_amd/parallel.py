@@ -64,6 +64,46 @@ def independent_stream(device, others, tries: int = 12) -> "torch.cuda.Stream":
     return cand
 
 
+def compute_stream_beside_collectives(device, process_group=None, candidates: int = 6) -> Optional["torch.cuda.Stream"]:
+    """Data-parallel start-up probe (world > 1): does a collective overlap work on the CURRENT stream?  torch runs RCCL kernels on
+    an internal stream of its own; if that stream shares a hardware queue with the compute stream, every all-reduce executes in
+    submission order with the backward pass instead of beside it.  Returns None when the current stream is fine, else a pool
+    stream that is (the caller then runs its step on it), else None again.  Every rank issues exactly candidates + 2 collectives,
+    whatever it finds, so the ranks stay in step."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) < 2 or torch.device(device).type != "cuda":
+        return None
+    try:
+        t = torch.ones(1 << 20, device=device)
+        side = torch.cuda.Stream(device=device)
+        dist.all_reduce(t, group=process_group)                   # warm-up: communicator and internal stream exist after this
+        torch.cuda.synchronize(device)
+
+        def beside(stream) -> bool:
+            with torch.cuda.stream(stream):
+                torch.cuda._sleep(8_000_000)                      # ~4 ms of spinning on the compute stream
+                es = torch.cuda.Event()
+                es.record(stream)
+            with torch.cuda.stream(side):
+                dist.all_reduce(t, group=process_group)
+                ec = torch.cuda.Event()
+                ec.record(side)
+            ec.synchronize()
+            ok = not es.query()                                   # the collective finished while the compute stream still spun
+            torch.cuda.synchronize(device)
+            return ok
+
+        current_ok = beside(torch.cuda.current_stream(device))
+        found = None
+        for _ in range(candidates):
+            cand = torch.cuda.Stream(device=device)
+            ok = beside(cand)
+            if ok and found is None:
+                found = cand
+        return None if current_ok else found
+    except (AttributeError, RuntimeError):
+        return None
+
+
 class GradSync:
     """All-reduce (SUM) of gradient-arena ranges as they become final, optionally followed by a per-range callback
     (the fused AdamW of that range) on the same side stream, so both overlap the rest of the backward pass.

@@ -62,6 +62,12 @@ class TrainStep:
             vit._shadow_key = None
         self._pg = process_group
         vit._grad_sync = None
+        # DP: if collectives would queue behind the current stream's kernels (shared hardware queue), run the step on a stream where
+        # they do not (parallel.compute_stream_beside_collectives; None = the current stream is fine, or nothing to probe)
+        self._compute_stream = None
+        if world > 1 and next(model.parameters()).is_cuda:
+            from .parallel import compute_stream_beside_collectives
+            self._compute_stream = compute_stream_beside_collectives(next(model.parameters()).device, process_group)
         # parameters outside the ViT's arena (the 4D temporal head), found once: the per-step straggler loop must not search
         ids = {id(q) for q in vit.parameters()}
         self._outside = [p for p in model.parameters() if id(p) not in ids]
@@ -71,6 +77,20 @@ class TrainStep:
         self.optimizer.step_range(self._vit, begin, end, grad_scale=1.0 / self.world, max_blocks=self._opt_blocks)
 
     def __call__(self, fmri: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        cs = self._compute_stream
+        if cs is None:
+            return self._step(fmri, labels)
+        cur = torch.cuda.current_stream(cs.device)
+        cs.wait_stream(cur)
+        with torch.cuda.stream(cs):
+            loss = self._step(fmri, labels)
+        cur.wait_stream(cs)
+        for t in (loss, self.last_outputs):
+            if t is not None:
+                t.record_stream(cur)
+        return loss
+
+    def _step(self, fmri: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         model, vit = self.model, self._vit
         last_micro = (self._micro + 1) % self.accumulation_steps == 0
         pipelined = self.sync is not None and last_micro
