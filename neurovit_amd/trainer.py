@@ -65,9 +65,12 @@ class TrainStep:
         # DP: if collectives would queue behind the current stream's kernels (shared hardware queue), run the step on a stream where
         # they do not (parallel.compute_stream_beside_collectives; None = the current stream is fine, or nothing to probe)
         self._compute_stream = None
-        if world > 1 and next(model.parameters()).is_cuda:
+        dev0 = next(model.parameters()).device
+        if world > 1 and dev0.type == "cuda":
             from .parallel import compute_stream_beside_collectives
-            self._compute_stream = compute_stream_beside_collectives(next(model.parameters()).device, process_group)
+            self._compute_stream = compute_stream_beside_collectives(dev0, process_group)
+        if os.environ.get("NEUROVIT_FORCE_COMPUTE_STREAM") == "1" and dev0.type == "cuda":     # tests: exercise the side-stream step
+            self._compute_stream = torch.cuda.Stream(device=dev0)
         # parameters outside the ViT's arena (the 4D temporal head), found once: the per-step straggler loop must not search
         ids = {id(q) for q in vit.parameters()}
         self._outside = [p for p in model.parameters() if id(p) not in ids]

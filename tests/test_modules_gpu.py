@@ -643,3 +643,28 @@ def test_neuro4d_fused_gather_equals_copy_path(nv):
     out.sum().backward()
     assert all(q.grad is None for q in model.volume_encoder.parameters())
     assert all(q.grad is not None for q in model.temporal_transformer.parameters())
+
+
+def test_train_step_on_a_side_compute_stream_equals_the_default_stream(nv, monkeypatch):
+    """Data-parallel runs may move the whole step to another stream (when collectives would queue behind the default one:
+    parallel.compute_stream_beside_collectives).  Forced here: same losses and parameters, bit for bit, as on the default stream."""
+    from neurovit_amd.trainer import TrainStep
+    x = W.make_volume((2, 32, 32, 32), 71).cuda()
+    y = torch.tensor([0, 1]).cuda()
+
+    def run(force):
+        if force:
+            monkeypatch.setenv("NEUROVIT_FORCE_COMPUTE_STREAM", "1")
+        else:
+            monkeypatch.delenv("NEUROVIT_FORCE_COMPUTE_STREAM", raising=False)
+        model = _micro_model(nv)
+        step = TrainStep(model, lr=1e-3, weight_decay=1e-2)
+        assert (step._compute_stream is not None) == force
+        losses = [float(step(x, y)) for _ in range(3)]
+        outs = step.last_outputs.clone()
+        torch.cuda.synchronize()
+        return losses, outs, model.volume_encoder.vit3d.flat_parameters()[0].detach().clone()
+
+    l0, o0, p0 = run(False)
+    l1, o1, p1 = run(True)
+    assert l0 == l1 and torch.equal(o0, o1) and torch.equal(p0, p1)
