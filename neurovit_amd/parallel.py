@@ -64,14 +64,14 @@ def independent_stream(device, others, tries: int = 12) -> "torch.cuda.Stream":
     return cand
 
 
-def compute_stream_beside_collectives(device, process_group=None, candidates: int = 6) -> Optional["torch.cuda.Stream"]:
-    """Data-parallel start-up probe (world > 1): does a collective overlap work on the CURRENT stream?  torch runs RCCL kernels on
-    an internal stream of its own; if that stream shares a hardware queue with the compute stream, every all-reduce executes in
-    submission order with the backward pass instead of beside it.  Returns None when the current stream is fine, else a pool
-    stream that is (the caller then runs its step on it), else None again.  Every rank issues exactly candidates + 2 collectives,
-    whatever it finds, so the ranks stay in step."""
+def streams_beside_collectives(device, process_group=None, candidates: int = 8):
+    """Data-parallel start-up probe (world > 1): which streams does a collective overlap?  torch runs RCCL kernels on an internal
+    stream of its own; a stream that shares that stream's hardware queue executes in submission order with every all-reduce instead
+    of beside it.  Returns (compute, aux): `compute` is None when the current stream is fine, else a pool stream that is (the
+    caller runs its step there); `aux` is a second such stream with a queue of its own for the engine's weight-gradient work (None:
+    let the engine pick).  Every rank issues exactly candidates + 2 collectives, whatever it finds, so the ranks stay in step."""
     if not dist.is_initialized() or dist.get_world_size(process_group) < 2 or torch.device(device).type != "cuda":
-        return None
+        return None, None
     try:
         t = torch.ones(1 << 20, device=device)
         side = torch.cuda.Stream(device=device)
@@ -80,7 +80,7 @@ def compute_stream_beside_collectives(device, process_group=None, candidates: in
 
         def beside(stream) -> bool:
             with torch.cuda.stream(stream):
-                torch.cuda._sleep(8_000_000)                      # ~4 ms of spinning on the compute stream
+                torch.cuda._sleep(8_000_000)                      # ~4 ms of spinning on the candidate
                 es = torch.cuda.Event()
                 es.record(stream)
             with torch.cuda.stream(side):
@@ -88,20 +88,25 @@ def compute_stream_beside_collectives(device, process_group=None, candidates: in
                 ec = torch.cuda.Event()
                 ec.record(side)
             ec.synchronize()
-            ok = not es.query()                                   # the collective finished while the compute stream still spun
+            ok = not es.query()                                   # the collective finished while the candidate still spun
             torch.cuda.synchronize(device)
             return ok
 
-        current_ok = beside(torch.cuda.current_stream(device))
-        found = None
+        current = torch.cuda.current_stream(device)
+        current_ok = beside(current)
+        good = []
         for _ in range(candidates):
             cand = torch.cuda.Stream(device=device)
-            ok = beside(cand)
-            if ok and found is None:
-                found = cand
-        return None if current_ok else found
+            if beside(cand):
+                good.append(cand)
+        compute = None
+        if not current_ok and good:
+            compute = good.pop(0)
+        main = compute if compute is not None else current
+        aux = next((c for c in good if _runs_beside(c, main)), None)
+        return compute, aux
     except (AttributeError, RuntimeError):
-        return None
+        return None, None
 
 
 class GradSync:

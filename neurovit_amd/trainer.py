@@ -63,12 +63,14 @@ class TrainStep:
         self._pg = process_group
         vit._grad_sync = None
         # DP: if collectives would queue behind the current stream's kernels (shared hardware queue), run the step on a stream where
-        # they do not (parallel.compute_stream_beside_collectives; None = the current stream is fine, or nothing to probe)
+        # they do not, and give the engine an auxiliary stream with the same property (parallel.streams_beside_collectives)
         self._compute_stream = None
         dev0 = next(model.parameters()).device
         if world > 1 and dev0.type == "cuda":
-            from .parallel import compute_stream_beside_collectives
-            self._compute_stream = compute_stream_beside_collectives(dev0, process_group)
+            from .parallel import streams_beside_collectives
+            self._compute_stream, aux = streams_beside_collectives(dev0, process_group)
+            if aux is not None and vit._rt.use_aux_stream:
+                vit._rt._aux[str(dev0)] = aux
         if os.environ.get("NEUROVIT_FORCE_COMPUTE_STREAM") == "1" and dev0.type == "cuda":     # tests: exercise the side-stream step
             self._compute_stream = torch.cuda.Stream(device=dev0)
         # parameters outside the ViT's arena (the 4D temporal head), found once: the per-step straggler loop must not search

@@ -647,7 +647,7 @@ def test_neuro4d_fused_gather_equals_copy_path(nv):
 
 def test_train_step_on_a_side_compute_stream_equals_the_default_stream(nv, monkeypatch):
     """Data-parallel runs may move the whole step to another stream (when collectives would queue behind the default one:
-    parallel.compute_stream_beside_collectives).  Forced here: same losses and parameters, bit for bit, as on the default stream."""
+    parallel.streams_beside_collectives).  Forced here: same losses and parameters, bit for bit, as on the default stream."""
     from neurovit_amd.trainer import TrainStep
     x = W.make_volume((2, 32, 32, 32), 71).cuda()
     y = torch.tensor([0, 1]).cuda()
