@@ -73,14 +73,12 @@ __device__ __forceinline__ void lane_pair32(float v, float& a, float& b) {
   a = v; b = v;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
-// single-instruction maxima: fmaxf on MFMA results / asm outputs gets a canonicalising v_max_f32 x, x, x in front of every operand
+// max of two / three (v_max_f32 / v_max3_f32).  Written as inline asm these lost the IEEE canonicalisation (v_max_f32 x, x, x) the
+// compiler puts in front of fmaxf operands, but an asm consumer placed right behind an MFMA is outside the compiler's hazard
+// bookkeeping (a NaN showed up in a test): plain builtins.  Scalar f32 helpers in the same style were tried for the softmax
+// arithmetic and measured 10 % slower than the packed forms.
 __device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ float vmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-// single-instruction f32 arithmetic: beside MFMAs the packed forms (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32, which the compiler
-// also builds by itself from adjacent scalar operations) cost more issue time than the two scalar instructions they replace
-__device__ __forceinline__ float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
-__device__ __forceinline__ float vmul(float a, float b) { return a * b; }
 __device__ __forceinline__ float group_max(float v) {   // over the 4 lane groups sharing r
   float a, b;
   lane_pair16(v, a, b);
