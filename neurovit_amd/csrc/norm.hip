@@ -541,22 +541,40 @@ extern "C" int nv_patch_ln_fwd_4d(const float* x, int Bo, int H, int W, int D, i
 
 // Backward of LayerNorm(patch_dim) w.r.t. its affine parameters only (the volume needs no gradient):
 // dgamma[k] = sum_tok dxp[tok,k] * xhat[tok,k], dbeta[k] = sum_tok dxp[tok,k]; xhat is re-gathered.
+// VEC (the conditions of the forward gather: one channel, frames contiguous, 16-byte aligned runs): four consecutive features per
+// thread - a float4 of the volume and one of dxp instead of four 4-byte gathers (53 -> 22 us at ViT3D-base).
+template <bool VEC>
 __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(const float* __restrict__ video, PatchGeom g, const float* __restrict__ dxp,
                                                            long ldd, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                            int tok_per_block, float* __restrict__ partials) {
   const int T = g.B * g.N;
   const int t0 = blockIdx.x * tok_per_block, t1 = min(T, t0 + tok_per_block);
-  for (int k = threadIdx.x; k < g.P; k += 256) {
-    float ag = 0.f, ab = 0.f;
-    for (int tok = t0; tok < t1; ++tok) {
-      const int b = tok / g.N, n = tok - b * g.N;
-      const float xh = (video[patch_elem_offset(g, b, n, k)] - mean_in[tok]) * rstd_in[tok];
-      const float dv = dxp[(long)tok * ldd + k];
-      ag += dv * xh;
-      ab += dv;
+  if constexpr (VEC) {
+    for (int k = threadIdx.x * 4; k < g.P; k += 1024) {
+      f32x4 ag = f32x4{0.f, 0.f, 0.f, 0.f}, ab = ag;
+      for (int tok = t0; tok < t1; ++tok) {
+        const int b = tok / g.N, n = tok - b * g.N;
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(video + patch_elem_offset(g, b, n, k)) - mean_in[tok]) * rstd_in[tok];
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dxp + (long)tok * ldd + k);
+        ag += dv * xh;
+        ab += dv;
+      }
+      *reinterpret_cast<f32x4*>(partials + (long)blockIdx.x * 2 * g.P + k) = ag;
+      *reinterpret_cast<f32x4*>(partials + (long)blockIdx.x * 2 * g.P + g.P + k) = ab;
     }
-    partials[(long)blockIdx.x * 2 * g.P + k] = ag;
-    partials[(long)blockIdx.x * 2 * g.P + g.P + k] = ab;
+  } else {
+    for (int k = threadIdx.x; k < g.P; k += 256) {
+      float ag = 0.f, ab = 0.f;
+      for (int tok = t0; tok < t1; ++tok) {
+        const int b = tok / g.N, n = tok - b * g.N;
+        const float xh = (video[patch_elem_offset(g, b, n, k)] - mean_in[tok]) * rstd_in[tok];
+        const float dv = dxp[(long)tok * ldd + k];
+        ag += dv * xh;
+        ab += dv;
+      }
+      partials[(long)blockIdx.x * 2 * g.P + k] = ag;
+      partials[(long)blockIdx.x * 2 * g.P + g.P + k] = ab;
+    }
   }
 }
 
@@ -583,7 +601,10 @@ extern "C" int nv_patch_ln_bwd(const float* video, const long* strides5, int B, 
   const int nb = patch_bwd_blocks(T, &tpb);
   NV_CHECK_ARG(ws_bytes >= (long)nb * 2 * g.P * (long)sizeof(float), "nv_patch_ln_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(patch_ln_bwd_kernel, dim3(nb), dim3(256), 0, s, video, g, dxp, ldd, mean, rstd, tpb, (float*)workspace);
+  if (patch_vec_ok(video, g, ldd) && nv_aligned16(dxp) && (ldd % 4) == 0 && (g.P % 4) == 0 && nv_aligned16(workspace))
+    hipLaunchKernelGGL(patch_ln_bwd_kernel<true>, dim3(nb), dim3(256), 0, s, video, g, dxp, ldd, mean, rstd, tpb, (float*)workspace);
+  else
+    hipLaunchKernelGGL(patch_ln_bwd_kernel<false>, dim3(nb), dim3(256), 0, s, video, g, dxp, ldd, mean, rstd, tpb, (float*)workspace);
   NV_CHECK_LAUNCH("nv_patch_ln_bwd");
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * g.P + 31) / 32), dim3(256), 0, s, (const float*)workspace, nb, g.P, 2, dgamma,
                      dbeta, (float*)nullptr, accumulate);
