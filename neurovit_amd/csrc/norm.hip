@@ -331,10 +331,10 @@ static int ln_bwd_launch(const float* dy, long lddy, const float* x, long ldx, c
 // second half of nv_ln_bwd(..., reduce_stream = NV_LN_NO_REDUCE): the caller orders `stream` after the main kernel
 extern "C" int nv_ln_bwd_reduce(const void* workspace, int M, int d, float* dgamma, float* dbeta, float* dcolsum, int accumulate, void* stream) {
   NV_CHECK_ARG(workspace && M > 0 && d > 0 && (d % 4) == 0 && d <= 2048, "nv_ln_bwd_reduce: bad arguments");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, ln_bwd_blocks(M),
-                     d, 3, dgamma, dbeta, dcolsum, accumulate);
-  NV_CHECK_LAUNCH("nv_ln_bwd_reduce");
-  return NV_OK;
+  // through nv_reduce_multi: the same kernel, hence the same summation order, as when the caller folds these partials into a
+  // multi-job launch - a staged (data-parallel) backward must reproduce the single-call one bit for bit
+  const nv_reduce_job job = {(const float*)workspace, ln_bwd_blocks(M), d, 3, {dgamma, dbeta, dcolsum}, accumulate};
+  return nv_reduce_multi(&job, 1, stream);
 }
 
 extern "C" int nv_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
