@@ -86,6 +86,16 @@ int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gemm_problem* 
  * kernel's minimum tile count, (7, 0|1) switches the grouped weight-gradient launch between the two kernel families */
 int nv_gemm_set_tile(int bm, int bn);
 
+/* ---- Linear layers on a few rows (the cls rows of the last block under pool='cls'): weight-streaming kernels, rows addressed through
+ * leading dimensions (a [B, n, d] tensor's cls rows: ld = n * d).  bf16 operands, fp32 accumulation, cast points of nv_gemm_bf16.
+ * nv_skinny_nt: W [N, K] row-major.  epi 0: out f32 [R, N] = resid + (bias + A W^T)   epi 1: u = bias + A W^T (bf16, optional), out bf16 = gelu(u)
+ * nv_skinny_nn: W [K, N] row-major.  epi 0: out bf16 = (A W) * gelu'(u), dcol[n] (+)= column sums of the stored values (optional, R <= 4)
+ *                                    epi 1: out f32 = A W     epi 2: out bf16 = A W */
+int nv_skinny_nt(int epi, int R, int N, int K, const void* A, long lda, const void* W, long ldw, const float* bias, const float* resid,
+                 long ldr, void* out, long ldo, void* u_out, long ldu, void* stream);
+int nv_skinny_nn(int epi, int R, int N, int K, const void* A, long lda, const void* W, long ldw, const void* u, long ldu, void* out, long ldo,
+                 float* dcol, int accumulate, void* stream);
+
 /* ---- LayerNorm of the residual stream (vit_3d.py:18,37): x f32 [M,d] -> y bf16, saves mean / rstd */
 int nv_ln_fwd(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, void* y, long ldy,
               float* mean, float* rstd, void* stream);
@@ -274,6 +284,11 @@ int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const float* video
                              int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
                              unsigned long drop_seed, void* stream, void* aux_stream, int join_aux);
 int nv_vit_stage_param_range(const nv_vit_config* cfg, int stage, long* begin, long* end);
+/* pool='cls': the last block's out-projection / LayerNorm / FeedForward, forward and backward, on the B cls rows only (training: when its
+ * dropout is off and B <= 4).  Logits and every gradient are unchanged (the other rows never reach the head and receive exact zeros
+ * in the backward pass), but rows 1..n-1 of the last block's x1 / xn2 / u / h / x2 workspace buffers are not produced.
+ * 1 (default) = on; 0 = every row, as the reference computes it.  Set it before the forward it should apply to. */
+int nv_vit_set_cls_tail(int on);
 /* dst[b .. b + len) = bf16(src[b .. b + len)) for `count` element ranges (HOST arrays begins / lens; any count) */
 int nv_cast_ranges_bf16(const float* src, void* dst, const long* begins, const long* lens, int count, void* stream);
 

@@ -8,6 +8,9 @@
 #include <vector>
 
 #include "../../include/neurovit_hip.h"
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 namespace {
@@ -19,6 +22,20 @@ struct Dims {
   int gf, gh, gw;
   int pool_mean;
 };
+
+// pool = 'cls' (the NeuroEncoder path, NeuroEncoder.py:194): behind the last block's attention only the B cls rows reach the head, and in
+// the backward pass the residual gradient entering the last block is exactly zero in every other row.  With this on (default) the
+// last block's out-projection, LayerNorm and FeedForward - forward and backward - run on those B rows only, as strided views (row
+// stride n) through the weight-streaming kernels of skinny.hip: the same values for the logits and every gradient (the skipped rows
+// contribute exact zeros), but rows 1..n-1 of the last block's x1 / xn2 / u / h / x2 buffers are not produced.  Off: every row, as
+// the reference computes it.  Training forwards remember per workspace which form they took; the backward follows.
+static int g_cls_tail = 1;
+extern "C" int nv_vit_set_cls_tail(int on) { g_cls_tail = on ? 1 : 0; return 0; }
+static std::mutex g_tail_mu;
+static std::unordered_map<const void*, bool> g_tail_of_ws;
+static bool cls_tail_wanted(const Dims& D, int training, float drop_p) {
+  return g_cls_tail && !D.pool_mean && (!training || (drop_p == 0.f && D.B <= 4));
+}
 
 int make_dims(const nv_vit_config* c, int B, Dims& D) {
   NV_CHECK_ARG(c && B > 0, "nv_vit: null config or B <= 0");
@@ -253,6 +270,8 @@ extern "C" int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* v
 
   const float scale = 1.0f / sqrtf((float)D.dh);
   const float* xin = (float*)(ws + W.x0);
+  const bool tail = cls_tail_wanted(D, training, drop_p);
+  if (training) { std::lock_guard<std::mutex> lk(g_tail_mu); g_tail_of_ws[workspace] = tail; }
   for (int l = 0; l < D.L; ++l) {
     const LayerP& q = T.layer[l];
     const LayerW& w = W.layer[l];
@@ -264,6 +283,16 @@ extern "C" int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* v
     RUN(nv_ln_fwd(xin, d, M, d, p + q.n1g, p + q.n1b, eps, ws + w.xn1, d, st1, st1 + M, stream));
     RUN(nv_gemm_bf16(0, 0, M, 3 * D.inner, d, ws + w.xn1, d, p16 + q.wqkv, d, ws + w.qkv, 3 * D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
     RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), site_seed(drop_seed, 4 * l + 0), drop_p, stream));
+    if (tail && l == D.L - 1) {
+      // cls rows only (row b of the small problem = row b * n of the buffers); LN2 statistics land at st2[0 .. B) / st2[M .. M + B)
+      const long rs = D.n;
+      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, stream));
+      RUN(nv_ln_fwd(x1, d * rs, B, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d * rs, st2, st2 + M, stream));
+      RUN(nv_skinny_nt(1, B, D.m, d, ws + w.xn2, d * rs, p16 + q.w1, d, p + q.b1, nullptr, 0, ws + w.h, D.m * rs, training ? ws + w.u : nullptr, D.m * rs, stream));
+      RUN(nv_skinny_nt(0, B, d, D.m, ws + w.h, D.m * rs, p16 + q.w2, D.m, p + q.b2, x1, d * rs, x2, d * rs, nullptr, 0, stream));
+      xin = x2;
+      continue;
+    }
     RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 1), drop_p, stream));
     RUN(nv_ln_fwd(x1, d, M, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d, st2, st2 + M, stream));
     RUN(nv_gemm_bf16(0, 3, M, D.m, d, ws + w.xn2, d, p16 + q.w1, d, ws + w.h, D.m, p + q.b1, nullptr, 0, training ? ws + w.u : nullptr, D.m, 0, 1.f, site_seed(drop_seed, 4 * l + 2), drop_p, stream));
@@ -392,6 +421,9 @@ extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const f
   NV_CHECK_ARG(video && strides5 && params && params16 && workspace && dlogits && grads, "nv_vit_backward: null pointer");
   NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_backward: workspace too small (%ld < %ld) - forward must run with training=1", ws_bytes, W.total);
   NV_CHECK_ARG(nv_aligned16(grads) && nv_aligned16(grads16), "nv_vit_backward: grads / grads16 must be 16-byte aligned");
+  bool tail_fwd = false;                           // did the forward of this workspace take the cls-rows form for the last block?
+  { std::lock_guard<std::mutex> lk(g_tail_mu); auto it = g_tail_of_ws.find(workspace); tail_fwd = (it != g_tail_of_ws.end()) && it->second; }
+  NV_CHECK_ARG(!tail_fwd || drop_p == 0.f, "nv_vit_backward: dropout differs from the forward of this workspace");
   bf16* gr16 = (bf16*)grads16;                     // optional bf16 mirror of the Linear weight gradients (data-parallel messages)
   auto M16 = [&](long off) -> void* { return gr16 ? (void*)(gr16 + off) : nullptr; };
   char* ws = (char*)workspace;
@@ -456,13 +488,27 @@ extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const f
     void* g16b = G16B(l);
     void* du = DU(l);
     void* dqkv = DQKV(l);
+    // last block in the cls-rows form (see g_cls_tail): the residual gradient is zero outside the B cls rows until the attention
+    // backward mixes the rows, so dU, dxn2, the LN2 backward, dAO and three of the four weight gradients are products of B rows
+    const bool tail = tail_fwd && l == D.L - 1;
+    const int Mr = tail ? B : M;                 // rows that carry a gradient; row r of the small problem is row r * rs of the buffers
+    const long rs = tail ? (long)D.n : 1;
     // ---- FeedForward backward (vit_3d.py:16-26)
+    if (tail) {
+      RUN(nv_skinny_nn(0, B, D.m, d, g16, d * rs, p16 + q.w2, D.m, ws + w.u, D.m * rs, du, D.m * rs, gr + q.b1, acc, stream));       // dU = (g W2) * gelu'(u), db1 = column sums
+      RUN(nv_skinny_nn(1, B, d, D.m, du, D.m * rs, p16 + q.w1, d, nullptr, 0, dxn, d * rs, nullptr, 0, stream));                     // dxn2 = dU W1
+    } else {
     RUN(nv_gemm_bf16(1, du_tile_rows ? 6 : 5, M, D.m, d, g16, d, p16 + q.w2, D.m, du, D.m, nullptr, ws + w.u, D.m, du_tile_rows ? CS1(l) : nullptr, D.m, 0, 1.f,
                      site_seed(drop_seed, 4 * l + 2), drop_p, stream));   // dU = (g W2 * mask) * gelu'(u)  [+ per-tile column sums -> db1]
     RUN(nv_gemm_bf16(1, 1, M, d, D.m, du, D.m, p16 + q.w1, d, dxn, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));                        // dxn2 = dU W1
-    RUN(nv_ln_bwd(dxn, d, (float*)(ws + w.x1), d, st2, st2 + M, p + q.n2g, M, d, g, g, d, g16b, d, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, RED(l),
+    }
+    RUN(nv_ln_bwd(dxn, d * rs, (float*)(ws + w.x1), d * rs, st2, st2 + M, p + q.n2g, Mr, d, g, g, d * rs, g16b, d * rs, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, RED(l),
                   W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream, ln_reduce));                                   // g += dLN2 -> g16b
     // ---- Attention backward (vit_3d.py:48-60)
+    if (tail) {
+      if (hipMemsetAsync(ws + W.dao, 0, (size_t)M * D.inner * 2, S) != hipSuccess) { nv_set_error("nv_vit_backward: hipMemsetAsync failed"); return NV_ERR_HIP; }
+      RUN(nv_skinny_nn(2, B, D.inner, d, g16b, d * rs, p16 + q.wo, D.inner, nullptr, 0, ws + W.dao, D.inner * rs, nullptr, 0, stream));                 // dAO = g Wo, cls rows
+    } else
     RUN(nv_gemm_bf16(1, 0, M, D.inner, d, g16b, d, p16 + q.wo, D.inner, ws + W.dao, D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));  // dAO = g Wo
     RUN(nv_attn_bwd(ws + w.qkv, 3 * D.inner, ws + w.ao, ws + W.dao, D.inner, (float*)(ws + w.lse), B, D.n, D.heads, D.dh, scale,
                     (float*)(ws + W.delta), dqkv, 3 * D.inner, site_seed(drop_seed, 4 * l + 0), drop_p, stream));
@@ -473,9 +519,10 @@ extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const f
       // (= colsum(g)), and dLN1 affine + db2 of the layer above (whose partials were written after that layer's block ran)
       nv_reduce_job jobs[3];
       int nj = 0;
-      if (du_tile_rows) jobs[nj++] = {CS1(l), (M + du_tile_rows - 1) / du_tile_rows, D.m, 1, {gr + q.b1, nullptr, nullptr}, acc};
+      if (tail) {}                                                  // db1 came out of the dU kernel
+      else if (du_tile_rows) jobs[nj++] = {CS1(l), (M + du_tile_rows - 1) / du_tile_rows, D.m, 1, {gr + q.b1, nullptr, nullptr}, acc};
       else RUN(nv_colsum_bf16(du, D.m, M, D.m, gr + q.b1, acc, RED2(l), W.red2_bytes, sA));
-      jobs[nj++] = {(const float*)RED(l), ln_rows, d, 3, {gr + q.n2g, gr + q.n2b, gr + q.bo}, acc};
+      jobs[nj++] = {(const float*)RED(l), nv_ln_bwd_partial_rows(Mr), d, 3, {gr + q.n2g, gr + q.n2b, gr + q.bo}, acc};
       if (pending_ln1 >= 0) {
         const LayerP& qp = T.layer[pending_ln1];
         jobs[nj++] = {(const float*)RED3(pending_ln1), ln_rows, d, 3, {gr + qp.n1g, gr + qp.n1b, (pending_ln1 > 0) ? gr + T.layer[pending_ln1 - 1].b2 : nullptr}, acc};
@@ -487,9 +534,9 @@ extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const f
       // the four weight gradients of the layer in ONE grouped launch (864 tiles keep two workgroups resident on every CU;
       // launched one by one their 72-288 tiles leave the CUs half empty and latency bound)
       nv_gemm_problem pr[4];
-      pr[0] = {d, D.m, M, g16, d, ws + w.h, D.m, gr + q.w2, D.m, acc, M16(q.w2), D.m};                     // dW2 = g^T h
-      pr[1] = {D.m, d, M, du, D.m, ws + w.xn2, d, gr + q.w1, d, acc, M16(q.w1), d};                        // dW1 = dU^T xn2
-      pr[2] = {d, D.inner, M, g16b, d, ws + w.ao, D.inner, gr + q.wo, D.inner, acc, M16(q.wo), D.inner};   // dWo = g^T ao
+      pr[0] = {d, D.m, Mr, g16, d * rs, ws + w.h, D.m * rs, gr + q.w2, D.m, acc, M16(q.w2), D.m};                     // dW2 = g^T h
+      pr[1] = {D.m, d, Mr, du, D.m * rs, ws + w.xn2, d * rs, gr + q.w1, d, acc, M16(q.w1), d};                        // dW1 = dU^T xn2
+      pr[2] = {d, D.inner, Mr, g16b, d * rs, ws + w.ao, D.inner * rs, gr + q.wo, D.inner, acc, M16(q.wo), D.inner};   // dWo = g^T ao
       pr[3] = {3 * D.inner, d, M, dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, acc, M16(q.wqkv), d};  // dWqkv = dqkv^T xn1
       RUN(nv_gemm_bf16_grouped(2, 1, 4, pr, sA));
     }

@@ -20,6 +20,10 @@ from ._cabi import VitConfig, VitInput, check, lib
 _BYTES = {torch.float32: 4, torch.bfloat16: 2}
 
 
+if os.environ.get("NEUROVIT_CLS_TAIL") == "0":      # last block on every row, as the reference computes it (A/B, debugging)
+    lib.nv_vit_set_cls_tail(0)
+
+
 def make_config(*, image_size, image_patch_size, frames, frame_patch_size, num_classes, dim, depth, heads, mlp_dim,
                 channels=3, dim_head=64, ln_eps=1e-5, pool='cls', **_) -> VitConfig:
     if pool not in ('cls', 'mean'):
@@ -130,7 +134,11 @@ class VitRuntime:
         """One bf16 forward of `video` with every layer's activations kept; returns the per-layer activation scales
         [depth][3] = 448 / (headroom * amax) of the LN1 output, the LN2 output and the GELU output.  e4m3 is a floating
         format: headroom costs no relative precision, it only moves the subnormal floor."""
-        self.forward(video, params, params16, training=True)
+        lib.nv_vit_set_cls_tail(0)           # the fp8 forward quantises every row of every block: calibrate on every row
+        try:
+            self.forward(video, params, params16, training=True)
+        finally:
+            lib.nv_vit_set_cls_tail(0 if os.environ.get("NEUROVIT_CLS_TAIL") == "0" else 1)
         B = video.shape[0]
         n = (self.cfg.frames // self.cfg.frame_patch_size) * (self.cfg.image_size // self.cfg.image_patch_size) ** 2 + 1
         scales = []

@@ -61,6 +61,28 @@ def load_arena(engine, cfgdict, sd):
 
 
 def run_case(engine, tag, cfgdict, seeds, B=2, dropout=(0.0, 0.0, 0)):
+    """Every stage, the logits and every gradient against both oracles with the last block computed on ALL rows (as the reference
+    does), then once more in the product's default form - the last block's out-projection / FeedForward on the cls rows only
+    (nv_vit_set_cls_tail) - which must reproduce the logits and every gradient."""
+    from neurovit_amd._cabi import lib
+    lib.nv_vit_set_cls_tail(0)
+    try:
+        out = _run_case_full_rows(engine, tag, cfgdict, seeds, B, dropout)
+    finally:
+        lib.nv_vit_set_cls_tail(1)
+    logits, rt, gcpu, (cfg, params, params16, video, dlogits) = out
+    rt2 = engine.VitRuntime(cfg)
+    logits2 = rt2.forward(video, params, params16, training=True, dropout=dropout)
+    grads2 = torch.zeros_like(params)
+    rt2.backward(dlogits, params, params16, grads2, accumulate=False)
+    assert rel_l2(logits2, logits) < 1e-5, (tag, "cls-rows form: logits")
+    e = rel_l2(grads2.cpu(), gcpu)
+    report(f"{tag} cls-rows form of the last block vs all rows: logits {rel_l2(logits2, logits):.2e}, gradient arena {e:.2e}")
+    assert e < 2e-5, (tag, "cls-rows form: gradients", e)
+    return logits, rt, None
+
+
+def _run_case_full_rows(engine, tag, cfgdict, seeds, B, dropout):
     sd = W.make_tensors(W.vit_param_spec(**cfgdict), seeds[0])
     S = cfgdict["image_size"]
     fmri = W.make_volume((B, S, S, S), seeds[1])
@@ -111,8 +133,7 @@ def run_case(engine, tag, cfgdict, seeds, B=2, dropout=(0.0, 0.0, 0)):
     # accumulate=True doubles every gradient
     rt.backward(dlogits.cuda(), params, params16, grads, accumulate=True)
     assert rel_err(grads.cpu(), 2 * gcpu) < 1e-5
-    errs = None
-    return logits, rt, errs
+    return logits, rt, gcpu, (cfg, params, params16, video, dlogits.cuda())
 
 
 G4_GATE = {"micro": 3.0e-3, "tiny": 2.4e-3}     # 1.5 x measured (1.92e-3, 1.49e-3): see the module docstring

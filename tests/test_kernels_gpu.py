@@ -277,6 +277,54 @@ def test_weight_gradient_bf16_mirror_and_cast_ranges(ops):
     assert torch.equal(dst, want)
 
 
+@pytest.mark.parametrize("R,n", [(4, 513), (2, 65), (8, 10), (11, 7)])
+def test_skinny_linear_kernels_on_strided_rows(ops, R, n):
+    """nv_skinny_nt / nv_skinny_nn (the last block's Linear layers on its cls rows, skinny.hip): rows addressed as every n-th row of
+    [R * n, .] buffers, all five epilogues against fp64 and against the tiled kernels on the same rows; the rows in between stay
+    untouched; R > 8 walks row slices."""
+    d, m = 768, 3072
+    x = bf(rnd(R * n, d, seed=1))
+    W1, W2 = bf(rnd(m, d, seed=2, scale=d ** -0.5)), bf(rnd(d, m, seed=3, scale=m ** -0.5))
+    b1, b2 = rnd(m, seed=4), rnd(d, seed=5)
+    res = rnd(R * n, d, seed=6)
+    xd, rd = dev(x), dev(res)
+    # forward: h = gelu(x W1^T + b1) (bf16, with u), y = res + (h W2^T + b2) (f32)
+    u = torch.full((R * n, m), 3.0, dtype=torch.bfloat16, device="cuda")
+    h = torch.full((R * n, m), 3.0, dtype=torch.bfloat16, device="cuda")
+    ops.skinny_nt(1, xd[::n], dev(W1), dev(b1), h[::n], u_out=u[::n])
+    uref = x[::n].double() @ W1.double().T + b1.double()
+    assert_close_bf16(u[::n], uref, "sk.u")
+    assert_close_bf16(h[::n], F.gelu(uref), "sk.h")
+    keep = torch.ones(R * n, dtype=torch.bool); keep[::n] = False
+    assert bool((h.cpu()[keep] == 3.0).all()) and bool((u.cpu()[keep] == 3.0).all())
+    y = torch.zeros((R * n, d), device="cuda")
+    ops.skinny_nt(0, h[::n], dev(W2), dev(b2), y[::n], resid=rd[::n])
+    yref = res[::n].double() + (h[::n].cpu().double() @ W2.double().T + b2.double())
+    assert_close_f32(y[::n], yref, "sk.resid", 1e-5)
+    tiled = ops.gemm(ops.NT, ops.EPI_BIAS_RESID, h[::n].contiguous(), dev(W2), bias=dev(b2), aux_in=rd[::n].contiguous())
+    assert rel_l2(y[::n], tiled) < 1e-6
+    # backward: dU = (g W2) * gelu'(u) (bf16, + column sums), dxn = dU W1 (f32), dAO-like bf16 store
+    g = bf(rnd(R * n, d, seed=7))
+    gd = dev(g)
+    du = torch.full((R * n, m), 5.0, dtype=torch.bfloat16, device="cuda")
+    dcol = torch.ones(m, device="cuda") if R <= 4 else None
+    ops.skinny_nn(0, gd[::n], dev(W2), du[::n], u=u[::n], dcol=dcol, accumulate=True)
+    duref = (g[::n].double() @ W2.double()) * ref_cpu._gelu_grad(u[::n].cpu().double())
+    assert_close_bf16(du[::n], duref, "sk.du")
+    assert bool((du.cpu()[keep] == 5.0).all())
+    if dcol is not None:
+        assert_close_f32(dcol, 1.0 + du[::n].cpu().double().sum(0), "sk.dcol", 1e-5)
+    dxn = torch.zeros((R * n, d), device="cuda")
+    ops.skinny_nn(1, du[::n], dev(W1), dxn[::n])
+    assert_close_f32(dxn[::n], du[::n].cpu().double() @ W1.double(), "sk.dxn", 1e-5)
+    o16 = torch.zeros((R * n, m), dtype=torch.bfloat16, device="cuda")
+    ops.skinny_nn(2, gd[::n], dev(W2), o16[::n])
+    assert_close_bf16(o16[::n], g[::n].double() @ W2.double(), "sk.bf16")
+    again = torch.zeros_like(o16)
+    ops.skinny_nn(2, gd[::n], dev(W2), again[::n])
+    assert torch.equal(again, o16)
+
+
 def test_gemm_ping_pong_grouped_equals_single_launches(ops):
     """Grouped weight gradients on the ping-pong tiles: bit-identical to single launches of the same kernel."""
     from neurovit_amd._cabi import lib
