@@ -27,7 +27,7 @@ struct Dims {
 // the backward pass the residual gradient entering the last block is exactly zero in every other row.  With this on (default) the
 // last block's out-projection, LayerNorm and FeedForward - forward and backward - run on those B rows only, as strided views (row
 // stride n) through the weight-streaming kernels of skinny.hip: the same values for the logits and every gradient (the skipped rows
-// contribute exact zeros), but rows 1..n-1 of the last block's x1 / xn2 / u / h / x2 buffers are not produced.  Off: every row, as
+// contribute exact zeros; in the fp8 inference path the block's FeedForward then runs in bf16), but rows 1..n-1 of the last block's x1 / xn2 / u / h / x2 buffers are not produced.  Off: every row, as
 // the reference computes it.  Training forwards remember per workspace which form they took; the backward follows.
 static int g_cls_tail = 1;
 extern "C" int nv_vit_set_cls_tail(int on) { g_cls_tail = on ? 1 : 0; return 0; }
@@ -372,6 +372,7 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
                           est + D.T, 0, 0.f, stream));
   const float scale = 1.0f / sqrtf((float)D.dh);
   const float* xin = (float*)(ws + W.x0);
+  const bool tail8 = cls_tail_wanted(D, 0, 0.f);
   for (int l = 0; l < D.L; ++l) {
     const LayerP& q = T.layer[l];
     const LayerW& w = W.layer[l];
@@ -382,6 +383,18 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
     RUN(nv_ln_fwd_f8(xin, d, M, d, p + q.n1g, p + q.n1b, eps, s_xn1, ws + w.xn1, d, stream));
     RUN(nv_gemm_f8(0, M, 3 * D.inner, d, ws + w.xn1, d, p8 + q.wqkv, d, ws + w.qkv, 3 * D.inner, cs, nullptr, nullptr, 0, 1.f, stream));
     RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), 0, 0.f, stream));
+    if (tail8 && l == D.L - 1) {
+      // the last block's out-projection / LayerNorm / FeedForward on the B cls rows (see g_cls_tail): bf16 operands through the
+      // weight-streaming kernels - these few rows gain nothing from fp8 and lose nothing by staying in bf16
+      const long rs = D.n;
+      float* st = (float*)(ws + w.st2);
+      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, stream));
+      RUN(nv_ln_fwd(x1, d * rs, B, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d * rs, st, st + M, stream));
+      RUN(nv_skinny_nt(1, B, D.m, d, ws + w.xn2, d * rs, p16 + q.w1, d, p + q.b1, nullptr, 0, ws + w.h, D.m * rs, nullptr, 0, stream));
+      RUN(nv_skinny_nt(0, B, d, D.m, ws + w.h, D.m * rs, p16 + q.w2, D.m, p + q.b2, x1, d * rs, x2, d * rs, nullptr, 0, stream));
+      xin = x2;
+      continue;
+    }
     RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, 0, 0.f, stream));
     RUN(nv_ln_fwd_f8(x1, d, M, d, p + q.n2g, p + q.n2b, eps, s_xn2, ws + w.xn2, d, stream));
     RUN(nv_gemm_f8(7, M, D.m, d, ws + w.xn2, d, p8 + q.w1, d, ws + w.h, D.m, cs + 3L * D.inner, p + q.b1, nullptr, 0, s_h, stream));
