@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 torch = None
 
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_F32_TFLOPS = 157.3         # fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak = the fp32 vector rate, same guide ("Matrix cores")
 # nv_prof kinds -> the rocprofv3 kernel names of the same launches (profiles/r02_*kernel_stats.csv)
 KIND_NAMES = {0: "gemm_ws_kernel<64,128,...,false,false,*> (NT: out-proj, FC2, patch embed)", 1: "gemm_ws_kernel<64,128,...,false,true,*> (NN: dxn1, dxn2, dAO)",
               2: "gemm_ws_kernel<...,true,true,1> (TN: patch-embed weight gradient)", 3: "attn_fwd_res_kernel", 4: "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
@@ -59,6 +60,8 @@ def parse():
     ap.add_argument("--forward-only", action="store_true", help="time inference forwards (validate path, Trainer.py:101-118) instead of train steps")
     ap.add_argument("--fp8", action="store_true", help="with --forward-only: the fp8 (OCP e4m3) inference path (BASELINE.json configs[4]), "
                                                        "activation scales calibrated on the bench batch")
+    ap.add_argument("--precise", action="store_true", help="with --forward-only: the fp32 inference path (every operand fp32 on the fp32 MFMA: the "
+                    "reference's fp32 validate, Trainer.py:101-118; logits within 1e-5 of its CPU forward)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous rehearsal without a GPU: every rank joins the process group, "
                                                             "runs the barrier + max-over-ranks timing plumbing around an empty step and rank 0 "
                                                             "prints the JSON line with value null (tests/test_bench_launcher_cpu.py)")
@@ -181,9 +184,13 @@ def forward_only_bench(a, model, x, size, S, p, B, world, rank, device, dist):
     from neurovit_amd.engine import flops_forward, make_config
     model.eval()
     vit = model.volume_encoder.vit3d
+    if a.fp8 and a.precise:
+        raise SystemExit("--fp8 and --precise are different arithmetic modes: choose one")
     if a.fp8:
         with torch.no_grad():
             vit.enable_fp8(x.permute(0, 3, 1, 2).unsqueeze(1))
+    if a.precise:
+        vit.eval_precision = "fp32"
 
     def fwd():
         with torch.no_grad():
@@ -214,10 +221,12 @@ def forward_only_bench(a, model, x, size, S, p, B, world, rank, device, dist):
     out_line = {"metric": f"fMRI volumes/sec (forward only) ViT3D {S}^3 p{p} d{size['TRAINING_VIT_DIM']} L{size['TRAINING_VIT_DEPTH']}",
                 "value": round(value, 2), "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "fp8 (e4m3 qkv/FC1/FC2 operands, bf16 elsewhere, fp32 accumulate)" if a.fp8 else "bf16", "data": "synthetic",
+                "dtype": "fp8 (e4m3 qkv/FC1/FC2 operands, bf16 elsewhere, fp32 accumulate)" if a.fp8 else ("f32 (fp32 MFMA, every operand fp32)" if a.precise else "bf16"),
+                "data": "synthetic",
                 "config": {"workload": f"ViT3D-{a.preset} {S}^3 patch {p}, inference forward, batch {B}/GPU", "global_batch": B * world, "parallelism": f"dp{world}"},
                 "mfma_frac_bf16_peak": round(value / world * f_fwd / (PEAK_BF16_TFLOPS * 1e12), 4),
                 "mfma_frac_fp8_peak": round(value / world * f_fwd / (2 * PEAK_BF16_TFLOPS * 1e12), 4) if a.fp8 else None,
+                "mfma_frac_fp32_peak": round(value / world * f_fwd / (PEAK_F32_TFLOPS * 1e12), 4) if a.precise else None,
                 "logits_finite": bool(torch.isfinite(out).all())}
     if rank == 0:
         print(json.dumps(out_line), flush=True)
@@ -325,6 +334,8 @@ def main():
         also = {"fwd_bwd_no_optimizer_volumes_s": round(timed(fwd_bwd, a.steps), 1)}
         model.eval()
         also["forward_only_eval_volumes_s"] = round(timed(fwd_only, a.steps), 1)
+        with model.precision("fp32"):           # the reference's validate arithmetic (Trainer.py:101-118): fp32 MFMA path
+            also["forward_only_eval_fp32_volumes_s"] = round(timed(fwd_only, max(3, a.steps // 3)), 1)
         model.train()
         torch.manual_seed(7)
         dcfg = dict(config, TRAINING_DROPOUT=0.1)

@@ -68,6 +68,21 @@ int nv_ln_fwd_f8(const float* x, long ldx, int M, int d, const float* gamma, con
 int nv_gemm_f8(int epi, int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc,
                const float* colscale, const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* stream);
 
+/* ---- fp32 inference path ("precise" mode).  The reference validates in fp32 without autocast (src/Trainer.py:101-118) and the logits
+ * are to match its CPU forward to 1e-3; bf16 MFMA operands cannot (weights rounded to bf16 alone cost 1e-3 ... 6e-3), so these entry
+ * points keep every operand fp32 and contract on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, 1/16 of the bf16 MFMA rate).
+ * nv_gemm_f32 (NT only: every nn.Linear forward, vit_3d.py:19,22,41,44,94): C[M,N] = epi(A[M,K] . B[N,K]^T), all fp32, B = the
+ * [out, in] weight as the state_dict holds it.  epi 0 store, 2 + bias, 3 exact-erf GELU(+ bias), 4 resid + (+ bias).  N % 4 == 0.
+ * Any K / lda / ldb (float4 operand loads when they are multiples of 4 and 16-byte aligned, scalar loads otherwise).
+ * nv_attn_fwd_f32 (vit_3d.py:53-59): qkv f32 [B, n, 3*inner] -> out f32 [B, n, inner]; dim_head a multiple of 4 up to 128. */
+int nv_gemm_f32(int epi, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                const float* bias, const float* resid, long ldr, void* stream);
+int nv_gemm_f32_set_tile(int wm, int wn);     /* tuning aid: wave tile (16 wm) x (16 wn), wm, wn in {2, 4}; (0, 0) = heuristic */
+int nv_attn_fwd_f32(const float* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, float* out, long ld_out,
+                    void* stream);
+int nv_ln_fwd_f32(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, float* y, long ldy,
+                  float* mean, float* rstd, void* stream);      /* as nv_ln_fwd with an fp32 output; mean / rstd may both be NULL */
+
 /* Up to four independent problems of one layout / epilogue in ONE launch (provided for layout 2 / TN with epilogue 1: the
  * four weight-gradient GEMMs of a transformer layer, vit_3d.py:19,22,41,44 backward).  Same arithmetic per tile as
  * nv_gemm_bf16; the point is occupancy: 864 tiles together instead of 72-288 at a time. */
@@ -151,6 +166,13 @@ int nv_patch_ln_fwd(const float* video, const long* strides5, int B, int C, int 
 int nv_patch_ln_fwd_4d(const float* x, int Bo, int H, int W, int D, int T, int p1, int p2, int pf, const float* gamma,
                        const float* beta, float eps, void* out, long ldo, float* mean, float* rstd, const float* vol_sigma,
                        void* stream);
+/* fp32 tokens (fp32 inference path): out f32 [B*N, ldo], ldo >= patch_dim */
+int nv_patch_ln_fwd_f32(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
+                        const float* gamma, const float* beta, float eps, float* out, long ldo, float* mean, float* rstd,
+                        const float* vol_sigma, void* stream);
+int nv_patch_ln_fwd_4d_f32(const float* x, int Bo, int H, int W, int D, int T, int p1, int p2, int pf, const float* gamma,
+                           const float* beta, float eps, float* out, long ldo, float* mean, float* rstd, const float* vol_sigma,
+                           void* stream);
 long nv_patch_ln_bwd_workspace_bytes(int tokens, int P);
 int nv_patch_ln_bwd(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
                     const float* dxp, long ldd, const float* mean, const float* rstd, float* dgamma, float* dbeta,
@@ -228,6 +250,7 @@ typedef struct nv_vit_config {
 
 long nv_vit_param_count(const nv_vit_config* cfg);
 int nv_vit_param_table(const nv_vit_config* cfg, long* offsets, long* numels, int max_entries);
+/* training: 0 = bf16 / fp8 inference layout, 1 = training layout (every layer's activations kept), 2 = fp32 inference layout */
 long nv_vit_workspace_bytes(const nv_vit_config* cfg, int B, int training);
 /* byte offset of a named activation inside the workspace (-1 if unknown); layer < 0 for global buffers */
 long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int training, const char* name, int layer);
@@ -251,6 +274,11 @@ int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* video, const
 int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
                    const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
                    unsigned long drop_seed, float* logits, void* stream);
+/* fp32 inference forward: ViT.forward (vit_3d.py:112-126) as the reference's fp32 validate computes it (Trainer.py:101-118) - every
+ * operand fp32 (weights straight from `params`, no shadow arena), contractions on the fp32 MFMA, eval mode (no dropout).
+ * Workspace: nv_vit_workspace_bytes(cfg, B, 2).  Input forms as nv_vit_forward_in. */
+int nv_vit_forward_f32(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
+                       const nv_vit_input* in, const float* params, void* workspace, long ws_bytes, float* logits, void* stream);
 /* fp8 inference forward (BASELINE.json configs[4] "ViT3D-large ... fp8 MFMA"): qkv / FC1 / FC2 of every block on e4m3 operands.
  * act_scales: HOST array [depth][3] (LN1 output, LN2 output, GELU output; calibrated: 448 / (headroom * amax)); params8: byte arena
  * with the element offsets of the parameter arena; colscales: f32 [nv_vit_fp8_scale_count].  Workspace: training = 0 layout. */

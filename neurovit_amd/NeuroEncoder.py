@@ -71,6 +71,10 @@ class NeuroEncoder(nn.Module):
         pooled = self.temporal_transformer(per_volume).mean(dim=1)
         return self.projection_head(pooled)
 
+    def precision(self, mode: str):
+        """Context manager: eval-mode no-grad forwards of the ViT3D encoder inside it run in `mode` ("bf16" | "fp32")."""
+        return self.volume_encoder.vit3d.precision(mode)
+
     def forward_raw(self, raw, crop=None):
         """3D model fed RAW scanner volumes [B, X, Y, Z] float32 on the device: the dataset's crop (DatasetADNI.py:212) is a strided
         view and its z-score (:213) is folded into the patch LayerNorm - one statistics pass, no normalised copy."""
@@ -188,6 +192,9 @@ class ViT3DEncoder(nn.Module):
             emb_dropout=self.dropout,
             pool='cls'
         ).to(self.device)
+        # arithmetic of eval-mode no-grad forwards: "bf16" (default; the training arithmetic) or "fp32" (the reference's validate,
+        # Trainer.py:101-118).  The Trainer shell's validate / evaluate_samples use VALIDATION_PRECISION (default "fp32").
+        self.vit3d.eval_precision = config.get('TRAINING_VIT_EVAL_PRECISION', 'bf16')
 
     def forward_raw(self, raw, crop=None):
         from .preprocess import ADNI_CROP, crop_view, volume_sigma

@@ -12,6 +12,8 @@ OPTIONAL_MODEL_KEYS = {
     "TRAINING_VIT_HEADS": 8,        # NeuroEncoder.py:189
     "TRAINING_VIT_DIM_HEAD": 64,    # vit_3d.py:78 default
     "TRAINING_VIT_MLP_DIM": 2048,   # NeuroEncoder.py:190
+    "TRAINING_VIT_EVAL_PRECISION": "bf16",   # arithmetic of model.eval() no-grad forwards: "bf16" | "fp32"
+    "VALIDATION_PRECISION": "fp32",          # Trainer.validate / evaluate_samples (the reference validates in fp32: Trainer.py:101-118)
 }
 
 REQUIRED_MODEL_KEYS = ("TRAINING_DIM", "TRAINING_DROPOUT", "TRAINING_VIT_INPUT_SIZE", "TRAINING_VIT_PATCH_SIZE",

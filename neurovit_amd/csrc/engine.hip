@@ -138,6 +138,21 @@ void make_ws(const Dims& D, int training, WS& W) {
   W.total = cur;
 }
 
+// ---- workspace of the fp32 inference path (precise.hip; `training` = 2 in the workspace queries): every activation fp32, one set of
+// layer buffers shared by all layers (x ping-pongs x1 <-> x2 / x0 as in the bf16 inference layout)
+struct WSF { long xp, pst, t, est, x0, xh, hst, xm, xn1, qkv, ao, x1, xn2, h, x2, total; };
+void make_wsf(const Dims& D, WSF& W) {
+  long cur = 0;
+  auto add = [&](long bytes) { const long o = cur; cur = align_up(cur + bytes, 256); return o; };
+  const long M = D.M, T = D.T, d = D.d;
+  W.xp = add(T * D.P * 4); W.pst = add(T * 2 * 4); W.t = add(T * d * 4); W.est = add(T * 2 * 4); W.x0 = add(M * d * 4);
+  W.xh = add((long)D.B * d * 4); W.hst = add((long)D.B * 2 * 4);
+  W.xm = D.pool_mean ? add((long)D.B * d * 4) : -1;
+  W.xn1 = add(M * d * 4); W.qkv = add(M * 3 * D.inner * 4); W.ao = add(M * D.inner * 4); W.x1 = add(M * d * 4);
+  W.xn2 = add(M * d * 4); W.h = add(M * D.m * 4); W.x2 = add(M * d * 4);
+  W.total = cur;
+}
+
 // per-site dropout seeds: site = 4*layer + {0 attention probs, 1 to_out, 2 FF hidden, 3 FF out}; 4*depth = embedding
 inline unsigned long site_seed(unsigned long seed, int site) { return seed ^ (0x9E3779B97F4A7C15ul * (unsigned long)(site + 1)); }
 
@@ -187,12 +202,22 @@ extern "C" int nv_vit_param_table(const nv_vit_config* cfg, long* offsets, long*
 
 extern "C" long nv_vit_workspace_bytes(const nv_vit_config* cfg, int B, int training) {
   Dims D; if (make_dims(cfg, B, D)) return -1;
+  if (training == 2) { WSF F; make_wsf(D, F); return F.total; }
   WS W; make_ws(D, training, W);
   return W.total;
 }
 
 extern "C" long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int training, const char* name, int layer) {
   Dims D; if (make_dims(cfg, B, D)) return -1;
+  if (training == 2) {        // fp32 inference layout: one set of layer buffers (they hold the LAST layer's values after a forward)
+    WSF F; make_wsf(D, F);
+    if (layer >= D.L) return -1;
+    if (!strcmp(name, "xn1")) return F.xn1; if (!strcmp(name, "qkv")) return F.qkv; if (!strcmp(name, "ao")) return F.ao;
+    if (!strcmp(name, "x1")) return F.x1; if (!strcmp(name, "xn2")) return F.xn2; if (!strcmp(name, "h")) return F.h;
+    if (!strcmp(name, "x2")) return (layer >= 0 && (layer & 1)) ? F.x0 : F.x2;
+    if (!strcmp(name, "xp")) return F.xp; if (!strcmp(name, "t")) return F.t; if (!strcmp(name, "x0")) return F.x0; if (!strcmp(name, "xh")) return F.xh;
+    return -1;
+  }
   WS W; make_ws(D, training, W);
   if (layer >= 0) {
     if (layer >= D.L) return -1;
@@ -308,6 +333,81 @@ extern "C" int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* v
   }
   RUN(nv_head_fwd(pooled, pooled_stride, B, d, p + T.hg, p + T.hb, eps, p + T.hw, p + T.hbias, D.C, (float*)(ws + W.xh), (float*)(ws + W.hst),
                   logits, stream));
+  return NV_OK;
+}
+
+// ---- fp32 inference forward (precise.hip): what the reference's fp32 validate computes (Trainer.py:101-118), every operand fp32,
+// contractions on the fp32 MFMA.  Weights come from the fp32 parameter arena itself; no shadow arena, no dropout (eval mode).
+extern "C" int nv_vit_forward_f32(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
+                                  const float* params, void* workspace, long ws_bytes, float* logits, void* stream) {
+  Dims D; RUN(make_dims(cfg, B, D));
+  ParamTab T; make_params(D, T);
+  WSF W; make_wsf(D, W);
+  NV_CHECK_ARG(video && shape5 && strides5 && params && workspace && logits, "nv_vit_forward_f32: null pointer");
+  if (in && in->time_points > 0)
+    NV_CHECK_ARG(shape5[0] * shape5[4] == B && shape5[4] == in->time_points && shape5[1] == cfg->image_size && shape5[2] == cfg->image_size && shape5[3] == cfg->frames &&
+                     B % in->time_points == 0 && cfg->channels == 1,
+                 "nv_vit_forward_f32: 4D input is [%ld,%ld,%ld,%ld,%ld], expected [B/T, %d, %d, %d, T=%d] with B = %d", shape5[0], shape5[1], shape5[2], shape5[3],
+                 shape5[4], cfg->image_size, cfg->image_size, cfg->frames, in->time_points, B);
+  else
+    NV_CHECK_ARG(shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == cfg->image_size,
+                 "nv_vit_forward_f32: video is [%ld,%ld,%ld,%ld,%ld], the model was built for [%d,%d,%d,%d,%d] (B, channels, frames, height, width)",
+                 shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size);
+  NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_forward_f32: workspace too small (%ld < %ld)", ws_bytes, W.total);
+  NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params), "nv_vit_forward_f32: alignment");
+  char* ws = (char*)workspace;
+  const float* p = params;
+  const float eps = cfg->ln_eps;
+  const int M = D.M, d = D.d;
+  auto F32 = [&](long off) -> float* { return (float*)(ws + off); };
+
+  // A1 + A2: gather + LayerNorm(patch_dim) -> fp32 tokens [T, P]
+  float* pst = F32(W.pst);
+  const float* sigma = in ? in->vol_sigma : nullptr;
+  if (in && in->time_points > 0)
+    RUN(nv_patch_ln_fwd_4d_f32(video, B / in->time_points, cfg->image_size, cfg->image_size, cfg->frames, in->time_points, cfg->image_patch_size,
+                               cfg->image_patch_size, cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, F32(W.xp), D.P, pst, pst + D.T, sigma, stream));
+  else
+    RUN(nv_patch_ln_fwd_f32(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
+                            cfg->image_patch_size, cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, F32(W.xp), D.P, pst, pst + D.T, sigma, stream));
+  // A3: Linear(patch_dim, dim)
+  RUN(nv_gemm_f32(2, D.T, d, D.P, F32(W.xp), D.P, p + T.pe_w, D.P, F32(W.t), d, p + T.pe_bias, nullptr, 0, stream));
+  // A4 + A5: LayerNorm(dim) + cls + pos
+  float* est = F32(W.est);
+  RUN(nv_embed_finish_fwd(F32(W.t), d, B, D.N, d, p + T.pe_g2, p + T.pe_b2, eps, p + T.pos, p + T.cls, F32(W.x0), d, est, est + D.T, 0, 0.f, stream));
+  const float scale = 1.0f / sqrtf((float)D.dh);
+  const float* xin = F32(W.x0);
+  for (int l = 0; l < D.L; ++l) {
+    const LayerP& q = T.layer[l];
+    float* x1 = F32(W.x1);
+    float* x2 = F32((l & 1) ? W.x0 : W.x2);
+    RUN(nv_ln_fwd_f32(xin, d, M, d, p + q.n1g, p + q.n1b, eps, F32(W.xn1), d, nullptr, nullptr, stream));
+    RUN(nv_gemm_f32(0, M, 3 * D.inner, d, F32(W.xn1), d, p + q.wqkv, d, F32(W.qkv), 3 * D.inner, nullptr, nullptr, 0, stream));
+    RUN(nv_attn_fwd_f32(F32(W.qkv), 3 * D.inner, B, D.n, D.heads, D.dh, scale, F32(W.ao), D.inner, stream));
+    if (l == D.L - 1 && !D.pool_mean) {
+      // pool = 'cls' (NeuroEncoder.py:194): behind the last attention only the B cls rows reach the head - the last block's
+      // out-projection, LayerNorm and FeedForward run on those rows as strided views (row stride n); same values for the logits
+      const long rs = D.n;
+      RUN(nv_gemm_f32(4, B, d, D.inner, F32(W.ao), D.inner * rs, p + q.wo, D.inner, x1, d * rs, p + q.bo, xin, d * rs, stream));
+      RUN(nv_ln_fwd_f32(x1, d * rs, B, d, p + q.n2g, p + q.n2b, eps, F32(W.xn2), d * rs, nullptr, nullptr, stream));
+      RUN(nv_gemm_f32(3, B, D.m, d, F32(W.xn2), d * rs, p + q.w1, d, F32(W.h), D.m * rs, p + q.b1, nullptr, 0, stream));
+      RUN(nv_gemm_f32(4, B, d, D.m, F32(W.h), D.m * rs, p + q.w2, D.m, x2, d * rs, p + q.b2, x1, d * rs, stream));
+      xin = x2;
+      continue;
+    }
+    RUN(nv_gemm_f32(4, M, d, D.inner, F32(W.ao), D.inner, p + q.wo, D.inner, x1, d, p + q.bo, xin, d, stream));
+    RUN(nv_ln_fwd_f32(x1, d, M, d, p + q.n2g, p + q.n2b, eps, F32(W.xn2), d, nullptr, nullptr, stream));
+    RUN(nv_gemm_f32(3, M, D.m, d, F32(W.xn2), d, p + q.w1, d, F32(W.h), D.m, p + q.b1, nullptr, 0, stream));
+    RUN(nv_gemm_f32(4, M, d, D.m, F32(W.h), D.m, p + q.w2, D.m, x2, d, p + q.b2, x1, d, stream));
+    xin = x2;
+  }
+  const float* pooled = xin;
+  long pooled_stride = (long)D.n * d;
+  if (D.pool_mean) {
+    RUN(nv_token_mean(xin, B, D.n, d, F32(W.xm), stream));
+    pooled = F32(W.xm); pooled_stride = d;
+  }
+  RUN(nv_head_fwd(pooled, pooled_stride, B, d, p + T.hg, p + T.hb, eps, p + T.hw, p + T.hbias, D.C, F32(W.xh), F32(W.hst), logits, stream));
   return NV_OK;
 }
 

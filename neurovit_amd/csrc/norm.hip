@@ -13,6 +13,15 @@
 
 #define WAVES_PER_BLOCK 4
 
+#include <type_traits>
+// Output element type of the forward row kernels: bf16 (MFMA operand of the bf16 / fp8 paths) or float (the fp32 inference path,
+// precise.hip: the reference validates in fp32, Trainer.py:101-118).
+template <typename OT>
+__device__ __forceinline__ void store4(OT* p, const f32x4& o) {
+  if constexpr (std::is_same<OT, float>::value) *reinterpret_cast<f32x4*>(p) = o;
+  else *reinterpret_cast<bf16x4*>(p) = cvt4(o[0], o[1], o[2], o[3]);
+}
+
 // --------------------------------------------------------------------------------------- helpers
 // Row of d floats (d % 4 == 0, d <= 256*NV) spread over a wave: lane holds float4 #(lane + 64 v).
 template <int NV>
@@ -42,9 +51,9 @@ __device__ __forceinline__ void row_stats(const f32x4 (&x)[NV], int d, int lane,
 }
 
 // --------------------------------------------------------------------------------------- ln_fwd
-template <int NV>
+template <int NV, typename OT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx, int M, int d, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float eps, bf16* __restrict__ y, long ldy,
+                                                     const float* __restrict__ beta, float eps, OT* __restrict__ y, long ldy,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -58,10 +67,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (c < d) {
       const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
       const f32x4 o = (xv[v] - mean) * rstd * gm + bt;
-      *reinterpret_cast<bf16x4*>(y + (long)row * ldy + c) = cvt4(o[0], o[1], o[2], o[3]);
+      store4<OT>(y + (long)row * ldy + c, o);
     }
   }
-  if (lane == 0) {
+  if (lane == 0 && mean_out) {
     mean_out[row] = mean;
     rstd_out[row] = rstd;
   }
@@ -74,9 +83,23 @@ extern "C" int nv_ln_fwd(const float* x, long ldx, int M, int d, const float* ga
                "nv_ln_fwd: alignment");
   const dim3 grid((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (d <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, x, ldx, M, d, gamma, beta, eps, (bf16*)y, ldy, mean, rstd);
-  else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, s, x, ldx, M, d, gamma, beta, eps, (bf16*)y, ldy, mean, rstd);
+  if (d <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<4, bf16>), grid, block, 0, s, x, ldx, M, d, gamma, beta, eps, (bf16*)y, ldy, mean, rstd);
+  else hipLaunchKernelGGL((ln_fwd_kernel<8, bf16>), grid, block, 0, s, x, ldx, M, d, gamma, beta, eps, (bf16*)y, ldy, mean, rstd);
   NV_CHECK_LAUNCH("nv_ln_fwd");
+  return NV_OK;
+}
+
+// fp32 output (the fp32 inference path); mean / rstd optional (both or neither)
+extern "C" int nv_ln_fwd_f32(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, float* y,
+                             long ldy, float* mean, float* rstd, void* stream) {
+  NV_CHECK_ARG(M > 0 && d > 0 && (d % 4) == 0 && d <= 2048, "nv_ln_fwd_f32: d=%d must be a multiple of 4 and <= 2048", d);
+  NV_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0 && nv_aligned16(x) && nv_aligned16(y) && nv_aligned16(gamma) && nv_aligned16(beta) && (!mean == !rstd),
+               "nv_ln_fwd_f32: alignment");
+  const dim3 grid((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (d <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<4, float>), grid, block, 0, s, x, ldx, M, d, gamma, beta, eps, y, ldy, mean, rstd);
+  else hipLaunchKernelGGL((ln_fwd_kernel<8, float>), grid, block, 0, s, x, ldx, M, d, gamma, beta, eps, y, ldy, mean, rstd);
+  NV_CHECK_LAUNCH("nv_ln_fwd_f32");
   return NV_OK;
 }
 
@@ -364,9 +387,9 @@ __device__ __forceinline__ long patch_elem_offset(const PatchGeom& g, int b, int
 }
 
 // VEC: C == 1, sf == 1, pf % 4 == 0, 16-byte aligned runs, P <= 4096: float4 gathers, row cached in registers.
-template <bool VEC>
+template <bool VEC, typename OT>
 __global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const float* __restrict__ video, PatchGeom g, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps, bf16* __restrict__ out, long ldo,
+                                                           const float* __restrict__ beta, float eps, OT* __restrict__ out, long ldo,
                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                            const float* __restrict__ vol_sigma) {
   const int lane = threadIdx.x & 63;
@@ -377,7 +400,7 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const float* __restri
   // eps * sigma^2 in place of eps (mu drops out, sigma scales numerator and denominator): the dataset's per-volume z-score
   // (DatasetADNI.py:213) costs one multiply here instead of a pass over the volume
   if (vol_sigma) { const float sg = vol_sigma[b]; eps *= sg * sg; }
-  bf16* orow = out + (long)tok * ldo;
+  OT* orow = out + (long)tok * ldo;
   float mean, rstd;
   if constexpr (VEC) {
     constexpr int NV = 16;
@@ -394,7 +417,7 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const float* __restri
       if (k < g.P) {
         const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + k), bt = *reinterpret_cast<const f32x4*>(beta + k);
         const f32x4 o = (xv[v] - mean) * rstd * gm + bt;
-        *reinterpret_cast<bf16x4*>(orow + k) = cvt4(o[0], o[1], o[2], o[3]);
+        store4<OT>(orow + k, o);
       }
     }
   } else {
@@ -408,7 +431,7 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const float* __restri
     }
     rstd = 1.0f / sqrtf(wave_sum(q) / (float)g.P + eps);
     for (int k = lane; k < ldo; k += 64)
-      orow[k] = (k < g.P) ? (bf16)((video[patch_elem_offset(g, b, n, k)] - mean) * rstd * gamma[k] + beta[k]) : (bf16)0.f;
+      orow[k] = (k < g.P) ? (OT)((video[patch_elem_offset(g, b, n, k)] - mean) * rstd * gamma[k] + beta[k]) : (OT)0.f;
   }
   if (lane == 0) {
     mean_out[tok] = mean;
@@ -432,21 +455,35 @@ static int make_geom(PatchGeom& g, const long* strides, int B, int C, int F, int
 }
 
 // out: [B*N, ldo] bf16 with ldo >= P (columns P..ldo-1 are written as zero), mean/rstd: [B*N].
-extern "C" int nv_patch_ln_fwd(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
-                               const float* gamma, const float* beta, float eps, void* out, long ldo, float* mean, float* rstd,
+template <typename OT>
+static int patch_ln_fwd_launch(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
+                               const float* gamma, const float* beta, float eps, OT* out, long ldo, float* mean, float* rstd,
                                const float* vol_sigma, void* stream) {
   PatchGeom g;
   int rc = make_geom(g, strides5, B, C, F, H, W, p1, p2, pf);
   if (rc) return rc;
-  NV_CHECK_ARG(ldo >= g.P && (ldo % 8) == 0, "nv_patch_ln_fwd: ldo=%ld must be >= patch_dim=%d and a multiple of 8", ldo, g.P);
+  if constexpr (std::is_same<OT, float>::value) NV_CHECK_ARG(ldo >= g.P, "nv_patch_ln_fwd_f32: ldo=%ld must be >= patch_dim=%d", ldo, g.P);
+  else NV_CHECK_ARG(ldo >= g.P && (ldo % 8) == 0, "nv_patch_ln_fwd: ldo=%ld must be >= patch_dim=%d and a multiple of 8", ldo, g.P);
   const dim3 grid((g.B * g.N + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (patch_vec_ok(video, g, ldo) && nv_aligned16(gamma) && nv_aligned16(beta) && nv_aligned16(out))
-    hipLaunchKernelGGL(patch_ln_fwd_kernel<true>, grid, block, 0, s, video, g, gamma, beta, eps, (bf16*)out, ldo, mean, rstd, vol_sigma);
+    hipLaunchKernelGGL((patch_ln_fwd_kernel<true, OT>), grid, block, 0, s, video, g, gamma, beta, eps, out, ldo, mean, rstd, vol_sigma);
   else
-    hipLaunchKernelGGL(patch_ln_fwd_kernel<false>, grid, block, 0, s, video, g, gamma, beta, eps, (bf16*)out, ldo, mean, rstd, vol_sigma);
+    hipLaunchKernelGGL((patch_ln_fwd_kernel<false, OT>), grid, block, 0, s, video, g, gamma, beta, eps, out, ldo, mean, rstd, vol_sigma);
   NV_CHECK_LAUNCH("nv_patch_ln_fwd");
   return NV_OK;
+}
+
+extern "C" int nv_patch_ln_fwd(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
+                               const float* gamma, const float* beta, float eps, void* out, long ldo, float* mean, float* rstd,
+                               const float* vol_sigma, void* stream) {
+  return patch_ln_fwd_launch<bf16>(video, strides5, B, C, F, H, W, p1, p2, pf, gamma, beta, eps, (bf16*)out, ldo, mean, rstd, vol_sigma, stream);
+}
+// fp32 tokens [B*N, ldo] (ldo >= patch_dim; no padding columns are needed: the fp32 GEMM takes any K)
+extern "C" int nv_patch_ln_fwd_f32(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
+                                   const float* gamma, const float* beta, float eps, float* out, long ldo, float* mean, float* rstd,
+                                   const float* vol_sigma, void* stream) {
+  return patch_ln_fwd_launch<float>(video, strides5, B, C, F, H, W, p1, p2, pf, gamma, beta, eps, out, ldo, mean, rstd, vol_sigma, stream);
 }
 
 // ---- 4D samples: patch gather + LayerNorm(patch_dim) of ALL timepoints of one patch position, straight from [Bo, H, W, D, T]
@@ -459,15 +496,16 @@ extern "C" int nv_patch_ln_fwd(const float* video, const long* strides5, int B, 
 struct PatchTGeom {
   int Bo, H, W, D, T, p1, p2, pf, gf, gh, gw, N, P;
 };
+template <typename OT>
 __global__ __launch_bounds__(256) void patch_ln_fwd_t_kernel(const float* __restrict__ x, PatchTGeom g, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float eps, bf16* __restrict__ out, long ldo,
+                                                             const float* __restrict__ beta, float eps, OT* __restrict__ out, long ldo,
                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                              const float* __restrict__ vol_sigma, int nact) {
   extern __shared__ __attribute__((aligned(16))) char tsm[];
   const int TG = g.T >> 2;                               // float4 groups per voxel
   const int KR = nact / TG;                              // voxels (features) per round
   float* red = reinterpret_cast<float*>(tsm);            // [nact][8] partial sums, then [T] mean | [T] rstd
-  bf16* tile = reinterpret_cast<bf16*>(tsm + (size_t)nact * 8 * sizeof(float));   // [T][KR] transposed round
+  OT* tile = reinterpret_cast<OT*>(tsm + (size_t)nact * 8 * sizeof(float));   // [T][KR] transposed round
   const int tid = threadIdx.x;
   const int bo = blockIdx.x / g.N, n = blockIdx.x - bo * g.N;
   const int wt = n % g.gw, ht = (n / g.gw) % g.gh, ft = n / (g.gw * g.gh);
@@ -534,7 +572,7 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_t_kernel(const float* __rest
       const float gm = gamma[k], bt = beta[k];
       const f32x4 y = (v - mu) * rs * gm + bt;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) tile[(4 * tg + c) * KR + kk] = (bf16)y[c];
+      for (int c = 0; c < 4; ++c) tile[(4 * tg + c) * KR + kk] = (OT)y[c];
     }
     __syncthreads();
     for (int e = tid; e < g.T * pieces; e += 256) {
@@ -542,7 +580,8 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_t_kernel(const float* __rest
       const int kf = k0 + 4 * pc;
       if (kf < g.P) {                                    // P % 4 == 0 and KR % 4 == 0: whole pieces
         const long tok = ((long)bo * g.T + t) * g.N + n;
-        *reinterpret_cast<bf16x4*>(out + tok * ldo + kf) = *reinterpret_cast<const bf16x4*>(tile + t * KR + 4 * pc);
+        typedef typename std::conditional<std::is_same<OT, float>::value, f32x4, bf16x4>::type V4;
+        *reinterpret_cast<V4*>(out + tok * ldo + kf) = *reinterpret_cast<const V4*>(tile + t * KR + 4 * pc);
       }
     }
     __syncthreads();
@@ -550,8 +589,9 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_t_kernel(const float* __rest
 }
 
 // x: contiguous [Bo, H, W, D, T] float32; tokens of volume (bo, t) are rows (bo*T + t)*N + n of `out` (bf16 [Bo*T*N, ldo]).
-extern "C" int nv_patch_ln_fwd_4d(const float* x, int Bo, int H, int W, int D, int T, int p1, int p2, int pf, const float* gamma,
-                                  const float* beta, float eps, void* out, long ldo, float* mean, float* rstd, const float* vol_sigma,
+template <typename OT>
+static int patch_ln_fwd_4d_launch(const float* x, int Bo, int H, int W, int D, int T, int p1, int p2, int pf, const float* gamma,
+                                  const float* beta, float eps, OT* out, long ldo, float* mean, float* rstd, const float* vol_sigma,
                                   void* stream) {
   NV_CHECK_ARG(x && gamma && beta && out && mean && rstd, "nv_patch_ln_fwd_4d: null pointer");
   NV_CHECK_ARG(Bo > 0 && T > 0 && (T % 4) == 0 && T <= 64 && p1 > 0 && p2 > 0 && pf > 0 && H % p1 == 0 && W % p2 == 0 && D % pf == 0,
@@ -564,11 +604,22 @@ extern "C" int nv_patch_ln_fwd_4d(const float* x, int Bo, int H, int W, int D, i
   int nact = (256 / TG) * TG;                            // active threads: a multiple of the float4 groups per voxel ...
   nact -= (nact / TG % 4) * TG;                          // ... with a multiple of four voxels per round (whole 8-byte output pieces)
   NV_CHECK_ARG(nact >= TG * 4, "nv_patch_ln_fwd_4d: T too large for one workgroup");
-  const size_t lds = (size_t)nact * 8 * sizeof(float) + (size_t)T * (nact / TG) * sizeof(bf16);
-  hipLaunchKernelGGL(patch_ln_fwd_t_kernel, dim3((unsigned)(Bo * g.N)), dim3(256), lds, (hipStream_t)stream, x, g, gamma, beta, eps, (bf16*)out, ldo,
+  const size_t lds = (size_t)nact * 8 * sizeof(float) + (size_t)T * (nact / TG) * sizeof(OT);
+  hipLaunchKernelGGL(patch_ln_fwd_t_kernel<OT>, dim3((unsigned)(Bo * g.N)), dim3(256), lds, (hipStream_t)stream, x, g, gamma, beta, eps, out, ldo,
                      mean, rstd, vol_sigma, nact);
   NV_CHECK_LAUNCH("nv_patch_ln_fwd_4d");
   return NV_OK;
+}
+
+extern "C" int nv_patch_ln_fwd_4d(const float* x, int Bo, int H, int W, int D, int T, int p1, int p2, int pf, const float* gamma,
+                                  const float* beta, float eps, void* out, long ldo, float* mean, float* rstd, const float* vol_sigma,
+                                  void* stream) {
+  return patch_ln_fwd_4d_launch<bf16>(x, Bo, H, W, D, T, p1, p2, pf, gamma, beta, eps, (bf16*)out, ldo, mean, rstd, vol_sigma, stream);
+}
+extern "C" int nv_patch_ln_fwd_4d_f32(const float* x, int Bo, int H, int W, int D, int T, int p1, int p2, int pf, const float* gamma,
+                                      const float* beta, float eps, float* out, long ldo, float* mean, float* rstd, const float* vol_sigma,
+                                      void* stream) {
+  return patch_ln_fwd_4d_launch<float>(x, Bo, H, W, D, T, p1, p2, pf, gamma, beta, eps, out, ldo, mean, rstd, vol_sigma, stream);
 }
 
 // Backward of LayerNorm(patch_dim) w.r.t. its affine parameters only (the volume needs no gradient):

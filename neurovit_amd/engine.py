@@ -71,7 +71,8 @@ class VitRuntime:
         self._aux = {}      # device -> auxiliary stream for the weight-gradient GEMMs
         self.use_aux_stream = os.environ.get("NEUROVIT_AUX_STREAM", "1") != "0"
 
-    def workspace(self, B: int, training: bool, device) -> torch.Tensor:
+    def workspace(self, B: int, training, device) -> torch.Tensor:
+        """training: False / True, or 2 for the fp32 inference layout."""
         key = (B, int(training), str(device))
         ws = self._ws.get(key)
         if ws is None:
@@ -129,6 +130,21 @@ class VitRuntime:
         self._dropout = dropout
         return logits
 
+    # ------------------------------------------------------------------ fp32 inference (the reference's fp32 validate, Trainer.py:101-118)
+    def forward_f32(self, video: torch.Tensor, params: torch.Tensor, vol_sigma=None, time_points: int = 0) -> torch.Tensor:
+        """Inference forward with every operand in fp32 (weights straight from the fp32 arena, contractions on the fp32 MFMA):
+        logits within 1e-5 of the reference's CPU fp32 forward instead of the bf16 path's 1e-3 ... 7e-3.  Eval mode only."""
+        B, inp = self._input_form(video, vol_sigma, time_points)
+        ws = self.workspace(B, 2, video.device)
+        logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
+        check(lib.nv_vit_forward_f32(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
+                                     None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p), params.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), logits.data_ptr(), torch.cuda.current_stream().cuda_stream), "nv_vit_forward_f32")
+        self._last = (B, 2, ws, video)          # 2 = fp32 inference layout (truthy as `training` only for the layout queries)
+        self.generation += 1
+        self.backward_done = False
+        return logits
+
     # ------------------------------------------------------------------ fp8 inference (BASELINE.json configs[4])
     def calibrate_fp8(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, headroom: float = 2.0):
         """One bf16 forward of `video` with every layer's activations kept; returns the per-layer activation scales
@@ -183,7 +199,7 @@ class VitRuntime:
         """Whole backward, or only stages [first, last] (0 = head, 1+k = layer depth-1-k, depth+1 = embedding).
         join_aux=False (only for ranges before the last stage): the current stream is not made to wait for the auxiliary
         stream - order the consumer of the range's gradients after `aux_stream_object()` as well."""
-        assert self._last is not None and self._last[1], "backward needs a preceding forward(training=True)"
+        assert self._last is not None and self._last[1] == 1, "backward needs a preceding forward(training=True)"
         B, _, ws, video = self._last
         if getattr(self, "_keep", (None, None))[1] is not None and self._keep[1].time_points:
             raise NotImplementedError("neurovit_amd: the fused 4D input form is forward-only (the 4D model's encoder is frozen, NeuroEncoder.py:34-36)")

@@ -96,6 +96,56 @@ def gemm(layout: int, epi: int, A: torch.Tensor, B: torch.Tensor, *, out: Option
     return out
 
 
+EPI_F32_STORE, EPI_F32_BIAS, EPI_F32_BIAS_GELU, EPI_F32_BIAS_RESID = 0, 2, 3, 4
+
+
+def gemm_f32(epi: int, A: torch.Tensor, W: torch.Tensor, *, bias=None, resid=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 inference path: out[M, N] = epi(A[M, K] @ W[N, K].T), every operand fp32, contraction on the fp32 MFMA.
+    A / resid / out may be row-strided 2-D views (last stride 1)."""
+    _need_cuda(A, W)
+    assert A.dtype == torch.float32 and W.dtype == torch.float32 and A.stride(1) == 1 and W.stride(1) == 1
+    M, K = A.shape
+    N = W.shape[0]
+    assert W.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
+    check(lib.nv_gemm_f32(epi, M, N, K, _p(A), A.stride(0), _p(W), W.stride(0), _p(out), out.stride(0), _p(bias), _p(resid),
+                          0 if resid is None else resid.stride(0), _stream()), "nv_gemm_f32")
+    return out
+
+
+def attn_fwd_f32(qkv: torch.Tensor, B: int, n: int, heads: int, dim_head: int = 64) -> torch.Tensor:
+    """qkv f32 [B*n, 3*inner] -> out f32 [B*n, inner] (softmax(q k^T / sqrt(dh)) v per head, fp32 MFMA)."""
+    _need_cuda(qkv)
+    assert qkv.dtype == torch.float32 and qkv.stride(1) == 1
+    inner = heads * dim_head
+    out = torch.empty((B * n, inner), dtype=torch.float32, device=qkv.device)
+    check(lib.nv_attn_fwd_f32(_p(qkv), qkv.stride(0), B, n, heads, dim_head, dim_head ** -0.5, _p(out), inner, _stream()), "nv_attn_fwd_f32")
+    return out
+
+
+def ln_fwd_f32(x: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
+    _need_cuda(x)
+    M, d = x.shape
+    y = torch.empty((M, d), dtype=torch.float32, device=x.device)
+    check(lib.nv_ln_fwd_f32(_p(x), x.stride(0), M, d, _p(gamma), _p(beta), eps, _p(y), d, None, None, _stream()), "nv_ln_fwd_f32")
+    return y
+
+
+def patch_ln_fwd_f32(video: torch.Tensor, p1: int, p2: int, pf: int, gamma, beta, eps: float = 1e-5, vol_sigma=None):
+    """As patch_ln_fwd with fp32 tokens [B*N, P] (fp32 inference path)."""
+    _need_cuda(video)
+    B, C, F, H, W = video.shape
+    P = C * p1 * p2 * pf
+    N = (F // pf) * (H // p1) * (W // p2)
+    out = torch.empty((B * N, P), dtype=torch.float32, device=video.device)
+    st = torch.empty((2, B * N), dtype=torch.float32, device=video.device)
+    check(lib.nv_patch_ln_fwd_f32(_p(video), strides5(video), B, C, F, H, W, p1, p2, pf, _p(gamma), _p(beta), eps, _p(out), P, _p(st[0]),
+                                  _p(st[1]), _p(vol_sigma), _stream()), "nv_patch_ln_fwd_f32")
+    return out, st
+
+
 class GemmProblem(ctypes.Structure):          # include/neurovit_hip.h::nv_gemm_problem
     _fields_ = [("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("A", ctypes.c_void_p), ("lda", ctypes.c_long),
                 ("B", ctypes.c_void_p), ("ldb", ctypes.c_long), ("C", ctypes.c_void_p), ("ldc", ctypes.c_long), ("accumulate", ctypes.c_int),

@@ -180,6 +180,8 @@ class Trainer:
       * the host -> device copy of the next batch runs on a side stream under the current step (`DevicePrefetcher`);
       * batches may be the 7-tuples of DatasetADNI or the 6-tuples of DatasetADNI_4D (README.md:100-102 asks users
         to hand-edit the unpacking): the volume is element 2 and the label the last element in both;
+      * `validate` / `evaluate_samples` run the encoder in config['VALIDATION_PRECISION'] (default "fp32": the reference validates
+        in fp32 without autocast, Trainer.py:101-118; "bf16" = the training arithmetic, about 3x faster);
       * `log_interval = len(dl)//10` is clamped to >= 1 (the reference divides by zero for < 10 batches,
         Trainer.py:34,89); TRAINING_ACCUMULATION_STEP is honoured as in the commented block (Trainer.py:82-86).
     """
@@ -214,6 +216,7 @@ class Trainer:
         trainable_params = sum(p.numel() for p in self.model.parameters() if p.requires_grad)
         print(f'Model total parameters: {total_params/1e6:.2f}M (trainable {trainable_params/1e6:.2f}M and frozen {(total_params-trainable_params)/1e6:.2f}M)')
         self._os = _os
+        self.validation_precision = config.get('VALIDATION_PRECISION', 'fp32')
 
     @staticmethod
     def _unpack(batch):
@@ -261,7 +264,7 @@ class Trainer:
     def validate(self, epoch):
         self.model.eval()
         val_loss, correct, total, i = 0.0, 0, 0, 0
-        with torch.no_grad():
+        with torch.no_grad(), self.model.precision(self.validation_precision):
             for i, batch in enumerate(self.val_dataloader):
                 fMRI, label = self._unpack(batch)
                 fMRI, label = fMRI.to(self.device), label.to(self.device)
@@ -280,7 +283,7 @@ class Trainer:
         self.model.eval()
         loader = torch.utils.data.DataLoader(self.val_data, batch_size=1, shuffle=False, num_workers=self.num_workers)
         accuracy, wrong = 0, []
-        with torch.no_grad():
+        with torch.no_grad(), self.model.precision(self.validation_precision):
             for batch in loader:
                 fMRI, label = self._unpack(batch)
                 prediction = self.model(fMRI.to(self.device)).argmax(dim=1).item()

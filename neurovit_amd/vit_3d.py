@@ -287,6 +287,11 @@ class ViT(nn.Module):
         self._last_logits = None   # most recent forward's logits (the Trainer shell reads them without a second forward)
         self._grad_sync = None     # parallel.GradSync: all-reduce gradient buckets while backward still runs
         self._fp8 = None           # enable_fp8(): e4m3 weights + scales for inference forwards
+        # Arithmetic of eval-mode forwards that record no graph: "bf16" (bf16 MFMA operands, the training arithmetic) or "fp32"
+        # (every operand fp32 on the fp32 MFMA: what the reference's validate computes, Trainer.py:101-118 - logits within 1e-5
+        # of its CPU forward, about 3x the time).  Set directly, through `precision(...)`, or by the config key
+        # TRAINING_VIT_EVAL_PRECISION of ViT3DEncoder.
+        self.eval_precision = "bf16"
 
     # ------------------------------------------------------------------ arena management
     def _build_arena(self):
@@ -364,6 +369,21 @@ class ViT(nn.Module):
     def disable_fp8(self):
         self._fp8 = None
 
+    def precision(self, mode: str):
+        """Context manager: eval-mode no-grad forwards inside it run in `mode` ("bf16" | "fp32")."""
+        import contextlib
+        if mode not in ("bf16", "fp32"):
+            raise ValueError(f"neurovit_amd.ViT: precision must be 'bf16' or 'fp32', got {mode!r}")
+
+        @contextlib.contextmanager
+        def scope():
+            before, self.eval_precision = self.eval_precision, mode
+            try:
+                yield self
+            finally:
+                self.eval_precision = before
+        return scope()
+
     # ------------------------------------------------------------------ execution
     def _run_forward(self, video, need_grad, extra=(None, 0)):
         vol_sigma, time_points = extra
@@ -373,6 +393,11 @@ class ViT(nn.Module):
             # torch's CPU generator (so torch.manual_seed reproduces runs); backward recomputes the same masks.
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             drop = (self._dropout_p[0], self._dropout_p[1], seed)
+        if self.eval_precision not in ("bf16", "fp32"):
+            raise ValueError(f"neurovit_amd.ViT: eval_precision must be 'bf16' or 'fp32', got {self.eval_precision!r}")
+        if self.eval_precision == "fp32" and not need_grad and not self.training:
+            self._last_logits = self._rt.forward_f32(video, self._arena, vol_sigma=vol_sigma, time_points=time_points)
+            return self._last_logits
         self._refresh_shadow()
         if self._fp8 is not None and not need_grad and not self.training:
             if self._fp8["key"] != tuple(p._version for p in self._plist):      # parameters changed since quantisation
@@ -468,10 +493,10 @@ class ViT(nn.Module):
 
     # activations / gradients of the last block's attention LayerNorm output (Grad-CAM contract, NeuroEncoder.py:70-82)
     def last_attn_norm_output_raw(self) -> torch.Tensor:
-        """bf16 [B, n, d] view into the workspace of the most recent forward (no copy)."""
+        """[B, n, d] view into the workspace of the most recent forward (no copy): bf16, or fp32 after an fp32 inference forward."""
         B = self._rt._last[0]
         n, d = self.pos_embedding.shape[1], self.pos_embedding.shape[2]
-        return self._rt.tap("xn1", self._cfg.depth - 1, (B, n, d), torch.bfloat16)
+        return self._rt.tap("xn1", self._cfg.depth - 1, (B, n, d), torch.float32 if self._rt._last[1] == 2 else torch.bfloat16)
 
     def last_attn_norm_grad_raw(self) -> torch.Tensor:
         """fp32 [B, n, d] view into the workspace; valid once a backward of the most recent training forward has run."""

@@ -1,0 +1,337 @@
+"""The fp32 inference path ("precise" mode) on MI355X against the fp32 oracle and the reference's fp32 fixtures.
+
+BASELINE.json asks for logits within 1e-3 of the reference's CPU forward, and the reference validates in fp32 without autocast
+(src/Trainer.py:101-118).  The bf16 MFMA path sits at 1.5e-3 ... 7e-3 (profiles/r02_parity_report.txt); this path keeps every
+operand fp32 and contracts on v_mfma_f32_16x16x4_f32, so the gates here are the stated tolerance or tighter:
+
+  kernels (GEMM, attention, LayerNorm, patch gather)   <= 1e-5 max-norm relative against float64 references;
+  whole encoder, every stage + logits                  <= 1e-4 relative L2 against the fp32 oracle (measured ~1e-6);
+  G4: logits vs the fixtures produced by the imported reference (tiny 64^3, micro, the d1024 L6 NeuroEncoder fixture)
+      and vs the fp32 oracle on ViT3D-base 128^3 (two seeds, incl. seed 31 where bf16 is 7e-3 off)   <= 1e-3 (measured ~1e-5).
+"""
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+from conftest import rel_err, rel_l2, report
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+KERNEL_TOL = 1e-5
+STAGE_TOL = 1e-4
+NORTH_STAR = 1e-3
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from neurovit_amd import engine
+    from neurovit_amd._cabi import require_gpu
+    require_gpu()
+    return engine
+
+
+def _arena(engine, cfgdict, sd):
+    cfg = engine.make_config(**cfgdict)
+    off, num, total = engine.param_layout(cfg)
+    arena = torch.zeros(total)
+    for (k, v), o, n in zip(sd.items(), off, num):
+        arena[o:o + n] = v.reshape(-1)
+    return cfg, arena.cuda()
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("M,N,K", [(2052, 768, 768), (130, 384, 120), (64, 128, 729), (4, 3072, 768), (513, 2304, 768), (33, 36, 20), (300, 64, 3072)])
+def test_gemm_f32_epilogues_all_tiles(eng, M, N, K):
+    """Every epilogue x every wave tile: ragged M / N (edge tiles, N only a multiple of 4), K with a tail (120 = 7.5 steps of 16)
+    and K = 729 (unaligned rows -> scalar operand loads: the reference's default patch_dim, configs/config.yaml:39-40)."""
+    from neurovit_amd import ops
+    from neurovit_amd._cabi import lib
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    Wt = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref = A.double() @ Wt.double().T
+    want = {ops.EPI_F32_STORE: ref, ops.EPI_F32_BIAS: ref + bias.double(),
+            ops.EPI_F32_BIAS_GELU: torch.nn.functional.gelu(ref + bias.double()),
+            ops.EPI_F32_BIAS_RESID: ref + bias.double() + resid.double()}
+    Ad, Wd, bd, rd = A.cuda(), Wt.cuda(), bias.cuda(), resid.cuda()
+    try:
+        for tile in ((0, 0), (2, 2), (2, 4), (4, 2), (4, 4)):
+            lib.nv_gemm_f32_set_tile(*tile)
+            for epi, w in want.items():
+                out = ops.gemm_f32(epi, Ad, Wd, bias=bd if epi >= 2 else None, resid=rd if epi == 4 else None)
+                e = rel_err(out, w)
+                assert e < KERNEL_TOL, (tile, epi, e)
+    finally:
+        lib.nv_gemm_f32_set_tile(0, 0)
+
+
+def test_gemm_f32_strided_rows(eng):
+    """The cls rows of a [B, n, d] tensor as a row-strided operand / residual / output (last block of the fp32 forward)."""
+    from neurovit_amd import ops
+    B, n, d, m = 4, 65, 192, 384
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B * n, d, generator=g).cuda()
+    Wt = (torch.randn(m, d, generator=g) / d ** 0.5).cuda()
+    bias = torch.randn(m, generator=g).cuda()
+    out = torch.full((B * n, m), 7.0, device="cuda")
+    ops.gemm_f32(ops.EPI_F32_BIAS_GELU, x[::n], Wt, bias=bias, out=out[::n])
+    ref = torch.nn.functional.gelu(x[::n].double().cpu() @ Wt.double().cpu().T + bias.double().cpu())
+    assert rel_err(out[::n], ref) < KERNEL_TOL
+    untouched = torch.ones(B * n, dtype=torch.bool)
+    untouched[::n] = False
+    assert bool((out[untouched.cuda()] == 7.0).all())          # rows between the cls rows are not written
+
+
+@pytest.mark.parametrize("B,n,heads,dh", [(2, 65, 3, 64), (1, 513, 2, 64), (2, 28, 4, 32), (1, 130, 2, 128), (3, 65, 5, 40), (2, 9, 1, 8), (1, 1001, 2, 64)])
+def test_attn_f32_vs_float64_softmax(eng, B, n, heads, dh):
+    """vit_3d.py:53-59 in fp32: ragged last key tile (n = N + 1 is never a multiple of 64), one-tile and many-tile sequences,
+    head dims that are not multiples of 16 (zero-filled fragment columns)."""
+    from neurovit_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + n + dh)
+    inner = heads * dh
+    qkv = torch.randn(B * n, 3 * inner, generator=g)
+    out = ops.attn_fwd_f32(qkv.cuda(), B, n, heads, dh)
+    q, k, v = (t.reshape(B, n, heads, dh).permute(0, 2, 1, 3).double() for t in qkv.chunk(3, dim=-1))
+    ref = torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1) @ v
+    ref = ref.permute(0, 2, 1, 3).reshape(B * n, inner)
+    e = rel_err(out, ref)
+    report(f"attn_f32 B{B} n{n} h{heads} dh{dh}: rel {e:.2e}")
+    assert e < KERNEL_TOL
+
+
+def test_row_kernels_f32_outputs(eng):
+    """LayerNorm(dim) and gather + LayerNorm(patch_dim) with fp32 outputs: same arithmetic as the bf16-output kernels (whose
+    results are these values rounded), checked against torch's layer_norm in float64; the index map stays bit exact."""
+    from neurovit_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(70, 192, generator=g)
+    gm, bt = 1 + 0.1 * torch.randn(192, generator=g), 0.1 * torch.randn(192, generator=g)
+    y = ops.ln_fwd_f32(x.cuda(), gm.cuda(), bt.cuda())
+    assert rel_err(y, torch.nn.functional.layer_norm(x.double(), (192,), gm.double(), bt.double(), 1e-5)) < KERNEL_TOL
+    for S, p in ((32, 8), (27, 9)):                             # vector gather path / scalar path (patch_dim 729)
+        P = p ** 3
+        vol = W.make_volume((2, S, S, S), 8)
+        video = ref_cpu.fmri_to_video(vol)
+        gm, bt = 1 + 0.1 * torch.randn(P, generator=g), 0.1 * torch.randn(P, generator=g)
+        tok, _ = ops.patch_ln_fwd_f32(ref_cpu.fmri_to_video(vol.cuda()), p, p, p, gm.cuda(), bt.cuda())
+        ref = torch.nn.functional.layer_norm(ref_cpu.patchify(video, p, p, p).double(), (P,), gm.double(), bt.double(), 1e-5)
+        assert rel_err(tok, ref.reshape(-1, P)) < KERNEL_TOL
+        ones, zeros = torch.ones(P).cuda(), torch.zeros(P).cuda()
+        # bit-exact index map: an integer-valued volume through LN with gamma = 1, beta = 0 keeps the ORDER of every token's values
+        ar = torch.arange(2 * S ** 3, dtype=torch.float32).reshape(2, S, S, S)
+        t2, _ = ops.patch_ln_fwd_f32(ref_cpu.fmri_to_video(ar.cuda()), p, p, p, ones, zeros)
+        want = ref_cpu.patchify(ref_cpu.fmri_to_video(ar), p, p, p).reshape(-1, P)
+        assert torch.equal(t2.cpu().argsort(dim=1), want.argsort(dim=1))
+
+
+# ------------------------------------------------------------------------------------------------ whole encoder
+def _stages_case(engine, tag, cfgdict, seeds, B):
+    sd = W.make_tensors(W.vit_param_spec(**cfgdict), seeds[0])
+    S = cfgdict["image_size"]
+    fmri = W.make_volume((B, S, S, S), seeds[1])
+    cfg, params = _arena(engine, cfgdict, sd)
+    rt = engine.VitRuntime(cfg)
+    logits = rt.forward_f32(ref_cpu.fmri_to_video(fmri.cuda()), params)
+    ocfg = ref_cpu.ViTCfg(**cfgdict)
+    taps = {}
+    with torch.no_grad():
+        ref = ref_cpu.vit_forward(sd, ocfg, ref_cpu.fmri_to_video(fmri), taps=taps)
+    n, d = ocfg.num_patches + 1, ocfg.dim
+    # stage taps the one-layer-set inference layout still holds after the forward: the last block's attention-LN output and input
+    last = ocfg.depth - 1
+    e_xn = rel_l2(rt.tap("xn1", last, (B, n, d), torch.float32), taps[f"transformer.layers.{last}.0.norm.out"])
+    assert e_xn < STAGE_TOL, (tag, "last attention-LN output", e_xn)
+    if ocfg.depth == 1:
+        assert rel_l2(rt.tap("x0", -1, (B, n, d), torch.float32), taps["A5"]) < STAGE_TOL
+    e = rel_err(logits, ref)
+    report(f"fp32 path {tag}: logits vs fp32 oracle rel {e:.2e}")
+    assert e < STAGE_TOL, (tag, e)
+    again = rt.forward_f32(ref_cpu.fmri_to_video(fmri.cuda()), params)
+    assert torch.equal(logits, again)                            # run-to-run deterministic
+    return logits, ref
+
+
+def test_precise_forward_small_geometries(eng, golden):
+    lg, _ = _stages_case(eng, "micro", dict(W.MICRO), (1, 2), 2)
+    e = rel_err(lg, golden("micro_vit.npz")["logits"])
+    report(f"fp32 path micro G4 vs reference golden: rel {e:.2e}")
+    assert e < NORTH_STAR
+    _stages_case(eng, "p9 (patch_dim 729)", dict(W.MICRO, image_size=27, image_patch_size=9, frames=27, frame_patch_size=9), (5, 6), 3)
+    _stages_case(eng, "pool=mean", dict(W.MICRO, pool="mean"), (11, 12), 2)
+    _stages_case(eng, "dh32", dict(W.MICRO, dim_head=32, heads=4), (21, 22), 2)
+    _stages_case(eng, "dh40 inner!=dim", dict(W.MICRO, dim_head=40, heads=3), (23, 24), 1)
+    _stages_case(eng, "depth1", dict(W.MICRO, depth=1), (25, 26), 2)
+
+
+def test_precise_forward_tiny_vs_reference_fixture(eng, golden):
+    """BASELINE.json configs[0] (ViT3D tiny 64^3, batch 2): logits of the fp32 path against the fixture the IMPORTED reference
+    produced (tests/golden/tiny_vit.npz) - the north-star comparison, at its stated 1e-3."""
+    lg, _ = _stages_case(eng, "tiny", dict(W.TINY), (3, 4), 2)
+    e = rel_err(lg, golden("tiny_vit.npz")["logits"])
+    report(f"fp32 path tiny G4 vs reference golden: rel {e:.2e}")
+    assert e < NORTH_STAR
+    assert e < 1e-4            # in fact two orders tighter: fp32 arithmetic, differing from the CPU's only in summation order
+
+
+@pytest.mark.parametrize("seeds", [(31, 32), (5, 6)])
+def test_precise_forward_base_128_vs_fp32_oracle(eng, seeds):
+    """BASELINE.json configs[1] at full size (128^3, p16, d768, L12, h12), one volume through the fp32 oracle (pinned to the reference
+    fixtures by tests/test_oracle_golden.py): seed 31 is the volume whose bf16-path logits are 7.06e-3 off, seed 5 the 4.4e-4 one."""
+    cfgdict = dict(W.BASE)
+    sd = W.make_tensors(W.vit_param_spec(**cfgdict), seeds[0])
+    fmri = W.make_volume((2, 128, 128, 128), seeds[1])
+    cfg, params = _arena(eng, cfgdict, sd)
+    rt = eng.VitRuntime(cfg)
+    lg = rt.forward_f32(ref_cpu.fmri_to_video(fmri.cuda()), params)
+    with torch.no_grad():
+        ref = ref_cpu.vit_forward(sd, ref_cpu.ViTCfg(**cfgdict), ref_cpu.fmri_to_video(fmri[:1]))
+    e = rel_err(lg[:1], ref)
+    single = rt.forward_f32(ref_cpu.fmri_to_video(fmri[1:2].cuda()), params)
+    bf = rt.forward(ref_cpu.fmri_to_video(fmri[:1].cuda()), params, params.bfloat16(), training=False)
+    report(f"fp32 path base 128^3 seeds {seeds}: logits vs fp32 oracle rel {e:.2e} (bf16 path: {rel_err(bf, ref):.2e})")
+    assert e < NORTH_STAR
+    assert torch.equal(single[0], lg[1])                         # batch independence, bit for bit
+
+
+def test_precise_forward_large_geometry_depth2(eng):
+    """BASELINE.json configs[4] geometry (128^3, patch 8 -> n = 4097, dim 1024, heads 16, mlp 4096), depth 2, one volume."""
+    cfgdict = dict(image_size=128, image_patch_size=8, frames=128, frame_patch_size=8, num_classes=2, dim=1024,
+                   depth=2, heads=16, mlp_dim=4096, channels=1, dim_head=64, pool="cls")
+    _stages_case(eng, "large geometry (L2)", cfgdict, (13, 14), 1)
+
+
+# ------------------------------------------------------------------------------------------------ module level
+def _neuro(nv_mod, S=32, p=8, **extra):
+    size = dict(TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
+    cfg = W.neuro_config(S, p, DEVICE="cuda", **size, **extra)
+    model = nv_mod.NeuroEncoder(cfg)
+    sd = W.make_tensors(W.vit_param_spec(**W.MICRO), 1, prefix="volume_encoder.vit3d.")
+    model.load_state_dict(sd, strict=True)
+    return model, cfg, sd
+
+
+def test_eval_precision_switch_on_the_module(eng):
+    """model.eval() + no_grad forwards follow `eval_precision` (config key TRAINING_VIT_EVAL_PRECISION, or the precision()
+    context); training forwards and forwards that record a graph stay on the bf16 path."""
+    import neurovit_amd.NeuroEncoder as ne
+    model, cfg, sd = _neuro(ne)
+    x = W.make_volume((3, 32, 32, 32), 9)
+    with torch.no_grad():
+        ref = ref_cpu.neuro_forward({k: v for k, v in sd.items()}, dict(cfg, DEVICE="cpu"), x)
+    model.eval()
+    vit = model.volume_encoder.vit3d
+    with torch.no_grad():
+        b16 = model(x.cuda()).clone()
+        assert vit._rt._last[1] == 0
+        with model.precision("fp32"):
+            f32 = model(x.cuda()).clone()
+            assert vit._rt._last[1] == 2
+            act = model.activations                              # hook contract: last block's attention-LN output, fp32 here
+        again = model(x.cuda())
+    assert torch.equal(again, b16) and vit.eval_precision == "bf16"
+    e32, e16 = rel_err(f32, ref), rel_err(b16, ref)
+    report(f"module eval precision: fp32 {e32:.2e}, bf16 {e16:.2e} vs fp32 oracle")
+    assert e32 < STAGE_TOL and e32 < e16
+    taps = {}
+    with torch.no_grad():
+        ref_cpu.neuro_forward({k: v for k, v in sd.items()}, dict(cfg, DEVICE="cpu"), x, taps=taps)
+    assert rel_l2(act, taps["transformer.layers.1.0.norm.out"]) < STAGE_TOL
+    with model.precision("fp32"):                                 # a forward that records a graph is a training-arithmetic forward
+        out = model(x.cuda())
+        assert out.requires_grad and vit._rt._last[1] == 1
+    model2, _, _ = _neuro(ne, TRAINING_VIT_EVAL_PRECISION="fp32")
+    model2.eval()
+    with torch.no_grad():
+        assert torch.equal(model2(x.cuda()), f32)
+    with pytest.raises(ValueError):
+        model.precision("fp16")
+
+
+def test_trainer_validate_runs_in_fp32_by_default(eng, tmp_path, monkeypatch):
+    """Trainer.validate / evaluate_samples (Trainer.py:101-118: fp32, no autocast) select the fp32 path through the config key
+    VALIDATION_PRECISION (default "fp32"); "bf16" keeps the training arithmetic.  Loss equals the fp32 oracle's CE."""
+    import neurovit_amd.NeuroEncoder as ne
+    from neurovit_amd.trainer import Trainer
+    from oracle import train_step
+    monkeypatch.chdir(tmp_path)
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self, n, seed):
+            self.x = W.make_volume((n, 32, 32, 32), seed)
+            self.y = torch.arange(n) % 2
+        def __len__(self): return len(self.y)
+        def __getitem__(self, i): return f"s{i}", torch.tensor(0), self.x[i], torch.tensor(0), torch.tensor(1), torch.tensor(70), self.y[i]
+
+    extra = dict(TRAINING_LEARNING_RATE=1e-3, TRAINING_WEIGHT_DECAY=1e-2, GLOBAL_OUTPUT_DIR=str(tmp_path / "runs"), TRAINING_EPOCHS=1,
+                 TRAINING_BATCH_SIZE=4, TRAINING_NUM_WORKERS=0)
+    model, cfg, sd = _neuro(ne, **extra)
+    val = DS(8, 2)
+    tr = Trainer(cfg, model, DS(8, 1), val)
+    loss32, acc32 = tr.validate(0)
+    vit = model.volume_encoder.vit3d
+    assert vit._rt._last[1] == 2 and vit.eval_precision == "bf16"
+    with torch.no_grad():
+        lg = ref_cpu.neuro_forward({k: v for k, v in sd.items()}, dict(cfg, DEVICE="cpu"), val.x)
+        want = 0.5 * (float(train_step.cross_entropy(lg[:4], val.y[:4])) + float(train_step.cross_entropy(lg[4:], val.y[4:])))
+    assert abs(loss32 - want) < 2e-5 * max(1.0, abs(want)) + 1e-5          # validate() rounds to 5 decimals
+    tr.evaluate_samples()
+    assert vit._rt._last[1] == 2
+    tr.validation_precision = "bf16"
+    tr.validate(0)
+    assert vit._rt._last[1] == 0
+
+
+def _neuro_sd(S, p, seed):
+    vc = dict(image_size=S, image_patch_size=p, frames=S, frame_patch_size=p, num_classes=2, dim=1024, depth=6,
+              heads=8, mlp_dim=2048, channels=1, dim_head=64)
+    return W.make_tensors(W.vit_param_spec(**vc), seed, prefix="volume_encoder.vit3d.")
+
+
+def test_neuro3d_fixture_logits_and_hook_activation_in_fp32(eng, golden):
+    """The reference's default model size (d1024 L6 h8 mlp2048) at 32^3: the fixture whose logits the bf16 path misses by 5.7e-3
+    (two small logits read from a large residual stream).  fp32 path: logits and the hooked activation (output of the last
+    block's attention LayerNorm, NeuroEncoder.py:70-75) against the imported reference's values."""
+    import neurovit_amd.NeuroEncoder as ne
+    g = golden("neuro3d.npz")
+    S, p = 32, 8
+    model = ne.NeuroEncoder(W.neuro_config(S, p, DEVICE="cuda", TRAINING_VIT_EVAL_PRECISION="fp32"))
+    model.load_state_dict(_neuro_sd(S, p, 11), strict=True)
+    model.eval()
+    x = W.make_volume((2, S, S, S), 12).cuda()
+    with torch.no_grad():
+        logits = model(x)
+    e, ea = rel_err(logits, g["logits"]), rel_l2(model.activations, g["activations"])
+    report(f"fp32 path neuro3d (d1024 L6, 32^3) G4 logits vs reference fixture: rel {e:.2e}; hook activations rel L2 {ea:.2e}")
+    assert e < NORTH_STAR and ea < STAGE_TOL
+    assert model.gradients == {}                                  # no backward has run
+
+
+def test_neuro4d_fp32_eval(eng, golden):
+    """4D model (NeuroEncoder.py:53-66) in fp32 eval against the reference's 4D fixture (T = 5: per-volume copy path), and the
+    fused [B, H, W, D, T] gather with fp32 tokens (T = 8) against the per-volume path."""
+    import os
+    import tempfile
+    import neurovit_amd.NeuroEncoder as ne
+    g = golden("neuro4d.npz")
+    S, p, T = 16, 8, 5
+    with tempfile.TemporaryDirectory() as td:
+        torch.save(dict(_neuro_sd(S, p, 21)), os.path.join(td, "ckpt3d.pth"))
+        model = ne.NeuroEncoder(W.neuro_config(S, p, dim=4, DEVICE="cuda", GLOBAL_BASE_PATH=td, BEST_MODEL_PATH="ckpt3d.pth"))
+    model.load_state_dict(W.make_tensors(W.temporal_param_spec(), 22), strict=False)
+    model.eval()
+    x = W.make_volume((2, S, S, S, T), 23).cuda()
+    vit = model.volume_encoder.vit3d
+    with torch.no_grad(), model.precision("fp32"):
+        logits = model(x)
+        assert vit._rt._last[1] == 2
+        vols = x.permute(0, 4, 1, 2, 3).reshape(2 * T, S, S, S)
+        ev = rel_err(model.volume_encoder(vols), g["volume_logits"])
+        x8 = W.make_volume((2, S, S, S, 8), 24).cuda()
+        fused = vit(x8, time_points=8)
+        per_vol = model.volume_encoder(x8.movedim(-1, 1).flatten(0, 1))
+    report(f"fp32 path neuro4d: logits vs fixture rel {rel_err(logits, g['logits']):.2e}; per-volume logits rel {ev:.2e}; fused gather vs per volume {rel_err(fused, per_vol):.2e}")
+    assert rel_err(logits, g["logits"]) < 1e-5 and ev < NORTH_STAR
+    assert rel_err(fused, per_vol) < 1e-5
