@@ -32,8 +32,9 @@ PEAK_F32_TFLOPS = 157.3         # fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak 
 KIND_NAMES = {0: "gemm_ws_kernel<64,128,...,false,false,*> (NT: out-proj, FC2, patch embed)", 1: "gemm_ws_kernel<64,128,...,false,true,*> (NN: dxn1, dxn2, dAO)",
               2: "gemm_ws_kernel<...,true,true,1> (TN: patch-embed weight gradient)", 3: "attn_fwd_res_kernel", 4: "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
               10: "gemm_pp_kernel<256,128,4,2,false,false,*> (NT: qkv, FC1)", 11: "gemm_pp_kernel<256,128,4,2,false,true,*> (NN: dU with fused GELU' and bias column sums)",
-              12: "gemm_pp_kernel<256,128,4,2,true,true,1> (TN)", 13: "gemm_pp_grouped_tn_kernel (four weight gradients of a layer, auxiliary stream)"}
-GEMM_KINDS = (0, 1, 2, 10, 11, 12, 13)
+              12: "gemm_pp_kernel<256,128,4,2,true,true,1> (TN)", 13: "gemm_pp_grouped_tn_kernel (four weight gradients of a layer, auxiliary stream)",
+              20: "gemm_pq_kernel<false,false,*> (NT, 256x256 tiles)", 21: "gemm_pq_kernel<false,true,*> (NN, 256x256 tiles)", 22: "gemm_pq_kernel<true,true,*> (TN, 256x256 tiles)"}
+GEMM_KINDS = (0, 1, 2, 10, 11, 12, 13, 20, 21, 22)
 
 
 def parse():
@@ -83,9 +84,34 @@ def launch_ranks(a):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
+    # rank 0's stdout is drained by a thread while the parent polls every child: the first rank that fails takes the others down
+    # with it (a rank that died before the rendezvous or inside a collective would otherwise leave its peers - and this parent,
+    # holding the GPU lease - waiting for the store timeout, or for ever)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        failed = next((i for i, p in enumerate(procs) if p.poll() not in (None, 0)), None)
+        if failed is None:
+            time.sleep(0.2)
+    if failed is None:
+        failed = next((i for i, p in enumerate(procs) if p.poll() not in (None, 0)), None)
+    if failed is not None:
+        log(f"launcher: rank {failed} exited with code {procs[failed].returncode}; stopping the other ranks")
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    reader.join(timeout=5)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     rc = max((abs(c) for c in rcs), default=0)
     if rc:
@@ -376,10 +402,11 @@ def main():
         torch.cuda.synchronize()
         kinds = {}
         for k in KIND_NAMES:
-            msk, wk, ck = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+            msk, wk, ck, bk = ctypes.c_double(), ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
             lib.nv_prof_summary(k, ctypes.byref(msk), ctypes.byref(wk), ctypes.byref(ck))
+            lib.nv_prof_summary_bytes(k, ctypes.byref(bk))
             if ck.value:
-                kinds[k] = dict(ms=msk.value, flops=wk.value, launches=ck.value)
+                kinds[k] = dict(ms=msk.value, flops=wk.value, launches=ck.value, bytes=bk.value)
         lib.nv_prof_enable(0)
         gemm = [kinds[k] for k in GEMM_KINDS if k in kinds]
         g_ms, g_fl, g_n = sum(k["ms"] for k in gemm), sum(k["flops"] for k in gemm), sum(k["launches"] for k in gemm)
@@ -397,22 +424,53 @@ def main():
     _, s_ms, s_fl, _ = prof_leg()
     rt.use_aux_stream = was
     achieved_serial = s_fl / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
-    traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(tfile):
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tfile):      # PMC counters cannot be read in-process: measured with rocprofv3 --pmc on this same command
-        tj = json.load(open(tfile))
-        traffic, traffic_src = tj["traffic_MB_per_launch"] * 1e6, tj["source"]
+    # HBM-side check.  PMC counters cannot be read in-process: they come from rocprofv3 --pmc passes of THIS command on an MI355X
+    # (tools/pmc_traffic_summary.py -> profiles/rNN_pmc_traffic.json, per nv_prof kind); the algorithmic bytes beside them are
+    # counted live, per launch, by the launchers (operands read once + outputs written once).  traffic / algorithmic = the waste.
+    pmc, traffic_src = {}, None
+    for tag in ("r03", "r02", "r01"):
+        tfile = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+        if os.path.exists(tfile):
+            tj = json.load(open(tfile))
+            pmc, traffic_src = tj.get("by_kind", {}), tj["source"]
+            if not pmc:                          # round-1/2 file: one family-wide figure only
+                pmc = {"family": {"fetch_MB_per_launch": tj["fetch_MB_per_launch"], "write_MB_per_launch": tj["write_MB_per_launch"]}}
+            break
+
+    def kind_traffic_mb(k):
+        d = pmc.get(str(k))
+        return None if d is None else d["fetch_MB_per_launch"] + d["write_MB_per_launch"]
+
+    by_kernel = {}
+    for k, v in kinds.items():
+        algo_mb = v["bytes"] / v["launches"] / 1e6 if v.get("bytes") else None
+        t_mb = kind_traffic_mb(k)
+        by_kernel[KIND_NAMES[k]] = {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "avg_us": round(v["ms"] * 1e3 / v["launches"], 2),
+                                    "launches_per_step": v["launches"] // prof_steps,
+                                    "algorithmic_MB": None if algo_mb is None else round(algo_mb, 2),
+                                    "traffic_MB": None if t_mb is None else round(t_mb, 2),
+                                    "traffic_over_algorithmic": None if (algo_mb is None or t_mb is None) else round(t_mb / algo_mb, 2)}
+    # family figure over exactly the launches `achieved` is computed from: per-kind PMC traffic weighted by this run's launch counts
+    gk = [k for k in GEMM_KINDS if k in kinds]
+    if gk and all(kind_traffic_mb(k) is not None for k in gk):
+        traffic = sum(kind_traffic_mb(k) * kinds[k]["launches"] for k in gk) / g_n * 1e6
+    elif "family" in pmc:
+        traffic = (pmc["family"]["fetch_MB_per_launch"] + pmc["family"]["write_MB_per_launch"]) * 1e6
+    else:
+        traffic = None
+    g_bytes = sum(kinds[k].get("bytes", 0.0) for k in gk)
     roofline = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family: gemm_pp_kernel / gemm_pp_grouped_tn_kernel (256x128 tiles) + gemm_ws_kernel (64x128 tiles), all fused epilogues",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "bytes/launch (fabric fetch + write, PMC)", "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_unit": "bytes/launch (fabric fetch + write, PMC), mean over the launches of `achieved`", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(g_bytes / max(g_n, 1), 1),
+                "traffic_over_algorithmic": None if not (traffic and g_bytes) else round(traffic / (g_bytes / g_n), 2),
                 "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches_per_step": g_n // prof_steps,
                 "achieved_single_stream": round(achieved_serial, 2), "frac_single_stream": round(achieved_serial / PEAK_BF16_TFLOPS, 4),
                 "note": "achieved = per-launch hipEvent durations inside the concurrent two-stream step (agrees with rocprofv3 of this command); "
-                        "achieved_single_stream = same kernels, same shapes, engine run on one stream (kernels alone on the chip)",
-                "by_kernel": {KIND_NAMES[k]: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "avg_us": round(v["ms"] * 1e3 / v["launches"], 2),
-                                              "launches_per_step": v["launches"] // prof_steps} for k, v in kinds.items()}}
+                        "achieved_single_stream = same kernels, same shapes, engine run on one stream (kernels alone on the chip); traffic = PMC "
+                        "counters of a rocprofv3 run of this command (not readable in-process), algorithmic bytes counted live per launch",
+                "by_kernel": by_kernel}
+    executed_flops_step = sum(v["flops"] for v in kinds.values()) / prof_steps       # what the MFMA kernels of a step really execute
 
     from neurovit_amd.engine import flops_forward, make_config
     vcfg = dict(image_size=S, image_patch_size=p, frames=S, frame_patch_size=p, num_classes=2, dim=size["TRAINING_VIT_DIM"],
@@ -431,6 +489,11 @@ def main():
                       "global_batch": B * world, "parallelism": f"dp{world}", "grad_buckets": a.buckets,
                       "grad_allreduce": ("none (1 GPU)" if world == 1 else f"{a.grad_comm} messages, sum, overlapped with backward")},
            "mfma_frac_step": round(value / world * f_step / (PEAK_BF16_TFLOPS * 1e12), 4),
+           # the last block runs on its B cls rows (pool='cls': the other rows never reach the head; tests prove identical logits and
+           # gradients), so ~5 % of the ALGORITHMIC FLOPs above are not executed: this is the fraction over the FLOPs the step's MFMA
+           # kernels really ran (GEMM + attention launches as counted by the per-launch profiler; skinny cls-row kernels excluded)
+           "mfma_frac_step_executed": round(executed_flops_step / (ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
+           "executed_over_algorithmic_flops": round(executed_flops_step / (B * f_step), 4),
            "loss": round(float(loss), 5), "roofline": roofline}
     if also is not None:
         also["forward_only_mfma_frac"] = round(also["forward_only_eval_volumes_s"] * f_fwd / (PEAK_BF16_TFLOPS * 1e12), 4)

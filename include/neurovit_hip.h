@@ -33,9 +33,11 @@ int nv_arch_ok(void);                 /* 1 iff the current HIP device is gfx950 
 const char* nv_last_error(void);
 
 /* ---- optional per-launch hipEvent profiler (bench.py roofline leg).  kind: warp-specialised GEMM kernels 0 NT, 1 NN, 2 TN;
- * 3 attention fwd, 4 attention bwd; 5 fp8 GEMM; eight-wave 256 x 128 GEMM kernel 10 NT, 11 NN, 12 TN, 13 grouped TN.  nv_prof_summary synchronises; call it outside timed regions. */
+ * 3 attention fwd, 4 attention bwd; 5 fp8 GEMM; eight-wave 256 x 128 GEMM kernel 10 NT, 11 NN, 12 TN, 13 grouped TN; 256 x 256 kernel 20 NT,
+ * 21 NN, 22 TN; fp32 path: 30 GEMM, 31 attention.  nv_prof_summary synchronises; call it outside timed regions. */
 int nv_prof_enable(int on);
 int nv_prof_summary(int kind, double* ms, double* work, long* count);
+int nv_prof_summary_bytes(int kind, double* bytes);   /* algorithmic bytes (operands read once + outputs written once) of the same records */
 
 /* ---- GEMM with fused epilogues (replaces every nn.Linear on the path: vit_3d.py:19,22,41,44,94)
  * layout 0 (NT): C[M,N] = A[M,K] . B[N,K]^T      forward  y = x W^T
@@ -197,6 +199,7 @@ int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const void* dout,
                 int heads, int dim_head, float scale, float* delta, void* dqkv, long ld_dqkv, unsigned long drop_seed,
                 float drop_p, void* stream);
 int nv_stream_sync(void* from, void* to);   /* stream `to` waits for everything enqueued so far on `from` (pooled events) */
+int nv_spin_us(int microseconds, void* stream);   /* one wave that keeps `stream` busy for the given time (<= 50 ms): stream-placement probes */
 
 /* ---- classification head (vit_3d.py:107-110,123-126): cls row -> LayerNorm -> Linear(dim, C), fp32 */
 int nv_head_fwd(const float* x, long row_stride, int B, int d, const float* gamma, const float* beta, float eps,
@@ -263,10 +266,13 @@ long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int training, cons
  *   vol_sigma   != NULL: `video` holds RAW volumes; [B] (or [B / time_points]) = std + 1e-8 per sample (nv_volume_sigma): the z-score
  *                        is folded into the patch LayerNorm (see nv_patch_ln_fwd); crop = the strides / base pointer of the view;
  *   time_points  > 0   : `video` is a contiguous 4D batch [B / T, H, W, D, T] (shape5 = that shape) and volume b*T + t is timepoint t
- *                        of sample b - no regroup copy (nv_patch_ln_fwd_4d; T % 4 == 0, channels = 1); strides5 is ignored. */
+ *                        of sample b - no regroup copy (nv_patch_ln_fwd_4d; T % 4 == 0, channels = 1); strides5 is ignored;
+ *   rows_form          : which rows of the LAST block's out-projection / LayerNorm / FeedForward are computed - see nv_vit_set_cls_tail.
+ *                        A backward must be given the rows_form (and dropout) of its forward. */
 typedef struct nv_vit_input {
   const float* vol_sigma;
   int time_points;
+  int rows_form;   /* last block under pool='cls': 0 = process default (nv_vit_set_cls_tail), 1 = every row, 2 = cls rows when eligible */
 } nv_vit_input;
 int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
                       const nv_vit_input* in, const float* params, const void* params16, void* workspace, long ws_bytes,
@@ -310,12 +316,13 @@ int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const float* video, 
 int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                              const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads, void* grads16,
                              int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
-                             unsigned long drop_seed, void* stream, void* aux_stream, int join_aux);
+                             unsigned long drop_seed, void* stream, void* aux_stream, int join_aux, int rows_form);
 int nv_vit_stage_param_range(const nv_vit_config* cfg, int stage, long* begin, long* end);
-/* pool='cls': the last block's out-projection / LayerNorm / FeedForward, forward and backward, on the B cls rows only (training: when its
- * dropout is off and B <= 4).  Logits and every gradient are unchanged (the other rows never reach the head and receive exact zeros
- * in the backward pass), but rows 1..n-1 of the last block's x1 / xn2 / u / h / x2 workspace buffers are not produced.
- * 1 (default) = on; 0 = every row, as the reference computes it.  Set it before the forward it should apply to. */
+/* pool='cls': the last block's out-projection / LayerNorm / FeedForward, forward and backward, on the B cls rows only (whenever the
+ * block dropout is off; training additionally B <= 4).  Logits and every gradient are unchanged (the other rows never reach the
+ * head and receive exact zeros in the backward pass), but rows 1..n-1 of the last block's x1 / xn2 / u / h / x2 workspace buffers
+ * are not produced.  The form is chosen PER CALL by rows_form (nv_vit_input / nv_vit_backward_stages16); this sets the process
+ * default used by rows_form = 0 and by the entry points without that argument: 1 (initial) = cls rows, 0 = every row. */
 int nv_vit_set_cls_tail(int on);
 /* dst[b .. b + len) = bf16(src[b .. b + len)) for `count` element ranges (HOST arrays begins / lens; any count) */
 int nv_cast_ranges_bf16(const float* src, void* dst, const long* begins, const long* lens, int count, void* stream);

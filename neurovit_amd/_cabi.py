@@ -27,7 +27,7 @@ class VitConfig(ctypes.Structure):
 
 class VitInput(ctypes.Structure):
     """struct nv_vit_input (neurovit_hip.h): optional input forms of nv_vit_forward_in / nv_vit_forward_fp8."""
-    _fields_ = [("vol_sigma", ctypes.c_void_p), ("time_points", ctypes.c_int)]
+    _fields_ = [("vol_sigma", ctypes.c_void_p), ("time_points", ctypes.c_int), ("rows_form", ctypes.c_int)]
 
 
 def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:

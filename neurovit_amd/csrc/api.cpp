@@ -32,7 +32,7 @@ extern "C" int nv_arch_ok(void) {
 #include <stdlib.h>
 #include <vector>
 namespace {
-struct Rec { hipEvent_t a, b; int kind; double work; };
+struct Rec { hipEvent_t a, b; int kind; double work, bytes; };
 std::vector<Rec> g_pool;
 size_t g_used = 0;
 bool g_on = false;
@@ -55,9 +55,14 @@ extern "C" int nv_prof_begin(int kind, double work, void* stream) {
     g_pool.push_back(r);
   }
   Rec& r = g_pool[g_used];
-  r.kind = kind; r.work = work;
+  r.kind = kind; r.work = work; r.bytes = 0.0;
   (void)hipEventRecord(r.a, (hipStream_t)stream);
   return (int)g_used++;
+}
+
+// algorithmic bytes of the launch in `slot` (operands read once + outputs written once): the HBM-side check of the roofline leg
+extern "C" void nv_prof_bytes(int slot, double bytes) {
+  if (slot >= 0 && (size_t)slot < g_pool.size()) g_pool[slot].bytes = bytes;
 }
 
 extern "C" void nv_prof_end(int slot, void* stream) {
@@ -77,6 +82,15 @@ extern "C" int nv_prof_summary(int kind, double* ms, double* work, long* count) 
     tms += e; tw += r.work; ++c;
   }
   if (ms) *ms = tms; if (work) *work = tw; if (count) *count = c;
+  return 0;
+}
+
+// total algorithmic bytes of the records of `kind` (see nv_prof_bytes); 0 for kinds whose launchers do not state them
+extern "C" int nv_prof_summary_bytes(int kind, double* bytes) {
+  double tb = 0;
+  for (size_t i = 0; i < g_used; ++i)
+    if (g_pool[i].kind == kind) tb += g_pool[i].bytes;
+  if (bytes) *bytes = tb;
   return 0;
 }
 
@@ -105,5 +119,20 @@ extern "C" int nv_stream_sync(void* from, void* to) {
     nv_set_error("nv_stream_sync: record / wait failed");
     return -2;
   }
+  return 0;
+}
+
+// ---- a kernel that only occupies its stream for a given time (one wave): the stream-placement probes of the data-parallel
+// start-up (neurovit_amd/parallel.py) need "work that is still running" on one stream while they watch another.  Timed on the
+// constant 100 MHz s_memrealtime counter, so the duration does not depend on the shader clock; bounded at 50 ms.
+__global__ void nv_spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+extern "C" int nv_spin_us(int microseconds, void* stream) {
+  if (microseconds < 0 || microseconds > 50000) { nv_set_error("nv_spin_us: 0 .. 50000 us"); return -1; }
+  hipLaunchKernelGGL(nv_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
+  if (hipGetLastError() != hipSuccess) { nv_set_error("nv_spin_us: launch failed"); return -2; }
   return 0;
 }

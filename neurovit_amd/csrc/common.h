@@ -15,6 +15,7 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 extern "C" void nv_set_error(const char* fmt, ...);
 extern "C" int nv_prof_begin(int kind, double work, void* stream);   // -1 when profiling is off
+extern "C" void nv_prof_bytes(int slot, double bytes);                // algorithmic bytes of that launch (optional)
 extern "C" void nv_prof_end(int slot, void* stream);
 extern "C" int nv_stream_sync(void* from, void* to);   // `to` waits for everything enqueued on `from` (pooled events)
 unsigned nv_sync_event_flags();                            // hipEventCreateWithFlags flags of those events (api.cpp)

@@ -8,8 +8,6 @@
 #include <vector>
 
 #include "../../include/neurovit_hip.h"
-#include <mutex>
-#include <unordered_map>
 
 #include "common.h"
 
@@ -24,17 +22,21 @@ struct Dims {
 };
 
 // pool = 'cls' (the NeuroEncoder path, NeuroEncoder.py:194): behind the last block's attention only the B cls rows reach the head, and in
-// the backward pass the residual gradient entering the last block is exactly zero in every other row.  With this on (default) the
+// the backward pass the residual gradient entering the last block is exactly zero in every other row.  In the cls-rows form the
 // last block's out-projection, LayerNorm and FeedForward - forward and backward - run on those B rows only, as strided views (row
 // stride n) through the weight-streaming kernels of skinny.hip: the same values for the logits and every gradient (the skipped rows
-// contribute exact zeros; in the fp8 inference path the block's FeedForward then runs in bf16), but rows 1..n-1 of the last block's x1 / xn2 / u / h / x2 buffers are not produced.  Off: every row, as
-// the reference computes it.  Training forwards remember per workspace which form they took; the backward follows.
+// contribute exact zeros; in the fp8 inference path the block's FeedForward then runs in bf16), but rows 1..n-1 of the last block's
+// x1 / xn2 / u / h / x2 buffers are not produced.  The form is an ARGUMENT of every call (rows_form: nv_vit_input for the forwards,
+// a parameter of nv_vit_backward_stages16): 1 = every row, as the reference computes it; 2 = cls rows when eligible; 0 = the process
+// default set by nv_vit_set_cls_tail (on unless switched off).  The decision is a pure function of (config, B, training, dropout,
+// rows_form), so a backward given the forward's values takes the forward's form - nothing is remembered per workspace.
+// The skinny kernels apply no dropout: the cls-rows form needs the block dropout off, in training AND in a train-mode forward
+// that records no graph (the frozen encoder of the 4D model under Trainer.train, config4D.yaml TRAINING_DROPOUT 0.2).
 static int g_cls_tail = 1;
 extern "C" int nv_vit_set_cls_tail(int on) { g_cls_tail = on ? 1 : 0; return 0; }
-static std::mutex g_tail_mu;
-static std::unordered_map<const void*, bool> g_tail_of_ws;
-static bool cls_tail_wanted(const Dims& D, int training, float drop_p) {
-  return g_cls_tail && !D.pool_mean && (!training || (drop_p == 0.f && D.B <= 4));
+static bool cls_tail_wanted(const Dims& D, int training, float drop_p, int rows_form) {
+  const bool want = rows_form == 1 ? false : (rows_form == 2 ? true : g_cls_tail != 0);
+  return want && !D.pool_mean && drop_p == 0.f && (!training || D.B <= 4);
 }
 
 int make_dims(const nv_vit_config* c, int B, Dims& D) {
@@ -295,8 +297,7 @@ extern "C" int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* v
 
   const float scale = 1.0f / sqrtf((float)D.dh);
   const float* xin = (float*)(ws + W.x0);
-  const bool tail = cls_tail_wanted(D, training, drop_p);
-  if (training) { std::lock_guard<std::mutex> lk(g_tail_mu); g_tail_of_ws[workspace] = tail; }
+  const bool tail = cls_tail_wanted(D, training, drop_p, in ? in->rows_form : 0);
   for (int l = 0; l < D.L; ++l) {
     const LayerP& q = T.layer[l];
     const LayerW& w = W.layer[l];
@@ -384,7 +385,7 @@ extern "C" int nv_vit_forward_f32(const nv_vit_config* cfg, int B, const float* 
     RUN(nv_ln_fwd_f32(xin, d, M, d, p + q.n1g, p + q.n1b, eps, F32(W.xn1), d, nullptr, nullptr, stream));
     RUN(nv_gemm_f32(0, M, 3 * D.inner, d, F32(W.xn1), d, p + q.wqkv, d, F32(W.qkv), 3 * D.inner, nullptr, nullptr, 0, stream));
     RUN(nv_attn_fwd_f32(F32(W.qkv), 3 * D.inner, B, D.n, D.heads, D.dh, scale, F32(W.ao), D.inner, stream));
-    if (l == D.L - 1 && !D.pool_mean) {
+    if (l == D.L - 1 && cls_tail_wanted(D, 0, 0.f, in ? in->rows_form : 0)) {
       // pool = 'cls' (NeuroEncoder.py:194): behind the last attention only the B cls rows reach the head - the last block's
       // out-projection, LayerNorm and FeedForward run on those rows as strided views (row stride n); same values for the logits
       const long rs = D.n;
@@ -472,7 +473,7 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
                           est + D.T, 0, 0.f, stream));
   const float scale = 1.0f / sqrtf((float)D.dh);
   const float* xin = (float*)(ws + W.x0);
-  const bool tail8 = cls_tail_wanted(D, 0, 0.f);
+  const bool tail8 = cls_tail_wanted(D, 0, 0.f, in ? in->rows_form : 0);
   for (int l = 0; l < D.L; ++l) {
     const LayerP& q = T.layer[l];
     const LayerW& w = W.layer[l];
@@ -521,22 +522,20 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
                                       int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
                                       unsigned long drop_seed, void* stream, void* aux_stream, int join_aux) {
   return nv_vit_backward_stages16(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, nullptr, accumulate, first_stage,
-                                  last_stage, drop_p, emb_drop_p, drop_seed, stream, aux_stream, join_aux);
+                                  last_stage, drop_p, emb_drop_p, drop_seed, stream, aux_stream, join_aux, 0);
 }
 
 extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                                         const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads, void* grads16,
                                         int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
-                                        unsigned long drop_seed, void* stream, void* aux_stream, int join_aux) {
+                                        unsigned long drop_seed, void* stream, void* aux_stream, int join_aux, int rows_form) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 1, W);
   NV_CHECK_ARG(video && strides5 && params && params16 && workspace && dlogits && grads, "nv_vit_backward: null pointer");
   NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_backward: workspace too small (%ld < %ld) - forward must run with training=1", ws_bytes, W.total);
   NV_CHECK_ARG(nv_aligned16(grads) && nv_aligned16(grads16), "nv_vit_backward: grads / grads16 must be 16-byte aligned");
-  bool tail_fwd = false;                           // did the forward of this workspace take the cls-rows form for the last block?
-  { std::lock_guard<std::mutex> lk(g_tail_mu); auto it = g_tail_of_ws.find(workspace); tail_fwd = (it != g_tail_of_ws.end()) && it->second; }
-  NV_CHECK_ARG(!tail_fwd || drop_p == 0.f, "nv_vit_backward: dropout differs from the forward of this workspace");
+  const bool tail_fwd = cls_tail_wanted(D, 1, drop_p, rows_form);     // the form the (training) forward took, given the same arguments
   bf16* gr16 = (bf16*)grads16;                     // optional bf16 mirror of the Linear weight gradients (data-parallel messages)
   auto M16 = [&](long off) -> void* { return gr16 ? (void*)(gr16 + off) : nullptr; };
   char* ws = (char*)workspace;

@@ -344,6 +344,7 @@ static int launch_tile(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int slot = nv_prof_begin((A_T ? 2 : (B_T ? 1 : 0)), 2.0 * a.M * a.N * a.K, s);
+  nv_prof_bytes(slot, gemm_algo_bytes(a, EPI, 2));
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), LDS, s, a);
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_bf16");
@@ -362,6 +363,7 @@ static int launch_ws(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int slot = nv_prof_begin((A_T ? 2 : (B_T ? 1 : 0)), 2.0 * a.M * a.N * a.K, s);
+  nv_prof_bytes(slot, gemm_algo_bytes(a, EPI, 2));
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(WS_THREADS), LDS, s, a);
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_bf16/ws");
@@ -575,6 +577,11 @@ extern "C" int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gem
   }
   hipStream_t s = (hipStream_t)stream;
   const int slot = nv_prof_begin(2, flops, s);
+  if (slot >= 0) {
+    double bytes = 0.0;
+    for (int i = 0; i < G.count; ++i) bytes += gemm_algo_bytes(G.p[i], EPI_STORE_F32, 2);
+    nv_prof_bytes(slot, bytes);
+  }
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(WS_THREADS), LDS, s, G);
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_bf16_grouped");

@@ -31,6 +31,23 @@ struct GemmArgs {
   const float* colscale;   // fp8 operands: acc *= colscale[n] (1 / (activation scale * weight-row scale)) before the epilogue; null otherwise
 };
 
+// algorithmic bytes of one GEMM launch: both operands read once, every output written once, epilogue inputs read once
+static inline double gemm_algo_bytes(const GemmArgs& a, int epi, int operand_bytes) {
+  const double mn = (double)a.M * a.N;
+  double b = ((double)a.M * a.K + (double)a.N * a.K) * operand_bytes;
+  switch (epi) {
+    case EPI_STORE_BF16: b += mn * 2; break;
+    case EPI_STORE_F32: b += mn * 4 * (a.accumulate ? 2 : 1) + (a.aux_out ? mn * 2 : 0); break;
+    case EPI_BIAS_F32: b += mn * 4; break;
+    case EPI_BIAS_GELU: b += mn * 2 + (a.aux_out ? mn * 2 : 0); break;
+    case EPI_BIAS_RESID: b += mn * 8; break;
+    case EPI_DGELU: case EPI_DGELU_COLSUM: b += mn * 4; break;
+    case EPI_BIAS_GELU_F8: b += mn; break;
+    default: break;
+  }
+  return b;
+}
+
 // OCP e4m3 (gfx950's fp8: v_cvt_pk_fp8_f32), saturating: four floats -> four bytes
 __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
 #pragma unroll

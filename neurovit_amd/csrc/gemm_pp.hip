@@ -275,6 +275,7 @@ int launch_pp_t(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int slot = nv_prof_begin(10 + (A_T ? 2 : (B_T ? 1 : 0)), 2.0 * a.M * a.N * a.K, s);
+  nv_prof_bytes(slot, gemm_algo_bytes(a, EPI, 2));
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(PP_THREADS), LDS, s, a);
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_bf16/pp");
@@ -333,6 +334,7 @@ static int launch_pp_f8_t(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int slot = nv_prof_begin(5, 2.0 * a.M * a.N * a.K, s);
+  nv_prof_bytes(slot, gemm_algo_bytes(a, EPI, 1));
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(PP_THREADS), LDS, s, a);
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_f8");
@@ -363,6 +365,11 @@ int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_
     attr_set = true;
   }
   const int slot = nv_prof_begin(13, flops, s);
+  if (slot >= 0) {
+    double bytes = 0.0;
+    for (int i = 0; i < G.count; ++i) bytes += gemm_algo_bytes(G.p[i], EPI_STORE_F32, 2);
+    nv_prof_bytes(slot, bytes);
+  }
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(PP_THREADS), LDS, s, G);
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_bf16_grouped/pp");

@@ -205,6 +205,7 @@ int launch_pq_t(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int slot = nv_prof_begin(F8 ? 5 : 20 + (A_T ? 2 : (B_T ? 1 : 0)), 2.0 * a.M * a.N * a.K, s);
+  nv_prof_bytes(slot, gemm_algo_bytes(a, EPI, (F8 ? 1 : 2)));
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(PQ_THREADS), PQ_LDS, s, a);
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm/pq");

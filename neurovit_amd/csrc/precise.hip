@@ -283,7 +283,8 @@ extern "C" int nv_gemm_f32(int epi, int M, int N, int K, const float* A, long ld
   TileChoice t = pick_tile(M, N);
   if (g_force_wm) t = TileChoice{g_force_wm, g_force_wn};
   hipStream_t s = (hipStream_t)stream;
-  const int slot = nv_prof_begin(20, 2.0 * M * N * (double)K, stream);
+  const int slot = nv_prof_begin(30, 2.0 * M * N * (double)K, stream);
+  nv_prof_bytes(slot, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (epi == 4 ? 2 : 1)));
 #define NV_F32_TILE(WM, WN)                                                                             \
   do {                                                                                                  \
     if (aligned) launch_gemm_f32<WM, WN, true>(epi, M, N, K, A, lda, B, ldb, C, ldc, bias, resid, ldr, s);    \
@@ -306,7 +307,7 @@ extern "C" int nv_attn_fwd_f32(const float* qkv, long ld_qkv, int B, int n, int 
   NV_CHECK_ARG((ld_qkv % 4) == 0 && (ld_out % 4) == 0 && nv_aligned16(qkv) && nv_aligned16(out) && ld_qkv >= 3L * heads * dim_head && ld_out >= (long)heads * dim_head,
                "nv_attn_fwd_f32: leading dimensions must be multiples of 4 and cover the heads, buffers 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const int slot = nv_prof_begin(21, 4.0 * B * heads * (double)n * n * dim_head, stream);
+  const int slot = nv_prof_begin(31, 4.0 * B * heads * (double)n * n * dim_head, stream);
   switch ((dim_head + 15) / 16) {
     case 1: launch_attn_f32<1>(qkv, ld_qkv, B, n, heads, dim_head, scale, out, ld_out, s); break;
     case 2: launch_attn_f32<2>(qkv, ld_qkv, B, n, heads, dim_head, scale, out, ld_out, s); break;

@@ -20,10 +20,6 @@ from ._cabi import VitConfig, VitInput, check, lib
 _BYTES = {torch.float32: 4, torch.bfloat16: 2}
 
 
-if os.environ.get("NEUROVIT_CLS_TAIL") == "0":      # last block on every row, as the reference computes it (A/B, debugging)
-    lib.nv_vit_set_cls_tail(0)
-
-
 def make_config(*, image_size, image_patch_size, frames, frame_patch_size, num_classes, dim, depth, heads, mlp_dim,
                 channels=3, dim_head=64, ln_eps=1e-5, pool='cls', **_) -> VitConfig:
     if pool not in ('cls', 'mean'):
@@ -70,6 +66,9 @@ class VitRuntime:
         self.backward_done = False   # a backward of the most recent forward has run (gates the Grad-CAM gradient tap)
         self._aux = {}      # device -> auxiliary stream for the weight-gradient GEMMs
         self.use_aux_stream = os.environ.get("NEUROVIT_AUX_STREAM", "1") != "0"
+        # last block under pool='cls': 0 = the library's process default (cls rows), 1 = every row (A/B runs, debugging)
+        self.rows_form = 1 if os.environ.get("NEUROVIT_CLS_TAIL") == "0" else 0
+        self._rows_form = 0
 
     def workspace(self, B: int, training, device) -> torch.Tensor:
         """training: False / True, or 2 for the fp32 inference layout."""
@@ -85,7 +84,7 @@ class VitRuntime:
             self._ws[key] = ws
         return ws
 
-    def _input_form(self, video: torch.Tensor, vol_sigma, time_points: int):
+    def _input_form(self, video: torch.Tensor, vol_sigma, time_points: int, rows_form: int = 0):
         """(B, nv_vit_input or None) after checking the extents: plain [B, C, F, H, W] view, or (time_points > 0) a contiguous
         4D batch [B / T, H, W, D, T]; vol_sigma marks RAW volumes (z-score folded into the patch LayerNorm)."""
         if not video.is_cuda:
@@ -104,18 +103,21 @@ class VitRuntime:
                 raise ValueError(f"neurovit_amd: video of shape {tuple(video.shape)} does not match the model's "
                                  f"[B, channels, frames, height, width] = [B, {', '.join(map(str, want))}]")
             B = video.shape[0]
-        if vol_sigma is None and not time_points:
+        if vol_sigma is None and not time_points and not rows_form:
             return B, None
         if vol_sigma is not None:
             assert vol_sigma.is_cuda and vol_sigma.dtype == torch.float32 and vol_sigma.numel() == video.shape[0] and vol_sigma.is_contiguous()
-        return B, VitInput(None if vol_sigma is None else vol_sigma.data_ptr(), int(time_points))
+        return B, VitInput(None if vol_sigma is None else vol_sigma.data_ptr(), int(time_points), int(rows_form))
 
     def forward(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, training: bool,
-                dropout: Tuple[float, float, int] = (0.0, 0.0, 0), vol_sigma=None, time_points: int = 0) -> torch.Tensor:
+                dropout: Tuple[float, float, int] = (0.0, 0.0, 0), vol_sigma=None, time_points: int = 0, rows_form: Optional[int] = None) -> torch.Tensor:
         """video: [B, C, F, H, W] fp32 view (any strides).  Returns logits [B, num_classes] fp32.
         dropout = (p of the blocks, p of the embedding, seed) - (0, 0, *) in eval mode.
-        vol_sigma / time_points: the optional input forms of nv_vit_forward_in (raw volumes; contiguous 4D batch)."""
-        B, inp = self._input_form(video, vol_sigma, time_points)
+        vol_sigma / time_points: the optional input forms of nv_vit_forward_in (raw volumes; contiguous 4D batch).
+        rows_form: 1 = the last block on every row (as the reference computes it), 2 = on the cls rows when eligible,
+        None = this runtime's default (`self.rows_form`: the process default unless NEUROVIT_CLS_TAIL=0)."""
+        rows_form = self.rows_form if rows_form is None else int(rows_form)
+        B, inp = self._input_form(video, vol_sigma, time_points, rows_form)
         ws = self.workspace(B, training, video.device)
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
         check(lib.nv_vit_forward_in(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
@@ -124,6 +126,7 @@ class VitRuntime:
                                  float(dropout[1]), int(dropout[2]), logits.data_ptr(),
                                  torch.cuda.current_stream().cuda_stream), "nv_vit_forward_in")
         self._keep = (vol_sigma, inp)                    # the backward re-gathers the same (raw) input
+        self._rows_form = rows_form                      # ... and takes the same form of the last block
         self._last = (B, training, ws, video)
         self.generation += 1
         self.backward_done = False
@@ -134,7 +137,7 @@ class VitRuntime:
     def forward_f32(self, video: torch.Tensor, params: torch.Tensor, vol_sigma=None, time_points: int = 0) -> torch.Tensor:
         """Inference forward with every operand in fp32 (weights straight from the fp32 arena, contractions on the fp32 MFMA):
         logits within 1e-5 of the reference's CPU fp32 forward instead of the bf16 path's 1e-3 ... 7e-3.  Eval mode only."""
-        B, inp = self._input_form(video, vol_sigma, time_points)
+        B, inp = self._input_form(video, vol_sigma, time_points, self.rows_form)
         ws = self.workspace(B, 2, video.device)
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
         check(lib.nv_vit_forward_f32(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
@@ -150,11 +153,7 @@ class VitRuntime:
         """One bf16 forward of `video` with every layer's activations kept; returns the per-layer activation scales
         [depth][3] = 448 / (headroom * amax) of the LN1 output, the LN2 output and the GELU output.  e4m3 is a floating
         format: headroom costs no relative precision, it only moves the subnormal floor."""
-        lib.nv_vit_set_cls_tail(0)           # the fp8 forward quantises every row of every block: calibrate on every row
-        try:
-            self.forward(video, params, params16, training=True)
-        finally:
-            lib.nv_vit_set_cls_tail(0 if os.environ.get("NEUROVIT_CLS_TAIL") == "0" else 1)
+        self.forward(video, params, params16, training=True, rows_form=1)    # the fp8 forward quantises every row of every block: calibrate on every row
         B = video.shape[0]
         n = (self.cfg.frames // self.cfg.frame_patch_size) * (self.cfg.image_size // self.cfg.image_patch_size) ** 2 + 1
         scales = []
@@ -180,7 +179,7 @@ class VitRuntime:
         return dict(params8=p8, colscales=cs, act_scales=host, act_list=act_scales)
 
     def forward_fp8(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, f8, vol_sigma=None, time_points: int = 0) -> torch.Tensor:
-        B, inp = self._input_form(video, vol_sigma, time_points)
+        B, inp = self._input_form(video, vol_sigma, time_points, self.rows_form)
         ws = self.workspace(B, False, video.device)
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
         check(lib.nv_vit_forward_fp8(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
@@ -212,7 +211,7 @@ class VitRuntime:
                                            params16.data_ptr(), ws.data_ptr(), ws.numel(), self._dlogits.data_ptr(),
                                            grads.data_ptr(), None if grads16 is None else grads16.data_ptr(), int(accumulate), first, last,
                                            float(self._dropout[0]), float(self._dropout[1]), int(self._dropout[2]),
-                                           torch.cuda.current_stream().cuda_stream, self._aux_stream(video.device), int(join_aux)),
+                                           torch.cuda.current_stream().cuda_stream, self._aux_stream(video.device), int(join_aux), int(self._rows_form)),
               "nv_vit_backward_stages16")
 
     def aux_stream_object(self, device) -> Optional[torch.cuda.Stream]:

@@ -87,6 +87,7 @@ class FusedAdamW(torch.optim.Optimizer):
         g0 = self.param_groups[0]
         ops.adamw_step(arena[begin:end], grads[begin:end], m[begin:end], v[begin:end], shadow[begin:end], self._steps, g0["lr"],
                        g0["betas"], g0["eps"], g0["weight_decay"], grad_scale, max_blocks)
+        vit._param_generation += 1             # the arena changed under derived copies (fp8 weights re-quantise on their next use)
 
     def begin_step(self):
         if not self._bound:

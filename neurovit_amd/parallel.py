@@ -27,6 +27,12 @@ def bucket_stages(n_stages: int, n_buckets: int) -> List[Tuple[int, int]]:
     return out
 
 
+def _spin(stream: "torch.cuda.Stream", microseconds: int) -> None:
+    """Keep `stream` busy for the given time with the library's own spin kernel (no private torch API)."""
+    from ._cabi import check, lib
+    check(lib.nv_spin_us(int(microseconds), stream.cuda_stream), "nv_spin_us")
+
+
 def _runs_beside(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
     """True when work on stream a is not queued behind work on stream b.  HIP multiplexes its streams onto a few hardware queues
     (four per priority by default); two streams that share one execute in submission order - a wait enqueued on one (a bucket's
@@ -35,7 +41,7 @@ def _runs_beside(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
     x = torch.empty(64, device=a.device)
     torch.cuda.synchronize(a.device)
     with torch.cuda.stream(b):
-        torch.cuda._sleep(4_000_000)                 # ~2 ms
+        _spin(b, 2000)                               # 2 ms
         eb = torch.cuda.Event()
         eb.record(b)
     with torch.cuda.stream(a):
@@ -54,13 +60,10 @@ def independent_stream(device, others, tries: int = 12) -> "torch.cuda.Stream":
     high-priority queue that mostly waits on events slowed the whole step by 80 % (measured)."""
     others = [o for o in others if o is not None]
     cand = torch.cuda.Stream(device=device)
-    try:
-        for _ in range(tries):
-            if all(_runs_beside(cand, o) for o in others):
-                return cand
-            cand = torch.cuda.Stream(device=device)
-    except (AttributeError, RuntimeError):           # no torch.cuda._sleep on this build: keep the first stream
-        pass
+    for _ in range(tries):
+        if all(_runs_beside(cand, o) for o in others):
+            return cand
+        cand = torch.cuda.Stream(device=device)
     return cand
 
 
@@ -69,44 +72,43 @@ def streams_beside_collectives(device, process_group=None, candidates: int = 8):
     stream of its own; a stream that shares that stream's hardware queue executes in submission order with every all-reduce instead
     of beside it.  Returns (compute, aux): `compute` is None when the current stream is fine, else a pool stream that is (the
     caller runs its step there); `aux` is a second such stream with a queue of its own for the engine's weight-gradient work (None:
-    let the engine pick).  Every rank issues exactly candidates + 2 collectives, whatever it finds, so the ranks stay in step."""
+    let the engine pick).  Every rank issues exactly candidates + 2 collectives, whatever it finds, so the ranks stay in step:
+    nothing between the first and the last collective may end a rank's probe early - an error there is raised, never swallowed
+    (a rank that silently left would strand its peers inside a collective).  The spin kernel is the library's own (nv_spin_us)."""
     if not dist.is_initialized() or dist.get_world_size(process_group) < 2 or torch.device(device).type != "cuda":
         return None, None
-    try:
-        t = torch.ones(1 << 20, device=device)
-        side = torch.cuda.Stream(device=device)
-        dist.all_reduce(t, group=process_group)                   # warm-up: communicator and internal stream exist after this
+    t = torch.ones(1 << 20, device=device)
+    side = torch.cuda.Stream(device=device)
+    dist.all_reduce(t, group=process_group)                   # warm-up: communicator and internal stream exist after this
+    torch.cuda.synchronize(device)
+
+    def beside(stream) -> bool:
+        with torch.cuda.stream(stream):
+            _spin(stream, 4000)                               # 4 ms of spinning on the candidate
+            es = torch.cuda.Event()
+            es.record(stream)
+        with torch.cuda.stream(side):
+            dist.all_reduce(t, group=process_group)
+            ec = torch.cuda.Event()
+            ec.record(side)
+        ec.synchronize()
+        ok = not es.query()                                   # the collective finished while the candidate still spun
         torch.cuda.synchronize(device)
+        return ok
 
-        def beside(stream) -> bool:
-            with torch.cuda.stream(stream):
-                torch.cuda._sleep(8_000_000)                      # ~4 ms of spinning on the candidate
-                es = torch.cuda.Event()
-                es.record(stream)
-            with torch.cuda.stream(side):
-                dist.all_reduce(t, group=process_group)
-                ec = torch.cuda.Event()
-                ec.record(side)
-            ec.synchronize()
-            ok = not es.query()                                   # the collective finished while the candidate still spun
-            torch.cuda.synchronize(device)
-            return ok
-
-        current = torch.cuda.current_stream(device)
-        current_ok = beside(current)
-        good = []
-        for _ in range(candidates):
-            cand = torch.cuda.Stream(device=device)
-            if beside(cand):
-                good.append(cand)
-        compute = None
-        if not current_ok and good:
-            compute = good.pop(0)
-        main = compute if compute is not None else current
-        aux = next((c for c in good if _runs_beside(c, main)), None)
-        return compute, aux
-    except (AttributeError, RuntimeError):
-        return None, None
+    current = torch.cuda.current_stream(device)
+    current_ok = beside(current)
+    good = []
+    for _ in range(candidates):
+        cand = torch.cuda.Stream(device=device)
+        if beside(cand):
+            good.append(cand)
+    compute = None
+    if not current_ok and good:
+        compute = good.pop(0)
+    main = compute if compute is not None else current
+    aux = next((c for c in good if _runs_beside(c, main)), None)
+    return compute, aux
 
 
 class GradSync:

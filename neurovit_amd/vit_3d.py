@@ -287,6 +287,7 @@ class ViT(nn.Module):
         self._last_logits = None   # most recent forward's logits (the Trainer shell reads them without a second forward)
         self._grad_sync = None     # parallel.GradSync: all-reduce gradient buckets while backward still runs
         self._fp8 = None           # enable_fp8(): e4m3 weights + scales for inference forwards
+        self._param_generation = 0 # bumped whenever the fused optimizer rewrites the arena (FusedAdamW.step / step_range)
         # Arithmetic of eval-mode forwards that record no graph: "bf16" (bf16 MFMA operands, the training arithmetic) or "fp32"
         # (every operand fp32 on the fp32 MFMA: what the reference's validate computes, Trainer.py:101-118 - logits within 1e-5
         # of its CPU forward, about 3x the time).  Set directly, through `precision(...)`, or by the config key
@@ -345,8 +346,13 @@ class ViT(nn.Module):
         return self._grads[off[i]:off[i] + num[i]].view(self._plist[i].shape)
 
     def mark_shadow_fresh(self):
-        """Called by the fused AdamW, which writes the bf16 shadow itself."""
+        """Called by the fused AdamW, which writes the arena and the bf16 shadow itself (through raw pointers: no tensor
+        `_version` moves, so the generation counter is what tells derived copies - the fp8 weights - that they are stale)."""
         self._shadow_key = tuple(p._version for p in self._plist)
+        self._param_generation += 1
+
+    def _param_key(self):
+        return (self._param_generation, tuple(p._version for p in self._plist))
 
     def _refresh_shadow(self):
         key = tuple(p._version for p in self._plist)
@@ -363,7 +369,7 @@ class ViT(nn.Module):
         self._refresh_shadow()
         scales = self._rt.calibrate_fp8(calibration_video.float(), self._arena, self._shadow, headroom)
         self._fp8 = self._rt.quantize_fp8(self._arena, scales)
-        self._fp8["key"] = tuple(p._version for p in self._plist)
+        self._fp8["key"] = self._param_key()
         return scales
 
     def disable_fp8(self):
@@ -400,8 +406,8 @@ class ViT(nn.Module):
             return self._last_logits
         self._refresh_shadow()
         if self._fp8 is not None and not need_grad and not self.training:
-            if self._fp8["key"] != tuple(p._version for p in self._plist):      # parameters changed since quantisation
-                self._fp8 = dict(self._rt.quantize_fp8(self._arena, self._fp8["act_list"]), key=tuple(p._version for p in self._plist))
+            if self._fp8["key"] != self._param_key():      # parameters changed since quantisation (stock or fused optimizer)
+                self._fp8 = dict(self._rt.quantize_fp8(self._arena, self._fp8["act_list"]), key=self._param_key())
             self._last_logits = self._rt.forward_fp8(video, self._arena, self._shadow, self._fp8, vol_sigma=vol_sigma, time_points=time_points)
             return self._last_logits
         self._last_logits = self._rt.forward(video, self._arena, self._shadow, training=need_grad, dropout=drop, vol_sigma=vol_sigma,

@@ -132,3 +132,20 @@ def test_bf16_message_buffer_is_the_rounded_gradient_arena():
     assert p.exitcode == 0
     assert same
     assert count == 4 * SIZE["TRAINING_VIT_DEPTH"] + 1 and covered / total > 0.8
+
+
+def test_rccl_process_group_runs_the_bucket_pipeline():
+    """RCCL under test (every other DP test uses gloo): a real "nccl" process group - one rank, the box has one GPU -
+    with the bucket pipeline forced on as at world > 1: 7 buckets all-reduced by RCCL kernels on the side stream during the staged
+    backward, fp32 and bf16 messages, broadcast + barrier.  With one rank the sum is the identity, so the loss curve must equal the
+    plain single-process run (exactly for fp32 messages).  Runs tools/rccl_rehearsal.py in a child process (the process group must
+    not outlive the test, and a HIP-initialised process must not be re-exec'ed: it is spawned, not exec'ed)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, REHEARSAL_TIMED_STEPS="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_rehearsal.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rccl rehearsal ok" in r.stdout
+    assert "torch.float32" in r.stdout and "torch.bfloat16" in r.stdout

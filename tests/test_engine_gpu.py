@@ -63,16 +63,11 @@ def load_arena(engine, cfgdict, sd):
 def run_case(engine, tag, cfgdict, seeds, B=2, dropout=(0.0, 0.0, 0)):
     """Every stage, the logits and every gradient against both oracles with the last block computed on ALL rows (as the reference
     does), then once more in the product's default form - the last block's out-projection / FeedForward on the cls rows only
-    (nv_vit_set_cls_tail) - which must reproduce the logits and every gradient."""
-    from neurovit_amd._cabi import lib
-    lib.nv_vit_set_cls_tail(0)
-    try:
-        out = _run_case_full_rows(engine, tag, cfgdict, seeds, B, dropout)
-    finally:
-        lib.nv_vit_set_cls_tail(1)
+    (rows_form = 2; the form is an argument of each call) - which must reproduce the logits and every gradient."""
+    out = _run_case_full_rows(engine, tag, cfgdict, seeds, B, dropout)
     logits, rt, gcpu, (cfg, params, params16, video, dlogits) = out
     rt2 = engine.VitRuntime(cfg)
-    logits2 = rt2.forward(video, params, params16, training=True, dropout=dropout)
+    logits2 = rt2.forward(video, params, params16, training=True, dropout=dropout, rows_form=2)
     grads2 = torch.zeros_like(params)
     rt2.backward(dlogits, params, params16, grads2, accumulate=False)
     assert rel_l2(logits2, logits) < 1e-5, (tag, "cls-rows form: logits")
@@ -92,7 +87,7 @@ def _run_case_full_rows(engine, tag, cfgdict, seeds, B, dropout):
     params16 = params.to(torch.bfloat16)
     rt = engine.VitRuntime(cfg)
     video = ref_cpu.fmri_to_video(fmri.cuda())
-    logits = rt.forward(video, params, params16, training=True, dropout=dropout)
+    logits = rt.forward(video, params, params16, training=True, dropout=dropout, rows_form=1)
 
     # ---- oracles: bf16-emulating (same cast points) and exact fp32, both with autograd for the gradients
     def oracle(emulate):
@@ -295,6 +290,32 @@ def test_inference_mode_matches_training_forward(eng):
     assert torch.equal(b, c)           # run-to-run deterministic
 
 
+def test_cls_rows_form_is_never_taken_with_dropout(eng):
+    """The weight-streaming kernels of the cls-rows form apply no dropout.  A train-mode forward that records no graph still runs
+    with the block dropout on (the frozen encoder of the 4D model under Trainer.train: Trainer.py:59, config4D.yaml TRAINING_DROPOUT
+    0.2), so it must take the all-rows path whatever form is asked for: bit-identical logits for rows_form 1 and 2, with dropout,
+    training workspace or not - and different from the dropout-free logits (the masks really are applied at every site)."""
+    cfgdict = dict(W.MICRO)
+    sd = W.make_tensors(W.vit_param_spec(**cfgdict), 1)
+    cfg, off, num, arena = load_arena(eng, cfgdict, sd)
+    params = arena.cuda()
+    p16 = params.bfloat16()
+    rt = eng.VitRuntime(cfg)
+    video = ref_cpu.fmri_to_video(W.make_volume((3, 32, 32, 32), 9).cuda())
+    drop = (0.2, 0.2, 424242)
+    for training in (False, True):
+        a = rt.forward(video, params, p16, training=training, dropout=drop, rows_form=1).clone()
+        b = rt.forward(video, params, p16, training=training, dropout=drop, rows_form=2).clone()
+        assert torch.equal(a, b), training
+    clean = rt.forward(video, params, p16, training=False, rows_form=2)
+    assert not torch.equal(clean, a)
+    # and without dropout the two forms agree to fp32 rounding, training or not
+    for training in (False, True):
+        a = rt.forward(video, params, p16, training=training, rows_form=1).clone()
+        b = rt.forward(video, params, p16, training=training, rows_form=2)
+        assert rel_l2(b, a) < 1e-5
+
+
 def test_base_config_properties(eng):
     """BASELINE.json configs[1] at full size (128^3, p16, d768, L12, h12, B=4): size-independent properties.
     (a) determinism, (b) batch independence: volume b's logits do not depend on its batch neighbours,
@@ -350,3 +371,59 @@ def test_fp8_inference_forward_vs_fp8_emulating_oracle(eng):
     report(f"fp8 forward (micro, depth 3): HIP vs fp32 {e_hip:.3e}; fp8 emulation vs fp32 {e_emu:.3e}; HIP vs emulation {e_pair:.3e}; bf16 path vs fp32 {e_bf:.3e}")
     assert e_hip <= RATIO * e_emu + 5e-3 and e_hip < 6e-2
     assert e_pair < 6e-2
+
+
+LARGE = dict(image_size=128, image_patch_size=8, frames=128, frame_patch_size=8, num_classes=2, dim=1024,
+             heads=16, mlp_dim=4096, channels=1, dim_head=64, pool="cls")
+
+
+def test_fp8_forward_large_geometry_depth2_vs_fp8_emulating_oracle(eng):
+    """BASELINE.json configs[4] ("ViT3D-large ... fp8 MFMA") at ITS geometry - 128^3, patch 8 -> n = 4097 tokens, dim 1024, 16 heads,
+    mlp 4096 - depth cut to 2 so the CPU oracles finish: the fp8 inference forward of one volume three-way against the fp8-emulating
+    oracle (same e4m3 cast points, per-row weight scales, calibrated activation scales) and the fp32 oracle.  Tolerance as in
+    test_fp8_inference_forward_vs_fp8_emulating_oracle: no further from fp32 than the emulation of its own arithmetic x 1.5 + 5e-3."""
+    cfgdict = dict(LARGE, depth=2)
+    sd = W.make_tensors(W.vit_param_spec(**cfgdict), 13)
+    cfg, off, num, arena = load_arena(eng, cfgdict, sd)
+    params = arena.cuda()
+    p16 = params.bfloat16()
+    rt = eng.VitRuntime(cfg)
+    fmri = W.make_volume((1, 128, 128, 128), 14)
+    video = ref_cpu.fmri_to_video(fmri.cuda())
+    scales = rt.calibrate_fp8(video, params, p16)
+    f8 = rt.quantize_fp8(params, scales)
+    a = rt.forward_fp8(video, params, p16, f8).clone()
+    assert torch.equal(a, rt.forward_fp8(video, params, p16, f8))
+    with torch.no_grad():
+        ocfg = ref_cpu.ViTCfg(**cfgdict)
+        v = ref_cpu.fmri_to_video(fmri)
+        ref32 = ref_cpu.vit_forward(sd, ocfg, v)
+        emu8 = ref_cpu.vit_forward(sd, ocfg, v, emulate_bf16=True, fp8_scales=scales)
+    e_hip, e_emu, e_pair = rel_err(a, ref32), rel_err(emu8, ref32), rel_err(a, emu8)
+    report(f"fp8 forward (large geometry, depth 2, n = 4097): HIP vs fp32 {e_hip:.3e}; fp8 emulation vs fp32 {e_emu:.3e}; HIP vs emulation {e_pair:.3e}")
+    assert e_hip <= RATIO * e_emu + 5e-3 and e_hip < 6e-2
+    assert e_pair < 6e-2
+
+
+def test_fp8_forward_large_full_depth_batch4_properties(eng):
+    """configs[4] at FULL size (depth 24, batch 4) in fp8: run-to-run determinism, batch independence bit for bit (volume 2 alone
+    == volume 2 in the batch), finite logits, and agreement with the bf16 forward of the same weights at the e4m3 noise level."""
+    cfgdict = dict(LARGE, depth=24)
+    sd = W.make_tensors(W.vit_param_spec(**cfgdict), 41)
+    cfg, off, num, arena = load_arena(eng, cfgdict, sd)
+    params = arena.cuda()
+    p16 = params.bfloat16()
+    rt = eng.VitRuntime(cfg)
+    fmri = W.make_volume((4, 128, 128, 128), 42)
+    video = ref_cpu.fmri_to_video(fmri.cuda())
+    scales = rt.calibrate_fp8(video[:2], params, p16)
+    f8 = rt.quantize_fp8(params, scales)
+    a = rt.forward_fp8(video, params, p16, f8).clone()
+    b = rt.forward_fp8(video, params, p16, f8).clone()
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    single = rt.forward_fp8(ref_cpu.fmri_to_video(fmri[2:3].cuda()), params, p16, f8)
+    assert torch.equal(single[0], a[2])
+    bf = rt.forward(video, params, p16, training=False)
+    e = rel_err(a, bf)
+    report(f"fp8 forward (large, depth 24, batch 4) vs bf16 forward: rel {e:.3e}")
+    assert e < 0.15           # 24 blocks of e4m3 operand noise on two small logits (depth-3 micro: 1.6e-2 vs fp32)

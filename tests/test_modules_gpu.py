@@ -281,6 +281,34 @@ def test_trainer_shell_runs_an_epoch_and_writes_reference_style_checkpoints(nv, 
     assert 0.0 <= a <= 100.0
 
 
+def test_fp8_weights_follow_the_fused_optimizer(nv):
+    """enable_fp8 -> train steps with the fused AdamW (which rewrites the arena through raw pointers: no tensor _version moves)
+    -> eval forward: the e4m3 weights must be re-quantised from the UPDATED parameters.  Logits after the steps equal those of a
+    fresh quantisation with the same activation scales, and differ from the stale ones."""
+    from neurovit_amd.trainer import TrainStep
+    model = _micro_model(nv, lr=5e-3)
+    vit = model.volume_encoder.vit3d
+    x = W.make_volume((4, 32, 32, 32), 60).cuda()
+    y = torch.tensor([0, 1, 1, 0], device="cuda")
+    video = x.permute(0, 3, 1, 2).unsqueeze(1)
+    model.eval()
+    with torch.no_grad():
+        scales = vit.enable_fp8(video)
+        stale = model(x).clone()
+    model.train()
+    step = TrainStep(model)
+    for _ in range(3):
+        step(x, y)
+    model.eval()
+    with torch.no_grad():
+        after = model(x).clone()                                 # must notice the optimizer's update
+        arena, _ = vit.flat_parameters()
+        vit._fp8 = dict(vit._rt.quantize_fp8(arena, scales), key=vit._param_key())
+        fresh = model(x).clone()
+    assert torch.equal(after, fresh)
+    assert not torch.equal(after, stale)
+
+
 def test_gradient_accumulation_matches_one_big_step(nv):
     """TrainStep(accumulation_steps=2) on two half batches == the sum of gradients (the reference's commented block,
     Trainer.py:82-86, steps every N iterations WITHOUT dividing the loss)."""
@@ -359,15 +387,15 @@ def test_neuro4d_full_size_config(nv):
         assert torch.equal(v, model.state_dict()[k])
     model.temporal_transformer.eval()                             # deterministic head (its torch-default dropout 0.1 off)
     g = torch.Generator().manual_seed(7)
-    x = torch.randn(2, S, S, S, T, generator=g).cuda()
+    x = torch.randn(4, S, S, S, T, generator=g).cuda()           # config4D.yaml: TRAINING_ACCUMULATION_STEP 4 (671 MB of samples)
     out = model(x)
-    assert out.shape == (2, 2) and torch.isfinite(out).all()
+    assert out.shape == (4, 2) and torch.isfinite(out).all()
     with torch.no_grad():
         # (.contiguous(): a T-strided view would take the scalar gather path, whose LayerNorm sums are ordered differently)
         per_volume = torch.stack([model.volume_encoder(x[0, ..., t].contiguous()[None]) for t in (0, 7, 19)])[:, 0]
-        batched = model.volume_encoder(x.permute(0, 4, 1, 2, 3).reshape(2 * T, S, S, S))
+        batched = model.volume_encoder(x[:2].permute(0, 4, 1, 2, 3).reshape(2 * T, S, S, S))
         assert torch.equal(per_volume, batched[[0, 7, 19]])       # batch independence at M = 20 * 513 rows
-    y = torch.tensor([0, 1], device="cuda")
+    y = torch.tensor([0, 1, 1, 0], device="cuda")
     crit = torch.nn.CrossEntropyLoss()
     model.zero_grad()
     crit(out, y).backward()
@@ -375,8 +403,8 @@ def test_neuro4d_full_size_config(nv):
     assert whole and all(k.startswith(("temporal_transformer.", "projection_head.")) for k in whole)
     assert all(q.grad is None for q in model.volume_encoder.parameters())
     model.zero_grad()
-    for b in range(2):                                            # accumulation over single samples (sum of per-sample mean losses / 2)
-        (crit(model(x[b:b + 1]), y[b:b + 1]) / 2).backward()
+    for b in range(4):                                            # accumulation over 4 single samples, as config4D.yaml asks (sum of per-sample mean losses / 4)
+        (crit(model(x[b:b + 1]), y[b:b + 1]) / 4).backward()
     for k, q in model.named_parameters():
         if q.requires_grad:
             assert torch.allclose(q.grad, whole[k], rtol=1e-4, atol=1e-6), k

@@ -72,3 +72,84 @@ def test_gradsync_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2]: DP over 8 ranks, 7 gradient buckets, bf16 messages (bench.py's defaults at N = 8), rehearsed on the
+# CPU over gloo with the REAL bucket plan of a depth-12 encoder (14 backward stages -> 7 buckets of two, arena ranges from the
+# library's nv_vit_stage_param_range; host-side calls only).  Checked: the buckets tile the arena exactly once; the 8-way sum of
+# bf16 messages stays within the stated bound of the fp32 sum; every rank ends with bit-identical values.
+DP8_CFG = dict(image_size=32, image_patch_size=8, frames=32, frame_patch_size=8, num_classes=2, dim=96, depth=12, heads=2,
+               mlp_dim=384, channels=1, dim_head=64)
+
+
+def _bucket_plan(n_buckets):
+    from neurovit_amd import engine
+    cfg = engine.make_config(**DP8_CFG)
+    rt = engine.VitRuntime(cfg)
+    _, _, total = engine.param_layout(cfg)
+    plan = [rt.stage_range(f, l) for f, l in bucket_stages(DP8_CFG["depth"] + 2, n_buckets)]
+    return plan, total
+
+
+def test_bucket_plan_tiles_the_arena_exactly_once():
+    for nb in (1, 4, 7, 14):
+        plan, total = _bucket_plan(nb)
+        cover = torch.zeros(total, dtype=torch.int32)
+        for b, e in plan:
+            assert 0 <= b < e <= total
+            cover[b:e] += 1
+        assert int(cover.min()) == 1 and int(cover.max()) == 1, nb
+        # backward order: the head's range (arena tail) first, the embedding's (arena head) last
+        assert plan[0][1] == total and plan[-1][0] == 0
+
+
+def _worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan, total = _bucket_plan(7)
+        gen = torch.Generator().manual_seed(1234 + rank)
+        grads = torch.randn(total, generator=gen) * (10.0 ** torch.randint(-3, 2, (total,), generator=gen).float())   # five decades of magnitude
+        exact = grads.double().clone()
+        dist.all_reduce(exact)                                    # the sum as float64 messages
+        abs_sum = grads.abs().double()
+        dist.all_reduce(abs_sum)
+        sync = GradSync(None, n_buckets=7, comm_dtype=torch.bfloat16)
+        assert sync.world == 8
+        sync.begin()
+        for b, e in plan:
+            sync.bucket_ready(grads, b, e)
+        sync.finish()
+        assert sync.bytes_reduced == total * 2                    # every element sent once, as bf16
+        err = (grads.double() - exact).abs()
+        # stated bound: each rank's message is rounded to bf16 (8 significant bits: unit roundoff 2^-8) and each of the 7 additions
+        # of the reduction rounds its partial sum to bf16 again: |error| <= 8 * 2^-8 * sum_i |g_i| = 2^-5 * sum_i |g_i| per element
+        bound = 2.0 ** -5 * abs_sum + 1e-30
+        worst = float((err / bound).max())
+        rms = float(err.norm() / exact.norm())
+        same = [torch.empty_like(grads) for _ in range(world)]
+        dist.all_gather(same, grads)
+        identical = all(torch.equal(same[0], t) for t in same)
+        q.put((rank, worst, rms, identical))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradsync_gloo_world8_bf16_messages_7_buckets():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(8))
+    for rank, worst, rms, identical in res:
+        assert identical, "replicas diverged"
+        assert worst <= 1.0, (rank, worst)                        # within the stated elementwise bound
+        assert rms < 2.0 ** -7, (rank, rms)                       # and far inside it on average (relative L2 of the whole arena)

@@ -1,18 +1,74 @@
 #!/usr/bin/env python3
-"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/<tag>_pmc_hbm_traffic.csv and
-profiles/<tag>_pmc_traffic.json (read by bench.py for roofline.traffic).
+"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/<tag>_pmc_hbm_traffic.csv (one row per
+kernel instantiation) and profiles/<tag>_pmc_traffic.json (per nv_prof kind; read by bench.py for roofline.traffic).
 
     python tools/pmc_traffic_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <tag>
 
 FETCH_SIZE / WRITE_SIZE are derived counters in kilobytes (x 1024 bytes here); MI355X_MICROARCH.md (HBM / rocprofv3 section)
 prescribes doubling FETCH_SIZE on gfx950 for wide coalesced reads.  The calibration line printed at the end (adamw_kernel:
 16 B/param read, 14 B/param written) checks both the unit and the correction on every run.
+
+Kernel names are keyed by their full template instantiation: a leading `void ` and the trailing argument list are dropped,
+`(anonymous namespace)::` is kept out of the key (round 2 split names at the FIRST parenthesis, which collapsed every kernel of
+an anonymous namespace - gemm_pp_kernel<...>, gemm_pp_grouped_tn_kernel, the skinny kernels - into the rows "void " and "").
 """
 import collections
 import csv
 import json
 import os
+import re
 import sys
+
+
+def kernel_key(name: str) -> str:
+    """'void (anonymous namespace)::gemm_pp_kernel<256, 128, 4, 2, false, true, 6>(GemmArgs)' -> 'gemm_pp_kernel<256, 128, 4, 2, false, true, 6>'"""
+    s = name.strip()
+    if s.endswith(")"):                      # strip the final balanced argument list
+        depth, i = 0, len(s) - 1
+        while i >= 0:
+            if s[i] == ")":
+                depth += 1
+            elif s[i] == "(":
+                depth -= 1
+                if depth == 0:
+                    break
+            i -= 1
+        if i > 0:
+            s = s[:i]
+    if s.startswith("void "):
+        s = s[5:]
+    return s.replace("(anonymous namespace)::", "").strip()
+
+
+# kernel instantiation -> nv_prof kind (include/neurovit_hip.h, nv_prof_enable): the same classes bench.py's roofline leg times
+def kind_of(key: str):
+    def tn(m, base):
+        a_t, b_t = m.group(1) == "true", m.group(2) == "true"
+        return base + (2 if a_t else (1 if b_t else 0))
+    m = re.match(r"gemm_ws_kernel<\d+, \d+, \d+, \d+, (true|false), (true|false), \d+>", key)
+    if m:
+        return tn(m, 0)
+    if key.startswith("gemm_ws_grouped_kernel"):
+        return 2
+    m = re.match(r"gemm_pp_kernel<\d+, \d+, \d+, \d+, (true|false), (true|false), \d+(, (true|false))?>", key)
+    if m:
+        return 5 if m.group(4) == "true" else tn(m, 10)
+    if key.startswith("gemm_pp_f8_kernel"):
+        return 5
+    if key.startswith("gemm_pp_grouped_tn_kernel"):
+        return 13
+    m = re.match(r"gemm_pq_kernel<(true|false), (true|false), \d+(, (true|false))?>", key)
+    if m:
+        return 5 if m.group(4) == "true" else tn(m, 20)
+    if key.startswith("attn_fwd"):
+        return 3
+    if key.startswith("attn_bwd"):
+        return 4
+    if key.startswith("gemm_f32_nt_kernel"):
+        return 30
+    if key.startswith("attn_f32_fwd_kernel"):
+        return 31
+    return None
 
 
 def load(path, counter):
@@ -20,7 +76,7 @@ def load(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        k = r["Kernel_Name"].split("(")[0]
+        k = kernel_key(r["Kernel_Name"])
         d = per.setdefault(k, [0, 0.0])
         d[0] += 1
         d[1] += float(r["Counter_Value"])
@@ -40,18 +96,37 @@ def main():
     with open(out_csv, "w") as f:
         f.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras`\n")
         f.write("# fetch corrected x2 as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; calibration: adamw_kernel = 16 B read + 14 B written per parameter (88.58 M)\n")
-        f.write("kernel,launches,fetch_MB_per_launch_corrected,write_MB_per_launch\n")
+        f.write("kernel,nv_prof_kind,launches,fetch_MB_per_launch_corrected,write_MB_per_launch\n")
         for k, n, fm, wm in rows:
-            f.write(f"\"{k}\",{n},{fm:.3f},{wm:.3f}\n")
-    gem = [r for r in rows if "gemm_" in r[0]]
-    n = sum(r[1] for r in gem)
-    fm = sum(r[2] * r[1] for r in gem) / n
-    wm = sum(r[3] * r[1] for r in gem) / n
-    js = {"kernel": "gemm_*_kernel (all instantiations)", "launches": n, "fetch_MB_per_launch": round(fm, 2), "write_MB_per_launch": round(wm, 2),
-          "traffic_MB_per_launch": round(fm + wm, 2),
-          "source": f"profiles/{tag}_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; fetch x2 gfx950 correction; counts fabric requests incl. Infinity-Cache hits)"}
+            kd = kind_of(k)
+            f.write(f"\"{k}\",{'' if kd is None else kd},{n},{fm:.3f},{wm:.3f}\n")
+    steps = next((n for k, n, _, _ in rows if k.startswith("adamw_kernel")), None)          # one AdamW launch per train step
+    by_kind = {}
+    for k, n, fm, wm in rows:
+        kd = kind_of(k)
+        if kd is None:
+            continue
+        d = by_kind.setdefault(kd, dict(launches=0, fetch_MB=0.0, write_MB=0.0, kernels=[]))
+        d["launches"] += n
+        d["fetch_MB"] += fm * n
+        d["write_MB"] += wm * n
+        d["kernels"].append(k)
+    for d in by_kind.values():
+        d["fetch_MB_per_launch"] = round(d.pop("fetch_MB") / d["launches"], 3)
+        d["write_MB_per_launch"] = round(d.pop("write_MB") / d["launches"], 3)
+        d["launches_per_step"] = None if not steps else round(d["launches"] / steps, 2)
+    gem = [d for kd, d in by_kind.items() if kd in (0, 1, 2, 10, 11, 12, 13, 20, 21, 22)]
+    n = sum(d["launches"] for d in gem)
+    fm = sum(d["fetch_MB_per_launch"] * d["launches"] for d in gem) / max(n, 1)
+    wm = sum(d["write_MB_per_launch"] * d["launches"] for d in gem) / max(n, 1)
+    js = {"kernel": "bf16 MFMA GEMM family (nv_prof kinds 0-2, 10-13, 20-22): gemm_ws_kernel<...>, gemm_pp_kernel<...>, gemm_pp_grouped_tn_kernel, gemm_pq_kernel<...>",
+          "steps_profiled": steps, "launches": n, "launches_per_step": None if not steps else round(n / steps, 2),
+          "fetch_MB_per_launch": round(fm, 2), "write_MB_per_launch": round(wm, 2), "traffic_MB_per_launch": round(fm + wm, 2),
+          "by_kind": {str(k): v for k, v in sorted(by_kind.items())},
+          "source": f"profiles/{tag}_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+                    "--no-extras`; fetch x2 gfx950 correction; counts fabric requests incl. Infinity-Cache hits)"}
     json.dump(js, open(os.path.join(root, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
-    print(json.dumps(js))
+    print(json.dumps({k: v for k, v in js.items() if k != "by_kind"}))
     for k, nn, a, b in rows:
         if k.startswith("adamw"):
             print(f"calibration adamw_kernel: read {a:.1f} MB (expect {16 * 88.58:.1f}), written {b:.1f} MB (expect {14 * 88.58:.1f})")

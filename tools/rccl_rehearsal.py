@@ -35,6 +35,7 @@ def main():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     x = torch.randn(4, 128, 128, 128, device="cuda")
     y = torch.tensor([0, 1, 1, 0], device="cuda")
+    timed = int(os.environ.get("REHEARSAL_TIMED_STEPS", "20"))
     ref = TrainStep(build())
     losses_ref = [float(ref(x, y)) for _ in range(4)]
     for dtype in (torch.float32, torch.bfloat16):
@@ -50,14 +51,14 @@ def main():
         losses = [float(step(x, y)) for _ in range(4)]
         torch.cuda.synchronize()
         t = time.perf_counter()
-        for _ in range(20):
+        for _ in range(timed):
             step(x, y)
-        host_ms = (time.perf_counter() - t) / 20 * 1e3
+        host_ms = (time.perf_counter() - t) / timed * 1e3
         dist.barrier()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t) / 20 * 1e3
+        ms = (time.perf_counter() - t) / timed * 1e3
         print(f"{dtype}: host enqueue {host_ms:.3f} ms/step; losses {['%.5f' % v for v in losses]} (reference {['%.5f' % v for v in losses_ref]}), {ms:.3f} ms/step, "
-              f"{step.sync.bytes_reduced / 24 / 1e6:.0f} MB reduced per step")
+              f"{step.sync.bytes_reduced / (4 + timed) / 1e6:.0f} MB reduced per step")
         tol = 0 if dtype == torch.float32 else 5e-2
         assert all(abs(a - b) <= tol * max(1.0, abs(b)) for a, b in zip(losses, losses_ref)), "loss curve differs from the single-process run"
     dist.destroy_process_group()
