@@ -27,73 +27,100 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __bui
 __device__ __forceinline__ float gelu_exact(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
 
 // ------------------------------------------------------------------------------------------------ GEMM
-// Wave tile (16 WM) x (16 WN), workgroup = 2 x 2 waves.  EPI: 0 store, 2 + bias, 3 gelu(+ bias), 4 resid + (+ bias).
-// ALIGNED: lda, ldb multiples of 4, 16-byte aligned bases, K % 4 == 0 (float4 operand loads); otherwise scalar loads with
-// per-element bounds (the reference's default patch_dim 729 = 9^3, configs/config.yaml:39-40).
+// Workgroup tile (32 WM) x (32 WN) x 32, 2 x 2 waves of (16 WM) x (16 WN).  EPI: 0 store, 2 + bias, 3 gelu(+ bias), 4 resid + (+ bias).
+// Operands are staged through LDS in whole 128-byte lines (eight lanes per row: 8 x 16 B), one register set in flight under the
+// MFMAs of the current step, two LDS buffers, one barrier per 32-deep step.  (First built with the fragments loaded straight from
+// global memory - no LDS, no barrier: 37 % of the fp32 MFMA peak.  A fragment-shaped load touches 16 rows x 64 B = sixteen half
+// cache lines per instruction, and the CU's one L1 / TA path serves four SIMDs: address-path time per MFMA time came out as
+// (WM + WN) / (WM WN) = 1 for the 2 x 2 tile the load balance wants.  Through LDS every line is fetched once per workgroup, whole.)
+// ALIGNED: lda, ldb multiples of 4, 16-byte aligned bases, K % 4 == 0 (float4 loads); otherwise scalar loads with per-element
+// bounds (the reference's default patch_dim 729 = 9^3, configs/config.yaml:39-40).
+constexpr int F32_BK = 32, F32_LD = F32_BK + 4;      // LDS row pitch in floats: 144 B = 9 x 16 B, sixteen rows hit sixteen different 16-byte bank groups
 template <int WM, int WN, int EPI, bool ALIGNED>
 __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(int M, int N, int K, const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb,
                                                           float* __restrict__ C, long ldc, const float* __restrict__ bias,
                                                           const float* __restrict__ resid, long ldr, int tiles_n) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  extern __shared__ __attribute__((aligned(16))) float fsm[];      // [2][(BM + BN)][F32_LD]
+  constexpr int BUF = (BM + BN) * F32_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m0 = tm * BM + (wid >> 1) * 16 * WM, n0 = tn * BN + (wid & 1) * 16 * WN;
-  if (m0 >= M || n0 >= N) return;            // whole wave outside (no barriers in this kernel)
-  const int i = lane & 15, g = lane >> 4;
+  const int m0 = tm * BM, n0 = tn * BN;
+  // staging: thread -> (row t / 8 + 32 u, chunk t % 8): eight lanes read one whole 128-byte line of a row
+  const int srow = tid >> 3, sch = tid & 7;
   const float* ap[WM];
   const float* bp[WN];
 #pragma unroll
-  for (int bm = 0; bm < WM; ++bm) { const int r = min(m0 + 16 * bm + i, M - 1); ap[bm] = A + (long)r * lda + 4 * g; }
+  for (int u = 0; u < WM; ++u) ap[u] = A + (long)min(m0 + srow + 32 * u, M - 1) * lda + 4 * sch;
 #pragma unroll
-  for (int bn = 0; bn < WN; ++bn) { const int r = min(n0 + 16 * bn + i, N - 1); bp[bn] = B + (long)r * ldb + 4 * g; }
-  f32x4 acc[WM][WN];
-#pragma unroll
-  for (int bm = 0; bm < WM; ++bm)
-#pragma unroll
-    for (int bn = 0; bn < WN; ++bn) acc[bm][bn] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 af[2][WM], bf[2][WN];
-  auto ld4 = [&](const float* p, int k0) -> f32x4 {     // elements k0 + 4g .. + 3 of the lane's row, zero beyond K
-    const int k = k0 + 4 * g;
+  for (int u = 0; u < WN; ++u) bp[u] = B + (long)min(n0 + srow + 32 * u, N - 1) * ldb + 4 * sch;
+  f32x4 ra[WM], rb[WN];
+  auto ld4 = [&](const float* p, int k0) -> f32x4 {     // elements k0 + 4 sch .. + 3 of the thread's row, zero beyond K
+    const int k = k0 + 4 * sch;
     if constexpr (ALIGNED) return (k < K) ? *reinterpret_cast<const f32x4*>(p + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (k + e < K) ? p[k0 + e] : 0.f;
     return v;
   };
-  auto load = [&](int buf, int k0) {
+  auto gload = [&](int k0) {
 #pragma unroll
-    for (int bm = 0; bm < WM; ++bm) af[buf][bm] = ld4(ap[bm], k0);
+    for (int u = 0; u < WM; ++u) ra[u] = ld4(ap[u], k0);
 #pragma unroll
-    for (int bn = 0; bn < WN; ++bn) bf[buf][bn] = ld4(bp[bn], k0);
+    for (int u = 0; u < WN; ++u) rb[u] = ld4(bp[u], k0);
   };
-  auto compute = [&](int buf) {
+  auto swrite = [&](float* buf) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int u = 0; u < WM; ++u) *reinterpret_cast<f32x4*>(buf + (srow + 32 * u) * F32_LD + 4 * sch) = ra[u];
 #pragma unroll
-      for (int bm = 0; bm < WM; ++bm)
-#pragma unroll
-        for (int bn = 0; bn < WN; ++bn) acc[bm][bn] = mfma4(bf[buf][bn][t], af[buf][bm][t], acc[bm][bn]);
+    for (int u = 0; u < WN; ++u) *reinterpret_cast<f32x4*>(buf + (BM + srow + 32 * u) * F32_LD + 4 * sch) = rb[u];
   };
-  const int nk = (K + 15) >> 4;
-  load(0, 0);
-  for (int s = 0; s < nk; s += 2) {
-    load(1, (s + 1) * 16);                   // beyond K: zeros, no memory access
-    compute(0);
-    if (s + 1 < nk) {
-      load(0, (s + 2) * 16);
-      compute(1);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int i = lane & 15, g = lane >> 4;
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int bm = 0; bm < WM; ++bm)
+#pragma unroll
+    for (int bn = 0; bn < WN; ++bn) acc[bm][bn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](const float* buf) {
+    const float* a0 = buf + (wm * 16 * WM + i) * F32_LD + 4 * g;
+    const float* b0 = buf + (BM + wn * 16 * WN + i) * F32_LD + 4 * g;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 af[WM], bf[WN];
+#pragma unroll
+      for (int bm = 0; bm < WM; ++bm) af[bm] = *reinterpret_cast<const f32x4*>(a0 + 16 * bm * F32_LD + 16 * ks);
+#pragma unroll
+      for (int bn = 0; bn < WN; ++bn) bf[bn] = *reinterpret_cast<const f32x4*>(b0 + 16 * bn * F32_LD + 16 * ks);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int bm = 0; bm < WM; ++bm)
+#pragma unroll
+          for (int bn = 0; bn < WN; ++bn) acc[bm][bn] = mfma4(bf[bn][t], af[bm][t], acc[bm][bn]);
     }
+  };
+  const int nk = (K + F32_BK - 1) / F32_BK;
+  gload(0);
+  swrite(fsm);
+  __syncthreads();
+  for (int s = 0; s < nk; ++s) {
+    float* cur = fsm + (s & 1) * BUF;
+    if (s + 1 < nk) gload((s + 1) * F32_BK);           // in flight under this step's MFMAs
+    compute(cur);
+    if (s + 1 < nk) swrite(fsm + ((s + 1) & 1) * BUF);  // that buffer was last read in step s - 1: every wave has passed its barrier
+    __syncthreads();
   }
-  // lane (j, q), register r of block (bm, bn) holds C[m0 + 16 bm + j][n0 + 16 bn + 4 q + r]
+  // lane (j, q), register r of block (bm, bn) holds C[m0 + 16 (WM wm + bm) + j][n0 + 16 (WN wn + bn) + 4 q + r]
   const int j = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int bm = 0; bm < WM; ++bm) {
-    const int row = m0 + 16 * bm + j;
+    const int row = m0 + 16 * (WM * wm + bm) + j;
     if (row >= M) continue;
 #pragma unroll
     for (int bn = 0; bn < WN; ++bn) {
-      const int col = n0 + 16 * bn + 4 * q;
+      const int col = n0 + 16 * (WN * wn + bn) + 4 * q;
       if (col >= N) continue;                // N % 4 == 0: whole float4 in or out
       f32x4 v = acc[bm][bn];
       if constexpr (EPI >= 2) v += *reinterpret_cast<const f32x4*>(bias + col);
@@ -104,23 +131,72 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(int M, int N, int K, c
   }
 }
 
-// tile choice: the machine has 1024 SIMDs and every wave tile is an indivisible unit of matrix-pipe time, so what counts is the
-// fill of the last round; larger wave tiles load fewer operand bytes per FLOP and win ties.
-struct TileChoice { int wm, wn; };
-TileChoice pick_tile(int M, int N) {
-  static const int cand[4][2] = {{4, 4}, {2, 4}, {4, 2}, {2, 2}};
-  double best = -1.0;
-  TileChoice c{2, 2};
-  for (int t = 0; t < 4; ++t) {
-    const int wm = cand[t][0], wn = cand[t][1];
-    const long waves = 4L * ((M + 32 * wm - 1) / (32 * wm)) * ((N + 32 * wn - 1) / (32 * wn));
-    const long useful = (long)((M + 15) / 16) * ((N + 15) / 16);               // 16 x 16 blocks that hold output
-    const long rounds = (waves + 1023) / 1024;
-    const double eff = (double)useful / ((double)rounds * 1024.0 * wm * wn);   // useful blocks per block slot of the rounds taken
-    const double score = eff * (1.0 + 0.02 * (wm * wn) / 16.0);                // ties go to the larger tile
-    if (score > best) { best = score; c = TileChoice{wm, wn}; }
+// A few rows (the cls rows of the last block: M = batch): weight streaming.  One wave per output column, lanes across K in 16-byte
+// pieces, up to SK_ROWS rows of A accumulated per pass; fp32 FMAs, fixed-order wave reduction.
+constexpr int SK_ROWS = 8;
+template <int EPI, bool ALIGNED>
+__global__ __launch_bounds__(256) void skinny_f32_nt_kernel(int M, int N, int K, const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb,
+                                                            float* __restrict__ C, long ldc, const float* __restrict__ bias,
+                                                            const float* __restrict__ resid, long ldr) {
+  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* w = B + (long)n * ldb;
+  for (int r0 = 0; r0 < M; r0 += SK_ROWS) {
+    float acc[SK_ROWS];
+#pragma unroll
+    for (int r = 0; r < SK_ROWS; ++r) acc[r] = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+      f32x4 wv;
+      if constexpr (ALIGNED) wv = *reinterpret_cast<const f32x4*>(w + k);
+      else { for (int e = 0; e < 4; ++e) wv[e] = (k + e < K) ? w[k + e] : 0.f; }
+#pragma unroll
+      for (int r = 0; r < SK_ROWS; ++r) {
+        if (r0 + r < M) {
+          const float* a = A + (long)(r0 + r) * lda + k;
+          f32x4 av;
+          if constexpr (ALIGNED) av = *reinterpret_cast<const f32x4*>(a);
+          else { for (int e = 0; e < 4; ++e) av[e] = (k + e < K) ? a[e] : 0.f; }
+          acc[r] = __builtin_fmaf(av[0], wv[0], __builtin_fmaf(av[1], wv[1], __builtin_fmaf(av[2], wv[2], __builtin_fmaf(av[3], wv[3], acc[r]))));
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < SK_ROWS; ++r) {
+      if (r0 + r < M) {
+        float v = wave_sum(acc[r]);
+        if (lane == 0) {
+          if constexpr (EPI >= 2) v += bias[n];
+          if constexpr (EPI == 3) v = gelu_exact(v);
+          if constexpr (EPI == 4) v += resid[(long)(r0 + r) * ldr + n];
+          C[(long)(r0 + r) * ldc + n] = v;
+        }
+      }
+    }
   }
-  return c;
+}
+
+// Tile choice between the 64 x 64 (2 x 2) and the 128 x 128 (4 x 4) workgroup tile, by a residency model calibrated on MI355X
+// (tools/gemm_f32_bench.py, profiles/r03_gemm_f32_shapes.log): a CU holds R workgroups at once (LDS: 4 of the small tile, 2 of the
+// large one), i.e. R waves per SIMD, and the matrix pipe's utilisation depends on how many waves share it - a lone 2 x 2 wave keeps
+// it 55 % busy, four keep it full; a lone 4 x 4 wave 48 %, two 100 % - so the time is the full rounds at residency R plus the tail
+// round at its own residency, times the tile's blocks per wave and its cost per block at full residency (1.30 / 1.12 of the MFMA
+// rate).  The 2 x 4 / 4 x 2 tiles never won a measured shape; they stay selectable for the tests.
+struct TileChoice { int wm, wn; };
+static double tile_cost(long wgs, int blocks_per_wave, int R, const double* f, double c) {
+  const double q = (double)wgs / 256.0;                 // workgroups per CU
+  const long full = (long)(q / R);
+  const double rem = q - (double)full * R;
+  int t = (int)(rem + 0.999999);
+  if (t > R) t = R;
+  double rounds = (double)full * R / f[R - 1];
+  if (t > 0) rounds += (double)t / f[t - 1];
+  return blocks_per_wave * c * rounds;
+}
+TileChoice pick_tile(int M, int N) {
+  static const double f22[4] = {0.55, 0.75, 0.90, 1.00}, f44[2] = {0.48, 1.00};
+  const long n22 = (long)((M + 63) / 64) * ((N + 63) / 64), n44 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const double c22 = tile_cost(n22, 4, 4, f22, 1.30), c44 = tile_cost(n44, 16, 2, f44, 1.12);
+  return c44 < c22 ? TileChoice{4, 4} : TileChoice{2, 2};
 }
 
 int g_force_wm = 0, g_force_wn = 0;   // tuning aid (nv_gemm_f32_set_tile)
@@ -130,7 +206,19 @@ void launch_gemm_f32(int epi, int M, int N, int K, const float* A, long lda, con
                      const float* resid, long ldr, hipStream_t s) {
   const int tiles_m = (M + 32 * WM - 1) / (32 * WM), tiles_n = (N + 32 * WN - 1) / (32 * WN);
   const dim3 grid(tiles_m * tiles_n), block(256);
-#define NV_F32_LAUNCH(E) hipLaunchKernelGGL((gemm_f32_nt_kernel<WM, WN, E, ALIGNED>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, resid, ldr, tiles_n)
+  constexpr size_t lds = (size_t)2 * (32 * WM + 32 * WN) * F32_LD * sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;              // per (WM, WN, ALIGNED) instantiation of this function: covers its four epilogues
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_nt_kernel<WM, WN, 0, ALIGNED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_nt_kernel<WM, WN, 2, ALIGNED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_nt_kernel<WM, WN, 3, ALIGNED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_nt_kernel<WM, WN, 4, ALIGNED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+  }
+#define NV_F32_LAUNCH(E) hipLaunchKernelGGL((gemm_f32_nt_kernel<WM, WN, E, ALIGNED>), grid, block, lds, s, M, N, K, A, lda, B, ldb, C, ldc, bias, resid, ldr, tiles_n)
   switch (epi) {
     case 0: NV_F32_LAUNCH(0); break;
     case 2: NV_F32_LAUNCH(2); break;
@@ -175,25 +263,47 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
   for (int s = 0; s < DHB; ++s) o[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_part = 0.f;     // l_part: this lane's share of the row sum (its own key columns)
   const int c4n = dh >> 2;                   // float4 chunks per row that exist
+  // staging of one 64-key tile: thread t handles elements t + 256 u (u < DHB) of K (key e / (4 DHB), chunk e % (4 DHB): whole rows
+  // per eight lanes) and of V (chunk e / 64, key e % 64: consecutive lanes = consecutive keys -> conflict-free transposed writes).
+  // The loads of tile k + 1 are in flight under the MFMAs of tile k (one register set).
+  f32x4 kreg[DHB], vreg[DHB];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < DHB; ++u) {
+      const int e = tid + 256 * u;
+      {
+        const int kk = e / (4 * DHB), c = e - kk * (4 * DHB);
+        const bool ok = (k0 + kk < n) && (c < c4n);
+        kreg[u] = ok ? *reinterpret_cast<const f32x4*>(base + (long)(k0 + kk) * ld + 4 * c + inner) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      {
+        const int c = e / ATK, kk = e - c * ATK;
+        const bool ok = (k0 + kk < n) && (c < c4n);
+        vreg[u] = ok ? *reinterpret_cast<const f32x4*>(base + (long)(k0 + kk) * ld + 4 * c + 2 * inner) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto swrite = [&]() {
+#pragma unroll
+    for (int u = 0; u < DHB; ++u) {
+      const int e = tid + 256 * u;
+      {
+        const int kk = e / (4 * DHB), c = e - kk * (4 * DHB);
+        *reinterpret_cast<f32x4*>(sk + kk * DHP + 4 * c) = kreg[u];
+      }
+      {
+        const int c = e / ATK, kk = e - c * ATK;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) svt[(4 * c + x) * KP + kk] = vreg[u][x];
+      }
+    }
+  };
+  gload(0);
   for (int k0 = 0; k0 < n; k0 += ATK) {
     __syncthreads();                         // previous tile consumed
-    // stage K (row-major) and V (transposed): chunk c of key kk
-    for (int e = tid; e < ATK * 4 * DHB; e += 256) {
-      const int kk = e / (4 * DHB), c = e - kk * (4 * DHB);
-      const bool ok = (k0 + kk < n) && (c < c4n);
-      const float* src = base + (long)min(k0 + kk, n - 1) * ld + 4 * c;
-      const f32x4 kv = ok ? *reinterpret_cast<const f32x4*>(src + inner) : f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(sk + kk * DHP + 4 * c) = kv;
-    }
-    for (int e = tid; e < ATK * 4 * DHB; e += 256) {
-      const int c = e / ATK, kk = e - c * ATK;          // consecutive lanes: consecutive keys -> conflict-free transposed writes
-      const bool ok = (k0 + kk < n) && (c < c4n);
-      const float* src = base + (long)min(k0 + kk, n - 1) * ld + 4 * c;
-      const f32x4 vv = ok ? *reinterpret_cast<const f32x4*>(src + 2 * inner) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int x = 0; x < 4; ++x) svt[(4 * c + x) * KP + kk] = vv[x];
-    }
+    swrite();
     __syncthreads();
+    if (k0 + ATK < n) gload(k0 + ATK);
     // S^T blocks: st[kb][r] = score of query j against key k0 + 16 kb + 4 g + r
     f32x4 st[4];
 #pragma unroll
@@ -284,6 +394,24 @@ extern "C" int nv_gemm_f32(int epi, int M, int N, int K, const float* A, long ld
   if (g_force_wm) t = TileChoice{g_force_wm, g_force_wn};
   hipStream_t s = (hipStream_t)stream;
   const int slot = nv_prof_begin(30, 2.0 * M * N * (double)K, stream);
+  if (M <= 2 * SK_ROWS && !g_force_wm) {          // a few rows: stream the weight once, one wave per output column
+    const dim3 grid((N + 3) / 4), block(256);
+#define NV_F32_SKINNY(E)                                                                                                              \
+    do {                                                                                                                              \
+      if (aligned) hipLaunchKernelGGL((skinny_f32_nt_kernel<E, true>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, resid, ldr);   \
+      else hipLaunchKernelGGL((skinny_f32_nt_kernel<E, false>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, resid, ldr);          \
+    } while (0)
+    switch (epi) {
+      case 0: NV_F32_SKINNY(0); break;
+      case 2: NV_F32_SKINNY(2); break;
+      case 3: NV_F32_SKINNY(3); break;
+      default: NV_F32_SKINNY(4); break;
+    }
+#undef NV_F32_SKINNY
+    nv_prof_end(slot, stream);
+    NV_CHECK_LAUNCH("nv_gemm_f32/skinny");
+    return NV_OK;
+  }
   nv_prof_bytes(slot, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (epi == 4 ? 2 : 1)));
 #define NV_F32_TILE(WM, WN)                                                                             \
   do {                                                                                                  \
