@@ -12,7 +12,8 @@ from typing import Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "neurovit_hip.h")
-LIB_PATH = os.path.join(_HERE, "lib", "libneurovit_hip.so")
+# NEUROVIT_HIP_LIB: another build of the same library (same-box A/B runs of two builds in one gpurun call: tools/_ab/); the tree's own otherwise
+LIB_PATH = os.environ.get("NEUROVIT_HIP_LIB") or os.path.join(_HERE, "lib", "libneurovit_hip.so")
 
 _SCALARS = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
 

@@ -214,11 +214,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   char* sK = smem;
   char* sV = smem + IMG;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const Grid2 gb = grid2d_xcd((n + TQ - 1) / TQ);                  // 1-D launch: whole heads per XCD
+  const int b = gb.by / heads, h = gb.by - b * heads, inner = heads * DH;
   const bf16* Q = qkv + (long)b * n * ld + h * DH;
   const bf16* K = Q + inner;
   const bf16* V = Q + 2 * inner;
-  const int q0 = blockIdx.x * TQ + 16 * wid;
+  const int q0 = gb.bx * TQ + 16 * wid;
   const int qrow = min(q0 + r, n - 1);
 
   bf16x8 qf[2];
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
       for (int t = 0; t < 4; ++t) { o0[t] = o[t]; o[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
-    fwd_tile<DROP>(sK, sV, kt, kt == nkt - 1, n, qf, o, m, l, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
+    fwd_tile<DROP>(sK, sV, kt, kt == nkt - 1, n, qf, o, m, l, scale_log2e, drop, gb.by, q0 + r, r, g);
   }
   if (nkt <= nh) {                       // single tile: the (empty) second state is merged all the same
     m0 = m; l0 = l; m = -INFINITY; l = 0.f;
@@ -297,10 +298,25 @@ __device__ __forceinline__ void res_dma(const bf16* X, long ld, int n, int nt, c
     lds_dma<16>(rs, img + t * IMG + wid * 1024, voff, t * step);
 }
 // this wave's 16-row group, or -1
-__device__ __forceinline__ int res_group(int n, int wid) {
+__device__ __forceinline__ int res_group(int n, int wid, int bx, int nblk) {
   const int groups = (n + 15) >> 4;
-  const int g0 = (int)((long)blockIdx.x * groups / gridDim.x), g1 = (int)((long)(blockIdx.x + 1) * groups / gridDim.x);
+  const int g0 = (int)((long)bx * groups / nblk), g1 = (int)((long)(bx + 1) * groups / nblk);
   return (g0 + wid < g1) ? g0 + wid : -1;
+}
+// workgroups per (batch, head) of the resident kernels
+__host__ __device__ __forceinline__ int attn_res_blocks(int n) { return (((n + 15) >> 4) + 7) / 8; }
+// The resident kernels run on a 1-D grid of nblk x (batch x heads) workgroups: consecutive block ids are dealt round-robin over the
+// eight XCDs, so a 2-D (nblk, batch x heads) grid put the nblk workgroups of ONE head on nblk different XCDs and every XCD's L2
+// fetched that head's K / V (or Q / dO) images separately (rocprofv3 FETCH_SIZE: 35-42 MB per launch against 10-20 MB of operands).
+// xcd_remap gives each XCD a contiguous run of logical ids, i.e. whole heads.
+struct ResBlock { int bx, by, nblk; };
+__device__ __forceinline__ ResBlock res_block(int n) {
+  ResBlock rb;
+  rb.nblk = attn_res_blocks(n);
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  rb.by = lid / rb.nblk;
+  rb.bx = lid - rb.by * rb.nblk;
+  return rb;
 }
 
 // SPLIT = 2: sixteen waves; waves w and w + 8 share a row group and take one half of the key tiles each (four waves per
@@ -313,12 +329,13 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = wid & 7, half = wid >> 3;          // half is 0 when SPLIT == 1
-  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const ResBlock rb = res_block(n);
+  const int b = rb.by / heads, h = rb.by - b * heads, inner = heads * DH;
   const bf16* Q = qkv + (long)b * n * ld + h * DH;
   const int nkt = (n + TK - 1) / TK;
   char* sK = rsmem;
   char* sV = rsmem + nkt * IMG;
-  const int grp = res_group(n, slot);
+  const int grp = res_group(n, slot, rb.bx, rb.nblk);
   const int q0 = (grp < 0 ? 0 : grp) * 16;
   const int qrow = min(q0 + r, n - 1);
   bf16x8 qf[2];
@@ -348,7 +365,7 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
       // four waves per SIMD hide the LDS latency by themselves; the plain tile step keeps the kernel within 128 VGPRs
       if (grp >= 0)
         for (int kt = k0; kt < k1; ++kt)
-          fwd_tile<DROP>(sK + kt * IMG, sV + kt * IMG, kt, kt == nkt - 1, n, qf, o1, m1, l1, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
+          fwd_tile<DROP>(sK + kt * IMG, sV + kt * IMG, kt, kt == nkt - 1, n, qf, o1, m1, l1, scale_log2e, drop, rb.by, q0 + r, r, g);
     } else if (grp >= 0 && k0 < k1) {
       // software pipeline: the V fragments of this tile and the K fragments of the next one are requested from LDS before the
       // softmax arithmetic, so the ds_read latency sits under ~130 VALU instructions instead of in front of the MFMAs
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
         load_tr_frags(sV + kt * IMG, r, g, VF);
         load_row_frags(sK + (kt + 1 < k1 ? kt + 1 : kt) * IMG, r, g, KF);
         __builtin_amdgcn_sched_barrier(0);
-        fwd_softmax<DROP>(sc, kt, kt == nkt - 1, n, o1, m1, l1, scale_log2e, drop, blockIdx.y, q0 + r, g);
+        fwd_softmax<DROP>(sc, kt, kt == nkt - 1, n, o1, m1, l1, scale_log2e, drop, rb.by, q0 + r, g);
         __builtin_amdgcn_sched_barrier(0);
         fwd_pv(VF, sc, o1);
       }
@@ -426,9 +443,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __res
   __shared__ __attribute__((aligned(16))) char wsmem[2 * 2 * IMG];      // [stage][K image | V image]
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const Grid2 gb = grid2d_xcd((n + WIDE_ROWS - 1) / WIDE_ROWS);                  // 1-D launch: whole heads per XCD
+  const int b = gb.by / heads, h = gb.by - b * heads, inner = heads * DH;
   const bf16* Q = qkv + (long)b * n * ld + h * DH;
-  const int q0 = blockIdx.x * WIDE_ROWS + 32 * wid;
+  const int q0 = gb.bx * WIDE_ROWS + 32 * wid;
 
   bf16x8 qf[2][2];
 #pragma unroll
@@ -484,8 +502,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __res
     __builtin_amdgcn_sched_barrier(0);
     load_tr_frags(cur + IMG, r, g, F);                    // V fragments requested before the softmax arithmetic
     __builtin_amdgcn_sched_barrier(0);
-    fwd_softmax<DROP>(s[0], kt, kt == nkt - 1, n, o[0], m[0], l[0], scale_log2e, drop, blockIdx.y, q0 + r, g);
-    fwd_softmax<DROP>(s[1], kt, kt == nkt - 1, n, o[1], m[1], l[1], scale_log2e, drop, blockIdx.y, q0 + 16 + r, g);
+    fwd_softmax<DROP>(s[0], kt, kt == nkt - 1, n, o[0], m[0], l[0], scale_log2e, drop, gb.by, q0 + r, g);
+    fwd_softmax<DROP>(s[1], kt, kt == nkt - 1, n, o[1], m[1], l[1], scale_log2e, drop, gb.by, q0 + 16 + r, g);
     __builtin_amdgcn_sched_barrier(0);
     fwd_pv(F, s[0], o[0]);
     fwd_pv(F, s[1], o[1]);
@@ -529,7 +547,6 @@ static bool attn_resident(int n) {
   const int nt = (n + TK - 1) / TK;
   return g_attn_mode != 1 && nt <= RES_MAX_TILES;
 }
-static int attn_res_blocks(int n) { return (((n + 15) >> 4) + 7) / 8; }
 template <typename Kern>
 static void attn_res_attr(Kern kern, int lds) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -562,24 +579,24 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
       attr = true;
     }
     if (g_attn_split == 2)
-      { if (dropping) hipLaunchKernelGGL((attn_fwd_res_kernel<2, true>), dim3(attn_res_blocks(n), B * heads), dim3(2 * RES_THREADS), lds, (hipStream_t)stream,
+      { if (dropping) hipLaunchKernelGGL((attn_fwd_res_kernel<2, true>), dim3(attn_res_blocks(n) * B * heads), dim3(2 * RES_THREADS), lds, (hipStream_t)stream,
                          (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
-    else hipLaunchKernelGGL((attn_fwd_res_kernel<2, false>), dim3(attn_res_blocks(n), B * heads), dim3(2 * RES_THREADS), lds, (hipStream_t)stream,
+    else hipLaunchKernelGGL((attn_fwd_res_kernel<2, false>), dim3(attn_res_blocks(n) * B * heads), dim3(2 * RES_THREADS), lds, (hipStream_t)stream,
                          (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p)); }
     else
-      { if (dropping) hipLaunchKernelGGL((attn_fwd_res_kernel<1, true>), dim3(attn_res_blocks(n), B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
+      { if (dropping) hipLaunchKernelGGL((attn_fwd_res_kernel<1, true>), dim3(attn_res_blocks(n) * B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
                          (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
-    else hipLaunchKernelGGL((attn_fwd_res_kernel<1, false>), dim3(attn_res_blocks(n), B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
+    else hipLaunchKernelGGL((attn_fwd_res_kernel<1, false>), dim3(attn_res_blocks(n) * B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
                          (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p)); }
   } else if (g_attn_mode != 1 && (long)n * ld_qkv < (1L << 30)) {
-    { if (dropping) hipLaunchKernelGGL((attn_fwd_wide_kernel<true>), dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv,
+    { if (dropping) hipLaunchKernelGGL((attn_fwd_wide_kernel<true>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv,
                        n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
-    else hipLaunchKernelGGL((attn_fwd_wide_kernel<false>), dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv,
+    else hipLaunchKernelGGL((attn_fwd_wide_kernel<false>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv,
                        n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p)); }
   } else
-  { if (dropping) hipLaunchKernelGGL((attn_fwd_kernel<true>), dim3((n + TQ - 1) / TQ, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
+  { if (dropping) hipLaunchKernelGGL((attn_fwd_kernel<true>), dim3(((n + TQ - 1) / TQ) * B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
                      heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
-    else hipLaunchKernelGGL((attn_fwd_kernel<false>), dim3((n + TQ - 1) / TQ, B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
+    else hipLaunchKernelGGL((attn_fwd_kernel<false>), dim3(((n + TQ - 1) / TQ) * B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
                      heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p)); }
   nv_prof_end(slot, stream);
   NV_CHECK_LAUNCH("nv_attn_fwd");
@@ -640,11 +657,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   char* sK = smem;
   char* sV = smem + IMG;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const Grid2 gb = grid2d_xcd((n + TQ - 1) / TQ);                  // 1-D launch: whole heads per XCD
+  const int b = gb.by / heads, h = gb.by - b * heads, inner = heads * DH;
   const bf16* Q = qkv + (long)b * n * ld + h * DH;
   const bf16* K = Q + inner;
   const bf16* V = Q + 2 * inner;
-  const int q0 = blockIdx.x * TQ + 16 * wid;
+  const int q0 = gb.bx * TQ + 16 * wid;
   const int qrow = min(q0 + r, n - 1);
   const float scale_log2e = scale * 1.44269504088896340736f;
 
@@ -680,7 +698,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       tile_gload(K, ld, (kt + 1) * TK, n, tid, rk);
       tile_gload(V, ld, (kt + 1) * TK, n, tid, rv);
     }
-    dq_tile<DROP>(sK, sV, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
+    dq_tile<DROP>(sK, sV, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, gb.by, q0 + r, r, g);
   }
   const int q = q0 + r;
   if (q < n) {
@@ -751,14 +769,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
   float* sL = reinterpret_cast<float*>(smem + 2 * IMG);
   float* sDl = sL + TQ;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const Grid2 gb = grid2d_xcd((n + TK - 1) / TK);                  // 1-D launch: whole heads per XCD
+  const int b = gb.by / heads, h = gb.by - b * heads, inner = heads * DH;
   const bf16* Q = qkv + (long)b * n * ld + h * DH;
   const bf16* K = Q + inner;
   const bf16* V = Q + 2 * inner;
   const bf16* dO = dout + (long)b * n * ldo + h * DH;
   const float* L = lse + ((long)b * heads + h) * n;
   const float* Dl = delta + ((long)b * heads + h) * n;
-  const int key0 = blockIdx.x * TK + 16 * wid;
+  const int key0 = gb.bx * TK + 16 * wid;
   const int krow = min(key0 + r, n - 1);
   const float scale_log2e = scale * 1.44269504088896340736f;
 
@@ -796,7 +815,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
       tile_gload(dO, ldo, (qt + 1) * TQ, n, tid, rd);
       stats_load(qt + 1);
     }
-    dkv_tile<DROP>(sQ, sD, sL, sDl, qt, n, kf, vf, dk, dv, scale_log2e, drop, blockIdx.y, key0 + r, r, g);
+    dkv_tile<DROP>(sQ, sD, sL, sDl, qt, n, kf, vf, dk, dv, scale_log2e, drop, gb.by, key0 + r, r, g);
   }
   const int key = key0 + r;
   if (key < n) {
@@ -818,14 +837,15 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const bf16
   extern __shared__ __attribute__((aligned(16))) char rsmem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const ResBlock rb = res_block(n);
+  const int b = rb.by / heads, h = rb.by - b * heads, inner = heads * DH;
   const bf16* Q = qkv + (long)b * n * ld + h * DH;
   const int nkt = (n + TK - 1) / TK;
   char* sK = rsmem;
   char* sV = rsmem + nkt * IMG;
   res_dma(Q + inner, ld, n, nkt, sK, wid, lane);
   res_dma(Q + 2 * inner, ld, n, nkt, sV, wid, lane);
-  const int grp = res_group(n, wid);
+  const int grp = res_group(n, wid, rb.bx, rb.nblk);
   const int q0 = (grp < 0 ? 0 : grp) * 16;
   const int qrow = min(q0 + r, n - 1);
   const float scale_log2e = scale * 1.44269504088896340736f;
@@ -852,7 +872,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const bf16
   for (int t = 0; t < 4; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   // (software-pipelining the fragment reads as in the forward kernel measured slower inside the train step: 901 vs 923 volumes/s)
   for (int kt = 0; kt < nkt; ++kt)
-    dq_tile<DROP>(sK + kt * IMG, sV + kt * IMG, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, blockIdx.y, q0 + r, r, g);
+    dq_tile<DROP>(sK + kt * IMG, sV + kt * IMG, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, rb.by, q0 + r, r, g);
   const int q = q0 + r;
   if (q < n) {
     bf16* drow = dqkv + ((long)b * n + q) * ldd + h * DH;
@@ -870,7 +890,8 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf1
   extern __shared__ __attribute__((aligned(16))) char rsmem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const ResBlock rb = res_block(n);
+  const int b = rb.by / heads, h = rb.by - b * heads, inner = heads * DH;
   const bf16* Q = qkv + (long)b * n * ld + h * DH;
   const bf16* K = Q + inner;
   const bf16* V = Q + 2 * inner;
@@ -888,7 +909,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf1
     sL[q] = (q < n) ? L[q] * 1.44269504088896340736f : INFINITY;   // exp2(x - inf) = 0 masks padded query rows
     sDl[q] = (q < n) ? Dl[q] : 0.f;
   }
-  const int grp = res_group(n, wid);
+  const int grp = res_group(n, wid, rb.bx, rb.nblk);
   const int key0 = (grp < 0 ? 0 : grp) * 16;
   const int krow = min(key0 + r, n - 1);
   const float scale_log2e = scale * 1.44269504088896340736f;
@@ -905,7 +926,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf1
 #pragma unroll
   for (int t = 0; t < 4; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int qt = 0; qt < nqt; ++qt)
-    dkv_tile<DROP>(sQ + qt * IMG, sD + qt * IMG, sL + qt * TQ, sDl + qt * TQ, qt, n, kf, vf, dk, dv, scale_log2e, drop, blockIdx.y, key0 + r, r, g);
+    dkv_tile<DROP>(sQ + qt * IMG, sD + qt * IMG, sL + qt * TQ, sDl + qt * TQ, qt, n, kf, vf, dk, dv, scale_log2e, drop, rb.by, key0 + r, r, g);
   const int key = key0 + r;
   if (key < n) {
     bf16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
@@ -930,9 +951,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const bf16* __
   __shared__ __attribute__((aligned(16))) char wsmem[2 * 2 * IMG];      // [stage][K image | V image]
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const Grid2 gb = grid2d_xcd((n + WIDE_ROWS - 1) / WIDE_ROWS);                  // 1-D launch: whole heads per XCD
+  const int b = gb.by / heads, h = gb.by - b * heads, inner = heads * DH;
   const bf16* Q = qkv + (long)b * n * ld + h * DH;
-  const int q0 = blockIdx.x * WIDE_ROWS + 32 * wid;
+  const int q0 = gb.bx * WIDE_ROWS + 32 * wid;
   const float scale_log2e = scale * 1.44269504088896340736f;
 
   bf16x8 qf[2][2], dof[2][2];
@@ -993,8 +1015,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const bf16* __
     load_row_frags(cur + IMG, r, g, F);
     mfma_rows(F, dof[0], dp[0], true);
     mfma_rows(F, dof[1], dp[1], true);
-    dq_softmax_grad<DROP>(sc[0], dp[0], ds[0], kt, n, dl[0], lse2[0], scale_log2e, drop, blockIdx.y, q0 + r, g);
-    dq_softmax_grad<DROP>(sc[1], dp[1], ds[1], kt, n, dl[1], lse2[1], scale_log2e, drop, blockIdx.y, q0 + 16 + r, g);
+    dq_softmax_grad<DROP>(sc[0], dp[0], ds[0], kt, n, dl[0], lse2[0], scale_log2e, drop, gb.by, q0 + r, g);
+    dq_softmax_grad<DROP>(sc[1], dp[1], ds[1], kt, n, dl[1], lse2[1], scale_log2e, drop, gb.by, q0 + 16 + r, g);
     load_tr_frags(cur, r, g, F);                          // (after the exponentials: requesting them earlier spills registers)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -1055,12 +1077,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* _
   __shared__ __attribute__((aligned(16))) char wsmem[2 * STG];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y / heads, h = blockIdx.y - b * heads, inner = heads * DH;
+  const Grid2 gb = grid2d_xcd((n + WIDE_ROWS - 1) / WIDE_ROWS);                  // 1-D launch: whole heads per XCD
+  const int b = gb.by / heads, h = gb.by - b * heads, inner = heads * DH;
   const bf16* Q = qkv + (long)b * n * ld + h * DH;
   const bf16* K = Q + inner;
   const bf16* V = Q + 2 * inner;
   const bf16* dO = dout + (long)b * n * ldo + h * DH;
-  const int key0 = blockIdx.x * WIDE_ROWS + 32 * wid;
+  const int key0 = gb.bx * WIDE_ROWS + 32 * wid;
   const float scale_log2e = scale * 1.44269504088896340736f;
 
   bf16x8 kf[2][2], vf[2][2];
@@ -1120,10 +1143,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* _
     mfma_rows(F, vf[1], dp[1], true);
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 pf[2][2], dsf[2][2];                           // rounded at once: 16 registers per group instead of 32
-    dkv_softmax_grad_inplace<DROP>(sc[0], dp[0], sL, sDl, qt, n, scale_log2e, drop, blockIdx.y, key0 + r, g);
+    dkv_softmax_grad_inplace<DROP>(sc[0], dp[0], sL, sDl, qt, n, scale_log2e, drop, gb.by, key0 + r, g);
     pf[0][0] = cvt8(sc[0][0], sc[0][1]); pf[0][1] = cvt8(sc[0][2], sc[0][3]);
     dsf[0][0] = cvt8(dp[0][0], dp[0][1]); dsf[0][1] = cvt8(dp[0][2], dp[0][3]);
-    dkv_softmax_grad_inplace<DROP>(sc[1], dp[1], sL, sDl, qt, n, scale_log2e, drop, blockIdx.y, key0 + 16 + r, g);
+    dkv_softmax_grad_inplace<DROP>(sc[1], dp[1], sL, sDl, qt, n, scale_log2e, drop, gb.by, key0 + 16 + r, g);
     pf[1][0] = cvt8(sc[1][0], sc[1][1]); pf[1][1] = cvt8(sc[1][2], sc[1][3]);
     dsf[1][0] = cvt8(dp[1][0], dp[1][1]); dsf[1][1] = cvt8(dp[1][2], dp[1][3]);
     __builtin_amdgcn_sched_barrier(0);
@@ -1161,7 +1184,7 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
   hipStream_t s = (hipStream_t)stream;
   if (dim_head != DH)
     return launch_attn_generic_bwd(qkv, ld_qkv, out, dout, ld_out, lse, B, n, heads, dim_head, scale, delta, dqkv, ld_dqkv, make_drop(drop_seed, drop_p), s);
-  const dim3 grid((n + TQ - 1) / TQ, B * heads);
+  const dim3 grid(((n + TQ - 1) / TQ) * B * heads);      // TQ == TK: the same 1-D grid serves the dQ and the dK / dV kernel
   const bool dropping = make_drop(drop_seed, drop_p).thresh != 0;
   const int slot = nv_prof_begin(4, 10.0 * B * heads * (double)n * n * DH, stream);   // algorithmic: 5 products
   if (attn_resident(n) && g_attn_mode != 3) {
@@ -1175,7 +1198,7 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
       attn_res_attr(attn_bwd_dkv_res_kernel<true>, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
       attr = true;
     }
-    const dim3 rgrid(attn_res_blocks(n), B * heads);
+    const dim3 rgrid(attn_res_blocks(n) * B * heads);       // 1-D: whole heads per XCD (res_block)
     { if (dropping) hipLaunchKernelGGL((attn_bwd_dq_res_kernel<true>), rgrid, dim3(RES_THREADS), 2 * nt * IMG, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
                        (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
     else hipLaunchKernelGGL((attn_bwd_dq_res_kernel<false>), rgrid, dim3(RES_THREADS), 2 * nt * IMG, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
@@ -1193,9 +1216,9 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
   const bool wide = g_attn_mode != 1 && (long)n * ld_qkv < (1L << 30) && (long)n * ld_out < (1L << 30) &&
                     (g_attn_mode >= 3 || (long)B * heads * ((n + WIDE_ROWS - 1) / WIDE_ROWS) >= 512);
   if (wide)
-    { if (dropping) hipLaunchKernelGGL((attn_bwd_dq_wide_kernel<true>), dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
+    { if (dropping) hipLaunchKernelGGL((attn_bwd_dq_wide_kernel<true>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
                        (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
-    else hipLaunchKernelGGL((attn_bwd_dq_wide_kernel<false>), dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
+    else hipLaunchKernelGGL((attn_bwd_dq_wide_kernel<false>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
                        (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
   else
   { if (dropping) hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out, lse, n,
@@ -1204,9 +1227,9 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
                      heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
   NV_CHECK_LAUNCH("nv_attn_bwd/dq");
   if (wide)
-    { if (dropping) hipLaunchKernelGGL((attn_bwd_dkv_wide_kernel<true>), dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
+    { if (dropping) hipLaunchKernelGGL((attn_bwd_dkv_wide_kernel<true>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
                        (const bf16*)dout, ld_out, lse, delta, n, heads, scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
-    else hipLaunchKernelGGL((attn_bwd_dkv_wide_kernel<false>), dim3((n + WIDE_ROWS - 1) / WIDE_ROWS, B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
+    else hipLaunchKernelGGL((attn_bwd_dkv_wide_kernel<false>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
                        (const bf16*)dout, ld_out, lse, delta, n, heads, scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
   else
   { if (dropping) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)dout, ld_out, lse, delta, n, heads,

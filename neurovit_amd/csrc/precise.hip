@@ -244,9 +244,10 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
   float* sk = smem;                          // [ATK][DHP]
   float* svt = smem + ATK * DHP;             // [16 DHB][KP]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads, inner = heads * dh;
+  const Grid2 gb = grid2d_xcd((n + 63) / 64);                  // 1-D launch: the row blocks of one head share an XCD (its K / V in one L2)
+  const int bh = gb.by, b = bh / heads, h = bh - b * heads, inner = heads * dh;
   const float* base = qkv + (long)b * n * ld + (long)h * dh;
-  const int q0 = blockIdx.x * 64 + wid * 16;
+  const int q0 = gb.bx * 64 + wid * 16;
   const int j = lane & 15, g = lane >> 4;
   // Q fragments: lane (j, g) holds Q[q0 + j][16 s + 4 g .. + 3], s < DHB
   f32x4 qf[DHB];
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
 template <int DHB>
 void launch_attn_f32(const float* qkv, long ld, int B, int n, int heads, int dh, float scale, float* out, long ldo, hipStream_t s) {
   const size_t lds = (size_t)(ATK * (16 * DHB + 4) + 16 * DHB * (ATK + 4)) * sizeof(float);
-  hipLaunchKernelGGL(attn_f32_fwd_kernel<DHB>, dim3((n + 63) / 64, B * heads), dim3(256), lds, s, qkv, ld, n, heads, dh, scale, out, ldo);
+  hipLaunchKernelGGL(attn_f32_fwd_kernel<DHB>, dim3(((n + 63) / 64) * B * heads), dim3(256), lds, s, qkv, ld, n, heads, dh, scale, out, ldo);
 }
 
 }  // namespace
