@@ -1,19 +1,27 @@
 # Round artefacts on the GPU box: parity report, bench line (+cpu baseline, secondary lines), rocprofv3 kernel stats, PMC traffic.
-# Usage (from the repo root, through gpurun): bash tools/final_artifacts.sh r01 v3
+# Usage (from the repo root, through gpurun): bash tools/final_artifacts.sh [skip-tests]
 set -e
-TAG=$1; VER=$2
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 rm -f $R/gpurun_out/parity_report.txt
-python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1 || { tail -30 $OUT/pytest_gpu.log; exit 1; }
-tail -1 $OUT/pytest_gpu.log
-cp $R/gpurun_out/parity_report.txt $OUT/parity_report.txt
+if [ "$1" != "skip-tests" ]; then
+  python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1 || { tail -30 $OUT/pytest_gpu.log; exit 1; }
+  tail -1 $OUT/pytest_gpu.log
+  cp $R/gpurun_out/parity_report.txt $OUT/parity_report.txt
+fi
 python bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
-cat $OUT/bench.json | cut -c1-400
+cut -c1-300 $OUT/bench.json
 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1 || { tail $OUT/smoke.log; exit 1; }
+# secondary lines: inference forwards (bf16 / fp8 / fp32), batch 20, the large preset
+( python bench.py --forward-only --steps 30 --warmup 5; python bench.py --forward-only --precise --steps 20 --warmup 3;
+  python bench.py --forward-only --batch 20 --steps 20 --warmup 3; python bench.py --forward-only --batch 20 --fp8 --steps 20 --warmup 3;
+  python bench.py --forward-only --batch 20 --precise --steps 10 --warmup 3;
+  python bench.py --preset large --steps 8 --warmup 2 --no-cpu-baseline --no-extras; python bench.py --preset large --forward-only --steps 8 --warmup 2;
+  python bench.py --preset large --forward-only --fp8 --steps 8 --warmup 2; python bench.py --dropout 0.1 --steps 30 --warmup 5 --no-cpu-baseline --no-extras ) > $OUT/bench_secondary.jsonl 2> $OUT/bench_secondary.err || true
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/stats_run.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f32 -- python3 $R/bench.py --forward-only --precise --steps 10 --warmup 3 > $OUT/stats_f32_run.log 2>&1
 echo done
