@@ -147,7 +147,8 @@ def cpu_baseline(model, vcfg, B, S, steps, warmup=3):
         nthreads = len(os.sched_getaffinity(0))
     except AttributeError:
         nthreads = os.cpu_count() or 1
-    nthreads = max(1, min(nthreads, 16))       # the GPU box grants a 16-core share per GPU
+    visible = nthreads
+    nthreads = max(1, min(nthreads, 16))       # the GPU box grants a 16-core share per GPU: more threads than that only oversubscribe it
     torch.set_num_threads(nthreads)
 
     def run(sd, cfg, batch, n_warm, n_timed, seed):
@@ -169,7 +170,8 @@ def cpu_baseline(model, vcfg, B, S, steps, warmup=3):
     tcfg = ref_cpu.ViTCfg(**W.TINY)
     tsd = W.make_tensors(W.vit_param_spec(**W.TINY), 3)
     tiny = run(tsd, tcfg, 2, warmup, max(steps, 20), 4243)
-    return {"value": value, "unit": "volumes/s", "cores": torch.get_num_threads(), "cpu_model": _cpu_model(), "kind": "port",
+    return {"value": value, "unit": "volumes/s", "cores": torch.get_num_threads(), "cores_visible": visible,
+            "cores_note": "threads used = min(cores visible to the process, 16: a one-GPU box's CPU share)", "cpu_model": _cpu_model(), "kind": "port",
             "sample": f"{steps} train steps (fwd+bwd+AdamW, fp32 eager PyTorch CPU) of the same workload, batch {B}, after {warmup} warm-up steps",
             "tiny_config": {"value": tiny, "unit": "volumes/s",
                             "workload": "BASELINE.json configs[0]: ViT3D tiny 64^3 patch 16 dim 192 depth 4 heads 3 mlp 384, batch 2, train step",
