@@ -79,7 +79,7 @@ int nv_gemm_f8(int epi, int M, int N, int K, const void* A8, long lda, const voi
  * nv_attn_fwd_f32 (vit_3d.py:53-59): qkv f32 [B, n, 3*inner] -> out f32 [B, n, inner]; dim_head a multiple of 4 up to 128. */
 int nv_gemm_f32(int epi, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                 const float* bias, const float* resid, long ldr, void* stream);
-int nv_gemm_f32_set_tile(int wm, int wn);     /* tuning aid: wave tile (16 wm) x (16 wn), wm, wn in {2, 4}; (0, 0) = heuristic */
+int nv_gemm_f32_set_tile(int wm, int wn);     /* tuning aid: wave tile (16 wm) x (16 wn), wm, wn in {2, 4}; (0, 0) = heuristic; (-1, 2 | 4 | 0): waves per workgroup of nv_attn_fwd_f32 */
 int nv_attn_fwd_f32(const float* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, float* out, long ld_out,
                     void* stream);
 int nv_ln_fwd_f32(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, float* y, long ldy,

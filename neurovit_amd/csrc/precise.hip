@@ -235,8 +235,9 @@ void launch_gemm_f32(int epi, int M, int N, int K, const float* A, long lda, con
 // gives lane (j, q) four consecutive head-dim columns of query j: row statistics are per lane, the output store is a float4.
 // DHB = ceil(dim_head / 16); columns beyond dim_head are zero-filled.
 constexpr int ATK = 64;                      // keys per tile
-template <int DHB>
-__global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restrict__ qkv, long ld, int n, int heads, int dh, float scale,
+// AW waves (16 query rows each) per workgroup: 4 (64 rows); 2 is a tuning aid (more, smaller workgroups: measured slower).
+template <int DHB, int AW>
+__global__ __launch_bounds__(64 * AW) void attn_f32_fwd_kernel(const float* __restrict__ qkv, long ld, int n, int heads, int dh, float scale,
                                                            float* __restrict__ out, long ldo) {
   constexpr int DHP = 16 * DHB + 4;          // K tile row stride (floats)
   constexpr int KP = ATK + 4;                // V^T tile row stride
@@ -244,10 +245,11 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
   float* sk = smem;                          // [ATK][DHP]
   float* svt = smem + ATK * DHP;             // [16 DHB][KP]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const Grid2 gb = grid2d_xcd((n + 63) / 64);                  // 1-D launch: the row blocks of one head share an XCD (its K / V in one L2)
+  constexpr int NT = 64 * AW, TQR = 16 * AW;                   // threads, query rows per workgroup
+  const Grid2 gb = grid2d_xcd((n + TQR - 1) / TQR);            // 1-D launch: the row blocks of one head share an XCD (its K / V in one L2)
   const int bh = gb.by, b = bh / heads, h = bh - b * heads, inner = heads * dh;
   const float* base = qkv + (long)b * n * ld + (long)h * dh;
-  const int q0 = gb.bx * 64 + wid * 16;
+  const int q0 = gb.bx * TQR + wid * 16;
   const int j = lane & 15, g = lane >> 4;
   // Q fragments: lane (j, g) holds Q[q0 + j][16 s + 4 g .. + 3], s < DHB
   f32x4 qf[DHB];
@@ -264,14 +266,15 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
   for (int s = 0; s < DHB; ++s) o[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_part = 0.f;     // l_part: this lane's share of the row sum (its own key columns)
   const int c4n = dh >> 2;                   // float4 chunks per row that exist
-  // staging of one 64-key tile: thread t handles elements t + 256 u (u < DHB) of K (key e / (4 DHB), chunk e % (4 DHB): whole rows
+  // staging of one 64-key tile: thread t handles elements t + NT u (u < 256 DHB / NT) of K (key e / (4 DHB), chunk e % (4 DHB): whole rows
   // per eight lanes) and of V (chunk e / 64, key e % 64: consecutive lanes = consecutive keys -> conflict-free transposed writes).
   // The loads of tile k + 1 are in flight under the MFMAs of tile k (one register set).
-  f32x4 kreg[DHB], vreg[DHB];
+  constexpr int NU = 256 * DHB / NT;
+  f32x4 kreg[NU], vreg[NU];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int u = 0; u < DHB; ++u) {
-      const int e = tid + 256 * u;
+    for (int u = 0; u < NU; ++u) {
+      const int e = tid + NT * u;
       {
         const int kk = e / (4 * DHB), c = e - kk * (4 * DHB);
         const bool ok = (k0 + kk < n) && (c < c4n);
@@ -286,8 +289,8 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
   };
   auto swrite = [&]() {
 #pragma unroll
-    for (int u = 0; u < DHB; ++u) {
-      const int e = tid + 256 * u;
+    for (int u = 0; u < NU; ++u) {
+      const int e = tid + NT * u;
       {
         const int kk = e / (4 * DHB), c = e - kk * (4 * DHB);
         *reinterpret_cast<f32x4*>(sk + kk * DHP + 4 * c) = kreg[u];
@@ -331,14 +334,17 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);    // finite: every tile holds at least one valid key
-    const float alpha = expf(m_run - m_new); // first tile: exp(-inf) = 0
+    // exp(x) as v_exp_f32(x log2 e): the hardware exp2 is good to about one ulp, the product rounds the exponent to 2^-24 |x|
+    // (|x| <= ~100): 1e-6 relative on a probability at worst, against ~20 VALU instructions per libm expf beside a matrix pipe that
+    // waits for them
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * 1.44269504088896340736f);   // first tile: exp2(-inf) = 0
     m_run = m_new;
     float ps = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = expf(st[kb][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f((st[kb][r] - m_new) * 1.44269504088896340736f);
         st[kb][r] = p;
         ps += p;
       }
@@ -369,15 +375,20 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
   }
 }
 
+int g_attn_f32_waves = 0;     // tuning aid: 0 = heuristic, 2 / 4 = forced
 template <int DHB>
 void launch_attn_f32(const float* qkv, long ld, int B, int n, int heads, int dh, float scale, float* out, long ldo, hipStream_t s) {
   const size_t lds = (size_t)(ATK * (16 * DHB + 4) + 16 * DHB * (ATK + 4)) * sizeof(float);
-  hipLaunchKernelGGL(attn_f32_fwd_kernel<DHB>, dim3(((n + 63) / 64) * B * heads), dim3(256), lds, s, qkv, ld, n, heads, dh, scale, out, ldo);
+  const long wg4 = (long)((n + 63) / 64) * B * heads;
+  const int aw = g_attn_f32_waves ? g_attn_f32_waves : 4;      // (two-wave workgroups measured slower at every size: 70 vs 63 us at batch 4)
+  if (aw == 4) hipLaunchKernelGGL((attn_f32_fwd_kernel<DHB, 4>), dim3((unsigned)wg4), dim3(256), lds, s, qkv, ld, n, heads, dh, scale, out, ldo);
+  else hipLaunchKernelGGL((attn_f32_fwd_kernel<DHB, 2>), dim3(((n + 31) / 32) * B * heads), dim3(128), lds, s, qkv, ld, n, heads, dh, scale, out, ldo);
 }
 
 }  // namespace
 
 extern "C" int nv_gemm_f32_set_tile(int wm, int wn) {
+  if (wm == -1) { g_attn_f32_waves = (wn == 2 || wn == 4) ? wn : 0; return NV_OK; }      // (-1, 2 | 4 | 0): waves per workgroup of the fp32 attention
   NV_CHECK_ARG((wm == 0 && wn == 0) || ((wm == 2 || wm == 4) && (wn == 2 || wn == 4)), "nv_gemm_f32_set_tile: (0, 0) or wm, wn in {2, 4}");
   g_force_wm = wm; g_force_wn = wn;
   return NV_OK;
