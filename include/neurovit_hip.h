@@ -241,6 +241,22 @@ long nv_gradcam_workspace_bytes(int B, int n);
 int nv_gradcam_reduce(const void* act, const float* grad, int B, int n, int d, float* cam, float* minmax, void* workspace,
                       long ws_bytes, void* stream);
 
+/* ---- the 4D model's temporal head (src/models/NeuroEncoder.py:60-66: temporal_transformer -> mean over time -> projection_head;
+ * :207-217 TemporalTransformer = one nn.TransformerEncoderLayer(d_model 2, nhead 2, batch_first, post-norm, ReLU, dim_feedforward ff,
+ * dropout p at its four sites); :219-230 ProjectionHead = nn.Linear(2, 2)) - ONE launch per direction.
+ * x [B, T, 2] f32 contiguous (the frozen encoder's logits per timepoint), T <= 64, ff <= 2048; out [B, 2].
+ * params / grads: one flat fp32 arena of nv_temporal_head_param_count(ff) = 40 + 5 ff floats in named_parameters() order:
+ *   in_proj_weight [6,2] | in_proj_bias [6] | out_proj.weight [2,2] | out_proj.bias [2] | linear1.weight [ff,2] | linear1.bias [ff] |
+ *   linear2.weight [2,ff] | linear2.bias [2] | norm1.weight | norm1.bias | norm2.weight | norm2.bias [2 each] |
+ *   projection_head.weight [2,2] | projection_head.bias [2].
+ * drop_p > 0 (training): counter-based masks from drop_seed; the backward call recomputes the forward from x (nothing else is saved)
+ * and must be given the forward's seed and p.  accumulate != 0 adds into grads; dx ([B, T, 2], may be NULL) receives the input gradient. */
+long nv_temporal_head_param_count(int ff);
+int nv_temporal_head_fwd(const float* x, int B, int T, int ff, const float* params, float eps, unsigned long drop_seed, float drop_p,
+                         float* out, void* stream);
+int nv_temporal_head_bwd(const float* x, int B, int T, int ff, const float* params, float eps, unsigned long drop_seed, float drop_p,
+                         const float* dout, float* grads, int accumulate, float* dx, void* stream);
+
 /* ---- whole-encoder engine: ViT.forward / its backward as ONE call each (vit_3d.py:112-126)
  * Parameters live in one flat fp32 arena (+ a bf16 shadow with identical element offsets) laid out by
  * nv_vit_param_table in the reference's state_dict order; gradients go to an arena of the same layout. */

@@ -46,6 +46,10 @@ class NeuroEncoder(nn.Module):
 
             self.temporal_transformer = TemporalTransformer(config)
             self.projection_head = ProjectionHead(config)
+            # the two modules above hold the parameters (reference classes, keys and initialisation); the computation
+            # transformer -> mean over time -> projection is one native launch per direction (temporal.py, csrc/temporal.hip)
+            from .temporal import TemporalHead
+            self._temporal_head = TemporalHead(self.temporal_transformer, self.projection_head)
 
         self.to(self.device)  # Move entire model to device
 
@@ -68,6 +72,10 @@ class NeuroEncoder(nn.Module):
         else:
             as_volumes = series.movedim(-1, 1).flatten(0, 1)          # [B, H, W, D, T] -> [B*T, H, W, D]  (strided copy)
             per_volume = self.volume_encoder(as_volumes).unflatten(0, (n_samples, n_time))
+        head = self._temporal_head
+        if head.supported(per_volume):                                # NeuroEncoder.py:60-66 in one launch
+            return head(per_volume)
+        # geometries outside the kernel's (more than 64 timepoints, an edited encoder layer): the stock modules, on the device
         pooled = self.temporal_transformer(per_volume).mean(dim=1)
         return self.projection_head(pooled)
 
@@ -217,8 +225,8 @@ class ViT3DEncoder(nn.Module):
 
 
 class TemporalTransformer(nn.Module):
-    """NeuroEncoder.py:207-217.  d_model = 2 (the frozen ViT3D emits 2 logits): 10 274 parameters and ~0 % of
-    the FLOPs, so it stays on stock torch modules (which also keeps the reference's state_dict keys)."""
+    """NeuroEncoder.py:207-217.  d_model = 2 (the frozen ViT3D emits 2 logits): 10 274 parameters.  The stock module is the
+    parameter holder (reference state_dict keys and initialisation); NeuroEncoder.forward computes it through temporal.TemporalHead."""
 
     def __init__(self, config):
         super().__init__()

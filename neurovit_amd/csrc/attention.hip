@@ -1133,6 +1133,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* _
     const float* sL = reinterpret_cast<const float*>(cur + 2 * IMG);
     const float* sDl = sL + TQ;
     RowFrags F;
+    if constexpr (DROP) {
+      // under dropout the mask hashes need ~40 more registers than the budget of two workgroups per CU leaves (29 VGPRs went to
+      // scratch inside the MFMA loop): the two 16-key groups run one after the other instead, so only one group's scores / dP are
+      // live next to the hash temporaries; the price is reading the four fragment sets twice from LDS
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f32x4 sc1[4], dp1[4];
+        load_row_frags(cur, r, g, F);
+        mfma_rows(F, kf[u], sc1, true);
+        __builtin_amdgcn_sched_barrier(0);
+        load_row_frags(cur + IMG, r, g, F);
+        mfma_rows(F, vf[u], dp1, true);
+        __builtin_amdgcn_sched_barrier(0);
+        dkv_softmax_grad_inplace<DROP>(sc1, dp1, sL, sDl, qt, n, scale_log2e, drop, gb.by, key0 + 16 * u + r, g);
+        bf16x8 pf1[2], dsf1[2];
+        pf1[0] = cvt8(sc1[0], sc1[1]); pf1[1] = cvt8(sc1[2], sc1[3]);
+        dsf1[0] = cvt8(dp1[0], dp1[1]); dsf1[1] = cvt8(dp1[2], dp1[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tr_frags(cur + IMG, r, g, F);
+        mfma_rows(F, pf1, dv[u], false);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tr_frags(cur, r, g, F);
+        mfma_rows(F, dsf1, dk[u], false);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      continue;
+    }
     f32x4 sc[2][4], dp[2][4];
     load_row_frags(cur, r, g, F);
     mfma_rows(F, kf[0], sc[0], true);

@@ -421,3 +421,33 @@ def patch_ln_fwd_4d(x: torch.Tensor, p1: int, p2: int, pf: int, gamma, beta, eps
     check(lib.nv_patch_ln_fwd_4d(_p(x), Bo, H, W, D, T, p1, p2, pf, _p(gamma), _p(beta), eps, _p(out), P, _p(st[0]), _p(st[1]), _p(vol_sigma),
                                  _stream()), "nv_patch_ln_fwd_4d")
     return out, st
+
+
+def temporal_head_param_count(ff: int) -> int:
+    return int(lib.nv_temporal_head_param_count(int(ff)))
+
+
+def temporal_head_fwd(x: torch.Tensor, params: torch.Tensor, ff: int, eps: float = 1e-5, drop_seed: int = 0, drop_p: float = 0.0) -> torch.Tensor:
+    """The 4D model's temporal head (NeuroEncoder.py:60-66): x f32 [B, T, 2] -> encoder layer -> mean over T -> Linear(2, 2) -> [B, 2]."""
+    _need_cuda(x, params)
+    assert x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == 2 and x.is_contiguous() and params.dtype == torch.float32
+    assert params.is_contiguous() and params.numel() == temporal_head_param_count(ff)
+    B, T, _ = x.shape
+    out = torch.empty((B, 2), dtype=torch.float32, device=x.device)
+    check(lib.nv_temporal_head_fwd(_p(x), B, T, int(ff), _p(params), eps, int(drop_seed), float(drop_p), _p(out), _stream()), "nv_temporal_head_fwd")
+    return out
+
+
+def temporal_head_bwd(x: torch.Tensor, params: torch.Tensor, ff: int, dout: torch.Tensor, grads: torch.Tensor, accumulate: bool = False,
+                      want_dx: bool = False, eps: float = 1e-5, drop_seed: int = 0, drop_p: float = 0.0):
+    """Gradients of temporal_head_fwd (forward recomputed from x, same seed / p): parameter gradients into the flat arena `grads`
+    (added when accumulate), returns dx [B, T, 2] when want_dx."""
+    _need_cuda(x, params, dout, grads)
+    assert x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == 2 and x.is_contiguous()
+    assert dout.dtype == torch.float32 and dout.shape == (x.shape[0], 2) and dout.is_contiguous()
+    assert grads.dtype == torch.float32 and grads.is_contiguous() and grads.numel() == params.numel() == temporal_head_param_count(ff)
+    B, T, _ = x.shape
+    dx = torch.empty_like(x) if want_dx else None
+    check(lib.nv_temporal_head_bwd(_p(x), B, T, int(ff), _p(params), eps, int(drop_seed), float(drop_p), _p(dout), _p(grads), int(bool(accumulate)),
+                                   _p(dx), _stream()), "nv_temporal_head_bwd")
+    return dx

@@ -3,8 +3,8 @@
 `FusedAdamW(model.parameters(), lr=..., weight_decay=...)` has the constructor of torch.optim.AdamW
 (defaults betas (0.9, 0.999), eps 1e-8, decoupled weight decay on every parameter).  Parameters that
 are views of a ViT arena are updated by ONE nv_adamw_step launch per arena (which also refreshes the
-bf16 shadow the MFMA kernels read); any other parameter (the 10 k-parameter temporal head of the 4D
-model) is delegated to torch.optim.AdamW.
+bf16 shadow the MFMA kernels read); the 4D model's temporal head is a second, 10 k-parameter arena
+(temporal.TemporalHead, fp32 only) stepped the same way; any other parameter is delegated to torch.optim.AdamW.
 """
 from __future__ import annotations
 
@@ -21,7 +21,7 @@ class FusedAdamW(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self._model = model
-        self._arenas: List[ViT] = []
+        self._arenas: List[object] = []      # ViT modules and TemporalHead objects: flat_parameters() / flat_gradients() / mark_shadow_fresh()
         self._state_mv: Dict[int, tuple] = {}
         self._rest = None
         self._bound = False
@@ -45,6 +45,14 @@ class FusedAdamW(torch.optim.Optimizer):
                     if all(i in mine for i in ids) and all(p.requires_grad for p in m._plist):
                         self._arenas.append(m)
                         claimed.update(ids)
+            for m in self._model.modules():             # the 4D model's temporal head: a second, small arena (temporal.TemporalHead)
+                th = getattr(m, "_temporal_head", None)
+                if th is not None:
+                    th.flat_parameters()
+                    ids = [id(p) for p in th._plist]
+                    if all(i in mine for i in ids) and all(p.requires_grad for p in th._plist):
+                        self._arenas.append(th)
+                        claimed.update(ids)
         rest = [p for g in self.param_groups for p in g["params"] if id(p) not in claimed and p.requires_grad]
         g0 = self.param_groups[0]
         self._rest = torch.optim.AdamW(rest, lr=g0["lr"], betas=g0["betas"], eps=g0["eps"], weight_decay=g0["weight_decay"]) if rest else None
@@ -58,17 +66,8 @@ class FusedAdamW(torch.optim.Optimizer):
             self._bind()
         self._steps += 1
         g0 = self.param_groups[0]
-        for vit in self._arenas:
-            arena, shadow = vit.flat_parameters()
-            grads = vit.flat_gradients()
-            key = id(vit)
-            if key not in self._state_mv or self._state_mv[key][0].data_ptr() == 0 or self._state_mv[key][0].device != arena.device:
-                self._state_mv[key] = (torch.zeros_like(arena), torch.zeros_like(arena))
-            m, v = self._state_mv[key]
-            if reduced_bf16 is not None and key in reduced_bf16:
-                grads = reduced_bf16[key]
-            ops.adamw_step(arena, grads, m, v, shadow, self._steps, g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"], grad_scale)
-            vit.mark_shadow_fresh()
+        for holder in self._arenas:
+            self._step_arena(holder, grad_scale, None if reduced_bf16 is None else reduced_bf16.get(id(holder)))
         if self._rest is not None:
             for g in self._rest.param_groups:
                 g["lr"] = g0["lr"]
@@ -94,9 +93,26 @@ class FusedAdamW(torch.optim.Optimizer):
             self._bind()
         self._steps += 1
 
+    def _step_arena(self, holder, grad_scale, reduced=None):
+        arena, shadow = holder.flat_parameters()
+        grads = holder.flat_gradients()
+        if hasattr(holder, "gather_foreign_grads"):
+            holder.gather_foreign_grads()
+        key = id(holder)
+        if key not in self._state_mv or self._state_mv[key][0].data_ptr() == 0 or self._state_mv[key][0].device != arena.device:
+            self._state_mv[key] = (torch.zeros_like(arena), torch.zeros_like(arena))
+        m, v = self._state_mv[key]
+        g0 = self.param_groups[0]
+        ops.adamw_step(arena, grads if reduced is None else reduced, m, v, shadow, self._steps, g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"], grad_scale)
+        holder.mark_shadow_fresh()
+
     @torch.no_grad()
-    def step_rest(self):
-        """Parameters outside the arenas (after the arena ranges were stepped bucket by bucket)."""
+    def step_rest(self, grad_scale: float = 1.0):
+        """Parameters outside the ViT arenas (after those ranges were stepped bucket by bucket): the temporal head's arena with
+        `grad_scale`, stock parameters as they are."""
+        for holder in self._arenas:
+            if not isinstance(holder, ViT):
+                self._step_arena(holder, grad_scale)
         if self._rest is not None:
             g0 = self.param_groups[0]
             for g in self._rest.param_groups:

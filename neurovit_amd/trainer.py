@@ -77,6 +77,11 @@ class TrainStep:
         ids = {id(q) for q in vit.parameters()}
         self._outside = [p for p in model.parameters() if id(p) not in ids]
         self._inside = [p for p in model.parameters() if id(p) in ids]
+        self._head = getattr(model, "_temporal_head", None)            # 4D: its 16 parameters are one arena (temporal.TemporalHead)
+        self._head_ids = set()
+        if self._head is not None:
+            self._head.flat_parameters()
+            self._head_ids = {id(p) for p in self._head._plist}
 
     def _bucket_update(self, begin: int, end: int):
         self.optimizer.step_range(self._vit, begin, end, grad_scale=1.0 / self.world, max_blocks=self._opt_blocks)
@@ -116,7 +121,15 @@ class TrainStep:
                 # stragglers, reduced inline: parameters outside the arena (the 10 k-parameter temporal head), and - when the
                 # ViT is only PARTIALLY trainable, so that no bucket pipeline runs over the arena - its trainable parameters
                 arena_synced = self.sync is not None
-                for p in (self._outside if arena_synced else self._outside + self._inside):
+                inline = self._outside if arena_synced else self._outside + self._inside
+                head = self._head
+                if head is not None and head._grads is not None and all(p.grad is not None and p.grad.data_ptr() == head._grad_view(i).data_ptr()
+                                                                        for i, p in enumerate(head._plist)):
+                    dist.all_reduce(head._grads, group=self._pg)       # the temporal head's gradient arena: one message
+                    if not arena_synced:
+                        head._grads.mul_(scale)                        # (otherwise the fused step applies grad_scale)
+                    inline = [p for p in inline if id(p) not in self._head_ids]
+                for p in inline:
                     if p.grad is not None:
                         dist.all_reduce(p.grad, group=self._pg)
                         p.grad.mul_(scale)
@@ -124,7 +137,7 @@ class TrainStep:
                     scale = 1.0                        # already averaged above
             if pipelined and self._overlap_opt:
                 vit.mark_shadow_fresh()                # every range was updated (and its bf16 shadow refreshed) by the buckets
-                self.optimizer.step_rest()
+                self.optimizer.step_rest(grad_scale=scale)
             else:
                 red = self.sync.reduced_buffer() if (pipelined and not self.sync.write_back) else None
                 self.optimizer.step(grad_scale=scale, reduced_bf16=None if red is None else {id(vit): red})

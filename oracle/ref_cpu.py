@@ -414,23 +414,36 @@ def neuro_cfg(config: dict) -> ViTCfg:
                   pool="cls", channels=1, dim_head=config.get("TRAINING_VIT_DIM_HEAD", 64))
 
 
-def temporal_transformer(sd, pre, x):
+TEMPORAL_SITE = 0x9E3779B97F4A7C15      # csrc/temporal.hip::th_drop: site k of the temporal head uses seed ^ (k * this), k = 1..4
+
+
+def temporal_transformer(sd, pre, x, drop=None):
     """nn.TransformerEncoder(TransformerEncoderLayer(d_model=2, nhead=2, batch_first=True), 1)
-    (NeuroEncoder.py:211-212) restated: post-norm, ReLU, eval mode (no dropout).
-    `pre` = 'temporal_transformer.transformer.layers.0.'."""
+    (NeuroEncoder.py:211-212) restated: post-norm, ReLU.  `pre` = 'temporal_transformer.transformer.layers.0.'.
+    drop = None: eval mode.  drop = (p, seed): train mode with the native kernel's counter-based masks at the layer's four
+    nn.Dropout sites (attention probabilities, dropout1, the FeedForward's inner dropout, dropout2) - torch's own Philox
+    masks cannot be reproduced, the sites and the 1/(1-p) scaling are nn.TransformerEncoderLayer's."""
     B, T, E = x.shape
     H = 2
     dh = E // H
+    ff = sd[pre + "linear1.weight"].shape[0]
+    one = lambda k, shape: 1.0 if drop is None else drop_mask((drop[1] ^ (TEMPORAL_SITE * k)) & 0xFFFFFFFFFFFFFFFF, drop[0], shape).to(x.dtype)
     qkv = F.linear(x, sd[pre + "self_attn.in_proj_weight"], sd[pre + "self_attn.in_proj_bias"])
     q, k, v = qkv.chunk(3, dim=-1)
     q, k, v = (t.reshape(B, T, H, dh).permute(0, 2, 1, 3) for t in (q, k, v))
-    a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+    a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh), dim=-1) * one(1, (B, H, T, T))
     o = torch.matmul(a, v).permute(0, 2, 1, 3).reshape(B, T, E)
-    o = F.linear(o, sd[pre + "self_attn.out_proj.weight"], sd[pre + "self_attn.out_proj.bias"])
+    o = F.linear(o, sd[pre + "self_attn.out_proj.weight"], sd[pre + "self_attn.out_proj.bias"]) * one(2, (B, T, E))
     x = F.layer_norm(x + o, (E,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], LN_EPS)
-    f = F.linear(F.relu(F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"])),
-                 sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
+    f = F.linear(F.relu(F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"])) * one(3, (B, T, ff)),
+                 sd[pre + "linear2.weight"], sd[pre + "linear2.bias"]) * one(4, (B, T, E))
     return F.layer_norm(x + f, (E,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], LN_EPS)
+
+
+def temporal_head(sd, per_volume, drop=None):
+    """NeuroEncoder.py:60-66: temporal transformer -> mean over time -> projection head, on the per-timepoint logits [B, T, 2]."""
+    enc = temporal_transformer(sd, "temporal_transformer.transformer.layers.0.", per_volume, drop).mean(dim=1)
+    return F.linear(enc, sd["projection_head.projection_head.weight"], sd["projection_head.projection_head.bias"])
 
 
 def neuro_forward(sd: Dict[str, torch.Tensor], config: dict, fmri: torch.Tensor,
@@ -444,9 +457,7 @@ def neuro_forward(sd: Dict[str, torch.Tensor], config: dict, fmri: torch.Tensor,
     B, T, H, W, D = f.shape
     vols = f.reshape(B * T, H, W, D)
     enc = vit_forward(vsd, cfg, fmri_to_video(vols), emulate_bf16, taps).reshape(B, T, -1)
-    enc = temporal_transformer(sd, "temporal_transformer.transformer.layers.0.", enc)
-    enc = enc.mean(dim=1)
-    return F.linear(enc, sd["projection_head.projection_head.weight"], sd["projection_head.projection_head.bias"])
+    return temporal_head(sd, enc)
 
 
 # --------------------------------------------------------------------------- Grad-CAM (§8f F1)

@@ -95,6 +95,64 @@ def test_dp2_bf16_messages_close_to_fp32_messages():
     assert float(((a[0] - start) - (b[0] - start)).norm() / (b[0] - start).norm()) < 0.05
 
 
+def _model4d():
+    """4D model: frozen micro encoder + the temporal head (the only trainable parameters; one 10 280-float arena)."""
+    import tempfile
+    import neurovit_amd.NeuroEncoder as ne
+    with tempfile.TemporaryDirectory() as td:
+        torch.save(dict(W.make_tensors(W.vit_param_spec(**W.MICRO), 1, prefix="volume_encoder.vit3d.")), os.path.join(td, "c.pth"))
+        cfg = W.neuro_config(32, 8, dim=4, DEVICE="cuda", TRAINING_LEARNING_RATE=1e-2, TRAINING_WEIGHT_DECAY=1e-2, GLOBAL_BASE_PATH=td,
+                             BEST_MODEL_PATH="c.pth", **SIZE)
+        model = ne.NeuroEncoder(cfg)
+    model.load_state_dict(W.make_tensors(W.temporal_param_spec(), 3), strict=False)
+    lay = model.temporal_transformer.transformer.layers[0]
+    lay.dropout.p = lay.dropout1.p = lay.dropout2.p = 0.0          # deterministic across processes
+    lay.self_attn.dropout = 0.0
+    model.train(); model.volume_encoder.eval()
+    return model
+
+
+def _run_steps4d(model, seeds, **kw):
+    from neurovit_amd.trainer import TrainStep
+    step = TrainStep(model, **kw)
+    for s in seeds:
+        step(W.make_volume((2, 32, 32, 32, 4), s).cuda(), torch.tensor([0, 1], device="cuda"))
+    torch.cuda.synchronize()
+    return model._temporal_head.flat_parameters()[0].detach().cpu().clone()
+
+
+def _worker4d(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        q.put((rank, _run_steps4d(_model4d(), (7, 8, 9, 10), accumulation_steps=2).numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp2_4d_temporal_head_arena_equals_single_process_bitwise():
+    """configs[3] under DP: the encoder is frozen, so the only gradient message is the temporal head's arena - ONE all-reduce of
+    10 280 floats per optimizer step (trainer.TrainStep), scaled by 1/world before the fused AdamW.  Same batches on both ranks:
+    (g + g) * 0.5 == g exactly, so two optimizer steps (two micro-steps each) must leave the head's parameters bit-identical to
+    the single-process run."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_worker4d, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {rank: torch.from_numpy(arr) for rank, arr in (q.get(timeout=240) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single = _run_steps4d(_model4d(), (7, 8, 9, 10), accumulation_steps=2)
+    start = _model4d()._temporal_head.flat_parameters()[0].detach().cpu()
+    assert torch.equal(res[0], res[1])
+    assert torch.equal(res[0], single)
+    assert not torch.equal(single, start)
+
+
 def _msg_worker(q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + (os.getpid() % 200)))
     dist.init_process_group("gloo", rank=0, world_size=1)

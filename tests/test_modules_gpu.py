@@ -410,6 +410,61 @@ def test_neuro4d_full_size_config(nv):
             assert torch.allclose(q.grad, whole[k], rtol=1e-4, atol=1e-6), k
 
 
+def test_neuro4d_native_head_train_steps_equal_stock_module_path(nv):
+    """The 4D train step (Trainer.py:65-79 with config4D's accumulation) through the native temporal head + fused AdamW on its arena
+    against the same model computed by the stock torch modules the reference instantiates (+ torch.optim.AdamW): two optimizer
+    steps of two micro-steps each, dropout 0 so that both paths are deterministic.  Also: the head's parameters are views of ONE
+    arena, the state_dict keys are the reference's, and train mode draws a dropout mask (outputs differ between two forwards)."""
+    from neurovit_amd.trainer import TrainStep
+    S, p, T = 16, 8, 8
+    small = dict(TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
+    with tempfile.TemporaryDirectory() as td:
+        torch.manual_seed(11)
+        m3 = nv.NeuroEncoder(W.neuro_config(S, p, DEVICE="cuda", **small))
+        torch.save(m3.state_dict(), os.path.join(td, "c.pth"))
+        cfg4 = W.neuro_config(S, p, dim=4, DEVICE="cuda", GLOBAL_BASE_PATH=td, BEST_MODEL_PATH="c.pth", TRAINING_LEARNING_RATE=1e-2, **small)
+        torch.manual_seed(12)
+        native = nv.NeuroEncoder(cfg4)
+        stock = nv.NeuroEncoder(cfg4)
+    stock.load_state_dict(native.state_dict())
+    assert set(W.make_tensors(W.temporal_param_spec(), 0)) <= set(native.state_dict())
+    x = W.make_volume((4, S, S, S, T), 13).cuda()
+    y = torch.tensor([0, 1, 1, 0], device="cuda")
+    native.train(); native.volume_encoder.eval()
+    a, b = native(x[:2]), native(x[:2])
+    assert not torch.equal(a, b)                                   # torch-default dropout 0.1 of the encoder layer is live in train mode
+    for m in (native, stock):
+        lay = m.temporal_transformer.transformer.layers[0]
+        lay.dropout.p = lay.dropout1.p = lay.dropout2.p = 0.0
+        lay.self_attn.dropout = 0.0
+        m.train(); m.volume_encoder.eval()
+    stock._temporal_head.supported = lambda t: False               # the stock-module branch of NeuroEncoder.forward
+    head = native._temporal_head
+    head.flat_parameters()
+    base = head._arena.data_ptr()
+    assert all(q.data_ptr() == base + 4 * o for q, o in zip(head._plist, head._offsets))
+    step = TrainStep(native, accumulation_steps=2)
+    opt = torch.optim.AdamW([q for q in stock.parameters() if q.requires_grad], lr=1e-2, weight_decay=cfg4.get("TRAINING_WEIGHT_DECAY", 1e-2))
+    crit = torch.nn.CrossEntropyLoss()
+    for it in range(2):
+        opt.zero_grad(set_to_none=True)
+        for mb in range(2):
+            xs, ys = x[2 * mb:2 * mb + 2], y[2 * mb:2 * mb + 2]
+            l_native = step(xs, ys)
+            l_stock = crit(stock(xs), ys)
+            l_stock.backward()
+            assert abs(l_native.item() - l_stock.item()) < 1e-5 * max(1.0, abs(l_stock.item())), (it, mb)
+        opt.step()
+        assert any(isinstance(h, type(head)) for h in step.optimizer._arenas) and step.optimizer._rest is None
+        for (k, q), (_, r) in zip(native.named_parameters(), stock.named_parameters()):
+            if r.requires_grad:
+                # AdamW's first steps move every entry by ~lr whatever the gradient's size: entries whose gradient is rounding noise
+                # (everything behind the saturated two-feature LayerNorms) may differ by up to 2 lr per step
+                tight = k.endswith(("norm2.weight", "norm2.bias", "projection_head.weight", "projection_head.bias"))
+                tol = 2e-4 if tight else 2.1e-2 * (it + 1)
+                assert (q - r).abs().max().item() <= tol, (it, k, (q - r).abs().max().item())
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # standalone blocks (vit_3d.py:25-26,48-60,72-75): the reference exposes FeedForward / Attention / Transformer as callable
 # modules; here they run the same gfx950 kernels stage by stage.  Checked against the oracle (fp32 and bf16-emulating).
