@@ -98,8 +98,9 @@ typedef struct nv_gemm_problem {
 } nv_gemm_problem;
 int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gemm_problem* problems, void* stream);
 
-/* tuning aid: force the workgroup tile (bm, bn in {64, 128}); bm = 0 restores the built-in heuristic; bm = 1..3 forces a
- * warp-specialised tile, bm = 4 the eight-wave 256 x 128 ping-pong kernel, bm = 5 forbids it; (6, n) sets the ping-pong
+/* tuning aid: force the workgroup tile ((64,64), (64,128), (128,128): the general small-tile kernel); bm = 0 restores the built-in
+ * heuristic; bm = 1 / 3 forces the warp-specialised 128 x 128 / 64 x 128 tile (bn: ring, 0 = heuristic, 1 = 3 x 64-deep, (3,3) =
+ * 3 x 128-deep), bm = 4 the eight-wave 256 x 128 ping-pong kernel, bm = 5 forbids it, bm = 9 the 256 x 256 kernel; (6, n) sets the ping-pong
  * kernel's minimum tile count, (7, 0|1) switches the grouped weight-gradient launch between the two kernel families */
 int nv_gemm_set_tile(int bm, int bn);
 
@@ -265,6 +266,8 @@ typedef struct nv_vit_config {
   int channels, num_classes, dim, depth, heads, dim_head, mlp_dim;
   float ln_eps;
   int pool_mean;   /* 0: pool='cls' (NeuroEncoder.py:194), 1: pool='mean' (vit_3d.py:127) */
+  int image_width, patch_width;   /* vit_3d.py:80-81 takes (height, width) pairs: image_size / image_patch_size are the HEIGHTS,
+                                     these the widths; 0 = square (the NeuroEncoder path is cubic: NeuroEncoder.py:183-186) */
 } nv_vit_config;
 
 long nv_vit_param_count(const nv_vit_config* cfg);
@@ -273,7 +276,7 @@ int nv_vit_param_table(const nv_vit_config* cfg, long* offsets, long* numels, in
 long nv_vit_workspace_bytes(const nv_vit_config* cfg, int B, int training);
 /* byte offset of a named activation inside the workspace (-1 if unknown); layer < 0 for global buffers */
 long nv_vit_workspace_offset(const nv_vit_config* cfg, int B, int training, const char* name, int layer);
-/* shape5 = {B, C, F, H, W} of `video`: must equal {B, cfg.channels, cfg.frames, cfg.image_size, cfg.image_size} (the reference
+/* shape5 = {B, C, F, H, W} of `video`: must equal {B, cfg.channels, cfg.frames, cfg.image_size, width (cfg.image_width or cfg.image_size)} (the reference
  * fails in einops / the pos_embedding add for any other volume, vit_3d.py:92,118; here a wrong extent would be gathered out of
  * bounds, so it is rejected with NV_ERR_ARG).
  * drop_p / emb_drop_p / drop_seed: nn.Dropout of the blocks (vit_3d.py:21,23,39,45) and of the embedding (:100); both 0

@@ -23,7 +23,8 @@ class VitConfig(ctypes.Structure):
     _fields_ = [("image_size", ctypes.c_int), ("image_patch_size", ctypes.c_int), ("frames", ctypes.c_int),
                 ("frame_patch_size", ctypes.c_int), ("channels", ctypes.c_int), ("num_classes", ctypes.c_int),
                 ("dim", ctypes.c_int), ("depth", ctypes.c_int), ("heads", ctypes.c_int), ("dim_head", ctypes.c_int),
-                ("mlp_dim", ctypes.c_int), ("ln_eps", ctypes.c_float), ("pool_mean", ctypes.c_int)]
+                ("mlp_dim", ctypes.c_int), ("ln_eps", ctypes.c_float), ("pool_mean", ctypes.c_int),
+                ("image_width", ctypes.c_int), ("patch_width", ctypes.c_int)]      # 0 = square
 
 
 class VitInput(ctypes.Structure):

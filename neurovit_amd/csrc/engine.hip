@@ -39,10 +39,14 @@ static bool cls_tail_wanted(const Dims& D, int training, float drop_p, int rows_
   return want && !D.pool_mean && drop_p == 0.f && (!training || D.B <= 4);
 }
 
+// image width / width of a patch: nv_vit_config.image_width / patch_width, 0 = square (vit_3d.py:80-81 takes pairs)
+static inline int img_w(const nv_vit_config* c) { return c->image_width > 0 ? c->image_width : c->image_size; }
+static inline int pat_w(const nv_vit_config* c) { return c->patch_width > 0 ? c->patch_width : c->image_patch_size; }
+
 int make_dims(const nv_vit_config* c, int B, Dims& D) {
   NV_CHECK_ARG(c && B > 0, "nv_vit: null config or B <= 0");
   NV_CHECK_ARG(c->image_size > 0 && c->image_patch_size > 0 && c->frames > 0 && c->frame_patch_size > 0 &&
-                   c->image_size % c->image_patch_size == 0,
+                   c->image_size % c->image_patch_size == 0 && c->image_width >= 0 && c->patch_width >= 0 && img_w(c) % pat_w(c) == 0,
                "Image dimensions must be divisible by the patch size.");
   NV_CHECK_ARG(c->frames % c->frame_patch_size == 0, "Frames must be divisible by frame patch size");
   NV_CHECK_ARG(c->dim_head >= 8 && c->dim_head <= 128 && c->dim_head % 8 == 0,
@@ -52,10 +56,11 @@ int make_dims(const nv_vit_config* c, int B, Dims& D) {
   NV_CHECK_ARG(c->depth >= 1 && c->num_classes >= 1 && c->channels >= 1, "nv_vit: bad depth/classes/channels");
   D.B = B;
   D.gf = c->frames / c->frame_patch_size;
-  D.gh = D.gw = c->image_size / c->image_patch_size;
+  D.gh = c->image_size / c->image_patch_size;
+  D.gw = img_w(c) / pat_w(c);
   D.N = D.gf * D.gh * D.gw;
   D.n = D.N + 1;
-  D.P = c->channels * c->image_patch_size * c->image_patch_size * c->frame_patch_size;
+  D.P = c->channels * c->image_patch_size * pat_w(c) * c->frame_patch_size;
   D.Ppad = (int)align_up(D.P, 8);
   D.d = c->dim; D.heads = c->heads; D.dh = c->dim_head; D.inner = c->heads * c->dim_head; D.m = c->mlp_dim;
   D.L = c->depth; D.C = c->num_classes;
@@ -244,11 +249,11 @@ static int patch_front(const nv_vit_config* cfg, const Dims& D, const ParamTab& 
   if (in && in->time_points > 0) {
     NV_CHECK_ARG(B % in->time_points == 0 && cfg->channels == 1, "nv_vit_forward: time_points=%d must divide B=%d (channels = 1)", in->time_points, B);
     // video = contiguous [B / T, H, W, D, T]: (H, W, D) of the dataset = (image, image, frames) of the ViT (NeuroEncoder.py:200-202)
-    return nv_patch_ln_fwd_4d(video, B / in->time_points, cfg->image_size, cfg->image_size, cfg->frames, in->time_points, cfg->image_patch_size,
-                              cfg->image_patch_size, cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, xp, D.Ppad, pst, pst + D.T, sigma, stream);
+    return nv_patch_ln_fwd_4d(video, B / in->time_points, cfg->image_size, img_w(cfg), cfg->frames, in->time_points, cfg->image_patch_size,
+                              pat_w(cfg), cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, xp, D.Ppad, pst, pst + D.T, sigma, stream);
   }
-  return nv_patch_ln_fwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
-                         cfg->image_patch_size, cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, xp, D.Ppad, pst, pst + D.T, sigma, stream);
+  return nv_patch_ln_fwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, img_w(cfg), cfg->image_patch_size,
+                         pat_w(cfg), cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, xp, D.Ppad, pst, pst + D.T, sigma, stream);
 }
 
 extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
@@ -265,13 +270,13 @@ extern "C" int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* v
   WS W; make_ws(D, training, W);
   NV_CHECK_ARG(video && shape5 && strides5 && params && params16 && workspace && logits, "nv_vit_forward: null pointer");
   if (in && in->time_points > 0)
-    NV_CHECK_ARG(shape5[0] * shape5[4] == B && shape5[4] == in->time_points && shape5[1] == cfg->image_size && shape5[2] == cfg->image_size && shape5[3] == cfg->frames,
+    NV_CHECK_ARG(shape5[0] * shape5[4] == B && shape5[4] == in->time_points && shape5[1] == cfg->image_size && shape5[2] == img_w(cfg) && shape5[3] == cfg->frames,
                  "nv_vit_forward: 4D input is [%ld,%ld,%ld,%ld,%ld], expected [B/T, %d, %d, %d, T=%d] with B = %d", shape5[0], shape5[1], shape5[2], shape5[3],
-                 shape5[4], cfg->image_size, cfg->image_size, cfg->frames, in->time_points, B);
+                 shape5[4], cfg->image_size, img_w(cfg), cfg->frames, in->time_points, B);
   else
-  NV_CHECK_ARG(shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == cfg->image_size,
+  NV_CHECK_ARG(shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == img_w(cfg),
                "nv_vit_forward: video is [%ld,%ld,%ld,%ld,%ld], the model was built for [%d,%d,%d,%d,%d] (B, channels, frames, height, width)",
-               shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size);
+               shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, img_w(cfg));
   NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_forward: workspace too small (%ld < %ld)", ws_bytes, W.total);
   NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params) && nv_aligned16(params16), "nv_vit_forward: alignment");
   char* ws = (char*)workspace;
@@ -346,14 +351,14 @@ extern "C" int nv_vit_forward_f32(const nv_vit_config* cfg, int B, const float* 
   WSF W; make_wsf(D, W);
   NV_CHECK_ARG(video && shape5 && strides5 && params && workspace && logits, "nv_vit_forward_f32: null pointer");
   if (in && in->time_points > 0)
-    NV_CHECK_ARG(shape5[0] * shape5[4] == B && shape5[4] == in->time_points && shape5[1] == cfg->image_size && shape5[2] == cfg->image_size && shape5[3] == cfg->frames &&
+    NV_CHECK_ARG(shape5[0] * shape5[4] == B && shape5[4] == in->time_points && shape5[1] == cfg->image_size && shape5[2] == img_w(cfg) && shape5[3] == cfg->frames &&
                      B % in->time_points == 0 && cfg->channels == 1,
                  "nv_vit_forward_f32: 4D input is [%ld,%ld,%ld,%ld,%ld], expected [B/T, %d, %d, %d, T=%d] with B = %d", shape5[0], shape5[1], shape5[2], shape5[3],
-                 shape5[4], cfg->image_size, cfg->image_size, cfg->frames, in->time_points, B);
+                 shape5[4], cfg->image_size, img_w(cfg), cfg->frames, in->time_points, B);
   else
-    NV_CHECK_ARG(shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == cfg->image_size,
+    NV_CHECK_ARG(shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == img_w(cfg),
                  "nv_vit_forward_f32: video is [%ld,%ld,%ld,%ld,%ld], the model was built for [%d,%d,%d,%d,%d] (B, channels, frames, height, width)",
-                 shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size);
+                 shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, img_w(cfg));
   NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_forward_f32: workspace too small (%ld < %ld)", ws_bytes, W.total);
   NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params), "nv_vit_forward_f32: alignment");
   char* ws = (char*)workspace;
@@ -366,11 +371,11 @@ extern "C" int nv_vit_forward_f32(const nv_vit_config* cfg, int B, const float* 
   float* pst = F32(W.pst);
   const float* sigma = in ? in->vol_sigma : nullptr;
   if (in && in->time_points > 0)
-    RUN(nv_patch_ln_fwd_4d_f32(video, B / in->time_points, cfg->image_size, cfg->image_size, cfg->frames, in->time_points, cfg->image_patch_size,
-                               cfg->image_patch_size, cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, F32(W.xp), D.P, pst, pst + D.T, sigma, stream));
+    RUN(nv_patch_ln_fwd_4d_f32(video, B / in->time_points, cfg->image_size, img_w(cfg), cfg->frames, in->time_points, cfg->image_patch_size,
+                               pat_w(cfg), cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, F32(W.xp), D.P, pst, pst + D.T, sigma, stream));
   else
-    RUN(nv_patch_ln_fwd_f32(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
-                            cfg->image_patch_size, cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, F32(W.xp), D.P, pst, pst + D.T, sigma, stream));
+    RUN(nv_patch_ln_fwd_f32(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, img_w(cfg), cfg->image_patch_size,
+                            pat_w(cfg), cfg->frame_patch_size, p + T.pe_g, p + T.pe_b, eps, F32(W.xp), D.P, pst, pst + D.T, sigma, stream));
   // A3: Linear(patch_dim, dim)
   RUN(nv_gemm_f32(2, D.T, d, D.P, F32(W.xp), D.P, p + T.pe_w, D.P, F32(W.t), d, p + T.pe_bias, nullptr, 0, stream));
   // A4 + A5: LayerNorm(dim) + cls + pos
@@ -446,9 +451,9 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 0, W);
   NV_CHECK_ARG(video && shape5 && strides5 && params && params16 && params8 && colscales && act_scales && workspace && logits, "nv_vit_forward_fp8: null pointer");
-  NV_CHECK_ARG((in && in->time_points > 0) || (shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == cfg->image_size),
+  NV_CHECK_ARG((in && in->time_points > 0) || (shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == img_w(cfg)),
                "nv_vit_forward_fp8: video is [%ld,%ld,%ld,%ld,%ld], the model was built for [%d,%d,%d,%d,%d] (B, channels, frames, height, width)",
-               shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size);
+               shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, img_w(cfg));
   NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_forward_fp8: workspace too small (%ld < %ld)", ws_bytes, W.total);
   NV_CHECK_ARG(D.d % 128 == 0 && D.m % 128 == 0, "nv_vit_forward_fp8: dim and mlp_dim must be multiples of 128");
   NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params) && nv_aligned16(params16) && nv_aligned16(params8), "nv_vit_forward_fp8: alignment");
@@ -697,8 +702,8 @@ extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const f
   if (forked) RUN(stream_sync(S, A));                                                                                          // dt16 and layer 0's LN1 partials ready
   if (pending_ln1 >= 0) RUN(reduce_ln1(pending_ln1));
   RUN(nv_gemm_bf16(1, 1, D.T, D.Ppad, d, ws + W.dt16, d, wpe, D.Ppad, ws + W.dxp, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, sA));              // [A] dxp = dt Wpe
-  RUN(nv_patch_ln_bwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, cfg->image_size, cfg->image_patch_size,
-                      cfg->image_patch_size, cfg->frame_patch_size, (float*)(ws + W.dxp), D.Ppad, pst, pst + D.T, gr + T.pe_g, gr + T.pe_b, acc, redA,
+  RUN(nv_patch_ln_bwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, img_w(cfg), cfg->image_patch_size,
+                      pat_w(cfg), cfg->frame_patch_size, (float*)(ws + W.dxp), D.Ppad, pst, pst + D.T, gr + T.pe_g, gr + T.pe_b, acc, redA,
                       redA_bytes, sA));                                                                                         // [A]
   if (D.P != D.Ppad) {
     RUN(nv_gemm_bf16(2, 1, d, D.Ppad, D.T, ws + W.dt16, d, ws + W.xp, D.Ppad, ws + W.dwpe, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));

@@ -316,8 +316,8 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_grouped_kernel(const GemmG
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
-static int g_ring_override = 0;   // 0 heuristic, 1 = 3 x 64, 2 = deep x 64, 3 = 3 x 128
-static int g_tile_override = 0;   // 0 = heuristic; 1..3 = warp-specialised 128x128 / 128x64 / 64x128; 4 = ping-pong 256x128; 5 = never ping-pong;
+static int g_ring_override = 0;   // 0 heuristic, 1 = 3 x 64, 3 = 3 x 128
+static int g_tile_override = 0;   // 0 = heuristic; 1 / 3 = warp-specialised 128x128 / 64x128; 4 = ping-pong 256x128; 5 = never ping-pong;
                                   // else BM*1000 + BN (small-tile kernel)
 static int g_pp_grouped = 1;      // grouped weight-gradient launch on ping-pong tiles
 static int g_pp_min_tiles = 128;
@@ -328,8 +328,11 @@ extern "C" int nv_gemm_set_tile(int bm, int bn) {   // tuning aid (tools/gemm_be
   if (bm == 7) { g_pp_grouped = bn; return 0; }
   if (bm == 8) { g_pp_dbg = bn; return 0; }
   if (bm == 10) { g_pq_min_tiles = bn; return 0; }
+  const bool small = (bm == 64 && (bn == 64 || bn == 128)) || (bm == 128 && bn == 128);
+  NV_CHECK_ARG(bm == 0 || bm == 1 || (bm >= 3 && bm <= 5) || bm == 9 || small, "nv_gemm_set_tile: (%d, %d) is not a compiled tile", bm, bn);
+  NV_CHECK_ARG(!(bm == 1 || bm == 3) || bn == 0 || bn == 1 || (bm == 3 && bn == 3), "nv_gemm_set_tile: ring %d is not compiled for tile %d", bn, bm);
   g_tile_override = (bm == 0) ? 0 : ((bm <= 5 || bm == 9) ? bm : bm * 1000 + bn);
-  g_ring_override = (bm >= 1 && bm <= 3) ? bn : 0;      // for the warp-specialised tiles bn selects the ring: 1 shallow, 2 deep
+  g_ring_override = (bm == 1 || bm == 3) ? bn : 0;      // for the warp-specialised tiles bn selects the ring: 1 = 3 x 64-deep, 3 = 3 x 128-deep (64 x 128 only)
   return 0;
 }
 
@@ -432,9 +435,10 @@ static int launch(const GemmArgs& a, hipStream_t s) {
   if (p.family == 2) return launch_pp(A_T ? 2 : (B_T ? 1 : 0), EPI, a, s);
   if (p.family == 1) {
     const int ws = p.ws, ring = p.ring;
-    if (ws == 1) return ring == 2 ? launch_ws<128, 128, 4, 1, A_T, B_T, EPI>(a, s) : launch_ws<128, 128, 3, 1, A_T, B_T, EPI>(a, s);
-    if (ws == 2) return ring == 3 ? launch_ws<128, 64, 3, 2, A_T, B_T, EPI>(a, s) : (ring == 2 ? launch_ws<128, 64, 6, 1, A_T, B_T, EPI>(a, s) : launch_ws<128, 64, 3, 1, A_T, B_T, EPI>(a, s));
-    return ring == 3 ? launch_ws<64, 128, 3, 2, A_T, B_T, EPI>(a, s) : (ring == 2 ? launch_ws<64, 128, 6, 1, A_T, B_T, EPI>(a, s) : launch_ws<64, 128, 3, 1, A_T, B_T, EPI>(a, s));
+    // (the 128 x 64 tile and the deep 6 / 4-stage rings, reachable only through nv_gemm_set_tile, lost every comparison of
+    // profiles/r01_gemm_shapes_tiles.log and are no longer compiled: 50 instantiations)
+    if (ws == 1) return launch_ws<128, 128, 3, 1, A_T, B_T, EPI>(a, s);
+    return ring == 3 ? launch_ws<64, 128, 3, 2, A_T, B_T, EPI>(a, s) : launch_ws<64, 128, 3, 1, A_T, B_T, EPI>(a, s);
   }
   if constexpr (EPI == EPI_DGELU_COLSUM) {
     nv_set_error("nv_gemm_bf16: the fused column-sum epilogue needs a large-tile kernel for this shape (ask nv_gemm_tile_rows first)");
@@ -443,7 +447,6 @@ static int launch(const GemmArgs& a, hipStream_t s) {
     switch (p.sel) {
       case 128128: return launch_tile<128, 128, A_T, B_T, EPI>(a, s);
       case 64128: return launch_tile<64, 128, A_T, B_T, EPI>(a, s);
-      case 128064: return launch_tile<128, 64, A_T, B_T, EPI>(a, s);
       default: return launch_tile<64, 64, A_T, B_T, EPI>(a, s);
     }
   }

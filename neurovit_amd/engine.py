@@ -21,11 +21,18 @@ _BYTES = {torch.float32: 4, torch.bfloat16: 2}
 
 
 def make_config(*, image_size, image_patch_size, frames, frame_patch_size, num_classes, dim, depth, heads, mlp_dim,
-                channels=3, dim_head=64, ln_eps=1e-5, pool='cls', **_) -> VitConfig:
+                channels=3, dim_head=64, ln_eps=1e-5, pool='cls', image_width=0, patch_width=0, **_) -> VitConfig:
+    """image_size / image_patch_size are the image / patch HEIGHT; image_width / patch_width (0 = same) the widths (vit_3d.py:80-81)."""
     if pool not in ('cls', 'mean'):
         raise ValueError("pool type must be either cls (cls token) or mean (mean pooling)")
     return VitConfig(image_size, image_patch_size, frames, frame_patch_size, channels, num_classes, dim, depth, heads,
-                     dim_head, mlp_dim, ln_eps, int(pool == 'mean'))
+                     dim_head, mlp_dim, ln_eps, int(pool == 'mean'), 0 if image_width == image_size else image_width,
+                     0 if patch_width == image_patch_size else patch_width)
+
+
+def image_hw(cfg: VitConfig):
+    """(image height, image width, patch height, patch width)"""
+    return cfg.image_size, cfg.image_width or cfg.image_size, cfg.image_patch_size, cfg.patch_width or cfg.image_patch_size
 
 
 def param_layout(cfg: VitConfig) -> Tuple[List[int], List[int], int]:
@@ -46,10 +53,10 @@ def flops_forward(cfg: VitConfig) -> float:
     """Algorithmic FLOPs per volume of one ViT forward (2 x MAC of the patch embedding, the four linears and the two
     attention products of every block, and the head; LayerNorm / softmax / GELU / bias excluded) - SURVEY.md 8(d).
     A train step counts 3 x this (backward = 2 x forward)."""
-    g = cfg.image_size // cfg.image_patch_size
-    N = (cfg.frames // cfg.frame_patch_size) * g * g
+    H, Wd, p1, p2 = image_hw(cfg)
+    N = (cfg.frames // cfg.frame_patch_size) * (H // p1) * (Wd // p2)
     n = N + 1
-    P = cfg.channels * cfg.image_patch_size * cfg.image_patch_size * cfg.frame_patch_size
+    P = cfg.channels * p1 * p2 * cfg.frame_patch_size
     d, inner, m = cfg.dim, cfg.heads * cfg.dim_head, cfg.mlp_dim
     per_layer = 2 * n * d * 3 * inner + 2 * n * n * inner + 2 * n * n * inner + 2 * n * inner * d + 4 * n * d * m
     return 2.0 * N * P * d + cfg.depth * per_layer + 2 * d * cfg.num_classes
@@ -92,13 +99,13 @@ class VitRuntime:
         assert video.dtype == torch.float32 and video.dim() == 5
         c = self.cfg
         if time_points:
-            want = (c.image_size, c.image_size, c.frames, time_points)
+            want = (c.image_size, c.image_width or c.image_size, c.frames, time_points)
             if tuple(video.shape[1:]) != want or not video.is_contiguous() or time_points % 4 or c.channels != 1:
                 raise ValueError(f"neurovit_amd: 4D batch of shape {tuple(video.shape)} (contiguous: {video.is_contiguous()}) does not match "
                                  f"[B, H, W, D, T] = [B, {', '.join(map(str, want))}] with T % 4 == 0")
             B = video.shape[0] * time_points
         else:
-            want = (c.channels, c.frames, c.image_size, c.image_size)
+            want = (c.channels, c.frames, c.image_size, c.image_width or c.image_size)
             if tuple(video.shape[1:]) != want:
                 raise ValueError(f"neurovit_amd: video of shape {tuple(video.shape)} does not match the model's "
                                  f"[B, channels, frames, height, width] = [B, {', '.join(map(str, want))}]")
@@ -155,7 +162,8 @@ class VitRuntime:
         format: headroom costs no relative precision, it only moves the subnormal floor."""
         self.forward(video, params, params16, training=True, rows_form=1)    # the fp8 forward quantises every row of every block: calibrate on every row
         B = video.shape[0]
-        n = (self.cfg.frames // self.cfg.frame_patch_size) * (self.cfg.image_size // self.cfg.image_patch_size) ** 2 + 1
+        H, Wd, p1, p2 = image_hw(self.cfg)
+        n = (self.cfg.frames // self.cfg.frame_patch_size) * (H // p1) * (Wd // p2) + 1
         scales = []
         for l in range(self.cfg.depth):
             row = []

@@ -266,14 +266,11 @@ class ViT(nn.Module):
         )
 
         # ---- native engine state (not part of the reference surface) ----
-        if image_height != image_width or patch_height != patch_width:
-            raise NotImplementedError("neurovit_amd: the gfx950 engine supports square images / patches (the NeuroEncoder "
-                                      "path is cubic: NeuroEncoder.py:183-186)")
         if heads == 1 and dim_head == dim:
             raise NotImplementedError("neurovit_amd: heads == 1 with dim_head == dim drops to_out (vit_3d.py:32,43-46); the "
                                       "engine's parameter table always carries to_out - not on the NeuroEncoder path")
         self._dropout_p = (float(dropout), float(emb_dropout))
-        self._cfg = engine.make_config(image_size=image_height, image_patch_size=patch_height, frames=frames,
+        self._cfg = engine.make_config(image_size=image_height, image_patch_size=patch_height, image_width=image_width, patch_width=patch_width, frames=frames,
                                        frame_patch_size=frame_patch_size, num_classes=num_classes, dim=dim, depth=depth,
                                        heads=heads, mlp_dim=mlp_dim, channels=channels, dim_head=dim_head,
                                        pool=pool)
@@ -440,7 +437,7 @@ class ViT(nn.Module):
         if getattr(self, "_mirrored", None) is not None:
             return self._mirrored
         off, num, _ = self._layout
-        P = self._cfg.channels * self._cfg.image_patch_size ** 2 * self._cfg.frame_patch_size
+        P = self._cfg.channels * self._cfg.image_patch_size * (self._cfg.patch_width or self._cfg.image_patch_size) * self._cfg.frame_patch_size
         out = []
         for (name, _), o, n in zip(self.named_parameters(), off, num):
             if name.startswith("transformer.layers.") and name.endswith((".to_qkv.weight", ".to_out.0.weight", ".net.1.weight", ".net.4.weight")):
@@ -480,13 +477,14 @@ class ViT(nn.Module):
         if not video.is_cuda:
             raise RuntimeError("neurovit_amd.ViT: input must live on the MI355X (cuda) device - there is no CPU fallback")
         c = self._cfg
+        width = c.image_width or c.image_size
         if time_points:
-            if video.dim() != 5 or tuple(video.shape[1:]) != (c.image_size, c.image_size, c.frames, time_points):
-                raise ValueError(f"neurovit_amd.ViT: expected a 4D batch [B, {c.image_size}, {c.image_size}, {c.frames}, {time_points}], got {tuple(video.shape)}")
-        elif video.dim() != 5 or tuple(video.shape[1:]) != (c.channels, c.frames, c.image_size, c.image_size):
+            if video.dim() != 5 or tuple(video.shape[1:]) != (c.image_size, width, c.frames, time_points):
+                raise ValueError(f"neurovit_amd.ViT: expected a 4D batch [B, {c.image_size}, {width}, {c.frames}, {time_points}], got {tuple(video.shape)}")
+        elif video.dim() != 5 or tuple(video.shape[1:]) != (c.channels, c.frames, c.image_size, width):
             # the reference fails here too (einops Rearrange / the pos_embedding add, vit_3d.py:92,118); the gather kernel
             # takes its extents from the config, so a wrong-sized volume must never reach it
-            raise ValueError(f"neurovit_amd.ViT: expected video [B, {c.channels}, {c.frames}, {c.image_size}, {c.image_size}] "
+            raise ValueError(f"neurovit_amd.ViT: expected video [B, {c.channels}, {c.frames}, {c.image_size}, {width}] "
                              f"(channels, frames, height, width), got {tuple(video.shape)}")
         if not self._arena_ok():
             self._build_arena()

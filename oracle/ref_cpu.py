@@ -51,12 +51,18 @@ class ViTCfg:
     pool: str = "cls"
     channels: int = 3
     dim_head: int = 64
+    image_width: int = 0        # vit_3d.py:80-81: image_size / image_patch_size may be (height, width) pairs; 0 = square
+    patch_width: int = 0
+
+    @property
+    def hw(self) -> Tuple[int, int, int, int]:
+        """(image height, image width, patch height, patch width)"""
+        return self.image_size, self.image_width or self.image_size, self.image_patch_size, self.patch_width or self.image_patch_size
 
     @property
     def grid(self) -> Tuple[int, int, int]:
-        return (self.frames // self.frame_patch_size,
-                self.image_size // self.image_patch_size,
-                self.image_size // self.image_patch_size)
+        H, Wd, p1, p2 = self.hw
+        return (self.frames // self.frame_patch_size, H // p1, Wd // p2)
 
     @property
     def num_patches(self) -> int:
@@ -65,7 +71,7 @@ class ViTCfg:
 
     @property
     def patch_dim(self) -> int:
-        return self.channels * self.image_patch_size ** 2 * self.frame_patch_size
+        return self.channels * self.hw[2] * self.hw[3] * self.frame_patch_size
 
     @property
     def inner(self) -> int:
@@ -363,7 +369,7 @@ def feed_forward(sd, pre, x, emulate=False, drop=None, f8=None):
 
 def patch_embed(sd, cfg: ViTCfg, video, emulate=False, taps=None, drop=None):
     """to_patch_embedding + cls/pos + emb dropout (vit_3d.py:91-96,113-119).  drop = (p_emb, seed) or None."""
-    tok = patchify(video, cfg.image_patch_size, cfg.image_patch_size, cfg.frame_patch_size)
+    tok = patchify(video, cfg.hw[2], cfg.hw[3], cfg.frame_patch_size)
     P, d = cfg.patch_dim, cfg.dim
     a2 = F.layer_norm(tok, (P,), sd["to_patch_embedding.1.weight"], sd["to_patch_embedding.1.bias"], LN_EPS)
     a3 = _linear(a2, sd["to_patch_embedding.2.weight"], sd["to_patch_embedding.2.bias"], emulate, "xp")

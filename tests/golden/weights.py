@@ -21,8 +21,10 @@ def vit_param_spec(*, image_size, image_patch_size, frames, frame_patch_size, nu
                    heads, mlp_dim, channels=3, dim_head=64, **_) -> List[Tuple[str, Tuple[int, ...], str]]:
     """(name, shape, kind) in the reference's ViT.state_dict() order (vit_3d.py:91-110).
     kind: 'w' weight matrix, 'b' bias, 'g' LN gain, 'e' embedding."""
-    N = (image_size // image_patch_size) ** 2 * (frames // frame_patch_size)
-    P = channels * image_patch_size ** 2 * frame_patch_size
+    (H, Wd), (p1, p2) = (image_size if isinstance(image_size, tuple) else (image_size, image_size)), \
+        (image_patch_size if isinstance(image_patch_size, tuple) else (image_patch_size, image_patch_size))   # vit_3d.py:80-81 pairs
+    N = (H // p1) * (Wd // p2) * (frames // frame_patch_size)
+    P = channels * p1 * p2 * frame_patch_size
     inner = heads * dim_head
     project_out = not (heads == 1 and dim_head == dim)
     spec = [("pos_embedding", (1, N + 1, dim), "e"), ("cls_token", (1, 1, dim), "e"),
@@ -97,6 +99,10 @@ MICRO = dict(image_size=32, image_patch_size=8, frames=32, frame_patch_size=8, n
              depth=2, heads=2, mlp_dim=256, channels=1, dim_head=64, pool="cls")         # fast unit tests
 BASE = dict(image_size=128, image_patch_size=16, frames=128, frame_patch_size=16, num_classes=2, dim=768,
             depth=12, heads=12, mlp_dim=3072, channels=1, dim_head=64, pool="cls")       # BASELINE.json configs[1]
+
+
+RECT = dict(image_size=(16, 24), image_patch_size=(8, 4), frames=12, frame_patch_size=4, num_classes=3, dim=64,
+            depth=2, heads=2, mlp_dim=128, channels=2, dim_head=64, pool="cls")          # non-square images / patches, 2 channels
 
 
 def neuro_config(S: int, p: int, dim: int = 3, dataset: str = "adni", **extra) -> dict:

@@ -137,10 +137,10 @@ def test_gemm_tn_grouped_equals_single_launches(ops):
     assert_close_f32(probs[2][2], probs[2][0].double().T @ probs[2][1].double(), "grouped_single", 1e-5)
 
 
-@pytest.mark.parametrize("ws", [1, 2, 3])
+@pytest.mark.parametrize("ws", [1, 3])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 264, 192), (130, 136, 128), (2052, 768, 768), (300, 8, 64)])
 def test_gemm_warp_specialised_kernel_forced(ops, M, N, K, ws):
-    """The warp-specialised LDS-DMA kernels (128x128, 128x64, 64x128) on ragged M / N (hardware bounds give
+    """The warp-specialised LDS-DMA kernels (128x128, 64x128) on ragged M / N (hardware bounds give
     zeros) and on a ragged token count."""
     from neurovit_amd._cabi import lib
     lib.nv_gemm_set_tile(ws, 0)
@@ -347,7 +347,7 @@ def test_gemm_ping_pong_grouped_equals_single_launches(ops):
         lib.nv_gemm_set_tile(0, 0)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 3, 4])
 def test_gemm_dgelu_fused_colsum_and_reduce_multi(ops, tile):
     """Epilogue 6: dU as epilogue 5 (bit-identical) plus per-tile column sums of the stored bf16 values; nv_reduce_multi sums the
     partial rows (and other jobs in the same launch) deterministically.  Every large-tile kernel family."""

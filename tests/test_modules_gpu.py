@@ -100,6 +100,44 @@ def test_neuro4d_vs_reference_fixture(nv, golden):
             assert (q.grad.cpu() - ref).abs().max().item() <= 5e-2 * ref.abs().max().item() + 1e-6, k
 
 
+def test_rect_vit_matches_reference_fixture(nv, golden):
+    """vit_3d.py:80-81: the ViT on (height, width) pairs for image and patch, two channels (nv_vit_config.image_width / patch_width)
+    against the fixture made by the imported reference: gather order bit exact, logits in both arithmetic modes, gradients."""
+    from neurovit_amd import ops
+    from neurovit_amd.vit_3d import ViT
+    g = golden("rect_vit.npz")
+    (H, Wd), (p1, p2), F_, C, pf = W.RECT["image_size"], W.RECT["image_patch_size"], W.RECT["frames"], W.RECT["channels"], W.RECT["frame_patch_size"]
+    idx = torch.from_numpy(g["tok"].astype(np.int64))                      # [N, P] flat element index of video[0], the reference's Rearrange
+    N, P = idx.shape
+    rs = np.random.RandomState(3)
+    flat = torch.zeros(C * F_ * H * Wd)
+    for n in range(N):                                                       # every patch: half +1, half -1 -> LayerNorm(eps = 0) is the identity
+        flat[idx[n][torch.from_numpy(rs.permutation(P))]] = torch.cat([torch.ones(P // 2), -torch.ones(P // 2)])
+    out, _ = ops.patch_ln_fwd(flat.reshape(1, C, F_, H, Wd).cuda(), p1, p2, pf, torch.ones(P).cuda(), torch.zeros(P).cuda(), eps=0.0)
+    assert torch.equal(out.float().cpu(), flat[idx])
+    m = ViT(**W.RECT).cuda()
+    m.load_state_dict(W.make_tensors(W.vit_param_spec(**W.RECT), 61), strict=True)
+    video = torch.from_numpy(np.random.RandomState(62).standard_normal(size=(3, C, F_, H, Wd)).astype(np.float32)).cuda()
+    m.train()
+    logits = m(video)
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(g["labels"]).long().cuda())
+    loss.backward()
+    e16 = rel_err(logits, g["logits"])
+    assert e16 < 2e-2 and abs(loss.item() - g["loss"][0]) < 2e-2
+    worst = 0.0
+    for k, q in m.named_parameters():
+        if "grad." + k in g.files:
+            worst = max(worst, rel_l2(q.grad, g["grad." + k]))
+            assert rel_l2(q.grad, g["grad." + k]) < 3e-2, k
+    m.eval()
+    with torch.no_grad(), m.precision("fp32"):
+        e32 = rel_err(m(video), g["logits"])
+    assert e32 < 1e-4                                                       # stated tolerance 1e-3
+    report(f"rect ViT (16x24 image, 8x4 patches, 2 channels) vs reference fixture: logits bf16 {e16:.2e}, fp32 {e32:.2e}, worst gradient rel-L2 {worst:.2e}")
+    with pytest.raises(ValueError):
+        m(video.transpose(3, 4).contiguous())                               # height / width swapped
+
+
 def _micro_model(nv, lr=1e-3, wd=1e-2):
     size = dict(TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
     cfg = W.neuro_config(32, 8, DEVICE="cuda", TRAINING_LEARNING_RATE=lr, TRAINING_WEIGHT_DECAY=wd, **size)

@@ -175,6 +175,32 @@ def test_neuro3d_hooks_and_gradcam(golden):
     assert rel_err(cam2, g["cam"]) < 1e-3      # percentile threshold amplifies last-bit differences
 
 
+def _rect_cfg():
+    v = dict(W.RECT)
+    (H, Wd), (p1, p2) = v.pop("image_size"), v.pop("image_patch_size")
+    return ref_cpu.ViTCfg(image_size=H, image_patch_size=p1, image_width=Wd, patch_width=p2, **v)
+
+
+def test_rect_vit(golden):
+    """vit_3d.py:80-81: (height, width) pairs for the image and the patch, two channels - gather order bit exact, logits / loss /
+    gradients of the restatement against the imported reference."""
+    g = golden("rect_vit.npz")
+    cfg = _rect_cfg()
+    sd = W.make_tensors(W.vit_param_spec(**W.RECT), 61)
+    H, Wd, p1, p2 = cfg.hw
+    idx = torch.arange(cfg.channels * cfg.frames * H * Wd, dtype=torch.float32).reshape(1, cfg.channels, cfg.frames, H, Wd)
+    assert np.array_equal(ref_cpu.patchify(idx, p1, p2, cfg.frame_patch_size)[0].numpy().astype(np.int32), g["tok"])
+    video = torch.from_numpy(np.random.RandomState(62).standard_normal(size=(3, cfg.channels, cfg.frames, H, Wd)).astype(np.float32))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    logits = ref_cpu.vit_forward(leaves, cfg, video)
+    assert rel_err(logits, g["logits"]) < TOL
+    loss = train_step.cross_entropy(logits, torch.from_numpy(g["labels"]).long())
+    assert abs(loss.item() - g["loss"][0]) < 1e-6
+    names = [k[5:] for k in g.files if k.startswith("grad.")]
+    for k, v in zip(names, torch.autograd.grad(loss, [leaves[k] for k in names])):
+        assert rel_err(v, g["grad." + k]) < 2e-5, k
+
+
 def test_neuro4d(golden):
     g = golden("neuro4d.npz")
     S, p, T = 16, 8, 5

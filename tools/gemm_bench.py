@@ -51,7 +51,7 @@ def main():
         _l.nv_gemm_set_tile(8, a.dbg)
     if a.tile:
         from neurovit_amd._cabi import lib
-        bm, bn = {"ws128x128": (1, 1), "ws128x64": (2, 1), "ws64x128": (3, 1), "ws128x128d": (1, 2), "ws128x64d": (2, 2), "ws64x128d": (3, 2), "ws128x64k": (2, 3), "ws64x128k": (3, 3), "pp": (4, 0), "nopp": (5, 0), "pq": (9, 0)}.get(a.tile) or tuple(int(v) for v in a.tile.split("x"))
+        bm, bn = {"ws128x128": (1, 1), "ws64x128": (3, 1), "ws64x128k": (3, 3), "pp": (4, 0), "nopp": (5, 0), "pq": (9, 0)}.get(a.tile) or tuple(int(v) for v in a.tile.split("x"))
         lib.nv_gemm_set_tile(bm, bn)
         print(f"--- tile {bm}x{bn}")
     dev = "cuda"
