@@ -391,6 +391,27 @@ def main():
         also["forward_only_batch20_volumes_s"] = round(20 * 10 / (time.perf_counter() - t20), 1)
         del x20
         model.train()
+        # BASELINE.json configs[3] as a train step: the 4D NeuroEncoder (this encoder frozen, loaded from a checkpoint as
+        # NeuroEncoder.py:23-36 does; native temporal head trained), one sample x T = 20 per micro-step, accumulation 4 (config4D.yaml)
+        if a.preset == "base":
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                torch.save(model.state_dict(), os.path.join(td, "best3d.pth"))
+                m4 = NeuroEncoder(dict(config, TRAINING_DIM=4, GLOBAL_BASE_PATH=td, BEST_MODEL_PATH="best3d.pth"))
+            m4.train(); m4.volume_encoder.eval()
+            step4 = TrainStep(m4, process_group=None, accumulation_steps=4)
+            x4 = torch.randn(1, S, S, S, 20, device=device)
+            y4 = torch.zeros(1, dtype=torch.long, device=device)
+            for _ in range(4):
+                step4(x4, y4)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for _ in range(12):
+                step4(x4, y4)
+            torch.cuda.synchronize()
+            also["neuro4d_train_microstep_T20_volumes_s"] = round(20 * 12 / (time.perf_counter() - t4), 1)
+            del step4, m4, x4
+            torch.cuda.empty_cache()
         log(f"extras: {also}")
 
     log(f"{ms:.3f} ms/step, {value:.1f} volumes/s; roofline leg")
