@@ -17,8 +17,11 @@ python __graft_entry__.py smoke > $OUT/smoke.log 2>&1 || { tail $OUT/smoke.log; 
 ( python bench.py --forward-only --steps 30 --warmup 5; python bench.py --forward-only --precise --steps 20 --warmup 3;
   python bench.py --forward-only --batch 20 --steps 20 --warmup 3; python bench.py --forward-only --batch 20 --fp8 --steps 20 --warmup 3;
   python bench.py --forward-only --batch 20 --precise --steps 10 --warmup 3;
+  python bench.py --forward-only --batch 64 --steps 10 --warmup 3; python bench.py --forward-only --batch 64 --fp8 --steps 10 --warmup 3;
   python bench.py --preset large --steps 8 --warmup 2 --no-cpu-baseline --no-extras; python bench.py --preset large --forward-only --steps 8 --warmup 2;
   python bench.py --preset large --forward-only --fp8 --steps 8 --warmup 2; python bench.py --dropout 0.1 --steps 30 --warmup 5 --no-cpu-baseline --no-extras ) > $OUT/bench_secondary.jsonl 2> $OUT/bench_secondary.err || true
+python tools/neuro4d_train_bench.py 2> /dev/null | tail -1 > $OUT/neuro4d_train.log || true
+cat $OUT/neuro4d_train.log
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/stats_run.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1
