@@ -270,6 +270,9 @@ typedef struct nv_vit_config {
                                      these the widths; 0 = square (the NeuroEncoder path is cubic: NeuroEncoder.py:183-186) */
 } nv_vit_config;
 
+/* heads == 1 && dim_head == dim: the reference has no output projection (vit_3d.py:32,43-46) but the table still carries every
+ * block's to_out weight / bias slot: fill them with the identity / zeros and leave them out of the optimizer (x + I ao + 0 == x + ao
+ * exactly, and the data gradient g I == g); neurovit_amd.ViT does that. */
 long nv_vit_param_count(const nv_vit_config* cfg);
 int nv_vit_param_table(const nv_vit_config* cfg, long* offsets, long* numels, int max_entries);
 /* training: 0 = bf16 / fp8 inference layout, 1 = training layout (every layer's activations kept), 2 = fp32 inference layout */

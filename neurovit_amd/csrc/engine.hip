@@ -52,7 +52,6 @@ int make_dims(const nv_vit_config* c, int B, Dims& D) {
   NV_CHECK_ARG(c->dim_head >= 8 && c->dim_head <= 128 && c->dim_head % 8 == 0,
                "nv_vit: dim_head=%d unsupported (multiples of 8 up to 128; 64 runs the MFMA attention kernels, the others scalar ones)", c->dim_head);
   NV_CHECK_ARG(c->dim % 8 == 0 && c->dim <= 2048 && c->mlp_dim % 8 == 0, "nv_vit: dim must be a multiple of 8 and <= 2048, mlp_dim a multiple of 8");
-  NV_CHECK_ARG(!(c->heads == 1 && c->dim_head == c->dim), "nv_vit: heads==1 && dim_head==dim (no output projection) is not supported");
   NV_CHECK_ARG(c->depth >= 1 && c->num_classes >= 1 && c->channels >= 1, "nv_vit: bad depth/classes/channels");
   D.B = B;
   D.gf = c->frames / c->frame_patch_size;

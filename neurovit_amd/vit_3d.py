@@ -156,12 +156,17 @@ class Attention(nn.Module):
 
     def forward(self, x):
         """Standalone use (vit_3d.py:48-60): x [batch, tokens, dim] fp32 on the device -> to_out(attention(norm(x)))."""
-        if isinstance(self.to_out, nn.Identity):
-            raise NotImplementedError("neurovit_amd: heads == 1 with dim_head == dim (no output projection) is not provided")
         if self.dim_head % 8 or not 8 <= self.dim_head <= 128:
             raise NotImplementedError("neurovit_amd: dim_head must be a multiple of 8 up to 128 (64, the vit_3d.py:78 default and "
                                       "the only value the NeuroEncoder path uses, runs the MFMA attention kernels; the others scalar ones)")
         p = float(self.dropout.p)
+        if isinstance(self.to_out, nn.Identity):
+            # heads == 1, dim_head == dim: no projection and no trailing dropout (vit_3d.py:43-46) - the same kernels with the
+            # identity as the weight (x I + 0 is exact) and the output-dropout site off
+            dim = self.heads * self.dim_head
+            eye, zero = torch.eye(dim, device=x.device), torch.zeros(dim, device=x.device)
+            return _AttentionFn.apply(x, self.norm.weight, self.norm.bias, self.to_qkv.weight, eye, zero, self.heads, self.dim_head, p,
+                                      (_new_seed(p, self.training), 0))
         seeds = (_new_seed(p, self.training), _new_seed(p, self.training))
         return _AttentionFn.apply(x, self.norm.weight, self.norm.bias, self.to_qkv.weight, self.to_out[0].weight, self.to_out[0].bias,
                                   self.heads, self.dim_head, p, seeds)
@@ -266,9 +271,12 @@ class ViT(nn.Module):
         )
 
         # ---- native engine state (not part of the reference surface) ----
-        if heads == 1 and dim_head == dim:
-            raise NotImplementedError("neurovit_amd: heads == 1 with dim_head == dim drops to_out (vit_3d.py:32,43-46); the "
-                                      "engine's parameter table always carries to_out - not on the NeuroEncoder path")
+        # heads == 1 with dim_head == dim: the reference drops to_out (nn.Identity, vit_3d.py:32,43-46).  The engine's parameter
+        # table always carries the projection, so the arena keeps those slots as CONSTANTS no nn.Parameter views - weight = identity,
+        # bias = 0: x + I ao + 0 is exactly x + ao (products with 1.0 and sums with 0.0 are exact), its data gradient g I is
+        # exactly g, and the optimizer never sees them (see _build_arena / mark_shadow_fresh)
+        self._no_proj = (heads == 1 and dim_head == dim)
+        self._phantom = []         # [(offset, fp32 constant)] of those slots
         self._dropout_p = (float(dropout), float(emb_dropout))
         self._cfg = engine.make_config(image_size=image_height, image_patch_size=patch_height, image_width=image_width, patch_width=patch_width, frames=frames,
                                        frame_patch_size=frame_patch_size, num_classes=num_classes, dim=dim, depth=depth,
@@ -299,12 +307,25 @@ class ViT(nn.Module):
         plist = [p for _, p in self.named_parameters()]
         if self._layout is None:
             off, num, total = engine.param_layout(self._cfg)
+            self._phantom_slots = []
+            if self._no_proj:      # entries 8 + 11 l + {3, 4} of the table are to_out.0.weight / .bias of block l: no module parameter
+                d = self._cfg.dim
+                drop = {8 + 11 * l + k for l in range(self._cfg.depth) for k in (3, 4)}
+                for i in sorted(drop):
+                    self._phantom_slots.append((off[i], num[i], (i - 8) % 11 == 3))
+                off = [o for i, o in enumerate(off) if i not in drop]
+                num = [n for i, n in enumerate(num) if i not in drop]
             assert len(off) == len(plist) and all(p.numel() == n for p, n in zip(plist, num)), \
                 "parameter table of the native engine does not match the module tree"
             self._layout = (off, num, total)
         off, num, total = self._layout
         dev = plist[0].device
         arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._phantom = []
+        for o, n, is_weight in self._phantom_slots:
+            if is_weight:
+                arena[o:o + n].copy_(torch.eye(self._cfg.dim, dtype=torch.float32, device=dev).reshape(-1))
+            self._phantom.append((o, arena[o:o + n].clone()))
         grads_alive = self._grads is not None and self._grads.device == dev
         with torch.no_grad():
             for p, o, n in zip(plist, off, num):
@@ -345,6 +366,9 @@ class ViT(nn.Module):
     def mark_shadow_fresh(self):
         """Called by the fused AdamW, which writes the arena and the bf16 shadow itself (through raw pointers: no tensor
         `_version` moves, so the generation counter is what tells derived copies - the fp8 weights - that they are stale)."""
+        for o, const in self._phantom:           # the fused step ran over the whole arena: put the constant slots back
+            self._arena[o:o + const.numel()].copy_(const)
+            self._shadow[o:o + const.numel()].copy_(const)
         self._shadow_key = tuple(p._version for p in self._plist)
         self._param_generation += 1
 
@@ -391,6 +415,10 @@ class ViT(nn.Module):
     def _run_forward(self, video, need_grad, extra=(None, 0)):
         vol_sigma, time_points = extra
         drop = (0.0, 0.0, 0)
+        if self._no_proj and self.training and self._dropout_p[0] > 0:
+            raise NotImplementedError("neurovit_amd.ViT: heads == 1 with dim_head == dim has no Dropout behind the (absent) output "
+                                      "projection (vit_3d.py:43-46); the engine's block dropout would put one there - train this "
+                                      "geometry with dropout = 0")
         if self.training and (self._dropout_p[0] > 0 or self._dropout_p[1] > 0):
             # nn.Dropout semantics (vit_3d.py:21,23,39,45,100) with a counter-based mask: a fresh seed per forward from
             # torch's CPU generator (so torch.manual_seed reproduces runs); backward recomputes the same masks.

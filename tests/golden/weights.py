@@ -105,6 +105,10 @@ RECT = dict(image_size=(16, 24), image_patch_size=(8, 4), frames=12, frame_patch
             depth=2, heads=2, mlp_dim=128, channels=2, dim_head=64, pool="cls")          # non-square images / patches, 2 channels
 
 
+NOPROJ = dict(image_size=16, image_patch_size=8, frames=16, frame_patch_size=8, num_classes=2, dim=64, depth=2, heads=1,
+              mlp_dim=128, channels=1, dim_head=64, pool="cls")                          # heads 1, dim_head == dim: no to_out (vit_3d.py:32)
+
+
 def neuro_config(S: int, p: int, dim: int = 3, dataset: str = "adni", **extra) -> dict:
     """Minimal reference-style config dict (keys of configs/config.yaml that the model reads)."""
     cfg = dict(DEVICE="cpu", TRAINING_DIM=dim, TRAINING_DROPOUT=0.0, TRAINING_VIT_INPUT_SIZE=S,

@@ -138,6 +138,63 @@ def test_rect_vit_matches_reference_fixture(nv, golden):
         m(video.transpose(3, 4).contiguous())                               # height / width swapped
 
 
+def test_noproj_vit_matches_reference_fixture(nv, golden):
+    """heads == 1 with dim_head == dim (vit_3d.py:32,43-46: to_out is nn.Identity): same state_dict keys as the reference (no to_out),
+    the engine's projection slots held as identity / zero constants outside the optimizer.  Logits, gradients and one fused AdamW
+    step against the fixture made by the imported reference; the constants survive the step; the standalone Attention module agrees
+    with the oracle; block dropout in this geometry is refused."""
+    from neurovit_amd.optim import FusedAdamW
+    from neurovit_amd.vit_3d import ViT
+    g = golden("noproj_vit.npz")
+    sd = W.make_tensors(W.vit_param_spec(**W.NOPROJ), 71)
+    m = ViT(**W.NOPROJ).cuda()
+    assert set(m.state_dict()) == set(sd)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    S = W.NOPROJ["image_size"]
+    video = ref_cpu.fmri_to_video(W.make_volume((3, S, S, S), 72)).cuda()
+    labels = torch.from_numpy(g["labels"]).long().cuda()
+    lr, wd = float(g["hp"][0]), float(g["hp"][1])
+    opt = FusedAdamW(m.parameters(), lr=lr, weight_decay=wd, model=m)
+    logits = m(video)
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    e16 = rel_err(logits, g["logits"])
+    assert e16 < 2e-2 and abs(loss.item() - g["loss"][0]) < 2e-2
+    worst = max(rel_l2(q.grad, g["grad." + k]) for k, q in m.named_parameters())
+    assert worst < 3e-2
+    arena, _ = m.flat_parameters()
+    d = W.NOPROJ["dim"]
+    assert len(m._phantom) == 2 * W.NOPROJ["depth"] and arena.numel() >= sum(q.numel() for q in m.parameters()) + W.NOPROJ["depth"] * (d * d + d)
+    opt.step()
+    for o, const in m._phantom:                                   # identity / zeros again after the fused step over the whole arena
+        assert torch.equal(arena[o:o + const.numel()], const) and torch.equal(m._shadow[o:o + const.numel()].float(), const)
+    for k, q in m.named_parameters():
+        if "step1." + k in g.files:
+            assert (q.detach().cpu() - torch.from_numpy(g["step1." + k])).abs().max().item() <= 2.1 * lr, k   # AdamW's first step moves every entry by ~lr
+    m.eval()
+    with torch.no_grad(), m.precision("fp32"):
+        sd2 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        ref = ref_cpu.vit_forward(sd2, ref_cpu.ViTCfg(**W.NOPROJ), video.cpu())
+        e32 = rel_err(m(video), ref)
+    assert e32 < 1e-4
+    report(f"no-projection ViT (heads 1, dim_head = dim = 64) vs reference fixture: logits bf16 {e16:.2e}, worst gradient rel-L2 {worst:.2e}; fp32 path vs oracle after the step {e32:.2e}")
+    # standalone Attention block of this geometry (vit_3d.py:48-60 with to_out = Identity)
+    from neurovit_amd.vit_3d import Attention
+    att = m.transformer.layers[0][0]
+    assert isinstance(att, Attention) and isinstance(att.to_out, torch.nn.Identity)
+    x = torch.randn(2, 9, d, device="cuda")
+    pre = "transformer.layers.0.0."
+    bsd = {k: v for k, v in sd2.items() if k.startswith(pre)}
+    want = ref_cpu.attention(bsd, pre, x.cpu(), 1, d)
+    got = att(x)
+    assert got.shape == x.shape and rel_l2(got, want) < 1e-2
+    m.train()
+    m._dropout_p = (0.1, 0.0)
+    with pytest.raises(NotImplementedError):
+        m(video)
+
+
 def _micro_model(nv, lr=1e-3, wd=1e-2):
     size = dict(TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
     cfg = W.neuro_config(32, 8, DEVICE="cuda", TRAINING_LEARNING_RATE=lr, TRAINING_WEIGHT_DECAY=wd, **size)

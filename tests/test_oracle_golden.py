@@ -201,6 +201,25 @@ def test_rect_vit(golden):
         assert rel_err(v, g["grad." + k]) < 2e-5, k
 
 
+def test_noproj_vit(golden):
+    """heads == 1 with dim_head == dim: the reference drops to_out (vit_3d.py:32,43-46).  Restatement against the imported reference:
+    logits, loss, every gradient."""
+    g = golden("noproj_vit.npz")
+    cfg = ref_cpu.ViTCfg(**W.NOPROJ)
+    sd = W.make_tensors(W.vit_param_spec(**W.NOPROJ), 71)
+    assert not any("to_out" in k for k in sd)
+    S = W.NOPROJ["image_size"]
+    video = ref_cpu.fmri_to_video(W.make_volume((3, S, S, S), 72))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    logits = ref_cpu.vit_forward(leaves, cfg, video)
+    assert rel_err(logits, g["logits"]) < TOL
+    loss = train_step.cross_entropy(logits, torch.from_numpy(g["labels"]).long())
+    assert abs(loss.item() - g["loss"][0]) < 1e-6
+    names = list(sd)
+    for k, v in zip(names, torch.autograd.grad(loss, [leaves[k] for k in names])):
+        assert rel_err(v, g["grad." + k]) < 2e-5, k
+
+
 def test_neuro4d(golden):
     g = golden("neuro4d.npz")
     S, p, T = 16, 8, 5
