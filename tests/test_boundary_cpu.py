@@ -146,11 +146,16 @@ def test_no_cpu_fallback():
     assert "import oracle" not in src and "from oracle" not in src
 
 
-def test_unsupported_constructions_raise():
-    """Outside the NeuroEncoder path the module refuses at construction instead of computing something else."""
+def test_constructions_off_the_neuroencoder_path():
+    """Geometries the NeuroEncoder never builds: no output projection (same keys as the reference, constants in the arena), mean
+    pooling, the reference's divisibility assert."""
     from neurovit_amd.vit_3d import ViT
-    with pytest.raises(NotImplementedError):
-        ViT(**dict(W.MICRO, dim=64, heads=1))            # to_out becomes Identity in the reference (vit_3d.py:32)
+    m = ViT(**dict(W.MICRO, dim=64, heads=1))            # to_out becomes Identity in the reference (vit_3d.py:32)
+    assert m._no_proj and not any("to_out" in k for k in m.state_dict())
+    assert set(m.state_dict()) == set(W.make_tensors(W.vit_param_spec(**dict(W.MICRO, dim=64, heads=1)), 0))
+    arena, _ = m.flat_parameters()                        # (the table itself comes from the library: no GPU needed)
+    assert len(m._phantom) == 2 * W.MICRO["depth"] and torch.equal(arena[m._phantom[0][0]:m._phantom[0][0] + 64 * 64].view(64, 64), torch.eye(64))
+    assert m._arena_ok() and all(q.data_ptr() == arena.data_ptr() + 4 * o for q, o in zip(m._plist, m._layout[0]))
     assert ViT(**dict(W.MICRO, pool="mean"))._cfg.pool_mean == 1 and ViT(**W.MICRO)._cfg.pool_mean == 0
     with pytest.raises(AssertionError):
         ViT(**dict(W.MICRO, image_size=30))              # vit_3d.py:83 divisibility assert
