@@ -196,6 +196,9 @@ int nv_attn_set_mode(int mode);   /* testing aid: 0 = heuristic, 1 = streaming k
                                     + 20: resident forward with two partner waves per row group (key range split, merged through LDS) */
 int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
                 float* lse, unsigned long drop_seed, float drop_p, void* stream);
+/* the same forward with the output as OCP e4m3 bytes of (value * out_scale): out = byte buffer [B*n, ld_out]; dim_head 64, no dropout, no lse */
+int nv_attn_fwd_o8(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
+                   float out_scale, void* stream);
 int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const void* dout, long ld_out, const float* lse, int B, int n,
                 int heads, int dim_head, float scale, float* delta, void* dqkv, long ld_dqkv, unsigned long drop_seed,
                 float drop_p, void* stream);
@@ -307,8 +310,10 @@ int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const lo
  * Workspace: nv_vit_workspace_bytes(cfg, B, 2).  Input forms as nv_vit_forward_in. */
 int nv_vit_forward_f32(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
                        const nv_vit_input* in, const float* params, void* workspace, long ws_bytes, float* logits, void* stream);
-/* fp8 inference forward (BASELINE.json configs[4] "ViT3D-large ... fp8 MFMA"): qkv / FC1 / FC2 of every block on e4m3 operands.
- * act_scales: HOST array [depth][3] (LN1 output, LN2 output, GELU output; calibrated: 448 / (headroom * amax)); params8: byte arena
+/* fp8 inference forward (BASELINE.json configs[4] "ViT3D-large ... fp8 MFMA"): all four linears of every block - qkv, the
+ * out-projection (its operand written as e4m3 by the attention kernel itself: nv_attn_fwd_o8), FC1, FC2 - on e4m3 operands.
+ * act_scales: HOST array [depth][4] (LN1 output, LN2 output, GELU output, attention output - <= 0 keeps that block's out-projection on
+ * bf16 operands; calibrated: 448 / (headroom * amax)); params8: byte arena
  * with the element offsets of the parameter arena; colscales: f32 [nv_vit_fp8_scale_count].  Workspace: training = 0 layout. */
 long nv_vit_fp8_scale_count(const nv_vit_config* cfg);
 int nv_vit_quantize_fp8(const nv_vit_config* cfg, const float* params, const float* act_scales, void* params8, float* colscales, void* stream);

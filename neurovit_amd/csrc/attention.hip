@@ -207,9 +207,24 @@ __device__ __forceinline__ void softmax_merge(float& m, float& l, f32x4 (&o)[4],
 // first key tile of the second half of the key range
 __device__ __forceinline__ int attn_half_tiles(int nkt) { return (nkt + 1) >> 1; }
 
+// One query row's 64 outputs of this lane (4 x 4 consecutive columns): bf16, or - o8 > 0, the fp8 inference path's out-projection
+// operand - OCP e4m3 bytes of (value * o8) at the same ELEMENT offsets of a byte buffer.
+__device__ __forceinline__ void store_out_row(bf16* out, long off, const f32x4 (&o)[4], float inv, float o8, int g) {
+  if (o8 > 0.f) {
+    unsigned char* row = reinterpret_cast<unsigned char*>(out) + off;
+    const float sc = inv * o8;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<unsigned*>(row + 16 * t + 4 * g) = pack_fp8x4(o[t] * sc);
+  } else {
+    bf16* row = out + off;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x4*>(row + 16 * t + 4 * g) = cvt4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
+  }
+}
+
 template <bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
-                                                       bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop) {
+                                                       bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop, float o8) {
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
   char* sK = smem;
   char* sV = smem + IMG;
@@ -266,10 +281,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const float inv = 1.0f / ltot;
   const int q = q0 + r;
   if (q < n) {
-    bf16* orow = out + ((long)b * n + q) * ldo + h * DH;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      *reinterpret_cast<bf16x4*>(orow + 16 * t + 4 * g) = cvt4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
+    store_out_row(out, ((long)b * n + q) * ldo + h * DH, o, inv, o8, g);
     if (g == 0 && lse) lse[((long)b * heads + h) * n + q] = (m + log2f(ltot)) * 0.69314718055994530942f;
   }
 }
@@ -324,7 +336,7 @@ __device__ __forceinline__ ResBlock res_block(int n) {
 template <int SPLIT, bool DROP>
 __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads,
                                                                            float scale_log2e, bf16* __restrict__ out, long ldo,
-                                                                           float* __restrict__ lse, DropCfg drop) {
+                                                                           float* __restrict__ lse, DropCfg drop, float o8) {
   extern __shared__ __attribute__((aligned(16))) char rsmem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -420,10 +432,7 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
   const float inv = 1.0f / ltot;
   const int q = q0 + r;
   if (q < n) {
-    bf16* orow = out + ((long)b * n + q) * ldo + h * DH;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      *reinterpret_cast<bf16x4*>(orow + 16 * t + 4 * g) = cvt4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
+    store_out_row(out, ((long)b * n + q) * ldo + h * DH, o, inv, o8, g);
     if (g == 0 && lse) lse[((long)b * heads + h) * n + q] = (m + log2f(ltot)) * 0.69314718055994530942f;
   }
 }
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
 constexpr int WIDE_ROWS = 128;     // query rows per workgroup (4 waves x 32)
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
-                                                               bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop) {
+                                                               bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop, float o8) {
   __shared__ __attribute__((aligned(16))) char wsmem[2 * 2 * IMG];      // [stage][K image | V image]
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -526,10 +535,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __res
     const float inv = 1.0f / ltot;
     const int q = q0 + 16 * u + r;
     if (q < n) {
-      bf16* orow = out + ((long)b * n + q) * ldo + h * DH;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        *reinterpret_cast<bf16x4*>(orow + 16 * t + 4 * g) = cvt4(o0[u][t][0] * inv, o0[u][t][1] * inv, o0[u][t][2] * inv, o0[u][t][3] * inv);
+      store_out_row(out, ((long)b * n + q) * ldo + h * DH, o0[u], inv, o8, g);
       if (g == 0 && lse) lse[((long)b * heads + h) * n + q] = (m0[u] + log2f(ltot)) * 0.69314718055994530942f;
     }
   }
@@ -552,8 +558,8 @@ static void attn_res_attr(Kern kern, int lds) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
-extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
-                           float* lse, unsigned long drop_seed, float drop_p, void* stream) {
+static int attn_fwd_impl(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
+                         float* lse, unsigned long drop_seed, float drop_p, float o8, void* stream) {
   NV_CHECK_ARG(attn_generic_supported(dim_head), "nv_attn_fwd: dim_head=%d unsupported (multiples of 8 up to 128)", dim_head);
   NV_CHECK_ARG(B > 0 && n > 0 && heads > 0 && ld_qkv >= 3 * heads * dim_head && ld_out >= heads * dim_head && (ld_qkv % 8) == 0 && (ld_out % 4) == 0,
                "nv_attn_fwd: bad dims");
@@ -580,27 +586,40 @@ extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads
     }
     if (g_attn_split == 2)
       { if (dropping) hipLaunchKernelGGL((attn_fwd_res_kernel<2, true>), dim3(attn_res_blocks(n) * B * heads), dim3(2 * RES_THREADS), lds, (hipStream_t)stream,
-                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
+                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8);
     else hipLaunchKernelGGL((attn_fwd_res_kernel<2, false>), dim3(attn_res_blocks(n) * B * heads), dim3(2 * RES_THREADS), lds, (hipStream_t)stream,
-                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p)); }
+                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8); }
     else
       { if (dropping) hipLaunchKernelGGL((attn_fwd_res_kernel<1, true>), dim3(attn_res_blocks(n) * B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
-                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
+                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8);
     else hipLaunchKernelGGL((attn_fwd_res_kernel<1, false>), dim3(attn_res_blocks(n) * B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
-                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p)); }
+                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8); }
   } else if (g_attn_mode != 1 && (long)n * ld_qkv < (1L << 30)) {
     { if (dropping) hipLaunchKernelGGL((attn_fwd_wide_kernel<true>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv,
-                       n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
+                       n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8);
     else hipLaunchKernelGGL((attn_fwd_wide_kernel<false>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv,
-                       n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p)); }
+                       n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8); }
   } else
   { if (dropping) hipLaunchKernelGGL((attn_fwd_kernel<true>), dim3(((n + TQ - 1) / TQ) * B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
-                     heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p));
+                     heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8);
     else hipLaunchKernelGGL((attn_fwd_kernel<false>), dim3(((n + TQ - 1) / TQ) * B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
-                     heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p)); }
+                     heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8); }
   nv_prof_end(slot, stream);
   NV_CHECK_LAUNCH("nv_attn_fwd");
   return NV_OK;
+}
+
+extern "C" int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
+                           float* lse, unsigned long drop_seed, float drop_p, void* stream) {
+  return attn_fwd_impl(qkv, ld_qkv, B, n, heads, dim_head, scale, out, ld_out, lse, drop_seed, drop_p, 0.f, stream);
+}
+
+// fp8 inference path: the attention output as OCP e4m3 bytes of (value * out_scale) - the operand of the fp8 out-projection;
+// out is a byte buffer [B * n, ld_out] (ld_out in elements = bytes); dim_head 64, no dropout.
+extern "C" int nv_attn_fwd_o8(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
+                              float out_scale, void* stream) {
+  NV_CHECK_ARG(dim_head == DH && out_scale > 0.f && (ld_out % 16) == 0, "nv_attn_fwd_o8: dim_head must be %d, out_scale > 0, ld_out a multiple of 16", DH);
+  return attn_fwd_impl(qkv, ld_qkv, B, n, heads, dim_head, scale, out, ld_out, nullptr, 0, 0.f, out_scale, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)

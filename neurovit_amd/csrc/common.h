@@ -95,6 +95,15 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
   return 0.5f * (1.0f + e) + u * g * 0.39894228040143267794f;
 }
 
+// OCP e4m3 (gfx950's fp8: v_cvt_pk_fp8_f32), saturating: four floats -> four bytes
+__device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = fminf(fmaxf(v[i], -448.f), 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+  return (unsigned)w;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

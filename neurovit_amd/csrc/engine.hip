@@ -420,25 +420,27 @@ extern "C" int nv_vit_forward_f32(const nv_vit_config* cfg, int B, const float* 
 // FLOPs; the output projection, whose input comes head by head out of the attention kernel, stays bf16, as do the patch embedding,
 // attention and the head).  Weights: per-output-row scales; activations (LN outputs, GELU output): one calibrated scale per
 // tensor, applied by the kernel that produces them.  Layout of the scale arena: layer l at l * (3*inner + m + d):
-// [colscale qkv (3*inner) | colscale FC1 (m) | colscale FC2 (d)].  act_scales: HOST array [depth][3] = xn1, xn2, h.
+// [colscale qkv (3*inner) | colscale FC1 (m) | colscale FC2 (d) | colscale out-projection (d)].  act_scales: HOST array [depth][4] = xn1, xn2, h, ao.
 extern "C" long nv_vit_fp8_scale_count(const nv_vit_config* cfg) {
   Dims D; if (make_dims(cfg, 1, D)) return -1;
-  return (long)D.L * (3L * D.inner + D.m + D.d);
+  return (long)D.L * (3L * D.inner + D.m + 2L * D.d);
 }
 
 extern "C" int nv_vit_quantize_fp8(const nv_vit_config* cfg, const float* params, const float* act_scales, void* params8, float* colscales, void* stream) {
   Dims D; RUN(make_dims(cfg, 1, D));
   ParamTab T; make_params(D, T);
   NV_CHECK_ARG(params && act_scales && params8 && colscales, "nv_vit_quantize_fp8: null pointer");
-  NV_CHECK_ARG(D.d % 128 == 0 && D.m % 128 == 0, "nv_vit_quantize_fp8: the fp8 GEMM needs dim and mlp_dim to be multiples of 128 (got %d, %d)", D.d, D.m);
+  NV_CHECK_ARG(D.d % 128 == 0 && D.m % 128 == 0 && D.inner % 128 == 0, "nv_vit_quantize_fp8: the fp8 GEMM needs dim, heads * dim_head and mlp_dim to be multiples of 128 (got %d, %d, %d)", D.d, D.inner, D.m);
   char* p8 = (char*)params8;
-  const long per = 3L * D.inner + D.m + D.d;
+  const long per = 3L * D.inner + D.m + 2L * D.d;
   for (int l = 0; l < D.L; ++l) {
     const LayerP& q = T.layer[l];
     float* cs = colscales + l * per;
-    RUN(nv_quant_rows_f8(params + q.wqkv, D.d, 3 * D.inner, D.d, p8 + q.wqkv, D.d, act_scales[3 * l + 0], cs, stream));
-    RUN(nv_quant_rows_f8(params + q.w1, D.d, D.m, D.d, p8 + q.w1, D.d, act_scales[3 * l + 1], cs + 3L * D.inner, stream));
-    RUN(nv_quant_rows_f8(params + q.w2, D.m, D.d, D.m, p8 + q.w2, D.m, act_scales[3 * l + 2], cs + 3L * D.inner + D.m, stream));
+    RUN(nv_quant_rows_f8(params + q.wqkv, D.d, 3 * D.inner, D.d, p8 + q.wqkv, D.d, act_scales[4 * l + 0], cs, stream));
+    RUN(nv_quant_rows_f8(params + q.w1, D.d, D.m, D.d, p8 + q.w1, D.d, act_scales[4 * l + 1], cs + 3L * D.inner, stream));
+    RUN(nv_quant_rows_f8(params + q.w2, D.m, D.d, D.m, p8 + q.w2, D.m, act_scales[4 * l + 2], cs + 3L * D.inner + D.m, stream));
+    if (act_scales[4 * l + 3] > 0.f)                      // <= 0: this block's out-projection stays on bf16 operands
+      RUN(nv_quant_rows_f8(params + q.wo, D.inner, D.d, D.inner, p8 + q.wo, D.inner, act_scales[4 * l + 3], cs + 3L * D.inner + D.m + D.d, stream));
   }
   return NV_OK;
 }
@@ -454,7 +456,7 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
                "nv_vit_forward_fp8: video is [%ld,%ld,%ld,%ld,%ld], the model was built for [%d,%d,%d,%d,%d] (B, channels, frames, height, width)",
                shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, img_w(cfg));
   NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_forward_fp8: workspace too small (%ld < %ld)", ws_bytes, W.total);
-  NV_CHECK_ARG(D.d % 128 == 0 && D.m % 128 == 0, "nv_vit_forward_fp8: dim and mlp_dim must be multiples of 128");
+  NV_CHECK_ARG(D.d % 128 == 0 && D.m % 128 == 0 && D.inner % 128 == 0, "nv_vit_forward_fp8: dim, heads * dim_head and mlp_dim must be multiples of 128");
   NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params) && nv_aligned16(params16) && nv_aligned16(params8), "nv_vit_forward_fp8: alignment");
   char* ws = (char*)workspace;
   const float* p = params;
@@ -462,7 +464,7 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
   const char* p8 = (const char*)params8;
   const float eps = cfg->ln_eps;
   const int M = D.M, d = D.d;
-  const long per = 3L * D.inner + D.m + D.d;
+  const long per = 3L * D.inner + D.m + 2L * D.d;
 
   float* pst = (float*)(ws + W.pst);
   RUN(patch_front(cfg, D, T, B, video, strides5, in, p, eps, ws + W.xp, pst, stream));
@@ -482,13 +484,16 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
     const LayerP& q = T.layer[l];
     const LayerW& w = W.layer[l];
     const float* cs = colscales + l * per;
-    const float s_xn1 = act_scales[3 * l], s_xn2 = act_scales[3 * l + 1], s_h = act_scales[3 * l + 2];
+    const float s_xn1 = act_scales[4 * l], s_xn2 = act_scales[4 * l + 1], s_h = act_scales[4 * l + 2], s_ao = act_scales[4 * l + 3];
+    const bool tail_here = tail8 && l == D.L - 1;
+    const bool ao8 = !tail_here && D.dh == 64 && s_ao > 0.f;           // the MFMA attention kernels write e4m3 themselves; the cls-rows tail and the generic kernels stay bf16
     float* x1 = (float*)(ws + w.x1);
     float* x2 = (float*)(ws + ((l & 1) ? W.x0 : w.x2));
     RUN(nv_ln_fwd_f8(xin, d, M, d, p + q.n1g, p + q.n1b, eps, s_xn1, ws + w.xn1, d, stream));
     RUN(nv_gemm_f8(0, M, 3 * D.inner, d, ws + w.xn1, d, p8 + q.wqkv, d, ws + w.qkv, 3 * D.inner, cs, nullptr, nullptr, 0, 1.f, stream));
-    RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), 0, 0.f, stream));
-    if (tail8 && l == D.L - 1) {
+    if (ao8) RUN(nv_attn_fwd_o8(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, s_ao, stream));
+    else RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), 0, 0.f, stream));
+    if (tail_here) {
       // the last block's out-projection / LayerNorm / FeedForward on the B cls rows (see g_cls_tail): bf16 operands through the
       // weight-streaming kernels - these few rows gain nothing from fp8 and lose nothing by staying in bf16
       const long rs = D.n;
@@ -500,7 +505,8 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
       xin = x2;
       continue;
     }
-    RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+    if (ao8) RUN(nv_gemm_f8(4, M, d, D.inner, ws + w.ao, D.inner, p8 + q.wo, D.inner, x1, d, cs + 3L * D.inner + D.m + D.d, p + q.bo, xin, d, 1.f, stream));
+    else RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, 0, 0.f, stream));
     RUN(nv_ln_fwd_f8(x1, d, M, d, p + q.n2g, p + q.n2b, eps, s_xn2, ws + w.xn2, d, stream));
     RUN(nv_gemm_f8(7, M, D.m, d, ws + w.xn2, d, p8 + q.w1, d, ws + w.h, D.m, cs + 3L * D.inner, p + q.b1, nullptr, 0, s_h, stream));
     RUN(nv_gemm_f8(4, M, d, D.m, ws + w.h, D.m, p8 + q.w2, D.m, x2, d, cs + 3L * D.inner + D.m, p + q.b2, x1, d, 1.f, stream));

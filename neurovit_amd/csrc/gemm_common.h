@@ -48,15 +48,6 @@ static inline double gemm_algo_bytes(const GemmArgs& a, int epi, int operand_byt
   return b;
 }
 
-// OCP e4m3 (gfx950's fp8: v_cvt_pk_fp8_f32), saturating: four floats -> four bytes
-__device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = fminf(fmaxf(v[i], -448.f), 448.f);
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
-  return (unsigned)w;
-}
-
 constexpr int BK = 64;
 constexpr int NTHREADS = 256;
 typedef __attribute__((address_space(3))) void lds_void_t;

@@ -156,9 +156,9 @@ class VitRuntime:
         return logits
 
     # ------------------------------------------------------------------ fp8 inference (BASELINE.json configs[4])
-    def calibrate_fp8(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, headroom: float = 2.0):
+    def calibrate_fp8(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, headroom: float = 2.0, out_proj: bool = True):
         """One bf16 forward of `video` with every layer's activations kept; returns the per-layer activation scales
-        [depth][3] = 448 / (headroom * amax) of the LN1 output, the LN2 output and the GELU output.  e4m3 is a floating
+        [depth][4] = 448 / (headroom * amax) of the LN1 output, the LN2 output, the GELU output and the attention output.  e4m3 is a floating
         format: headroom costs no relative precision, it only moves the subnormal floor."""
         self.forward(video, params, params16, training=True, rows_form=1)    # the fp8 forward quantises every row of every block: calibrate on every row
         B = video.shape[0]
@@ -167,9 +167,11 @@ class VitRuntime:
         scales = []
         for l in range(self.cfg.depth):
             row = []
-            for name, width in (("xn1", self.cfg.dim), ("xn2", self.cfg.dim), ("h", self.cfg.mlp_dim)):
+            for name, width in (("xn1", self.cfg.dim), ("xn2", self.cfg.dim), ("h", self.cfg.mlp_dim), ("ao", self.cfg.heads * self.cfg.dim_head)):
                 amax = float(self.tap(name, l, (B * n, width), torch.bfloat16).abs().max())     # calibration only: off the hot path
                 row.append(448.0 / (headroom * max(amax, 1e-6)))
+            if not out_proj:
+                row[3] = 0.0          # the out-projection stays on bf16 operands (measured: fp8 there buys 1-2 % and adds ~15 % to the logits' error)
             scales.append(row)
         return scales
 

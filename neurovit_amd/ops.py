@@ -251,6 +251,15 @@ def attn_fwd(qkv: torch.Tensor, B: int, n: int, heads: int, dim_head: int = 64, 
     return out, lse
 
 
+def attn_fwd_o8(qkv: torch.Tensor, B: int, n: int, heads: int, out_scale: float, dim_head: int = 64) -> torch.Tensor:
+    """Attention forward with the output as OCP e4m3 bytes of (value * out_scale): uint8 [B*n, heads*dim_head] (fp8 inference path)."""
+    _need_cuda(qkv)
+    inner = heads * dim_head
+    out = torch.empty((B * n, inner), dtype=torch.uint8, device=qkv.device)
+    check(lib.nv_attn_fwd_o8(_p(qkv), qkv.stride(0), B, n, heads, dim_head, dim_head ** -0.5, _p(out), inner, float(out_scale), _stream()), "nv_attn_fwd_o8")
+    return out
+
+
 def attn_bwd(qkv, out, dout, lse, B, n, heads, dim_head=64, drop_seed=0, drop_p=0.0):
     inner = heads * dim_head
     dqkv = torch.empty((B * n, 3 * inner), dtype=torch.bfloat16, device=qkv.device)

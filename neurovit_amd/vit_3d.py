@@ -382,13 +382,13 @@ class ViT(nn.Module):
             self._shadow_key = key
 
     # ------------------------------------------------------------------ fp8 inference (BASELINE.json configs[4])
-    def enable_fp8(self, calibration_video: torch.Tensor, headroom: float = 2.0):
-        """Switch inference forwards (no grad being recorded) to the fp8 path: qkv / FC1 / FC2 of every block on OCP e4m3 MFMA
-        operands.  `calibration_video` ([B, C, F, H, W] on the device) fixes the per-tensor activation scales; weights are
+    def enable_fp8(self, calibration_video: torch.Tensor, headroom: float = 2.0, out_proj: bool = True):
+        """Switch inference forwards (no grad being recorded) to the fp8 path: qkv / out-projection / FC1 / FC2 of every block on OCP
+        e4m3 MFMA operands (out_proj = False keeps the out-projection, 8 % of the linear FLOPs, on bf16).  `calibration_video` ([B, C, F, H, W] on the device) fixes the per-tensor activation scales; weights are
         re-quantised from the fp32 master parameters (call again after training steps).  Training forwards keep using bf16."""
         self.flat_parameters()
         self._refresh_shadow()
-        scales = self._rt.calibrate_fp8(calibration_video.float(), self._arena, self._shadow, headroom)
+        scales = self._rt.calibrate_fp8(calibration_video.float(), self._arena, self._shadow, headroom, out_proj)
         self._fp8 = self._rt.quantize_fp8(self._arena, scales)
         self._fp8["key"] = self._param_key()
         return scales

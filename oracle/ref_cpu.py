@@ -312,8 +312,9 @@ def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None, drop=None, 
     xn = F.layer_norm(x, (d,), sd[pre + "norm.weight"], sd[pre + "norm.bias"], LN_EPS)
     if taps is not None:
         taps[pre + "norm.out"] = xn
-    if f8 is not None:          # fp8 path: LN output and to_qkv weight in e4m3, fp32 accumulate, bf16 qkv (f8 = scale of the LN output)
-        qkv = _r(F.linear(_q8(xn, f8), _q8_rows(sd[pre + "to_qkv.weight"])), "qkv")
+    if f8 is not None:          # fp8 path: LN output and to_qkv weight in e4m3, fp32 accumulate, bf16 qkv (f8 = scale of the LN output, or
+                                # (that, scale of the attention output or None): the out-projection in e4m3 too)
+        qkv = _r(F.linear(_q8(xn, f8[0] if isinstance(f8, tuple) else f8), _q8_rows(sd[pre + "to_qkv.weight"])), "qkv")
     elif emulate:
         xn = _r(xn, "xn1")
         qkv = _r(_linear(xn, sd[pre + "to_qkv.weight"], None, True, "xn1"), "qkv")
@@ -338,6 +339,8 @@ def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None, drop=None, 
         taps[pre + "q"], taps[pre + "k"], taps[pre + "v"] = q, k, v
         taps[pre + "attn.out"] = out
     if (pre + "to_out.0.weight") in sd:            # project_out (vit_3d.py:32,43-46)
+        if f8 is not None and isinstance(f8, tuple) and f8[1]:    # fp8 path: attention output and to_out weight in e4m3 (f8[1] = its scale)
+            return F.linear(_q8(out, f8[1]), _q8_rows(sd[pre + "to_out.0.weight"])) + sd[pre + "to_out.0.bias"]
         out = _linear(out, sd[pre + "to_out.0.weight"], sd[pre + "to_out.0.bias"], emulate, "ao")
         if drop:
             out = out * drop_mask(drop[2], drop[0], (B * n, out.shape[-1])).reshape(out.shape)
@@ -396,7 +399,8 @@ def vit_forward(sd: Dict[str, torch.Tensor], cfg: ViTCfg, video: torch.Tensor,
         pa, pf = f"transformer.layers.{i}.0.", f"transformer.layers.{i}.1."
         da = (dp[0], site_seed(dp[2], 4 * i + 0), site_seed(dp[2], 4 * i + 1)) if dp and dp[0] > 0 else None
         df = (dp[0], site_seed(dp[2], 4 * i + 2), site_seed(dp[2], 4 * i + 3)) if dp and dp[0] > 0 else None
-        f8a = fp8_scales[i][0] if fp8_scales is not None else None      # fp8 inference path (csrc/engine.hip::nv_vit_forward_fp8)
+        # fp8 inference path (csrc/engine.hip::nv_vit_forward_fp8); rows of 4 scales carry the attention-output scale (out-projection in e4m3)
+        f8a = None if fp8_scales is None else ((fp8_scales[i][0], fp8_scales[i][3] or None) if len(fp8_scales[i]) > 3 else fp8_scales[i][0])
         f8f = (fp8_scales[i][1], fp8_scales[i][2]) if fp8_scales is not None else None
         x = attention(sd, pa, x, cfg.heads, cfg.dim_head, emulate_bf16, taps, da, f8a) + x
         x = feed_forward(sd, pf, x, emulate_bf16, df, f8f) + x

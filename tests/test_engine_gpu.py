@@ -343,7 +343,7 @@ def test_base_config_properties(eng):
 
 
 def test_fp8_inference_forward_vs_fp8_emulating_oracle(eng):
-    """BASELINE.json configs[4] asks for fp8 MFMA on the large model.  The fp8 inference path (qkv / FC1 / FC2 on OCP e4m3
+    """BASELINE.json configs[4] asks for fp8 MFMA on the large model.  The fp8 inference path (qkv / out-projection / FC1 / FC2 on OCP e4m3
     operands, per-row weight scales, calibrated per-tensor activation scales) against an oracle with the same cast points
     (oracle/ref_cpu.py: fp8_scales=...), three-way against fp32.  Tolerance, stated: e4m3 carries 3 mantissa bits (2^-4 relative
     per element), so logits sit at a few 1e-2 of the fp32 result - ten times the bf16 path; the gate is that the HIP path is no
@@ -371,6 +371,15 @@ def test_fp8_inference_forward_vs_fp8_emulating_oracle(eng):
     report(f"fp8 forward (micro, depth 3): HIP vs fp32 {e_hip:.3e}; fp8 emulation vs fp32 {e_emu:.3e}; HIP vs emulation {e_pair:.3e}; bf16 path vs fp32 {e_bf:.3e}")
     assert e_hip <= RATIO * e_emu + 5e-3 and e_hip < 6e-2
     assert e_pair < 6e-2
+    # out-projection kept on bf16 operands (scale <= 0 for that linear): the three-linear form of round 2, same gates
+    scales3 = rt.calibrate_fp8(video, params, p16, out_proj=False)
+    assert all(row[3] == 0.0 for row in scales3) and all(row[3] > 0 for row in scales)
+    c = rt.forward_fp8(video, params, p16, rt.quantize_fp8(params, scales3))
+    with torch.no_grad():
+        emu3 = ref_cpu.vit_forward(sd, ocfg, v, emulate_bf16=True, fp8_scales=scales3)
+    e3, e3_emu = rel_err(c, ref32), rel_err(emu3, ref32)
+    report(f"fp8 forward (micro, depth 3), out-projection on bf16: HIP vs fp32 {e3:.3e}; emulation vs fp32 {e3_emu:.3e}")
+    assert not torch.equal(a, c) and e3 <= RATIO * e3_emu + 5e-3 and e3 < 6e-2
 
 
 LARGE = dict(image_size=128, image_patch_size=8, frames=128, frame_patch_size=8, num_classes=2, dim=1024,

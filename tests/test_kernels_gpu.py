@@ -619,6 +619,27 @@ def test_attention_resident_equals_streaming(ops, B, n, heads, drop):
     assert torch.isfinite(res[2][2].float()).all()
 
 
+@pytest.mark.parametrize("B,n,heads,mode", [(2, 513, 2, 2), (1, 700, 2, 1), (2, 1001, 2, 3), (20, 513, 12, 0)])
+def test_attention_forward_fp8_output(ops, B, n, heads, mode):
+    """nv_attn_fwd_o8 (the fp8 path's out-projection operand written by the attention kernel itself): every forward kernel
+    (2 resident, 1 streaming, 3 wide, 0 the dispatcher's choice) - the e4m3 bytes decode to the bf16 output within e4m3's rounding
+    (2^-4 relative, half an ulp of the 3-bit mantissa) plus the bf16 rounding of the comparison value; saturating scale handled."""
+    from neurovit_amd._cabi import lib
+    qkv = dev(bf(rnd(B * n, 3 * heads * 64, seed=n + heads)))
+    lib.nv_attn_set_mode(mode)
+    try:
+        ref, _ = ops.attn_fwd(qkv, B, n, heads)
+        scale = 448.0 / (2.0 * float(ref.float().abs().max()))
+        o8 = ops.attn_fwd_o8(qkv, B, n, heads, scale)
+    finally:
+        lib.nv_attn_set_mode(0)
+    deq = o8.view(torch.float8_e4m3fn).float() / scale
+    r = ref.float()
+    tol = r.abs() * (2.0 ** -4 + 2.0 ** -8) + 2.0 ** -9 / scale * 2      # relative rounding + the subnormal floor of e4m3 at this scale
+    assert ((deq - r).abs() <= tol).all(), float(((deq - r).abs() - tol).max())
+    assert float((deq - r).norm() / r.norm()) < 0.04                        # mean relative error of a 3-bit mantissa: ~2.5 %
+
+
 @pytest.mark.parametrize("B,n,heads,drop", [(2, 1001, 2, 0.0), (1, 4097, 1, 0.0), (20, 513, 12, 0.0), (3, 700, 2, 0.1), (1, 129, 1, 0.0), (2, 65, 3, 0.2)])
 def test_attention_wide_forward_equals_streaming(ops, B, n, heads, drop):
     """The wide streaming forward (32 query rows per wave, K / V tiles by LDS-DMA into a two-stage ring, one barrier per tile)
