@@ -377,13 +377,21 @@ struct PatchGeom {
 };
 
 // feature k = ((i1*p2 + i2)*pf + ifr)*C + c  ('p1 p2 pf c');  token n = (ft*gh + ht)*gw + wt  ('f h w')
-__device__ __forceinline__ long patch_elem_offset(const PatchGeom& g, int b, int n, int k) {
+// The offset separates into a part of the token and a part of the feature: the kernels compute each once where it is invariant
+// (the six integer divisions of the full form, once per element, were most of the gather kernels' instructions).
+__device__ __forceinline__ long patch_tok_offset(const PatchGeom& g, int b, int n) {
+  const int wt = n % g.gw; int u = n / g.gw;
+  const int ht = u % g.gh, ft = u / g.gh;
+  return (long)b * g.sb + (long)(ft * g.pf) * g.sf + (long)(ht * g.p1) * g.sh + (long)(wt * g.p2) * g.sw;
+}
+__device__ __forceinline__ long patch_feat_offset(const PatchGeom& g, int k) {
   const int c = k % g.C; int t = k / g.C;
   const int ifr = t % g.pf; t /= g.pf;
   const int i2 = t % g.p2, i1 = t / g.p2;
-  const int wt = n % g.gw; int u = n / g.gw;
-  const int ht = u % g.gh, ft = u / g.gh;
-  return (long)b * g.sb + (long)c * g.sc + (long)(ft * g.pf + ifr) * g.sf + (long)(ht * g.p1 + i1) * g.sh + (long)(wt * g.p2 + i2) * g.sw;
+  return (long)c * g.sc + (long)ifr * g.sf + (long)i1 * g.sh + (long)i2 * g.sw;
+}
+__device__ __forceinline__ long patch_elem_offset(const PatchGeom& g, int b, int n, int k) {
+  return patch_tok_offset(g, b, n) + patch_feat_offset(g, k);
 }
 
 // VEC: C == 1, sf == 1, pf % 4 == 0, 16-byte aligned runs, P <= 4096: float4 gathers, row cached in registers.
@@ -405,10 +413,21 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const float* __restri
   if constexpr (VEC) {
     constexpr int NV = 16;
     f32x4 xv[NV];
+    const float* tokp = video + patch_tok_offset(g, b, n);
+    const int inner = g.pf * g.p2;                          // C == 1 here: features per patch row i1
+    if ((256 % inner) == 0) {
+      // lane's features 4 lane + 256 v: adding 256 only advances the patch row i1 (by 256 / inner): one decomposition per lane
+      const float* lp = tokp + patch_feat_offset(g, 4 * lane);
+      const long vstep = (long)(256 / inner) * g.sh;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int k = (lane + 64 * v) * 4;
-      xv[v] = (k < g.P) ? *reinterpret_cast<const f32x4*>(video + patch_elem_offset(g, b, n, k)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int v = 0; v < NV; ++v)
+        xv[v] = ((lane + 64 * v) * 4 < g.P) ? *reinterpret_cast<const f32x4*>(lp + v * vstep) : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int k = (lane + 64 * v) * 4;
+        xv[v] = (k < g.P) ? *reinterpret_cast<const f32x4*>(tokp + patch_feat_offset(g, k)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
     row_stats<NV>(xv, g.P, lane, eps, mean, rstd);
 #pragma unroll
@@ -635,9 +654,10 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(const float* __restri
   if constexpr (VEC) {
     for (int k = threadIdx.x * 4; k < g.P; k += 1024) {
       f32x4 ag = f32x4{0.f, 0.f, 0.f, 0.f}, ab = ag;
+      const float* fp = video + patch_feat_offset(g, k);   // the feature part once per thread, the token part is wave-uniform
       for (int tok = t0; tok < t1; ++tok) {
         const int b = tok / g.N, n = tok - b * g.N;
-        const f32x4 xh = (*reinterpret_cast<const f32x4*>(video + patch_elem_offset(g, b, n, k)) - mean_in[tok]) * rstd_in[tok];
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(fp + patch_tok_offset(g, b, n)) - mean_in[tok]) * rstd_in[tok];
         const f32x4 dv = *reinterpret_cast<const f32x4*>(dxp + (long)tok * ldd + k);
         ag += dv * xh;
         ab += dv;
@@ -648,9 +668,10 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(const float* __restri
   } else {
     for (int k = threadIdx.x; k < g.P; k += 256) {
       float ag = 0.f, ab = 0.f;
+      const float* fp = video + patch_feat_offset(g, k);
       for (int tok = t0; tok < t1; ++tok) {
         const int b = tok / g.N, n = tok - b * g.N;
-        const float xh = (video[patch_elem_offset(g, b, n, k)] - mean_in[tok]) * rstd_in[tok];
+        const float xh = (fp[patch_tok_offset(g, b, n)] - mean_in[tok]) * rstd_in[tok];
         const float dv = dxp[(long)tok * ldd + k];
         ag += dv * xh;
         ab += dv;
