@@ -201,8 +201,9 @@ def dry_run(a, world, rank):
         elapsed = t.item()
     if rank == 0:
         print(json.dumps({"metric": "dry run (launcher rehearsal, no GPU work)", "value": None, "unit": "volumes/s", "n_gpus": n,
-                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / max(a.steps, 1) * 1e3,
-                          "config": {"workload": "none", "parallelism": f"dp{n}"}}), flush=True)
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / max(a.steps, 1) * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "none",
+                          "config": {"workload": "none", "global_batch": a.batch * n, "parallelism": f"dp{n}"}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

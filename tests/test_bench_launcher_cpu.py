@@ -35,3 +35,20 @@ def test_default_is_one_rank_without_launcher():
     assert r.returncode == 0, r.stderr
     assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
     assert "launcher" not in r.stderr
+
+
+def test_driver_launch_form_eight_ranks_under_torchrun():
+    """The driver's N > 1 command line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 ...` - every rank reads RANK / WORLD_SIZE / MASTER_* from the environment, joins the group
+    (gloo here: no GPU), runs the barrier + max-over-ranks timing plumbing; exactly one JSON line, n_gpus = 8."""
+    port = 29900 + (os.getpid() % 90)
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    e["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--backend", "gloo", "--dry-run"], capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
