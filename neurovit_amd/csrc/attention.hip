@@ -446,8 +446,12 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
 //     the DMA of tile kt+1 is in flight while tile kt is computed.
 // Same tile order, same two-state online softmax, same per-group arithmetic as the other forward kernels: bit-identical.
 constexpr int WIDE_ROWS = 128;     // query rows per workgroup (4 waves x 32)
+#ifndef NV_WIDE_FWD_BLOCKS
+#define NV_WIDE_FWD_BLOCKS 3       // workgroups per CU the register budget is set for.  3 = 168 VGPRs (10 spilled, 44 B of scratch) against 178 at 2:
+                                   // same-box A/B, ViT3D-large forward 161.9 / 162.4 -> 167.3 / 167.5 volumes/s, base batch 64 6113 / 6119 -> 6181 / 6174
+#endif
 template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
+__global__ __launch_bounds__(256, NV_WIDE_FWD_BLOCKS) void attn_fwd_wide_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
                                                                bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop, float o8) {
   __shared__ __attribute__((aligned(16))) char wsmem[2 * 2 * IMG];      // [stage][K image | V image]
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
@@ -1086,6 +1090,7 @@ __device__ __forceinline__ void dkv_softmax_grad_inplace(f32x4 (&sc)[4], f32x4 (
     }
 }
 
+// (two workgroups per CU: at three - 168 VGPRs, 38 spilled - the ViT3D-large train step drops from 50.5 to 45.6 volumes/s, same box)
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout, long ldo,
                                                                    const float* __restrict__ lse, const float* __restrict__ delta, int n,
