@@ -79,12 +79,21 @@ __device__ __forceinline__ void lane_pair32(float v, float& a, float& b) {
 // arithmetic and measured 10 % slower than the packed forms.
 __device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ float vmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+// ... and the bare instruction for operands that do NOT come out of an MFMA (the cross-lane maximum behind the lane swaps, the running
+// maximum): __builtin_fmaxf is llvm.maxnum, which must quiet signalling NaNs, so hipcc puts a canonicalising `v_max_f32 x, x, x` in
+// front of every operand it cannot prove canonical - six of the ~75 VALU instructions of a 16-score softmax step, in VALU-bound kernels.
+// No NaN reaches these (-inf for masked keys is handled by the instruction as by fmaxf): bit-identical results.
+__device__ __forceinline__ float vmax_bare(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float group_max(float v) {   // over the 4 lane groups sharing r
   float a, b;
   lane_pair16(v, a, b);
-  v = vmax(a, b);
+  v = vmax_bare(a, b);
   lane_pair32(v, a, b);
-  return vmax(a, b);
+  return vmax_bare(a, b);
 }
 __device__ __forceinline__ float group_sum(float v) {
   float a, b;
@@ -145,7 +154,7 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4], int kt, bool last, in
       mloc = vmax3(mloc, s[t][1], s[t][2]);
     }
     mloc = vmax(mloc, s[3][3]);
-    const float mnew = vmax(m, group_max(mloc) * scale_log2e);
+    const float mnew = vmax_bare(m, group_max(mloc) * scale_log2e);
     const float alpha = (mnew != m) ? fast_exp2(m - mnew) : 1.0f;      // m = mnew = -inf cannot make a NaN this way
     m = mnew;
     const f32x2 c2 = {scale_log2e, scale_log2e}, m2 = {-mnew, -mnew};
