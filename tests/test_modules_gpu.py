@@ -22,6 +22,7 @@ from oracle import ref_cpu, train_step
 pytestmark = pytest.mark.gpu
 G4_NEURO32 = 8.6e-3       # logits of the d1024 L6 fixture model: 1.5 x the measured 5.73e-3
 G4_NEURO16 = 9.4e-3       # per-volume logits of the 4D fixture (16^3 volumes): 1.5 x 6.23e-3
+GRADCAM_OVERLAP, GRADCAM_L2 = 0.97, 2.6e-2   # Grad-CAM map of the fixture model: measured support overlap 1.0000, rel L2 1.67e-2 (gate 1.5 x)
 
 
 @pytest.fixture(scope="module")
@@ -67,8 +68,10 @@ def test_neuro3d_forward_hooks_gradcam_vs_reference_fixture(nv, golden):
     ref = torch.from_numpy(g["cam"])
     # the 5 % percentile threshold makes the map discontinuous in its input: compare where both agree on support
     both = (cam > 0) & (ref > 0)
-    assert both.float().mean() > 0.8 * (ref > 0).float().mean()
-    assert rel_l2(cam[both], ref[both]) < 5e-2
+    overlap = float(both.float().mean() / (ref > 0).float().mean())
+    e_cam = rel_l2(cam[both], ref[both])
+    report(f"Grad-CAM map vs reference fixture: support overlap {overlap:.4f}, rel L2 on the common support {e_cam:.3e}")
+    assert overlap > GRADCAM_OVERLAP and e_cam < GRADCAM_L2
     img, attn = model.visualize_slice(cam, x1)
     assert img.shape == (S, S) and attn.shape == (S, S)
 
