@@ -193,7 +193,9 @@ int nv_embed_finish_bwd(const float* g, long ldg, const float* t, long ldt, cons
 
 /* ---- multi-head attention core (vit_3d.py:51-59): qkv bf16 [B,n,3*inner] -> out bf16 [B,n,inner], lse f32 [B,heads,n] */
 int nv_attn_set_mode(int mode);   /* testing aid: 0 = heuristic, 1 = streaming kernels, 2 = LDS-resident kernels (n <= 576), 3 = wide streaming forward;
-                                    + 20: resident forward with two partner waves per row group (key range split, merged through LDS) */
+                                    + 20: resident forward with two partner waves per row group (key range split, merged through LDS);
+                                    + 100: resident backward as ONE launch whose dK / dV workgroups compute delta themselves, instead of two
+                                    dependent launches (dQ, then dK / dV reading its delta): same results bit for bit, measured slower */
 int nv_attn_fwd(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
                 float* lse, unsigned long drop_seed, float drop_p, void* stream);
 /* the same forward with the output as OCP e4m3 bytes of (value * out_scale): out = byte buffer [B*n, ld_out]; dim_head 64, no dropout, no lse */
@@ -351,6 +353,31 @@ int nv_vit_stage_param_range(const nv_vit_config* cfg, int stage, long* begin, l
  * are not produced.  The form is chosen PER CALL by rows_form (nv_vit_input / nv_vit_backward_stages16); this sets the process
  * default used by rows_form = 0 and by the entry points without that argument: 1 (initial) = cls rows, 0 = every row. */
 int nv_vit_set_cls_tail(int on);
+
+/* ---- the reference's whole train step (src/Trainer.py:65-79) as ONE call: ViT forward (training layout) -> nn.CrossEntropyLoss
+ * (mean) -> backward of every stage -> torch.optim.AdamW update of the whole arena (+ bf16 shadow refresh).  ~225 kernel launches
+ * enqueued from native code with no interpreter in between; nothing synchronises, `loss` and `logits` stay on the device.
+ * hp: see the struct (struct_size = sizeof(nv_train_hparams): checked, NV_ERR_ARG on mismatch).  labels: int64 [B].
+ * logits / dlogits: f32 [B, num_classes] (dlogits is scratch the backward reads); loss: f32 [1].
+ * accumulate = 1: gradients are added to `grads` (micro-steps 2.. of an accumulation window); update = 0: no optimizer update
+ * (every micro-step but the last).  The arguments a separate backward would need (rows_form of `in`, dropout) are the forward's
+ * by construction. */
+typedef struct nv_train_hparams {
+  int struct_size;
+  int step;                 /* AdamW step count (>= 1) of this update: bias corrections (ignored when update = 0) */
+  double lr, beta1, beta2, eps, weight_decay;
+  float grad_scale;         /* the update reads grad * grad_scale */
+  int accumulate, update;
+} nv_train_hparams;
+int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
+                      float* params, void* params16, float* grads, float* adam_m, float* adam_v, void* workspace, long ws_bytes,
+                      const long* labels, float* logits, float* loss, float* dlogits, const nv_train_hparams* hp,
+                      float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream, void* aux_stream);
+
+/* ABI revision of this header: bumped whenever a struct gains a field or an entry point changes its argument list (the list is in
+ * INTEGRATION.md "ABI revisions").  A caller built against revision R must refuse a library whose nv_abi_version() != R. */
+#define NV_ABI_VERSION 4
+int nv_abi_version(void);
 /* dst[b .. b + len) = bf16(src[b .. b + len)) for `count` element ranges (HOST arrays begins / lens; any count) */
 int nv_cast_ranges_bf16(const float* src, void* dst, const long* begins, const long* lens, int count, void* stream);
 

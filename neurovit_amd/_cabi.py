@@ -32,6 +32,16 @@ class VitInput(ctypes.Structure):
     _fields_ = [("vol_sigma", ctypes.c_void_p), ("time_points", ctypes.c_int), ("rows_form", ctypes.c_int)]
 
 
+class TrainHparams(ctypes.Structure):
+    """struct nv_train_hparams (neurovit_hip.h): optimizer constants and accumulation flags of nv_vit_train_step."""
+    _fields_ = [("struct_size", ctypes.c_int), ("step", ctypes.c_int), ("lr", ctypes.c_double), ("beta1", ctypes.c_double),
+                ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double), ("grad_scale", ctypes.c_float),
+                ("accumulate", ctypes.c_int), ("update", ctypes.c_int)]
+
+
+ABI_VERSION = 4      # NV_ABI_VERSION of the header this binding was written against (checked at load time)
+
+
 def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
     """{symbol: (restype, [argtypes])} for every `nv_*` prototype declared in the header."""
     src = open(path).read()
@@ -69,6 +79,12 @@ class _Lib:
             for name, (restype, argtypes) in self.protos.items():
                 fn = getattr(dll, name)          # AttributeError if the .so lacks a declared symbol
                 fn.restype, fn.argtypes = restype, argtypes
+            got = dll.nv_abi_version()
+            if got != ABI_VERSION:
+                raise RuntimeError(f"neurovit_amd: {LIB_PATH} has ABI revision {got}, this binding expects {ABI_VERSION} - rebuild the library "
+                                   "(make -C neurovit_amd/csrc); see INTEGRATION.md 'ABI revisions'")
+            if os.environ.get("NEUROVIT_ATTN_MODE"):           # A/B aid: nv_attn_set_mode for the whole process (see the header)
+                dll.nv_attn_set_mode(int(os.environ["NEUROVIT_ATTN_MODE"]))
             self._dll = dll
         return self._dll
 

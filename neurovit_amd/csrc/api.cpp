@@ -17,6 +17,9 @@ extern "C" const char* nv_last_error(void) { return g_err; }
 
 extern "C" int nv_version(void) { return 1; }
 
+#include "../../include/neurovit_hip.h"
+extern "C" int nv_abi_version(void) { return NV_ABI_VERSION; }   // see INTEGRATION.md "ABI revisions"
+
 // 1 when the current HIP device is gfx950 (MI355X), 0 otherwise, negative on HIP error.
 extern "C" int nv_arch_ok(void) {
   int dev = 0;

@@ -559,7 +559,13 @@ __global__ __launch_bounds__(256, NV_WIDE_FWD_BLOCKS) void attn_fwd_wide_kernel(
 static int g_attn_mode = 0;    // 0 = heuristic, 1 = streaming kernels, 2 = resident kernels (tests compare the two bit for bit)
 static int g_attn_split = 1;   // resident forward: waves per row group.  Two (partner waves split the key range, four waves per
                                // SIMD) measured the same 13.5 us as one at n = 513: the kernel is VALU/MFMA-issue bound, not latency bound
+static int g_attn_bwd_merged = 0;   // resident backward: mode + 100 = dQ and dK / dV as ONE launch (attn_bwd_res_kernel) instead of two.  Measured
+                                    // SLOWER in the train step (same-box A/B, ViT3D-base batch 4: 36.3 us per layer against 16.3 + 15.5, step
+                                    // 1122 -> 1088 volumes/s; profiles/r04_negative_results.log): 480 workgroups of 144 KiB on 256 CUs run as two
+                                    // uneven rounds, which costs more than the dependent launch boundary and the 16 idle CUs it removes
 extern "C" int nv_attn_set_mode(int mode) {
+  g_attn_bwd_merged = (mode >= 100) ? 1 : 0;
+  mode %= 100;
   g_attn_mode = mode % 10;
   g_attn_split = (mode / 10 == 2) ? 2 : 1;
   return 0;
@@ -863,39 +869,44 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ resident backward kernels
+// delta of one query row (16 lanes r, 4 lane groups g): rowsum(dO . O) over the head's 64 columns.  ONE function for every place that
+// needs it, so the value is the same to the last bit wherever it is computed (the dQ pass, or - merged launch - the dK/dV pass itself).
+__device__ __forceinline__ float row_delta(const bf16* __restrict__ dout, const bf16* __restrict__ out, long off, int g, bf16x8 (&dof)[2]) {
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    dof[ks] = *reinterpret_cast<const bf16x8*>(dout + off + 32 * ks + 8 * g);
+    const bf16x8 of = *reinterpret_cast<const bf16x8*>(out + off + 32 * ks + 8 * g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[j];
+  }
+  return group_sum(dl);
+}
+
+// body of the dQ pass for workgroup (bx of nblk) of (batch, head) pair `by`
 template <bool DROP>
-__global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
-                                                                      const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse,
-                                                                      int n, int heads, float scale, float* __restrict__ delta,
-                                                                      bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) char rsmem[];
+__device__ __forceinline__ void attn_bwd_dq_res_body(char* rsmem, int by, int bx, int nblk, const bf16* __restrict__ qkv, long ld,
+                                                     const bf16* __restrict__ out, const bf16* __restrict__ dout, long ldo,
+                                                     const float* __restrict__ lse, int n, int heads, float scale, float* __restrict__ delta,
+                                                     bf16* __restrict__ dqkv, long ldd, const DropCfg& drop) {
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const ResBlock rb = res_block(n);
-  const int b = rb.by / heads, h = rb.by - b * heads, inner = heads * DH;
+  const int b = by / heads, h = by - b * heads, inner = heads * DH;
   const bf16* Q = qkv + (long)b * n * ld + h * DH;
   const int nkt = (n + TK - 1) / TK;
   char* sK = rsmem;
   char* sV = rsmem + nkt * IMG;
   res_dma(Q + inner, ld, n, nkt, sK, wid, lane);
   res_dma(Q + 2 * inner, ld, n, nkt, sV, wid, lane);
-  const int grp = res_group(n, wid, rb.bx, rb.nblk);
+  const int grp = res_group(n, wid, bx, nblk);
   const int q0 = (grp < 0 ? 0 : grp) * 16;
   const int qrow = min(q0 + r, n - 1);
   const float scale_log2e = scale * 1.44269504088896340736f;
 
   bf16x8 qf[2], dof[2];
-  float dl = 0.f;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
-    const long off = ((long)b * n + qrow) * ldo + h * DH + 32 * ks + 8 * g;
-    dof[ks] = *reinterpret_cast<const bf16x8*>(dout + off);
-    const bf16x8 of = *reinterpret_cast<const bf16x8*>(out + off);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[j];
-  }
-  dl = group_sum(dl);
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+  const float dl = row_delta(dout, out, ((long)b * n + qrow) * ldo + h * DH, g, dof);
   const float lse2 = lse[((long)b * heads + h) * n + qrow] * 1.44269504088896340736f;
   __syncthreads();                                   // drains the DMA (vmcnt(0)) of every wave
   if (grp < 0) return;
@@ -906,7 +917,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const bf16
   for (int t = 0; t < 4; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   // (software-pipelining the fragment reads as in the forward kernel measured slower inside the train step: 901 vs 923 volumes/s)
   for (int kt = 0; kt < nkt; ++kt)
-    dq_tile<DROP>(sK + kt * IMG, sV + kt * IMG, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, rb.by, q0 + r, r, g);
+    dq_tile<DROP>(sK + kt * IMG, sV + kt * IMG, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, by, q0 + r, r, g);
   const int q = q0 + r;
   if (q < n) {
     bf16* drow = dqkv + ((long)b * n + q) * ldd + h * DH;
@@ -916,22 +927,22 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const bf16
   }
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout,
-                                                                       long ldo, const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                       int n, int heads, float scale, bf16* __restrict__ dqkv, long ldd,
-                                                                       DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) char rsmem[];
+// body of the dK / dV pass.  OWN_DELTA: delta = rowsum(dO . O) of every query row of the head is computed HERE (from `out`), with
+// row_delta - the dQ pass's own function - instead of being read from what a preceding dQ launch wrote: that dependency was the only
+// reason for two launches.  48 KiB of dO / O re-read per workgroup out of L2, under the wait for the resident tiles.
+template <bool DROP, bool OWN_DELTA>
+__device__ __forceinline__ void attn_bwd_dkv_res_body(char* rsmem, int by, int bx, int nblk, const bf16* __restrict__ qkv, long ld,
+                                                      const bf16* __restrict__ out, const bf16* __restrict__ dout, long ldo,
+                                                      const float* __restrict__ lse, const float* __restrict__ delta, int n, int heads,
+                                                      float scale, bf16* __restrict__ dqkv, long ldd, const DropCfg& drop) {
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const ResBlock rb = res_block(n);
-  const int b = rb.by / heads, h = rb.by - b * heads, inner = heads * DH;
+  const int b = by / heads, h = by - b * heads, inner = heads * DH;
   const bf16* Q = qkv + (long)b * n * ld + h * DH;
   const bf16* K = Q + inner;
   const bf16* V = Q + 2 * inner;
   const bf16* dO = dout + (long)b * n * ldo + h * DH;
   const float* L = lse + ((long)b * heads + h) * n;
-  const float* Dl = delta + ((long)b * heads + h) * n;
   const int nqt = (n + TQ - 1) / TQ;
   char* sQ = rsmem;
   char* sD = rsmem + nqt * IMG;
@@ -939,11 +950,23 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf1
   float* sDl = sL + nqt * TQ;
   res_dma(Q, ld, n, nqt, sQ, wid, lane);
   res_dma(dO, ldo, n, nqt, sD, wid, lane);
-  for (int q = tid; q < nqt * TQ; q += RES_THREADS) {
-    sL[q] = (q < n) ? L[q] * 1.44269504088896340736f : INFINITY;   // exp2(x - inf) = 0 masks padded query rows
-    sDl[q] = (q < n) ? Dl[q] : 0.f;
+  if constexpr (OWN_DELTA) {
+    for (int q = tid; q < nqt * TQ; q += RES_THREADS) sL[q] = (q < n) ? L[q] * 1.44269504088896340736f : INFINITY;   // exp2(x - inf) = 0 masks padded query rows
+    const bf16* O = out + (long)b * n * ldo + h * DH;
+    for (int q0 = 16 * wid; q0 < nqt * TQ; q0 += 16 * (RES_THREADS / 64)) {
+      bf16x8 scratch[2];
+      const int q = q0 + r;
+      const float dl = row_delta(dO, O, (long)min(q, n - 1) * ldo, g, scratch);
+      if (g == 0) sDl[q] = (q < n) ? dl : 0.f;
+    }
+  } else {
+    const float* Dl = delta + ((long)b * heads + h) * n;
+    for (int q = tid; q < nqt * TQ; q += RES_THREADS) {
+      sL[q] = (q < n) ? L[q] * 1.44269504088896340736f : INFINITY;
+      sDl[q] = (q < n) ? Dl[q] : 0.f;
+    }
   }
-  const int grp = res_group(n, wid, rb.bx, rb.nblk);
+  const int grp = res_group(n, wid, bx, nblk);
   const int key0 = (grp < 0 ? 0 : grp) * 16;
   const int krow = min(key0 + r, n - 1);
   const float scale_log2e = scale * 1.44269504088896340736f;
@@ -960,7 +983,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf1
 #pragma unroll
   for (int t = 0; t < 4; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int qt = 0; qt < nqt; ++qt)
-    dkv_tile<DROP>(sQ + qt * IMG, sD + qt * IMG, sL + qt * TQ, sDl + qt * TQ, qt, n, kf, vf, dk, dv, scale_log2e, drop, rb.by, key0 + r, r, g);
+    dkv_tile<DROP>(sQ + qt * IMG, sD + qt * IMG, sL + qt * TQ, sDl + qt * TQ, qt, n, kf, vf, dk, dv, scale_log2e, drop, by, key0 + r, r, g);
   const int key = key0 + r;
   if (key < n) {
     bf16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
@@ -970,6 +993,44 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf1
       *reinterpret_cast<bf16x4*>(drow + 2 * inner + 16 * t + 4 * g) = cvt4(dv[t][0], dv[t][1], dv[t][2], dv[t][3]);
     }
   }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
+                                                                      const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse,
+                                                                      int n, int heads, float scale, float* __restrict__ delta,
+                                                                      bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char rsmem[];
+  const ResBlock rb = res_block(n);
+  attn_bwd_dq_res_body<DROP>(rsmem, rb.by, rb.bx, rb.nblk, qkv, ld, out, dout, ldo, lse, n, heads, scale, delta, dqkv, ldd, drop);
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout,
+                                                                       long ldo, const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                       int n, int heads, float scale, bf16* __restrict__ dqkv, long ldd,
+                                                                       DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char rsmem[];
+  const ResBlock rb = res_block(n);
+  attn_bwd_dkv_res_body<DROP, false>(rsmem, rb.by, rb.bx, rb.nblk, qkv, ld, nullptr, dout, ldo, lse, delta, n, heads, scale, dqkv, ldd, drop);
+}
+
+// dQ and dK / dV of the resident form as ONE grid of 2 x nblk workgroups per (batch, head): logical ids [0, nblk)
+// of a head run the dK / dV pass (computing delta themselves), [nblk, 2 nblk) the dQ pass; the ten workgroups of a head are
+// consecutive logical ids, i.e. one XCD (xcd_remap).  Results are those of the two launches bit for bit (same bodies, same delta
+// arithmetic: tests/test_kernels_gpu.py).  NOT the default: ViT3D-base at batch 4 is 480 workgroups of 144 KiB on 256 CUs - two
+// uneven rounds - and measured 36.3 us per layer against 16.3 + 15.5 for the two launches (nv_attn_set_mode(+100) selects it).
+template <bool DROP>
+__global__ __launch_bounds__(RES_THREADS) void attn_bwd_res_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
+                                                                   const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse,
+                                                                   int n, int heads, float scale, float* __restrict__ delta,
+                                                                   bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char rsmem[];
+  const int nblk = attn_res_blocks(n);
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int by = lid / (2 * nblk), rem = lid - by * 2 * nblk;
+  if (rem < nblk) attn_bwd_dkv_res_body<DROP, true>(rsmem, by, rem, nblk, qkv, ld, out, dout, ldo, lse, nullptr, n, heads, scale, dqkv, ldd, drop);
+  else attn_bwd_dq_res_body<DROP>(rsmem, by, rem - nblk, nblk, qkv, ld, out, dout, ldo, lse, n, heads, scale, delta, dqkv, ldd, drop);
 }
 
 // ------------------------------------------------------------------------------------------------ wide streaming backward
@@ -1261,6 +1322,23 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
       attr = true;
     }
     const dim3 rgrid(attn_res_blocks(n) * B * heads);       // 1-D: whole heads per XCD (res_block)
+    if (g_attn_bwd_merged) {
+      static bool attr2 = false;
+      if (!attr2) {
+        attn_res_attr(attn_bwd_res_kernel<false>, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
+        attn_res_attr(attn_bwd_res_kernel<true>, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
+        attr2 = true;
+      }
+      const dim3 mgrid(2 * rgrid.x);
+      const int lds = 2 * nt * IMG + 2 * nt * TQ * 4;
+      if (dropping) hipLaunchKernelGGL((attn_bwd_res_kernel<true>), mgrid, dim3(RES_THREADS), lds, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out,
+                                       lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+      else hipLaunchKernelGGL((attn_bwd_res_kernel<false>), mgrid, dim3(RES_THREADS), lds, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out,
+                              lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+      nv_prof_end(slot, stream);
+      NV_CHECK_LAUNCH("nv_attn_bwd(resident, one launch)");
+      return NV_OK;
+    }
     { if (dropping) hipLaunchKernelGGL((attn_bwd_dq_res_kernel<true>), rgrid, dim3(RES_THREADS), 2 * nt * IMG, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
                        (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
     else hipLaunchKernelGGL((attn_bwd_dq_res_kernel<false>), rgrid, dim3(RES_THREADS), 2 * nt * IMG, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/neurovit_hip.h"
@@ -180,9 +181,24 @@ inline hipEvent_t deferred_event() {
 }
 
 // nv_vit_backward_stages(join_aux = 0) leaves the auxiliary stream running; the next call on the same workspace must order
-// its first buffer reuse after that work: the event recorded at the end of the unjoined call is carried over here.
-void* g_carry_ws = nullptr;
-hipEvent_t g_carry_done = nullptr;
+// its first buffer reuse after that work: the event recorded at the end of the unjoined call is carried over, PER WORKSPACE
+// (two encoders whose staged backward calls interleave each keep their own dependency), on an event of its own (never one of
+// the pooled events above, which another call may have re-recorded by then).
+struct Carry { hipEvent_t ev = nullptr; bool pending = false; };
+std::unordered_map<void*, Carry>& carry_map() { static std::unordered_map<void*, Carry> m; return m; }
+hipEvent_t carry_take(void* workspace) {                 // the pending dependency of `workspace`, consumed
+  auto it = carry_map().find(workspace);
+  if (it == carry_map().end() || !it->second.pending) return nullptr;
+  it->second.pending = false;
+  return it->second.ev;
+}
+int carry_record(void* workspace, hipStream_t on) {
+  Carry& c = carry_map()[workspace];
+  if (!c.ev && hipEventCreateWithFlags(&c.ev, nv_sync_event_flags()) != hipSuccess) { nv_set_error("nv_vit_backward: event create failed"); return NV_ERR_HIP; }
+  if (hipEventRecord(c.ev, on) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; }
+  c.pending = true;
+  return NV_OK;
+}
 
 #define RUN(call)            \
   do {                       \
@@ -587,9 +603,7 @@ extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const f
   // One cross-stream event per layer in each direction (an event record costs several microseconds of queue time): the main
   // stream signals once, after the attention backward; the auxiliary stream then runs, one layer behind the main stream,
   // [db1 column sum, LN2 reduction, LN1 reduction of the layer above, grouped weight-gradient GEMMs] and signals back once.
-  hipEvent_t prev_done = nullptr;     // everything the previous (higher) layer queued on [A]
-  if (g_carry_ws == workspace) prev_done = g_carry_done;      // ... in the previous, unjoined call
-  g_carry_ws = nullptr;
+  hipEvent_t prev_done = carry_take(workspace);     // everything the previous (higher) layer queued on [A] - in the previous, unjoined call
   bool layers_here = false;
   int pending_ln1 = -1;               // layer whose LN1-backward partials still wait for their reduction
   auto reduce_ln1 = [&](int lp) -> int {
@@ -681,9 +695,7 @@ extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const f
       if (join_aux) {
         RUN(stream_sync(A, S));   // every gradient written on [A] (weight GEMMs, reductions) is ordered before what follows on the main stream
       } else {                    // the caller orders the consumer of this range after BOTH streams; the next call inherits the dependency
-        hipEvent_t e = deferred_event();
-        if (!e || hipEventRecord(e, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; }
-        g_carry_ws = workspace; g_carry_done = e;
+        RUN(carry_record(workspace, A));
       }
     }
     return NV_OK;
@@ -738,5 +750,27 @@ extern "C" int nv_vit_stage_param_range(const nv_vit_config* cfg, int stage, lon
   const int l = D.L - stage;
   *begin = T.layer[l].n1g;
   *end = (l + 1 < D.L) ? T.layer[l + 1].n1g : T.hg;
+  return NV_OK;
+}
+
+// ---- the whole train step in one call (Trainer.py:65-79): forward -> CrossEntropyLoss -> backward -> AdamW.  Host-side sequencing
+// only: the same launches, in the same order, on the same streams as the four separate calls - enqueued without a Python
+// interpreter (or an autograd graph walk) between them.
+extern "C" int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
+                                 float* params, void* params16, float* grads, float* adam_m, float* adam_v, void* workspace, long ws_bytes,
+                                 const long* labels, float* logits, float* loss, float* dlogits, const nv_train_hparams* hp,
+                                 float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream, void* aux_stream) {
+  NV_CHECK_ARG(cfg && hp && hp->struct_size == (int)sizeof(nv_train_hparams), "nv_vit_train_step: nv_train_hparams.struct_size = %d, this library expects %d (ABI revision %d)",
+               hp ? hp->struct_size : -1, (int)sizeof(nv_train_hparams), NV_ABI_VERSION);
+  NV_CHECK_ARG(labels && loss && dlogits && grads && (!hp->update || (adam_m && adam_v && hp->step >= 1)), "nv_vit_train_step: null pointer (labels / loss / dlogits / grads / optimizer state) or step < 1");
+  NV_CHECK_ARG(!(in && in->time_points > 0), "nv_vit_train_step: the fused 4D input form is forward-only (the 4D model's encoder is frozen, NeuroEncoder.py:34-36)");
+  RUN(nv_vit_forward_in(cfg, B, video, shape5, strides5, in, params, params16, workspace, ws_bytes, 1, drop_p, emb_drop_p, drop_seed, logits, stream));
+  RUN(nv_ce_loss(logits, labels, B, cfg->num_classes, 1.f, loss, dlogits, stream));
+  RUN(nv_vit_backward_stages16(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, nullptr, hp->accumulate ? 1 : 0, 0, cfg->depth + 1,
+                               drop_p, emb_drop_p, drop_seed, stream, aux_stream, 1, in ? in->rows_form : 0));
+  if (hp->update) {
+    const long total = nv_vit_param_count(cfg);
+    RUN(nv_adamw_step(params, grads, 0, adam_m, adam_v, params16, total, hp->step, hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, hp->grad_scale, 0, stream));
+  }
   return NV_OK;
 }

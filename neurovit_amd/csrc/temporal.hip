@@ -50,18 +50,22 @@ struct THArgs {
 
 __device__ __forceinline__ float dropf(const DropCfg& d, unsigned long long idx) { return d.thresh ? drop_factor(d, idx) : 1.0f; }
 
-// LayerNorm over the two elements of a token (biased variance, like nn.LayerNorm)
+// LayerNorm over the TWO elements of a token (biased variance, like nn.LayerNorm), in closed form: with c = (z0 - z1) / 2 the centred
+// values are (+c, -c) and the variance is c^2, so h0 = c / sqrt(c^2 + eps) = -h1.  One rounding in front of the square root instead of
+// the generic form's mean -> subtract -> square -> average chain.
 __device__ __forceinline__ void ln2(float z0, float z1, float eps, float& h0, float& h1, float& rstd) {
-  const float mean = 0.5f * (z0 + z1);
-  const float c0 = z0 - mean, c1 = z1 - mean;
-  rstd = 1.0f / sqrtf(0.5f * (c0 * c0 + c1 * c1) + eps);
-  h0 = c0 * rstd; h1 = c1 * rstd;
+  const float c = 0.5f * (z0 - z1);
+  rstd = 1.0f / sqrtf(c * c + eps);
+  h0 = c * rstd; h1 = -h0;
 }
-// its backward: dh = gradient w.r.t. the normalised values -> gradient w.r.t. z
-__device__ __forceinline__ void ln2_bwd(float dh0, float dh1, float h0, float h1, float rstd, float& dz0, float& dz1) {
-  const float m1 = 0.5f * (dh0 + dh1), m2 = 0.5f * (dh0 * h0 + dh1 * h1);
-  dz0 = rstd * (dh0 - m1 - h0 * m2);
-  dz1 = rstd * (dh1 - m1 - h1 * m2);
+// its backward: dh = gradient w.r.t. the normalised values -> gradient w.r.t. z.  The generic form rstd * (dh - mean(dh) - h * mean(dh h))
+// collapses, for two features, to  dz0 = -dz1 = (dh0 - dh1) / 2 * (1 - h0^2) * rstd  with  1 - h0^2 = eps / (c^2 + eps) = eps * rstd^2:
+// a product, no cancellation.  The generic form subtracts two nearly equal numbers whenever the row is saturated (|c| >> sqrt(eps):
+// every row at fixture-scale parameters), leaving fp32 noise of a few 1e-2 of the result - torch's own kernels have it too
+// (profiles/r03_parity_report.txt); this form is exact to rounding against a float64 evaluation.
+__device__ __forceinline__ void ln2_bwd(float dh0, float dh1, float rstd, float eps, float& dz0, float& dz1) {
+  dz0 = 0.5f * (dh0 - dh1) * (eps * rstd * rstd) * rstd;
+  dz1 = -dz0;
 }
 
 template <bool BWD>
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(TH_THREADS) void temporal_head_kernel(const THArgs 
         const float h0 = sh2[tid][0], h1 = sh2[tid][1];
         gg2[0] += dy0 * h0; gg2[1] += dy1 * h1; gbe2[0] += dy0; gbe2[1] += dy1;
         float dz0, dz1;
-        ln2_bwd(dy0 * g2[0], dy1 * g2[1], h0, h1, srs2[tid], dz0, dz1);
+        ln2_bwd(dy0 * g2[0], dy1 * g2[1], srs2[tid], a.eps, dz0, dz1);
         sdy1[tid][0] = dz0; sdy1[tid][1] = dz1;
         const float df0 = dz0 * dropf(a.d_out, (tok0 + tid) * 2), df1 = dz1 * dropf(a.d_out, (tok0 + tid) * 2 + 1);
         sdf[tid][0] = df0; sdf[tid][1] = df1;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(TH_THREADS) void temporal_head_kernel(const THArgs 
         const float h0 = sh1[tid][0], h1 = sh1[tid][1];
         gg1[0] += dy0 * h0; gg1[1] += dy1 * h1; gbe1[0] += dy0; gbe1[1] += dy1;
         float dz0, dz1;
-        ln2_bwd(dy0 * g1[0], dy1 * g1[1], h0, h1, srs1[tid], dz0, dz1);
+        ln2_bwd(dy0 * g1[0], dy1 * g1[1], srs1[tid], a.eps, dz0, dz1);
         sdz1[tid][0] = dz0; sdz1[tid][1] = dz1;
         const float da0 = dz0 * dropf(a.d_sa, (tok0 + tid) * 2), da1 = dz1 * dropf(a.d_sa, (tok0 + tid) * 2 + 1);
         const float c0 = sctx[tid][0], c1 = sctx[tid][1];

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from ._cabi import VitConfig, VitInput, check, lib
+from ._cabi import TrainHparams, VitConfig, VitInput, check, lib
 
 _BYTES = {torch.float32: 4, torch.bfloat16: 2}
 
@@ -223,6 +223,37 @@ class VitRuntime:
                                            float(self._dropout[0]), float(self._dropout[1]), int(self._dropout[2]),
                                            torch.cuda.current_stream().cuda_stream, self._aux_stream(video.device), int(join_aux), int(self._rows_form)),
               "nv_vit_backward_stages16")
+
+    def train_step(self, video: torch.Tensor, labels: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, grads: torch.Tensor,
+                   adam_m: torch.Tensor, adam_v: torch.Tensor, *, step: int, lr: float, betas, eps: float, weight_decay: float,
+                   grad_scale: float = 1.0, accumulate: bool = False, update: bool = True,
+                   dropout: Tuple[float, float, int] = (0.0, 0.0, 0), vol_sigma=None, rows_form: Optional[int] = None):
+        """The reference's whole train step (Trainer.py:65-79) as ONE native call (nv_vit_train_step): forward, CrossEntropyLoss,
+        backward of every stage, AdamW over the arena + bf16 shadow refresh.  Returns (loss [1], logits [B, C]) on the device.
+        Same launches, streams and arithmetic as forward() + ops.ce_loss + backward() + ops.adamw_step."""
+        rows_form = self.rows_form if rows_form is None else int(rows_form)
+        B, inp = self._input_form(video, vol_sigma, 0, rows_form)
+        ws = self.workspace(B, True, video.device)
+        dev = video.device
+        logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        self._dlogits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=dev)
+        assert labels.is_cuda and labels.dtype == torch.int64 and labels.numel() == B and labels.is_contiguous()
+        hp = TrainHparams(ctypes.sizeof(TrainHparams), int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                          float(grad_scale), int(bool(accumulate)), int(bool(update)))
+        check(lib.nv_vit_train_step(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
+                                    None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p),
+                                    params.data_ptr(), params16.data_ptr(), grads.data_ptr(), adam_m.data_ptr(), adam_v.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), labels.data_ptr(), logits.data_ptr(), loss.data_ptr(), self._dlogits.data_ptr(),
+                                    ctypes.byref(hp), float(dropout[0]), float(dropout[1]), int(dropout[2]),
+                                    torch.cuda.current_stream().cuda_stream, self._aux_stream(dev)), "nv_vit_train_step")
+        self._keep = (vol_sigma, inp)
+        self._rows_form = rows_form
+        self._last = (B, True, ws, video)
+        self.generation += 1
+        self.backward_done = True                        # the Grad-CAM gradient tap holds this step's gradient
+        self._dropout = dropout
+        return loss, logits
 
     def aux_stream_object(self, device) -> Optional[torch.cuda.Stream]:
         """The torch stream object behind the engine's auxiliary stream (None when the engine runs single-stream)."""

@@ -67,6 +67,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._steps += 1
         g0 = self.param_groups[0]
         for holder in self._arenas:
+            if self._no_gradients(holder):
+                continue
             self._step_arena(holder, grad_scale, None if reduced_bf16 is None else reduced_bf16.get(id(holder)))
         if self._rest is not None:
             for g in self._rest.param_groups:
@@ -93,15 +95,33 @@ class FusedAdamW(torch.optim.Optimizer):
             self._bind()
         self._steps += 1
 
+    def arenas(self):
+        """The flat arenas (ViT modules, TemporalHead objects) this optimizer steps with one fused launch each."""
+        if not self._bound:
+            self._bind()
+        return list(self._arenas)
+
+    def arena_state(self, holder):
+        """(exp_avg, exp_avg_sq) arenas of `holder` (a ViT or a TemporalHead), created on first use."""
+        arena, _ = holder.flat_parameters()
+        key = id(holder)
+        if key not in self._state_mv or self._state_mv[key][0].data_ptr() == 0 or self._state_mv[key][0].device != arena.device:
+            self._state_mv[key] = (torch.zeros_like(arena), torch.zeros_like(arena))
+        return self._state_mv[key]
+
+    @staticmethod
+    def _no_gradients(holder) -> bool:
+        """torch.optim.AdamW skips a parameter whose .grad is None (no weight decay, no moment decay, no step count): an arena none of
+        whose parameters has a gradient - zero_grad(set_to_none=True) followed by step(), or a head no backward reached - is skipped
+        as a whole.  (A PARTIALLY populated arena is stepped with zeros for the missing gradients: see TemporalHead.gather_foreign_grads.)"""
+        return all(p.grad is None for p in holder._plist)
+
     def _step_arena(self, holder, grad_scale, reduced=None):
         arena, shadow = holder.flat_parameters()
         grads = holder.flat_gradients()
         if hasattr(holder, "gather_foreign_grads"):
             holder.gather_foreign_grads()
-        key = id(holder)
-        if key not in self._state_mv or self._state_mv[key][0].data_ptr() == 0 or self._state_mv[key][0].device != arena.device:
-            self._state_mv[key] = (torch.zeros_like(arena), torch.zeros_like(arena))
-        m, v = self._state_mv[key]
+        m, v = self.arena_state(holder)
         g0 = self.param_groups[0]
         ops.adamw_step(arena, grads if reduced is None else reduced, m, v, shadow, self._steps, g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"], grad_scale)
         holder.mark_shadow_fresh()
@@ -111,7 +131,7 @@ class FusedAdamW(torch.optim.Optimizer):
         """Parameters outside the ViT arenas (after those ranges were stepped bucket by bucket): the temporal head's arena with
         `grad_scale`, stock parameters as they are."""
         for holder in self._arenas:
-            if not isinstance(holder, ViT):
+            if not isinstance(holder, ViT) and not self._no_gradients(holder):
                 self._step_arena(holder, grad_scale)
         if self._rest is not None:
             g0 = self.param_groups[0]

@@ -119,7 +119,10 @@ class TemporalHead:
 
     def gather_foreign_grads(self):
         """Before a fused optimizer step: gradients that autograd produced outside the arena (the stock-module path of
-        NeuroEncoder.forward) are moved into it; a parameter without a gradient contributes zeros."""
+        NeuroEncoder.forward) are moved into it; a parameter without a gradient contributes zeros - the fused step runs over the
+        whole arena, so such a parameter still sees weight decay and moment decay where torch.optim.AdamW would skip it.  The
+        optimizer skips the arena altogether when NO parameter has a gradient (FusedAdamW._no_gradients: the case torch skips
+        entirely); a partially used head does not occur on the NeuroEncoder path (every parameter is on the forward path)."""
         grads = self.flat_gradients()
         for i, p in enumerate(self._plist):
             view = self._grad_view(i)

@@ -25,7 +25,7 @@ from .parallel import GradSync, broadcast_parameters
 class TrainStep:
     def __init__(self, model: NeuroEncoder, lr: Optional[float] = None, weight_decay: Optional[float] = None, process_group=None,
                  n_buckets: int = 4, accumulation_steps: int = 1, overlap_optimizer: bool = False,
-                 grad_comm_dtype: torch.dtype = torch.float32):
+                 grad_comm_dtype: torch.dtype = torch.float32, grad_comm_algo: Optional[str] = None):
         cfg = model.config
         self.model = model
         self.criterion = CrossEntropyLoss()
@@ -49,7 +49,7 @@ class TrainStep:
         self._opt_blocks = int(os.environ.get("NEUROVIT_OPT_BLOCKS", "0"))
         if self._arena_trainable and (world > 1 or overlap_optimizer):
             self.sync = GradSync(process_group, n_buckets, after_bucket=self._bucket_update if overlap_optimizer else None,
-                                 comm_dtype=grad_comm_dtype)
+                                 comm_dtype=grad_comm_dtype, algo=grad_comm_algo)
             # bf16 messages: the fused AdamW reads the reduced bf16 gradients directly; param.grad then keeps the LOCAL
             # (pre-reduction) gradients, which nothing downstream of this fused step reads
             self.sync.write_back = bool(overlap_optimizer) or grad_comm_dtype != torch.bfloat16
@@ -77,6 +77,7 @@ class TrainStep:
         ids = {id(q) for q in vit.parameters()}
         self._outside = [p for p in model.parameters() if id(p) not in ids]
         self._inside = [p for p in model.parameters() if id(p) in ids]
+        self._native = None                                            # decided at the first step (see _native_ok)
         self._head = getattr(model, "_temporal_head", None)            # 4D: its 16 parameters are one arena (temporal.TemporalHead)
         self._head_ids = set()
         if self._head is not None:
@@ -100,7 +101,68 @@ class TrainStep:
                 t.record_stream(cur)
         return loss
 
+    # ------------------------------------------------------------------ the step as ONE native call (world = 1, 3D model)
+    def _native_ok(self, fmri, labels) -> bool:
+        """nv_vit_train_step runs the whole step - forward, CrossEntropyLoss, backward, AdamW - from native code when nothing needs
+        the autograd graph or a collective in between: the 3D model with its whole arena trainable, one process, every parameter in
+        the ViT's arena, no module hooks.  Everything else (4D, data parallel, partially frozen encoders, foreign .grad tensors)
+        takes the general path below; both give the same parameters after a step (tests/test_modules_gpu.py)."""
+        if self._native is None:
+            model, vit = self.model, self._vit
+            self._native = bool(
+                os.environ.get("NEUROVIT_NATIVE_STEP", "1") != "0" and model.config.get('TRAINING_DIM') == 3 and self._arena_trainable
+                and self.sync is None and self.world == 1 and not self._outside and self._compute_stream is None
+                and not any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None)
+                            for m in model.modules()))
+        if not self._native or not (torch.is_tensor(fmri) and fmri.is_cuda and fmri.dtype == torch.float32 and fmri.dim() == 4):
+            return False
+        if not (torch.is_tensor(labels) and labels.is_cuda and labels.dtype == torch.int64 and labels.dim() == 1 and labels.shape[0] == fmri.shape[0]):
+            return False
+        vit = self._vit
+        if not vit._arena_ok():
+            vit._build_arena()
+        # .grad tensors that are not views of the gradient arena (set by foreign code) need the general path's accumulate-and-copy;
+        # the first and the last parameter stand for all (the arena path sets or clears every .grad together)
+        for i in (0, len(vit._plist) - 1):
+            g = vit._plist[i].grad
+            if g is not None and (vit._grads is None or g.data_ptr() != vit._grad_view(i).data_ptr()):
+                return False
+        return True
+
+    def _native_step(self, fmri: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        vit, opt = self._vit, self.optimizer
+        last_micro = (self._micro + 1) % self.accumulation_steps == 0
+        video = fmri.permute(0, 3, 1, 2).unsqueeze(1)                    # NeuroEncoder.py:200-202 as a VIEW (the gather kernel reads the strides)
+        vit.check_video(video, arena_checked=True)                       # (_native_ok has just validated / rebuilt the arena)
+        arena, shadow = vit._arena, vit._shadow
+        if vit._grads is None:
+            vit._grads = torch.zeros_like(arena)
+        grads = vit._grads
+        vit._refresh_shadow()
+        if not opt._bound:
+            opt._bind()
+        m, v = opt.arena_state(vit)
+        if last_micro:
+            opt._steps += 1
+        g0 = opt.param_groups[0]
+        accumulate = self._micro > 0        # the first micro-step of a window overwrites (zero_grad(set_to_none=True), Trainer.py:72), the others add
+        loss, logits = vit._rt.train_step(video, labels.contiguous(), arena, shadow, grads, m, v, step=max(opt._steps, 1), lr=g0["lr"], betas=g0["betas"],
+                                          eps=g0["eps"], weight_decay=g0["weight_decay"], grad_scale=1.0, accumulate=accumulate, update=last_micro,
+                                          dropout=vit.draw_dropout())
+        vit._last_logits = logits
+        self.last_outputs = logits
+        if vit._plist[0].grad is None:                                   # .grad = views of the gradient arena (once; they stay valid)
+            for i, p in enumerate(vit._plist):
+                p.grad = vit._grad_view(i)
+        self._micro += 1
+        if last_micro:
+            vit.mark_shadow_fresh()
+            self._micro = 0
+        return loss.reshape(())
+
     def _step(self, fmri: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        if self._native_ok(fmri, labels):
+            return self._native_step(fmri, labels)
         model, vit = self.model, self._vit
         last_micro = (self._micro + 1) % self.accumulation_steps == 0
         pipelined = self.sync is not None and last_micro
@@ -129,10 +191,14 @@ class TrainStep:
                     if not arena_synced:
                         head._grads.mul_(scale)                        # (otherwise the fused step applies grad_scale)
                     inline = [p for p in inline if id(p) not in self._head_ids]
+                # a head parameter whose gradient is NOT an arena view (stock-module path) is copied into the head's arena by
+                # gather_foreign_grads and scaled there by the fused step's grad_scale: it must not be scaled here as well
+                fused_scales_head = arena_synced and head is not None and any(h is head for h in self.optimizer.arenas())
                 for p in inline:
                     if p.grad is not None:
                         dist.all_reduce(p.grad, group=self._pg)
-                        p.grad.mul_(scale)
+                        if not (fused_scales_head and id(p) in self._head_ids):
+                            p.grad.mul_(scale)
                 if not arena_synced:
                     scale = 1.0                        # already averaged above
             if pipelined and self._overlap_opt:

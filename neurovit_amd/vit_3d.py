@@ -412,9 +412,8 @@ class ViT(nn.Module):
         return scope()
 
     # ------------------------------------------------------------------ execution
-    def _run_forward(self, video, need_grad, extra=(None, 0)):
-        vol_sigma, time_points = extra
-        drop = (0.0, 0.0, 0)
+    def draw_dropout(self):
+        """(p of the blocks, p of the embedding, seed) of the next forward: (0, 0, 0) in eval mode or without dropout."""
         if self._no_proj and self.training and self._dropout_p[0] > 0:
             raise NotImplementedError("neurovit_amd.ViT: heads == 1 with dim_head == dim has no Dropout behind the (absent) output "
                                       "projection (vit_3d.py:43-46); the engine's block dropout would put one there - train this "
@@ -423,7 +422,12 @@ class ViT(nn.Module):
             # nn.Dropout semantics (vit_3d.py:21,23,39,45,100) with a counter-based mask: a fresh seed per forward from
             # torch's CPU generator (so torch.manual_seed reproduces runs); backward recomputes the same masks.
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            drop = (self._dropout_p[0], self._dropout_p[1], seed)
+            return (self._dropout_p[0], self._dropout_p[1], seed)
+        return (0.0, 0.0, 0)
+
+    def _run_forward(self, video, need_grad, extra=(None, 0)):
+        vol_sigma, time_points = extra
+        drop = self.draw_dropout()
         if self.eval_precision not in ("bf16", "fp32"):
             raise ValueError(f"neurovit_amd.ViT: eval_precision must be 'bf16' or 'fp32', got {self.eval_precision!r}")
         if self.eval_precision == "fp32" and not need_grad and not self.training:
@@ -498,10 +502,8 @@ class ViT(nn.Module):
             sync.bucket_ready(grads, begin, end, also_after=None if last == last_stage else self._rt.aux_stream_object(grads.device))
         sync.finish()
 
-    def forward(self, video, vol_sigma=None, time_points=0):
-        """video [B, C, F, H, W] -> [B, num_classes] (vit_3d.py:112-126).  Beyond the reference (SURVEY 8f F3, both optional):
-        vol_sigma [B] marks `video` as RAW volumes whose per-volume z-score (std + 1e-8) is folded into the patch LayerNorm;
-        time_points = T > 0 takes a contiguous 4D batch [B, H, W, D, T] and encodes its B*T volumes without the regroup copy."""
+    def check_video(self, video, time_points=0, arena_checked=False):
+        """Device, extents and arena placement of an input batch (raises as the reference's einops / pos_embedding add would)."""
         if not video.is_cuda:
             raise RuntimeError("neurovit_amd.ViT: input must live on the MI355X (cuda) device - there is no CPU fallback")
         c = self._cfg
@@ -514,10 +516,16 @@ class ViT(nn.Module):
             # takes its extents from the config, so a wrong-sized volume must never reach it
             raise ValueError(f"neurovit_amd.ViT: expected video [B, {c.channels}, {c.frames}, {c.image_size}, {width}] "
                              f"(channels, frames, height, width), got {tuple(video.shape)}")
-        if not self._arena_ok():
+        if not arena_checked and not self._arena_ok():
             self._build_arena()
         if self._arena.device != video.device:
             raise RuntimeError(f"neurovit_amd.ViT: parameters on {self._arena.device}, input on {video.device}")
+
+    def forward(self, video, vol_sigma=None, time_points=0):
+        """video [B, C, F, H, W] -> [B, num_classes] (vit_3d.py:112-126).  Beyond the reference (SURVEY 8f F3, both optional):
+        vol_sigma [B] marks `video` as RAW volumes whose per-volume z-score (std + 1e-8) is folded into the patch LayerNorm;
+        time_points = T > 0 takes a contiguous 4D batch [B, H, W, D, T] and encodes its B*T volumes without the regroup copy."""
+        self.check_video(video, time_points)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)
         if time_points and need_grad:
             raise NotImplementedError("neurovit_amd.ViT: the fused 4D input form is forward-only (frozen encoder of the 4D model)")

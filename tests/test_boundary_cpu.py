@@ -216,12 +216,13 @@ def test_flops_formula_in_package_equals_survey_numbers():
     assert abs(engine.flops_forward(engine.make_config(**{k: v for k, v in W.BASE.items() if k != "pool"})) / 1e9 - 100.07) < 0.01
 
 def test_ctypes_structs_match_the_header_layout(tmp_path):
-    """The ctypes mirrors of the header's structs (nv_vit_config, nv_vit_input, nv_gemm_problem, nv_reduce_job) against what a C
+    """The ctypes mirrors of the header's structs (nv_vit_config, nv_vit_input, nv_gemm_problem, nv_reduce_job, nv_train_hparams) against what a C
     compiler makes of include/neurovit_hip.h: same size, same offset for every field (the header is plain C: gcc compiles it)."""
     import subprocess
     from neurovit_amd import ops
-    from neurovit_amd._cabi import HEADER, VitConfig, VitInput
-    structs = {"nv_vit_config": VitConfig, "nv_vit_input": VitInput, "nv_gemm_problem": ops.GemmProblem, "nv_reduce_job": ops.ReduceJob}
+    from neurovit_amd._cabi import HEADER, TrainHparams, VitConfig, VitInput
+    structs = {"nv_vit_config": VitConfig, "nv_vit_input": VitInput, "nv_gemm_problem": ops.GemmProblem, "nv_reduce_job": ops.ReduceJob,
+               "nv_train_hparams": TrainHparams}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
@@ -238,3 +239,14 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         assert got[(cname, "size")] == ctypes.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
+
+def test_abi_revision_of_library_header_and_binding_agree():
+    """nv_abi_version() of the built library == NV_ABI_VERSION of the header == the revision the ctypes binding was written for
+    (a caller built against another revision must refuse the library: INTEGRATION.md 'ABI revisions')."""
+    import re
+    from neurovit_amd import _cabi
+    header = int(re.search(r"#define\s+NV_ABI_VERSION\s+(\d+)", open(_cabi.HEADER).read()).group(1))
+    assert header == _cabi.ABI_VERSION
+    assert _cabi.lib.nv_abi_version() == header            # no GPU needed: loads the library and asks

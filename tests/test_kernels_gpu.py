@@ -606,14 +606,16 @@ def test_attention_resident_equals_streaming(ops, B, n, heads, drop):
     do = dev(bf(rnd(B * n, inner, seed=3)))
     res = {}
     try:
-        for mode in (1, 2, 22):      # streaming; resident (default: one wave per row group); resident with two partner waves
+        # streaming; resident (default: one wave per row group); resident with two partner waves; resident backward as ONE launch
+        # whose dK/dV workgroups compute delta themselves (+100)
+        for mode in (1, 2, 22, 102):
             lib.nv_attn_set_mode(mode)
             out, lse = ops.attn_fwd(qkv, B, n, heads, drop_seed=99, drop_p=drop)
             dqkv, delta = ops.attn_bwd(qkv, out, do, lse, B, n, heads, drop_seed=99, drop_p=drop)
             res[mode] = (out, lse, dqkv, delta)
     finally:
         lib.nv_attn_set_mode(0)
-    for other in (2, 22):
+    for other in (2, 22, 102):
         for a, b, name in zip(res[1], res[other], ("out", "lse", "dqkv", "delta")):
             assert torch.equal(a, b), (other, name)
     assert torch.isfinite(res[2][2].float()).all()

@@ -282,6 +282,57 @@ def test_drop_in_with_stock_torch_optimizer_and_accumulation(nv):
     assert not out.requires_grad and torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("case", ["plain", "accumulate2", "dropout"])
+def test_native_train_step_equals_the_general_path_bitwise(nv, case):
+    """nv_vit_train_step (forward + CrossEntropyLoss + backward + AdamW in ONE C-ABI call) against the same step driven through
+    autograd (engine forward, CE Function, staged backward, FusedAdamW): the same launches in the same order - losses, logits,
+    gradient arena and parameters after three steps must be equal bit for bit; the Grad-CAM taps stay valid."""
+    from neurovit_amd.trainer import TrainStep
+    drop = 0.1 if case == "dropout" else 0.0
+    acc = 2 if case == "accumulate2" else 1
+    size = dict(TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
+    x = W.make_volume((2, 32, 32, 32), 2).cuda()
+    y = torch.tensor([1, 0], device="cuda")
+    runs = []
+    for native in (True, False):
+        cfg = W.neuro_config(32, 8, DEVICE="cuda", TRAINING_DROPOUT=drop, TRAINING_LEARNING_RATE=1e-3, TRAINING_WEIGHT_DECAY=1e-2, **size)
+        model = nv.NeuroEncoder(cfg)
+        model.load_state_dict(W.make_tensors(W.vit_param_spec(**W.MICRO), 1, prefix="volume_encoder.vit3d."), strict=True)
+        model.train()
+        step = TrainStep(model, accumulation_steps=acc)
+        if not native:
+            step._native = False
+        torch.manual_seed(11)
+        losses = [step(x, y).clone() for _ in range(3 * acc)]
+        assert step._native == native, "the 3D single-process step must take the native call"
+        vit = model.volume_encoder.vit3d
+        runs.append((torch.stack(losses), step.last_outputs.clone(), vit.flat_gradients().clone(), vit.flat_parameters()[0].clone(),
+                     vit.flat_parameters()[1].clone(), model.gradients, [p.grad is not None for p in model.parameters()]))
+    a, b = runs
+    for i, name in enumerate(("losses", "logits", "gradient arena", "parameters", "bf16 shadow")):
+        assert torch.equal(a[i], b[i]), f"{case}: {name} differ between the native call and the general path"
+    assert torch.equal(a[5], b[5]) and a[5].shape == (2, 65, 128)          # hook gradient of the last step
+    assert all(a[6]) and all(b[6])                                         # .grad populated (views of the arena)
+    report(f"native train step [{case}] == general path (losses, logits, gradients, parameters, shadow: bitwise)")
+
+
+def test_native_train_step_leaves_foreign_grads_to_the_general_path(nv):
+    """.grad tensors that are not views of the gradient arena (foreign code put them there) need accumulate-and-copy: the step must
+    not take the native call then, and must still add to them."""
+    from neurovit_amd.trainer import TrainStep
+    model = _micro_model(nv)
+    step = TrainStep(model, accumulation_steps=2)
+    x = W.make_volume((2, 32, 32, 32), 2).cuda()
+    y = torch.tensor([1, 0], device="cuda")
+    step(x, y)                                                             # micro-step 1 of 2: native, .grad = arena views
+    assert step._native
+    p0 = model.volume_encoder.vit3d._plist[0]
+    p0.grad = p0.grad.clone()                                              # foreign tensor
+    assert not step._native_ok(x, y)
+    step(x, y)
+    assert torch.isfinite(p0.grad).all()
+
+
 def test_fused_step_equals_stock_optimizer_step(nv):
     """FusedAdamW (one launch over the arena) == torch.optim.AdamW on the same gradients."""
     from neurovit_amd.optim import FusedAdamW

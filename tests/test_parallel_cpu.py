@@ -153,3 +153,81 @@ def test_gradsync_gloo_world8_bf16_messages_7_buckets():
         assert identical, "replicas diverged"
         assert worst <= 1.0, (rank, worst)                        # within the stated elementwise bound
         assert rms < 2.0 ** -7, (rank, rms)                       # and far inside it on average (relative L2 of the whole arena)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reduce-scatter + all-gather form and the one-hop (all-to-all, local rank-order sum, all-to-all) form of the
+# bucket reduction against the plain all-reduce, on gloo.  fp32 messages: every form must leave the SAME values on every rank;
+# "one_hop" must equal the left-to-right rank-order sum bit for bit (that is its definition: it is deterministic by construction),
+# every form equals the all-reduce bit for bit at world 2 (a + b is commutative) and to fp32 rounding at world 8.  bf16 messages:
+# "one_hop" rounds once (sum in fp32) and must be at least as close to the float64 sum as the all-reduce of bf16 messages.
+def _worker_algos(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 10007                                                 # not a multiple of the world size or of the 8-element shard alignment
+        gen = torch.Generator().manual_seed(77 + rank)
+        base = torch.randn(n, generator=gen) * (10.0 ** torch.randint(-2, 2, (n,), generator=gen).float())
+        everyone = [torch.empty_like(base) for _ in range(world)]
+        dist.all_gather(everyone, base)
+        fold = everyone[0].clone()
+        for r in range(1, world):
+            fold = fold + everyone[r]                             # left-to-right rank-order sum in fp32
+        exact = torch.stack(everyone).double().sum(0)
+        out = {}
+        buckets = [(6000, n), (2500, 6000), (0, 2500)]
+        for dtype in (torch.float32, torch.bfloat16):
+            for algo in GradSync.ALGOS:
+                g = base.clone()
+                sync = GradSync(None, n_buckets=3, comm_dtype=dtype, algo=algo)
+                sync.begin()
+                for b, e in buckets:
+                    sync.bucket_ready(g, b, e)
+                sync.finish()
+                same = [torch.empty_like(g) for _ in range(world)]
+                dist.all_gather(same, g)
+                out[(str(dtype), algo)] = dict(identical=all(torch.equal(same[0], t) for t in same),
+                                               eq_fold=bool(torch.equal(g, fold)),
+                                               err=float((g.double() - exact).abs().max() / exact.abs().max()),
+                                               rms=float((g.double() - exact).norm() / exact.norm()), g=g)
+        f32 = {a: out[(str(torch.float32), a)] for a in GradSync.ALGOS}
+        res = dict(rank=rank,
+                   identical=all(v["identical"] for v in out.values()),
+                   one_hop_is_rank_order_fold=f32["one_hop"]["eq_fold"],
+                   f32_bitwise_vs_allreduce={a: bool(torch.equal(f32[a]["g"], f32["allreduce"]["g"])) for a in ("rs_ag", "one_hop")},
+                   f32_err={a: f32[a]["err"] for a in GradSync.ALGOS},
+                   bf16_rms={a: out[(str(torch.bfloat16), a)]["rms"] for a in GradSync.ALGOS})
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_gradsync_reduce_scatter_and_one_hop_forms_against_allreduce(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker_algos, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r["rank"] for r in res) == list(range(world))
+    for r in res:
+        assert r["identical"], "replicas diverged"
+        assert r["one_hop_is_rank_order_fold"], "the one-hop form must be the rank-order fp32 sum, bit for bit"
+        for a, err in r["f32_err"].items():
+            assert err < 1e-6, (a, err)                           # fp32 messages: every form is the sum to fp32 rounding
+        if world == 2:
+            assert all(r["f32_bitwise_vs_allreduce"].values()), r["f32_bitwise_vs_allreduce"]
+        # bf16 messages: one rounding per rank's message + (one_hop) one of the result, against W - 1 roundings of partial sums
+        assert r["bf16_rms"]["one_hop"] <= r["bf16_rms"]["allreduce"] * 1.05 + 1e-9, r["bf16_rms"]
+        assert r["bf16_rms"]["rs_ag"] < 2.0 ** -6 and r["bf16_rms"]["one_hop"] < 2.0 ** -7, r["bf16_rms"]
+
+
+def test_gradsync_rejects_an_unknown_algorithm():
+    with pytest.raises(ValueError, match="algo must be one of"):
+        GradSync(None, algo="butterfly")

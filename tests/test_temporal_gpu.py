@@ -3,10 +3,13 @@
 (nn.TransformerEncoderLayer(d_model 2, nhead 2) -> mean -> nn.Linear(2, 2): NeuroEncoder.py:60-66, 207-230).
 
 Tolerances: the kernel is fp32 and differs from torch in summation order only; the oracle runs in float64.  Outputs 1e-5 of the
-largest value; gradients 2e-4 of the tensor's largest entry plus an absolute floor.  LayerNorm over TWO features maps a row to
-(+-1, -+1) whenever its two entries differ by more than sqrt(eps): gradients through it are then ~1e-4 of the upstream gradient
-and carry its fp32 cancellation noise (floor 2e-5 of the head's largest gradient for the fixture-scale parameters); the "soft"
-parameter set scales the pre-norm differences down to the eps scale so that every path carries signal (floor 1e-7).
+largest value; gradients 2e-4 of the tensor's largest entry plus a floor of 1e-7 (the "soft" parameter set, whose pre-norm
+differences sit at the eps scale so that every path carries signal) or 2e-7 of the head's largest gradient (fixture-scale
+parameters).  LayerNorm over TWO features maps a row to (+-1, -+1) whenever its two entries differ by more than sqrt(eps): the
+gradient through it is eps / (c^2 + eps) ~ 1e-4 of the upstream gradient.  The kernel evaluates that factor in closed form (a
+product, csrc/temporal.hip::ln2_bwd), so fixture-scale parameters are held to the same relative gate as the soft ones; the generic
+LayerNorm backward - torch's own fp32 kernels included - leaves cancellation noise of 1e-2 ... 8e-2 of a tensor's largest entry
+there (round 3 needed a floor of 2e-5 of the head's largest gradient, 100 x this one).
 """
 import numpy as np
 import pytest
@@ -62,11 +65,10 @@ def _check(ops, sd, x, dout, drop, tag, soft):
     ref_out, ref_g, ref_dx = _oracle(sd, x, dout, drop)
     e_out = rel_err(out, ref_out)
     assert e_out < 1e-5, (tag, e_out)
-    # fixture-scale parameters saturate both LayerNorms: what flows through them is the difference of nearly equal fp32 numbers
-    # (the exact value is ~eps/(c^2 + eps) = 1e-4 of the upstream gradient), so those entries carry an absolute error of a few
-    # ulp of the UPSTREAM gradient whatever the arithmetic order - floor relative to the largest gradient of the head
+    # fixture-scale parameters saturate both LayerNorms (what flows through them is ~eps / (c^2 + eps) = 1e-4 of the upstream gradient);
+    # the closed-form two-feature backward carries no cancellation, so the floor is an fp32 epsilon of the head's largest gradient
     gmax = max(v.abs().max().item() for v in ref_g.values())
-    floor = 1e-7 if soft else 2e-5 * gmax
+    floor = 1e-7 if soft else 2e-7 * max(gmax, 1.0)
     off, worst = 0, 0.0
     for k, shape, _ in W.temporal_param_spec():
         n = int(np.prod(shape))
