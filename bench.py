@@ -31,10 +31,11 @@ PEAK_F32_TFLOPS = 157.3         # fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak 
 # nv_prof kinds -> the rocprofv3 kernel names of the same launches (profiles/r02_*kernel_stats.csv)
 KIND_NAMES = {0: "gemm_ws_kernel<64,128,...,false,false,*> (NT: out-proj, FC2, patch embed)", 1: "gemm_ws_kernel<64,128,...,false,true,*> (NN: dxn1, dxn2, dAO)",
               2: "gemm_ws_kernel<...,true,true,1> (TN: patch-embed weight gradient)", 3: "attn_fwd_res_kernel", 4: "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
+              5: "gemm_pp_f8_kernel / gemm_pq_kernel<...,true> (fp8 e4m3 operands: qkv, FC1, FC2 of an --fp8 run; priced against the bf16 peak here)",
               10: "gemm_pp_kernel<256,128,4,2,false,false,*> (NT: qkv, FC1)", 11: "gemm_pp_kernel<256,128,4,2,false,true,*> (NN: dU with fused GELU' and bias column sums)",
               12: "gemm_pp_kernel<256,128,4,2,true,true,1> (TN)", 13: "gemm_pp_grouped_tn_kernel (four weight gradients of a layer, auxiliary stream)",
               20: "gemm_pq_kernel<false,false,*> (NT, 256x256 tiles)", 21: "gemm_pq_kernel<false,true,*> (NN, 256x256 tiles)", 22: "gemm_pq_kernel<true,true,*> (TN, 256x256 tiles)"}
-GEMM_KINDS = (0, 1, 2, 10, 11, 12, 13, 20, 21, 22)
+GEMM_KINDS = (0, 1, 2, 5, 10, 11, 12, 13, 20, 21, 22)
 
 
 def parse():
@@ -50,17 +51,24 @@ def parse():
     ap.add_argument("--overlap-optimizer", action="store_true", help="AdamW per gradient bucket on the side stream")
     ap.add_argument("--grad-comm", default="bf16", choices=["bf16", "fp32"],
                     help="dtype of the gradient all-reduce messages (N > 1 only; compute and optimizer are unaffected)")
+    ap.add_argument("--grad-algo", default=None, choices=["allreduce", "rs_ag", "one_hop"],
+                    help="how a gradient bucket is summed over the ranks (N > 1): one all-reduce (default), reduce-scatter + all-gather, or the "
+                         "one-hop all-to-all form for a fully connected xGMI node (neurovit_amd/parallel.py::GradSync)")
+    ap.add_argument("--no-probe", action="store_true", help="N > 1: skip the start-up stream-placement probes (streams_beside_collectives): the step "
+                                                            "runs on the current stream, the engine picks its auxiliary stream itself")
     ap.add_argument("--dropout", type=float, default=0.0, help="TRAINING_DROPOUT of the timed model (headline: 0, SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (forward-only, fwd+bwd, dropout)")
     ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-leg", type=int, default=0, help="internal: run only the CPU baseline's train steps on this many threads and print a JSON value")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--same-data", action="store_true", help="rehearsal: every rank gets rank 0's batch (with --grad-comm fp32 the "
                                                               "averaged gradients, hence the loss curve, must equal the 1-GPU run bit for bit)")
     ap.add_argument("--forward-only", action="store_true", help="time inference forwards (validate path, Trainer.py:101-118) instead of train steps")
-    ap.add_argument("--fp8", action="store_true", help="with --forward-only: the fp8 (OCP e4m3) inference path (BASELINE.json configs[4]), "
-                                                       "activation scales calibrated on the bench batch")
+    ap.add_argument("--fp8", action="store_true", help="the fp8 (OCP e4m3) path of BASELINE.json configs[4], activation scales calibrated on the bench batch: with "
+                                                       "--forward-only the inference forward (all four linears in e4m3); without it the train step whose FORWARD runs "
+                                                       "qkv / FC1 / FC2 in e4m3 (bf16 backward; needs --dropout 0)")
     ap.add_argument("--precise", action="store_true", help="with --forward-only: the fp32 inference path (every operand fp32 on the fp32 MFMA: the "
                     "reference's fp32 validate, Trainer.py:101-118; logits within 1e-5 of its CPU forward)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous rehearsal without a GPU: every rank joins the process group, "
@@ -138,7 +146,50 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(model, vcfg, B, S, steps, warmup=3):
+def _cgroup_cpu_quota():
+    """CPU quota of this process's cgroup in cores (cgroup v2 cpu.max, v1 cfs_quota_us / cfs_period_us), or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(float(q) / float(per) + 0.5))
+        return None
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return max(1, int(q / per + 0.5)) if q > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_leg(a):
+    """--cpu-leg THREADS: the oracle's train step of the preset on THREADS host threads, CPU only (child of cpu_baseline)."""
+    import torch as _t
+    from neurovit_amd import config as nvcfg
+    from oracle import ref_cpu, train_step
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import weights as W
+    _t.set_num_threads(a.cpu_leg)
+    size = nvcfg.preset(a.preset)
+    S, p = size["TRAINING_VIT_INPUT_SIZE"], size["TRAINING_VIT_PATCH_SIZE"]
+    vcfg = dict(image_size=S, image_patch_size=p, frames=S, frame_patch_size=p, num_classes=2, dim=size["TRAINING_VIT_DIM"],
+                depth=size["TRAINING_VIT_DEPTH"], heads=size["TRAINING_VIT_HEADS"], mlp_dim=size["TRAINING_VIT_MLP_DIM"], channels=1, dim_head=64)
+    cfg = ref_cpu.ViTCfg(**vcfg)
+    sd = W.make_tensors(W.vit_param_spec(**vcfg), 3)                  # timing only: random weights of the right shapes
+    opt = train_step.AdamW(sd, lr=1e-4, weight_decay=1e-2)
+    g = _t.Generator().manual_seed(4244)
+    x = _t.randn(a.batch, S, S, S, generator=g)
+    y = _t.randint(0, 2, (a.batch,), generator=g)
+    video = ref_cpu.fmri_to_video(x)
+    train_step.train_step(sd, cfg, opt, video, y)
+    t0 = time.perf_counter()
+    for _ in range(a.cpu_steps):
+        train_step.train_step(sd, cfg, opt, video, y)
+    print(json.dumps({"value": a.batch * a.cpu_steps / (time.perf_counter() - t0), "unit": "volumes/s", "cores": _t.get_num_threads()}), flush=True)
+
+
+def cpu_baseline(model, vcfg, B, S, steps, warmup=3, preset="base"):
     """The oracle's restatement of the same train step (eager PyTorch CPU fp32 = the reference's own CPU path,
     SURVEY.md 8d), timed on this host's cores on a bounded sample: `warmup` + `steps` steps of the bench workload, plus
     BASELINE.json configs[0] (ViT3D tiny, batch 2: the reference's own CPU-runnable case) as a second line."""
@@ -148,7 +199,8 @@ def cpu_baseline(model, vcfg, B, S, steps, warmup=3):
     except AttributeError:
         nthreads = os.cpu_count() or 1
     visible = nthreads
-    nthreads = max(1, min(nthreads, 16))       # the GPU box grants a 16-core share per GPU: more threads than that only oversubscribe it
+    usable = min(visible, _cgroup_cpu_quota() or visible)      # cores this process may really use: affinity AND the cgroup's CPU quota
+    nthreads = max(1, min(usable, 16))         # the GPU box grants a 16-core share per GPU: more threads than that only oversubscribe it
     torch.set_num_threads(nthreads)
 
     def run(sd, cfg, batch, n_warm, n_timed, seed):
@@ -164,14 +216,37 @@ def cpu_baseline(model, vcfg, B, S, steps, warmup=3):
 
     sd = {k[len("volume_encoder.vit3d."):]: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
     value = run(sd, ref_cpu.ViTCfg(**vcfg), B, warmup, steps, 4242)
+    # the same sample on EVERY core the process can see (north_star: "the node's host cores"): more threads than the box's share of the
+    # host may oversubscribe it, so both figures are reported and `value` stays the one measured inside the share
     # tiny: random weights of the right shapes (timing only)
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import weights as W
     tcfg = ref_cpu.ViTCfg(**W.TINY)
     tsd = W.make_tensors(W.vit_param_spec(**W.TINY), 3)
     tiny = run(tsd, tcfg, 2, warmup, max(steps, 20), 4243)
+    all_cores = {"value": None, "cores": usable, "cores_visible": visible,
+                 "note": f"not run: the process may use {usable} cores (affinity {visible}, cgroup CPU quota {_cgroup_cpu_quota()}), which `value` already uses"}
+    if usable > nthreads:
+        # In a CHILD process with a wall-clock limit: threads beyond the real share of the host - a quota this process cannot see - make
+        # eager PyTorch crawl (measured: minutes per step at 256 threads on a 16-core share); the child never touches the GPU
+        n_all = max(2, steps // 2)
+        limit = 90
+        log(f"cpu baseline: all-cores leg on {usable} threads (child process, {limit} s limit)")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", str(usable), "--batch", str(B), "--preset", preset, "--cpu-steps", str(n_all)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and line:
+                all_cores = dict(json.loads(line[-1]), cores_visible=visible, sample=f"{n_all} train steps after 1 warm-up step, same workload, child process")
+            else:
+                all_cores["note"] = f"child failed (rc {r.returncode}): {r.stderr.strip()[-200:]}"
+        except subprocess.TimeoutExpired:
+            all_cores["note"] = (f"abandoned after {limit} s: {usable} threads oversubscribe this process's share of the host "
+                                 f"({nthreads} threads: {value:.2f} volumes/s)")
     return {"value": value, "unit": "volumes/s", "cores": torch.get_num_threads(), "cores_visible": visible,
-            "cores_note": "threads used = min(cores visible to the process, 16: a one-GPU box's CPU share)", "cpu_model": _cpu_model(), "kind": "port",
+            "cores_note": "threads used = min(cores this process may use [affinity and cgroup CPU quota], 16: a one-GPU box's CPU share); all_cores = the same "
+                          "sample on every usable core (probed with one step first, abandoned when that step shows the share is oversubscribed)",
+            "all_cores": all_cores, "cpu_model": _cpu_model(), "kind": "port",
             "sample": f"{steps} train steps (fwd+bwd+AdamW, fp32 eager PyTorch CPU) of the same workload, batch {B}, after {warmup} warm-up steps",
             "tiny_config": {"value": tiny, "unit": "volumes/s",
                             "workload": "BASELINE.json configs[0]: ViT3D tiny 64^3 patch 16 dim 192 depth 4 heads 3 mlp 384, batch 2, train step",
@@ -266,6 +341,8 @@ def forward_only_bench(a, model, x, size, S, p, B, world, rank, device, dist):
 def main():
     global torch
     a = parse()
+    if a.cpu_leg:
+        return cpu_leg(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(a)                                     # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -279,8 +356,21 @@ def main():
     import torch.distributed as dist
     if a.dry_run:
         return dry_run(a, world, rank)
+    if a.no_probe:
+        os.environ["NEUROVIT_DP_PROBE"] = "0"
+    rccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC - without it RCCL's peer-buffer exchange (and any
+        # CUDA-tensor sharing across processes) fails with `hipIpcGetMemHandle: invalid argument`.  Set here too (not only by launch_ranks)
+        # because the driver starts the ranks through torch.distributed.run
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if rank == 0 and a.backend == "nccl" and "NCCL_DEBUG" not in os.environ:
+            # rank 0 relays what RCCL chose (algorithm / protocol / channels / transport) to stderr after the run: the scaling record
+            # then shows whether the all-reduce ran as a ring over one xGMI link or used the fully connected topology
+            import tempfile
+            rccl_log = os.path.join(tempfile.gettempdir(), f"rccl_rank0_{os.getpid()}.log")
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING", NCCL_DEBUG_FILE=rccl_log)
         if a.same_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)
@@ -306,7 +396,7 @@ def main():
     model = NeuroEncoder(config)
     model.train()
     step = TrainStep(model, process_group=None, n_buckets=a.buckets, overlap_optimizer=a.overlap_optimizer,
-                     grad_comm_dtype=torch.bfloat16 if a.grad_comm == "bf16" else torch.float32)
+                     grad_comm_dtype=torch.bfloat16 if a.grad_comm == "bf16" else torch.float32, grad_comm_algo=a.grad_algo)
     B = a.batch
     x, y = make_batch(B, S, device, 42 + (0 if a.same_data else rank))
 
@@ -317,6 +407,11 @@ def main():
 
     if a.forward_only:
         return forward_only_bench(a, model, x, size, S, p, B, world, rank, device, dist)
+    if a.fp8:
+        # BASELINE.json configs[4] ("fp8 MFMA", quoted fwd / fwd+bwd): training forwards with qkv / FC1 / FC2 on e4m3 operands, bf16 backward;
+        # activation scales calibrated on the bench batch, weights re-quantised (in place) after every optimizer step - inside the timed step
+        with torch.no_grad():
+            model.volume_encoder.vit3d.enable_fp8(x.permute(0, 3, 1, 2).unsqueeze(1), out_proj=False, training=True)
     log(f"model built on {device}, warm-up {a.warmup} steps")
     for _ in range(a.warmup):
         step(x, y)
@@ -328,7 +423,14 @@ def main():
     enqueued = time.perf_counter() - t0          # host time to enqueue the K steps: far below `elapsed` = the GPU is the limiter
     barrier()
     elapsed = time.perf_counter() - t0
-    log(f"host enqueue {enqueued / a.steps * 1e3:.3f} ms/step of {elapsed / a.steps * 1e3:.3f} ms/step")
+    # host cost of enqueueing ONE step, measured from an idle queue (over the K timed steps the host runs into the runtime's queue
+    # depth and is throttled to the GPU's pace, so `enqueued` only bounds it from above)
+    t1 = time.perf_counter()
+    step(x, y)
+    host_step_ms = (time.perf_counter() - t1) * 1e3
+    torch.cuda.synchronize()
+    log(f"host enqueue {host_step_ms:.3f} ms for one step from an idle queue ({enqueued / a.steps * 1e3:.3f} ms/step inside the timed loop) "
+        f"of {elapsed / a.steps * 1e3:.3f} ms/step")
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -452,7 +554,7 @@ def main():
     # (tools/pmc_traffic_summary.py -> profiles/rNN_pmc_traffic.json, per nv_prof kind); the algorithmic bytes beside them are
     # counted live, per launch, by the launchers (operands read once + outputs written once).  traffic / algorithmic = the waste.
     pmc, traffic_src = {}, None
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         tfile = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
@@ -485,7 +587,7 @@ def main():
     g_bytes = sum(kinds[k].get("bytes", 0.0) for k in gk)
     roofline = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family: gemm_pp_kernel / gemm_pp_grouped_tn_kernel (256x128 tiles) + gemm_ws_kernel (64x128 tiles), all fused epilogues",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "bytes/launch (fabric fetch + write, PMC), mean over the launches of `achieved`", "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_unit": "bytes/launch of FABRIC traffic (L2 memory-side read + write requests, rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE: Infinity-Cache hits are counted, so this is an upper bound of the HBM bytes, not the HBM bytes), mean over the launches of `achieved`", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(g_bytes / max(g_n, 1), 1),
                 "traffic_over_algorithmic": None if not (traffic and g_bytes) else round(traffic / (g_bytes / g_n), 2),
                 "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches_per_step": g_n // prof_steps,
@@ -508,7 +610,8 @@ def main():
               " [timed step = fwd+bwd+AdamW update]")
     out = {"metric": metric, "value": round(value, 2), "unit": "volumes/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None,
+           "dtype": "fp8 forward (e4m3 qkv/FC1/FC2 operands, fp32 accumulate), bf16 backward" if a.fp8 else "bf16", "data": "synthetic",
            "config": {"workload": f"ViT3D-{a.preset} {S}^3 patch {p}, train step (fwd+bwd+AdamW), batch {B}/GPU, dropout {a.dropout:g}",
                       "global_batch": B * world, "parallelism": f"dp{world}", "grad_buckets": a.buckets,
                       "grad_allreduce": ("none (1 GPU)" if world == 1 else f"{a.grad_comm} messages, sum, overlapped with backward")},
@@ -518,17 +621,46 @@ def main():
            # kernels really ran (GEMM + attention launches as counted by the per-launch profiler; skinny cls-row kernels excluded)
            "mfma_frac_step_executed": round(executed_flops_step / (ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
            "executed_over_algorithmic_flops": round(executed_flops_step / (B * f_step), 4),
+           "host_enqueue_ms_per_step": round(host_step_ms, 3),
            "loss": round(float(loss), 5), "roofline": roofline}
     if also is not None:
         also["forward_only_mfma_frac"] = round(also["forward_only_eval_volumes_s"] * f_fwd / (PEAK_BF16_TFLOPS * 1e12), 4)
         out["also"] = also
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline leg")
-        out["cpu_baseline"] = cpu_baseline(model, vcfg, B, S, a.cpu_steps)
+        out["cpu_baseline"] = cpu_baseline(model, vcfg, B, S, a.cpu_steps, preset=a.preset)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rccl_log and os.path.exists(rccl_log):
+        relay_rccl_choices(rccl_log)
+
+
+def relay_rccl_choices(path, limit=40):
+    """stderr summary of rank 0's RCCL INFO log: topology / algorithm / protocol / channel lines, deduplicated."""
+    import re
+    keep = re.compile(r"(Channel \d+/\d+ *:|\d+ coll channels|nChannels|Trees|Ring \d+ *:|Algo|algorithm|protocol|Proto|via P2P|via SHM|via NET|XGMI|xgmi|"
+                      r"comm 0x[0-9a-f]+ rank|Connected all (rings|trees)|threadThresholds|Using tuner|NCCL_ALGO|NCCL_PROTO)")
+    seen, n = set(), 0
+    try:
+        for line in open(path, errors="replace"):
+            if not keep.search(line):
+                continue
+            body = re.sub(r"^.*?NCCL INFO ", "", line.strip())
+            key = re.sub(r"\d+", "#", body)
+            if key in seen:
+                continue
+            seen.add(key)
+            log(f"rccl: {body[:200]}")
+            n += 1
+            if n >= limit:
+                log("rccl: ... (more in the NCCL_DEBUG_FILE)")
+                break
+        if n == 0:
+            log(f"rccl: no topology / algorithm lines in {path}")
+    except OSError as e:
+        log(f"rccl: could not read {path}: {e}")
 
 
 if __name__ == "__main__":

@@ -69,6 +69,14 @@ int nv_ln_fwd_f8(const float* x, long ldx, int M, int d, const float* gamma, con
                  long ldy, void* stream);
 int nv_gemm_f8(int epi, int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc,
                const float* colscale, const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* stream);
+/* Training forward on fp8 operands (BASELINE.json configs[4], "fwd / fwd+bwd"): the forward linears run on e4m3 operands, the backward
+ * pass stays on bf16 operands and reads bf16 copies that the SAME forward kernels write.
+ * nv_ln_fwd_f8_train: nv_ln_fwd_f8 + the bf16 output and the row statistics of nv_ln_fwd (bit for bit) in one pass over x.
+ * nv_gemm_f8_gelu_train (FC1): h8 e4m3 = sat(gelu(u) * out_scale), h16 bf16 = gelu(u), u16 bf16 (optional) = u = acc * colscale + bias. */
+int nv_ln_fwd_f8_train(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, float out_scale, void* y8, long ldy8,
+                       void* y16, long ldy16, float* mean, float* rstd, void* stream);
+int nv_gemm_f8_gelu_train(int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, const float* colscale, const float* bias,
+                          float out_scale, void* h8, long ldh8, void* h16, long ldh16, void* u16, long ldu16, void* stream);
 
 /* ---- fp32 inference path ("precise" mode).  The reference validates in fp32 without autocast (src/Trainer.py:101-118) and the logits
  * are to match its CPU forward to 1e-3; bf16 MFMA operands cannot (weights rounded to bf16 alone cost 1e-3 ... 6e-3), so these entry
@@ -101,7 +109,8 @@ int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gemm_problem* 
 /* tuning aid: force the workgroup tile ((64,64), (64,128), (128,128): the general small-tile kernel); bm = 0 restores the built-in
  * heuristic; bm = 1 / 3 forces the warp-specialised 128 x 128 / 64 x 128 tile (bn: ring, 0 = heuristic, 1 = 3 x 64-deep, (3,3) =
  * 3 x 128-deep), bm = 4 the eight-wave 256 x 128 ping-pong kernel, bm = 5 forbids it, bm = 9 the 256 x 256 kernel; (6, n) sets the ping-pong
- * kernel's minimum tile count, (7, 0|1) switches the grouped weight-gradient launch between the two kernel families */
+ * kernel's minimum tile count, (7, 0|1) switches the grouped weight-gradient launch between the two kernel families, (11, 0|1) runs
+ * the NT problems of the 256 x 128 kernel on v_mfma_f32_32x32x16_bf16 instead of 16x16x32 */
 int nv_gemm_set_tile(int bm, int bn);
 
 /* ---- Linear layers on a few rows (the cls rows of the last block under pool='cls'): weight-streaming kernels, rows addressed through
@@ -322,6 +331,16 @@ int nv_vit_quantize_fp8(const nv_vit_config* cfg, const float* params, const flo
 int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
                        const nv_vit_input* in, const float* params, const void* params16, const void* params8, const float* colscales,
                        const float* act_scales, void* workspace, long ws_bytes, float* logits, void* stream);
+/* fp8 TRAINING forward: as nv_vit_forward_in(training = 1) - every activation the backward pass reads is written, in bf16 / fp32, where
+ * the bf16 forward writes it - with qkv, FC1 and FC2 of every block on e4m3 operands (params8 / colscales / act_scales as for
+ * nv_vit_forward_fp8; act_scales[4 l + 3], the out-projection's, is ignored: that linear stays on bf16 operands, as do attention, the
+ * patch embedding, the head and a last block in the cls-rows form).  The block dropout must be 0 (drop_p; emb_drop_p is free).
+ * Follow it with nv_vit_backward[_stages16] exactly as after nv_vit_forward_in; re-quantise the weights (nv_vit_quantize_fp8) after
+ * every optimizer step.  Workspace: the training layout (nv_vit_workspace_bytes(cfg, B, 1)). */
+int nv_vit_forward_fp8_train(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
+                             const nv_vit_input* in, const float* params, const void* params16, const void* params8, const float* colscales,
+                             const float* act_scales, void* workspace, long ws_bytes, float emb_drop_p, unsigned long drop_seed,
+                             float* logits, void* stream);
 int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                     const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,
                     int accumulate, float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream, void* aux_stream);
@@ -373,6 +392,11 @@ int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* video, const
                       float* params, void* params16, float* grads, float* adam_m, float* adam_v, void* workspace, long ws_bytes,
                       const long* labels, float* logits, float* loss, float* dlogits, const nv_train_hparams* hp,
                       float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream, void* aux_stream);
+
+/* diagnostic: where do the workgroups of a grid run?  out u32 [blocks][2] = (HW_REG_HW_ID, HW_REG_XCC_ID) of each workgroup, which then
+ * holds its CU for hold_us microseconds (threads per workgroup / dynamic LDS bytes shape its footprint).  Used to read the CU set of a
+ * CU-masked stream (hipExtStreamCreateWithCUMask) and the XCD placement the 1-D grids rely on for speed. */
+int nv_cu_census(unsigned* out, int blocks, int threads, int lds_bytes, int hold_us, void* stream);
 
 /* ABI revision of this header: bumped whenever a struct gains a field or an entry point changes its argument list (the list is in
  * INTEGRATION.md "ABI revisions").  A caller built against revision R must refuse a library whose nv_abi_version() != R. */

@@ -139,3 +139,26 @@ extern "C" int nv_spin_us(int microseconds, void* stream) {
   if (hipGetLastError() != hipSuccess) { nv_set_error("nv_spin_us: launch failed"); return -2; }
   return 0;
 }
+
+// ---- placement census (diagnostic; tools/cu_mask_probe.py, tests of the XCD-aware grids): every workgroup of a `blocks`-wide grid
+// records where it ran - out[2 b] = HW_REG_HW_ID (wave / simd / cu / sh / se fields), out[2 b + 1] = HW_REG_XCC_ID - and then holds its
+// CU for `hold_us` so that the grid spreads over the CUs its stream may use (a CU-masked stream: hipExtStreamCreateWithCUMask).
+__global__ void nv_census_kernel(unsigned* out, unsigned long long ticks) {
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID, 32 bits
+    out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+  }
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+extern "C" int nv_cu_census(unsigned* out, int blocks, int threads, int lds_bytes, int hold_us, void* stream) {
+  if (!out || blocks < 1 || threads < 64 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024 || hold_us < 0 || hold_us > 50000) {
+    nv_set_error("nv_cu_census: bad arguments");
+    return -1;
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nv_census_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(nv_census_kernel, dim3(blocks), dim3(threads), lds_bytes, (hipStream_t)stream, out, (unsigned long long)hold_us * 100ull);
+  if (hipGetLastError() != hipSuccess) { nv_set_error("nv_cu_census: launch failed"); return -2; }
+  return 0;
+}

@@ -96,6 +96,7 @@ void make_params(const Dims& D, ParamTab& T) {
 struct LayerW { long xn1, st1, qkv, lse, ao, x1, xn2, st2, u, h, x2; };
 struct WS {
   long xp, pst, t, est, x0, xh, hst, wpe16, xm;
+  long f8x, f8h;   // training layout: transient e4m3 operands of an fp8 training forward (LayerNorm output [M, d], GELU output [M, m])
   std::vector<LayerW> layer;
   // backward scratch
   long g, g16, g16b, dxn, hookg, du, dao, dqkv, delta, dt, dt16, dxp, dwpe, red, red2, red3, cs1;
@@ -120,6 +121,7 @@ void make_ws(const Dims& D, int training, WS& W) {
     w.u = add(M * D.m * 2); w.h = add(M * D.m * 2); w.x2 = add(M * d * 4);
   }
   for (int l = nl; l < D.L; ++l) W.layer[l] = W.layer[0];
+  W.f8x = W.f8h = -1;
   if (training) {
     W.g = add(M * d * 4); W.g16 = add(M * d * 2); W.dxn = add(M * d * 4); W.hookg = add(M * d * 4); W.du = add(M * D.m * 2);
     W.dao = add(M * D.inner * 2); W.dqkv = add(M * 3 * D.inner * 2); W.delta = add((long)D.B * D.heads * D.n * 4);
@@ -137,6 +139,7 @@ void make_ws(const Dims& D, int training, WS& W) {
     W.alt[4] = add(W.red_bytes); W.alt[5] = add(W.red2_bytes); W.alt[6] = add(nv_ln_bwd_workspace_bytes(D.M, D.d));
     const long cs1_bytes = (long)((M + 63) / 64) * D.m * 4;          // per-tile column sums of dU (bias gradient of FC1), <= M / 64 tile rows
     W.cs1 = add(cs1_bytes); W.alt[7] = add(cs1_bytes);
+    W.f8x = add(M * d); W.f8h = add(M * (long)D.m);
   } else {
     W.g = W.g16 = W.dxn = W.hookg = W.du = W.dao = W.dqkv = W.delta = W.dt = W.dt16 = W.dxp = W.dwpe = W.red = W.g16b = W.red2 = W.red3 = W.cs1 = -1;
     for (int i = 0; i < 8; ++i) W.alt[i] = -1;
@@ -446,7 +449,11 @@ extern "C" int nv_vit_quantize_fp8(const nv_vit_config* cfg, const float* params
   Dims D; RUN(make_dims(cfg, 1, D));
   ParamTab T; make_params(D, T);
   NV_CHECK_ARG(params && act_scales && params8 && colscales, "nv_vit_quantize_fp8: null pointer");
-  NV_CHECK_ARG(D.d % 128 == 0 && D.m % 128 == 0 && D.inner % 128 == 0, "nv_vit_quantize_fp8: the fp8 GEMM needs dim, heads * dim_head and mlp_dim to be multiples of 128 (got %d, %d, %d)", D.d, D.inner, D.m);
+  // heads * dim_head is the K of the out-projection only: it matters when some block runs that linear in e4m3 (act scale > 0)
+  bool out_proj8 = false;
+  for (int l = 0; l < D.L; ++l) out_proj8 = out_proj8 || act_scales[4 * l + 3] > 0.f;
+  NV_CHECK_ARG(D.d % 128 == 0 && D.m % 128 == 0 && (!out_proj8 || D.inner % 128 == 0),
+               "nv_vit_quantize_fp8: the fp8 GEMM needs dim and mlp_dim - and heads * dim_head when the out-projection runs in e4m3 - to be multiples of 128 (got %d, %d, %d)", D.d, D.m, D.inner);
   char* p8 = (char*)params8;
   const long per = 3L * D.inner + D.m + 2L * D.d;
   for (int l = 0; l < D.L; ++l) {
@@ -472,7 +479,7 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
                "nv_vit_forward_fp8: video is [%ld,%ld,%ld,%ld,%ld], the model was built for [%d,%d,%d,%d,%d] (B, channels, frames, height, width)",
                shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, img_w(cfg));
   NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_forward_fp8: workspace too small (%ld < %ld)", ws_bytes, W.total);
-  NV_CHECK_ARG(D.d % 128 == 0 && D.m % 128 == 0 && D.inner % 128 == 0, "nv_vit_forward_fp8: dim, heads * dim_head and mlp_dim must be multiples of 128");
+  NV_CHECK_ARG(D.d % 128 == 0 && D.m % 128 == 0, "nv_vit_forward_fp8: dim and mlp_dim must be multiples of 128");
   NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params) && nv_aligned16(params16) && nv_aligned16(params8), "nv_vit_forward_fp8: alignment");
   char* ws = (char*)workspace;
   const float* p = params;
@@ -502,7 +509,8 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
     const float* cs = colscales + l * per;
     const float s_xn1 = act_scales[4 * l], s_xn2 = act_scales[4 * l + 1], s_h = act_scales[4 * l + 2], s_ao = act_scales[4 * l + 3];
     const bool tail_here = tail8 && l == D.L - 1;
-    const bool ao8 = !tail_here && D.dh == 64 && s_ao > 0.f;           // the MFMA attention kernels write e4m3 themselves; the cls-rows tail and the generic kernels stay bf16
+    const bool ao8 = !tail_here && D.dh == 64 && s_ao > 0.f && D.inner % 128 == 0;   // the MFMA attention kernels write e4m3 themselves; the cls-rows tail, the generic
+                                                                                     // kernels and a heads * dim_head the fp8 GEMM cannot take as K stay bf16
     float* x1 = (float*)(ws + w.x1);
     float* x2 = (float*)(ws + ((l & 1) ? W.x0 : w.x2));
     RUN(nv_ln_fwd_f8(xin, d, M, d, p + q.n1g, p + q.n1b, eps, s_xn1, ws + w.xn1, d, stream));
@@ -526,6 +534,88 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
     RUN(nv_ln_fwd_f8(x1, d, M, d, p + q.n2g, p + q.n2b, eps, s_xn2, ws + w.xn2, d, stream));
     RUN(nv_gemm_f8(7, M, D.m, d, ws + w.xn2, d, p8 + q.w1, d, ws + w.h, D.m, cs + 3L * D.inner, p + q.b1, nullptr, 0, s_h, stream));
     RUN(nv_gemm_f8(4, M, d, D.m, ws + w.h, D.m, p8 + q.w2, D.m, x2, d, cs + 3L * D.inner + D.m, p + q.b2, x1, d, 1.f, stream));
+    xin = x2;
+  }
+  const float* pooled = xin;
+  long pooled_stride = (long)D.n * d;
+  if (D.pool_mean) {
+    RUN(nv_token_mean(xin, B, D.n, d, (float*)(ws + W.xm), stream));
+    pooled = (float*)(ws + W.xm); pooled_stride = d;
+  }
+  RUN(nv_head_fwd(pooled, pooled_stride, B, d, p + T.hg, p + T.hb, eps, p + T.hw, p + T.hbias, D.C, (float*)(ws + W.xh), (float*)(ws + W.hst),
+                  logits, stream));
+  return NV_OK;
+}
+
+// ---- fp8 TRAINING forward (BASELINE.json configs[4] is quoted "fwd / fwd+bwd"): the forward of the train step with qkv / FC1 / FC2 of
+// every block on e4m3 operands, writing every buffer of the training layout the (bf16) backward pass reads: LayerNorm outputs and
+// statistics (nv_ln_fwd_f8_train: e4m3 + bf16 + stats in one pass), qkv bf16 (the fp8 GEMM's plain store), attention in bf16 with
+// its lse, u / h in bf16 beside h in e4m3 (nv_gemm_f8_gelu_train).  The out-projection stays on bf16 operands (its A operand comes
+// head by head out of the attention kernel, which would have to write a second copy; 8 % of the linear FLOPs).
+extern "C" int nv_vit_forward_fp8_train(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
+                                        const float* params, const void* params16, const void* params8, const float* colscales, const float* act_scales,
+                                        void* workspace, long ws_bytes, float emb_drop_p, unsigned long drop_seed, float* logits, void* stream) {
+  Dims D; RUN(make_dims(cfg, B, D));
+  ParamTab T; make_params(D, T);
+  WS W; make_ws(D, 1, W);
+  NV_CHECK_ARG(video && shape5 && strides5 && params && params16 && params8 && colscales && act_scales && workspace && logits, "nv_vit_forward_fp8_train: null pointer");
+  NV_CHECK_ARG(!(in && in->time_points > 0), "nv_vit_forward_fp8_train: the fused 4D input form is forward-only");
+  NV_CHECK_ARG(shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == img_w(cfg),
+               "nv_vit_forward_fp8_train: video is [%ld,%ld,%ld,%ld,%ld], the model was built for [%d,%d,%d,%d,%d] (B, channels, frames, height, width)",
+               shape5[0], shape5[1], shape5[2], shape5[3], shape5[4], B, cfg->channels, cfg->frames, cfg->image_size, img_w(cfg));
+  NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_forward_fp8_train: workspace too small (%ld < %ld): the training layout is needed", ws_bytes, W.total);
+  NV_CHECK_ARG(D.d % 128 == 0 && D.m % 128 == 0, "nv_vit_forward_fp8_train: dim and mlp_dim must be multiples of 128 (got %d, %d)", D.d, D.m);
+  NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params) && nv_aligned16(params16) && nv_aligned16(params8), "nv_vit_forward_fp8_train: alignment");
+  char* ws = (char*)workspace;
+  const float* p = params;
+  const bf16* p16 = (const bf16*)params16;
+  const char* p8 = (const char*)params8;
+  const float eps = cfg->ln_eps;
+  const int M = D.M, d = D.d;
+  const long per = 3L * D.inner + D.m + 2L * D.d;
+
+  float* pst = (float*)(ws + W.pst);
+  RUN(patch_front(cfg, D, T, B, video, strides5, in, p, eps, ws + W.xp, pst, stream));
+  const void* wpe = p16 + T.pe_w;
+  if (D.P != D.Ppad) {
+    RUN(nv_cast_bf16_2d(p + T.pe_w, D.P, d, D.P, ws + W.wpe16, D.Ppad, stream));
+    wpe = ws + W.wpe16;
+  }
+  RUN(nv_gemm_bf16(0, 2, D.T, d, D.Ppad, ws + W.xp, D.Ppad, wpe, D.Ppad, ws + W.t, d, p + T.pe_bias, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+  float* est = (float*)(ws + W.est);
+  RUN(nv_embed_finish_fwd((float*)(ws + W.t), d, B, D.N, d, p + T.pe_g2, p + T.pe_b2, eps, p + T.pos, p + T.cls, (float*)(ws + W.x0), d, est,
+                          est + D.T, site_seed(drop_seed, 4 * D.L), emb_drop_p, stream));
+  const float scale = 1.0f / sqrtf((float)D.dh);
+  const float* xin = (float*)(ws + W.x0);
+  const bool tail = cls_tail_wanted(D, 1, 0.f, in ? in->rows_form : 0);
+  void* x8 = ws + W.f8x;
+  void* h8 = ws + W.f8h;
+  for (int l = 0; l < D.L; ++l) {
+    const LayerP& q = T.layer[l];
+    const LayerW& w = W.layer[l];
+    const float* cs = colscales + l * per;
+    const float s_xn1 = act_scales[4 * l], s_xn2 = act_scales[4 * l + 1], s_h = act_scales[4 * l + 2];
+    NV_CHECK_ARG(s_xn1 > 0.f && s_xn2 > 0.f && s_h > 0.f, "nv_vit_forward_fp8_train: activation scales of layer %d must be positive", l);
+    float* x1 = (float*)(ws + w.x1);
+    float* x2 = (float*)(ws + w.x2);
+    float* st1 = (float*)(ws + w.st1);
+    float* st2 = (float*)(ws + w.st2);
+    RUN(nv_ln_fwd_f8_train(xin, d, M, d, p + q.n1g, p + q.n1b, eps, s_xn1, x8, d, ws + w.xn1, d, st1, st1 + M, stream));
+    RUN(nv_gemm_f8(0, M, 3 * D.inner, d, x8, d, p8 + q.wqkv, d, ws + w.qkv, 3 * D.inner, cs, nullptr, nullptr, 0, 1.f, stream));
+    RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), 0, 0.f, stream));
+    if (tail && l == D.L - 1) {       // the last block on its B cls rows: the bf16 weight-streaming kernels, as in nv_vit_forward_in
+      const long rs = D.n;
+      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, stream));
+      RUN(nv_ln_fwd(x1, d * rs, B, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d * rs, st2, st2 + M, stream));
+      RUN(nv_skinny_nt(1, B, D.m, d, ws + w.xn2, d * rs, p16 + q.w1, d, p + q.b1, nullptr, 0, ws + w.h, D.m * rs, ws + w.u, D.m * rs, stream));
+      RUN(nv_skinny_nt(0, B, d, D.m, ws + w.h, D.m * rs, p16 + q.w2, D.m, p + q.b2, x1, d * rs, x2, d * rs, nullptr, 0, stream));
+      xin = x2;
+      continue;
+    }
+    RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+    RUN(nv_ln_fwd_f8_train(x1, d, M, d, p + q.n2g, p + q.n2b, eps, s_xn2, x8, d, ws + w.xn2, d, st2, st2 + M, stream));
+    RUN(nv_gemm_f8_gelu_train(M, D.m, d, x8, d, p8 + q.w1, d, cs + 3L * D.inner, p + q.b1, s_h, h8, D.m, ws + w.h, D.m, ws + w.u, D.m, stream));
+    RUN(nv_gemm_f8(4, M, d, D.m, h8, D.m, p8 + q.w2, D.m, x2, d, cs + 3L * D.inner + D.m, p + q.b2, x1, d, 1.f, stream));
     xin = x2;
   }
   const float* pooled = xin;

@@ -328,6 +328,7 @@ extern "C" int nv_gemm_set_tile(int bm, int bn) {   // tuning aid (tools/gemm_be
   if (bm == 7) { g_pp_grouped = bn; return 0; }
   if (bm == 8) { g_pp_dbg = bn; return 0; }
   if (bm == 10) { g_pq_min_tiles = bn; return 0; }
+  if (bm == 11) { g_pp_w32 = bn ? 1 : 0; return 0; }     // NT problems of the 256 x 128 kernel on 32 x 32 x 16 MFMAs
   const bool small = (bm == 64 && (bn == 64 || bn == 128)) || (bm == 128 && bn == 128);
   NV_CHECK_ARG(bm == 0 || bm == 1 || (bm >= 3 && bm <= 5) || bm == 9 || small, "nv_gemm_set_tile: (%d, %d) is not a compiled tile", bm, bn);
   NV_CHECK_ARG(!(bm == 1 || bm == 3) || bn == 0 || bn == 1 || (bm == 3 && bn == 3), "nv_gemm_set_tile: ring %d is not compiled for tile %d", bn, bm);
@@ -474,6 +475,7 @@ extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void
   NV_CHECK_ARG(ldc >= N, "nv_gemm_bf16: ldc < N");
   GemmArgs a;
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C; a.bias = bias; a.aux_in = aux_in; a.aux_out = aux_out;
+  a.aux_out2 = nullptr; a.ld_aux_out2 = 0;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ld_aux_in = ld_aux_in; a.ld_aux_out = ld_aux_out;
   a.M = M; a.N = N; a.K = K; a.accumulate = accumulate; a.alpha = alpha;
   a.drop = make_drop(drop_seed, drop_p);
@@ -510,19 +512,38 @@ extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void
 
 // fp8 (OCP e4m3) operands, NT layout: C = epilogue((A8 . B8^T) * colscale[n]).  Eight-wave 256 x 128 kernel only (the path exists for
 // the large-M inference shapes of ViT3D-large); K % 128 == 0.
+static int gemm_f8_impl(int epi, int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc, const float* colscale,
+                        const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* u16, long ldu16, void* h16, long ldh16, void* stream);
+
 extern "C" int nv_gemm_f8(int epi, int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc, const float* colscale,
                           const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* stream) {
+  NV_CHECK_ARG(epi != EPI_BIAS_GELU_F8T, "nv_gemm_f8: epilogue 8 has two more outputs: call nv_gemm_f8_gelu_train");
+  return gemm_f8_impl(epi, M, N, K, A8, lda, B8, ldb, C, ldc, colscale, bias, aux_in, ld_aux_in, out_scale, nullptr, 0, nullptr, 0, stream);
+}
+
+// FC1 of a TRAINING forward on fp8 operands (vit_3d.py:19-20): h8 (e4m3) = sat(gelu(u) * out_scale) feeds the fp8 FC2; u16 = the
+// pre-activation (optional) and h16 = gelu(u), both bf16, are what the bf16 backward pass reads (GELU' and the FC2 weight gradient).
+extern "C" int nv_gemm_f8_gelu_train(int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, const float* colscale, const float* bias,
+                                     float out_scale, void* h8, long ldh8, void* h16, long ldh16, void* u16, long ldu16, void* stream) {
+  NV_CHECK_ARG(h16 && nv_aligned16(h16) && (ldh16 % 4) == 0 && ldh16 >= N && (!u16 || (nv_aligned16(u16) && (ldu16 % 4) == 0 && ldu16 >= N)),
+               "nv_gemm_f8_gelu_train: h16 (required) / u16 (optional) must be 16-byte aligned bf16 [M, ld >= N], ld a multiple of 4");
+  return gemm_f8_impl(EPI_BIAS_GELU_F8T, M, N, K, A8, lda, B8, ldb, h8, ldh8, colscale, bias, nullptr, 0, out_scale, u16, ldu16, h16, ldh16, stream);
+}
+
+static int gemm_f8_impl(int epi, int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc, const float* colscale,
+                        const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* u16, long ldu16, void* h16, long ldh16, void* stream) {
   NV_CHECK_ARG(M > 0 && N > 0 && K > 0 && A8 && B8 && C && colscale, "nv_gemm_f8: null operand / empty problem");
   NV_CHECK_ARG((K % 128) == 0 && (N % 8) == 0 && (lda % 16) == 0 && (ldb % 16) == 0 && lda >= K && ldb >= K && ldc >= N && (ldc % 4) == 0,
                "nv_gemm_f8: K must be a multiple of 128, N of 8, lda / ldb of 16, ldc of 4");
   NV_CHECK_ARG(nv_aligned16(A8) && nv_aligned16(B8) && nv_aligned16(C) && nv_aligned16(colscale), "nv_gemm_f8: 16-byte alignment");
   NV_CHECK_ARG((long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31), "nv_gemm_f8: operand too large for 32-bit offsets");
-  const bool need_bias = (epi == EPI_BIAS_RESID || epi == EPI_BIAS_GELU_F8);
+  const bool need_bias = (epi == EPI_BIAS_RESID || epi == EPI_BIAS_GELU_F8 || epi == EPI_BIAS_GELU_F8T);
   NV_CHECK_ARG(!need_bias || (bias && nv_aligned16(bias)), "nv_gemm_f8: epilogue %d needs a bias", epi);
   NV_CHECK_ARG(epi != EPI_BIAS_RESID || (aux_in && nv_aligned16(aux_in) && (ld_aux_in % 4) == 0), "nv_gemm_f8: epilogue 4 needs aux_in");
   GemmArgs a;
-  a.A = (const bf16*)A8; a.B = (const bf16*)B8; a.C = C; a.bias = bias; a.aux_in = aux_in; a.aux_out = nullptr;
-  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ld_aux_in = ld_aux_in; a.ld_aux_out = 0;
+  a.A = (const bf16*)A8; a.B = (const bf16*)B8; a.C = C; a.bias = bias; a.aux_in = aux_in; a.aux_out = u16;
+  a.aux_out2 = h16; a.ld_aux_out2 = ldh16;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ld_aux_in = ld_aux_in; a.ld_aux_out = ldu16;
   a.M = M; a.N = N; a.K = K; a.accumulate = 0; a.alpha = out_scale;
   a.drop = make_drop(0, 0.f);
   a.colscale = colscale;
@@ -551,6 +572,7 @@ extern "C" int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gem
     GemmArgs& a = G.p[i];
     NV_CHECK_ARG(!q.C16 || (((uintptr_t)q.C16 & 7) == 0 && (q.ldc16 % 4) == 0 && q.ldc16 >= q.N), "nv_gemm_bf16_grouped: problem %d: bf16 mirror alignment / leading dimension", i);
     a.A = (const bf16*)q.A; a.B = (const bf16*)q.B; a.C = q.C; a.bias = nullptr; a.aux_in = nullptr; a.aux_out = q.C16;
+    a.aux_out2 = nullptr; a.ld_aux_out2 = 0;
     a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ld_aux_in = 0; a.ld_aux_out = q.ldc16;
     a.M = q.M; a.N = q.N; a.K = q.K; a.accumulate = q.accumulate; a.alpha = 1.f;
     a.drop = make_drop(0, 0.f);

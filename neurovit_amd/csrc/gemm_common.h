@@ -11,6 +11,8 @@ enum {
   EPI_BIAS_RESID = 4,   // C(f32)  = aux_in(f32)[m,n] + acc + bias[n]
   EPI_DGELU = 5,        // C(bf16) = acc * gelu'(aux_in(bf16)[m,n])
   EPI_BIAS_GELU_F8 = 7, // C(fp8 e4m3) = sat(gelu(acc * colscale[n] + bias[n]) * alpha): FC1 of the fp8 inference path, feeding FC2 directly
+  EPI_BIAS_GELU_F8T = 8, // the same for a TRAINING forward on fp8 operands: C(fp8) as 7, and what the bf16 backward pass reads - aux_out(bf16) = the
+                        // pre-activation u, aux_out2(bf16) = gelu(u) - out of the same epilogue (one pass over the tile instead of a quantise pass)
   EPI_DGELU_COLSUM = 6, // EPI_DGELU + aux_out(f32)[tile_row, n] = column sums of the stored bf16 values over the tile's rows: the bias
                         // gradient of the Linear in front of the GELU, produced where the tile already is (large-tile kernels only)
 };
@@ -22,7 +24,8 @@ struct GemmArgs {
   const float* bias;
   const void* aux_in;
   void* aux_out;
-  long lda, ldb, ldc, ld_aux_in, ld_aux_out;
+  void* aux_out2;   // EPI_BIAS_GELU_F8T only
+  long lda, ldb, ldc, ld_aux_in, ld_aux_out, ld_aux_out2;
   int M, N, K;
   int accumulate;
   DropCfg drop;    // EPI_BIAS_RESID: on (acc + bias); EPI_BIAS_GELU: on gelu(u); EPI_DGELU: on acc (the incoming dH)
@@ -43,6 +46,7 @@ static inline double gemm_algo_bytes(const GemmArgs& a, int epi, int operand_byt
     case EPI_BIAS_RESID: b += mn * 8; break;
     case EPI_DGELU: case EPI_DGELU_COLSUM: b += mn * 4; break;
     case EPI_BIAS_GELU_F8: b += mn; break;
+    case EPI_BIAS_GELU_F8T: b += mn * 5; break;
     default: break;
   }
   return b;
@@ -180,7 +184,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int rc0, int ks, in
 template <int EPI>
 __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, int n) {
   if (g.colscale) v *= *reinterpret_cast<const f32x4*>(g.colscale + n);
-  if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_GELU_F8) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+  if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_GELU_F8 || EPI == EPI_BIAS_GELU_F8T) v += *reinterpret_cast<const f32x4*>(g.bias + n);
   f32x4 keep = f32x4{1.f, 1.f, 1.f, 1.f};
   if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_DGELU || EPI == EPI_DGELU_COLSUM) {
     if (g.drop.thresh) {
@@ -207,6 +211,11 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, in
   } else if constexpr (EPI == EPI_BIAS_GELU_F8) {
     const f32x4 h = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])} * g.alpha;
     *reinterpret_cast<unsigned*>((char*)g.C + (long)m * g.ldc + n) = pack_fp8x4(h);
+  } else if constexpr (EPI == EPI_BIAS_GELU_F8T) {
+    const f32x4 h = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+    if (g.aux_out) __builtin_nontemporal_store(cvt4(v[0], v[1], v[2], v[3]), reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n));
+    *reinterpret_cast<bf16x4*>((bf16*)g.aux_out2 + (long)m * g.ld_aux_out2 + n) = cvt4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<unsigned*>((char*)g.C + (long)m * g.ldc + n) = pack_fp8x4(h * g.alpha);
   } else if constexpr (EPI == EPI_BIAS_RESID) {
     v = v * keep + *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
     *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;

@@ -23,6 +23,8 @@
 //   * epilogue: accumulators parked as an fp32 [256][128] tile in the (now idle) ring, then all twelve waves run the row-wise
 //     fused epilogue (gemm_common.h::epilogue_lds);
 //   * F8: OCP e4m3 operands on v_mfma_scale_f32_16x16x128_f8f6f4 (see gemm_pp_body).
+#include <type_traits>
+
 #include "gemm_common.h"
 #include "gemm_pp.h"
 
@@ -37,13 +39,21 @@ constexpr int PP_GM = 4;        // tile rows per group of the tile order (4 x 25
 
 // per-lane DMA source offsets (bytes) of pieces I = lw, lw + 4, lw + 8, lw + 12 of one 128-wide sub-image (four loader waves);
 // rc0 = first matrix row (K-contiguous operand) / first matrix column (K-strided operand) of the sub-image
-template <bool T, int ESZ = 2>
+// W32: the K-contiguous image for 32-row fragments (v_mfma_f32_32x32x16_bf16): chunk XOR ((row >> 1) & 7) instead of (row & 7).  A
+// ds_read_b128 serves 16 lanes per LDS cycle - lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 - which for a 32-row
+// fragment (lane l: row l & 31, chunk 2 ks + (l >> 5)) are 16 different rows at ONE chunk: with 128-byte rows the even rows share one
+// half of the 256-byte bank line and the odd rows the other, so the eight even (odd) rows of a group need eight different chunk
+// positions - (row >> 1) & 7 gives {0,1,6,7,2,3,4,5} and {2,3,4,5,0,1,6,7} for the two groups (row & 7 puts rows 12 and 20 on one slot).
+__device__ __forceinline__ int img128w_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <bool T, int ESZ = 2, bool W32 = false>
 __device__ __forceinline__ void pp_offsets(long ld, int rc0, int lw, int lane, int (&voff)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int I = lw + 4 * i;
     if constexpr (!T) {
-      const int row = I * 8 + (lane >> 3), ch = (lane & 7) ^ ((lane >> 3) & 7);            // img128_off inverse
+      const int row = I * 8 + (lane >> 3);
+      const int ch = W32 ? ((lane & 7) ^ ((row >> 1) & 7)) : ((lane & 7) ^ ((lane >> 3) & 7));   // img128w_off / img128_off inverse
       voff[i] = (int)(((long)(rc0 + row)) * ld * ESZ + (ch << 4));
     } else {
       static_assert(ESZ == 2, "K-strided operands are bf16 only");
@@ -79,13 +89,20 @@ __device__ __forceinline__ i32x8 f8cat(bf16x8 lo, bf16x8 hi) {      // 2 x 16 by
 // and fragment reads as bf16) and each 16 x 16 output block takes ONE v_mfma_scale_f32_16x16x128_f8f6f4 per stage (unit block
 // scales; 32 cycles, i.e. the cycles of the two bf16 MFMAs it replaces at twice their K: double the FLOPs per byte and per cycle).
 // The k order inside a lane's 32 bytes is [chunk g | chunk 4 + g] of the row for BOTH operands - a dot product does not care.
-template <int BM, int BN, int WM, int WN, bool A_T, bool B_T, int EPI, int DBG = 0, bool F8 = false>
+// W32: the same structure on v_mfma_f32_32x32x16_bf16 (NT / bf16 only): a 64 x 64 wave tile is 2 x 2 blocks of 32 x 32, four 16-deep
+// MFMAs per block and K tile - the same fragment bytes, accumulator registers and matrix cycles as 4 x 4 blocks of 16 x 16 x 32, at
+// half the operand register reads per FLOP.  A bare loop of either shape on random data (tools/mfma_shape_bench.hip,
+// profiles/r04_mfma_shape_microbench.log): 1.27 against 1.08 PFLOP/s at one wave per SIMD with the fragments re-read from LDS,
+// 1.82 against 1.43 from registers - the chip holds a higher clock on the wider shape.
+template <int BM, int BN, int WM, int WN, bool A_T, bool B_T, int EPI, int DBG = 0, bool F8 = false, bool W32 = false>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the declaration (it rejects the TN instantiation of this body)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NSA = BM / 128, NSB = BN / 128, NSUB = NSA + NSB, STAGE = NSUB * PP_SUB;
-  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+  constexpr int MB = W32 ? 32 : 16;                                       // rows / columns of one MFMA block
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / MB, NI = TN / MB;
   static_assert(WM * WN == PP_CWAVES && MI % 2 == 0, "wave layout");
+  static_assert(!W32 || (!A_T && !B_T && !F8), "the 32 x 32 x 16 form is built for K-contiguous bf16 operands");
   static_assert(128 % TM == 0 && 128 % TN == 0, "a wave tile must not straddle two sub-images");
   constexpr int MH = MI / 2;                  // m-tiles per half
   constexpr int NP = 4 * NSUB;                // DMA pieces per loader wave per K tile
@@ -116,9 +133,9 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, bytesB, 0x00020000);
     int voA[NSA][4], voB[NSB][4];
 #pragma unroll
-    for (int s = 0; s < NSA; ++s) pp_offsets<A_T, ESZ>(g.lda, ((DBG & 2) ? 0 : m0) + 128 * s, lw, lane, voA[s]);
+    for (int s = 0; s < NSA; ++s) pp_offsets<A_T, ESZ, W32>(g.lda, ((DBG & 2) ? 0 : m0) + 128 * s, lw, lane, voA[s]);
 #pragma unroll
-    for (int s = 0; s < NSB; ++s) pp_offsets<B_T, ESZ>(g.ldb, ((DBG & 2) ? 0 : n0) + 128 * s, lw, lane, voB[s]);
+    for (int s = 0; s < NSB; ++s) pp_offsets<B_T, ESZ, W32>(g.ldb, ((DBG & 2) ? 0 : n0) + 128 * s, lw, lane, voB[s]);
     const int stepA = (DBG & 2) ? 0 : (int)((A_T ? (long)BK * g.lda : KT) * ESZ), stepB = (DBG & 2) ? 0 : (int)((B_T ? (long)BK * g.ldb : KT) * ESZ);
     auto issue_tile = [&](int t, char* dst) {
 #pragma unroll
@@ -157,28 +174,50 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
   // -------------------------------------------------------------------- compute waves
   const int grp = wid >> 2;                   // waves w and w + 4 share a SIMD: group 1 runs half a tile behind group 0
   const int wm = wid / WN, wn = wid % WN;
-  f32x4 acc[MI][NI];
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef typename std::conditional<W32, f32x16, f32x4>::type acc_t;
+  acc_t acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < (W32 ? 16 : 4); ++e) acc[i][j][e] = 0.f;
   // sub-image and row / column inside it of this wave's tile
   const int a_off = ((wm * TM) / 128) * PP_SUB, a_rc = (wm * TM) % 128;
   const int b_off = (NSA + (wn * TN) / 128) * PP_SUB, b_rc = (wn * TN) % 128;
-  bf16x8 fb[NI][2], fa[MI][2];
+  constexpr int KS = W32 ? 4 : 2;                    // fragments per block and 64-deep K tile (16- or 32-deep MFMAs)
+  bf16x8 fb[NI][KS], fa[MI][KS];
+  // 32-row fragment: lane l holds row l & 31, k = 16 ks + 8 (l >> 5) .. + 7: ONE ds_read_b128 at chunk 2 ks + (l >> 5)
+  auto frag32 = [&](const char* img, int rc0, int ks) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(img + img128w_off(rc0 + (lane & 31), 2 * ks + (lane >> 5)));
+  };
 
 #define PP_READ_B(img)                                                          \
   _Pragma("unroll") for (int j = 0; j < NI; ++j) {                             \
+    if constexpr (W32) {                                                        \
+      _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) fb[j][ks] = frag32((img) + b_off, b_rc + 32 * j, ks);   \
+    } else {                                                                    \
     fb[j][0] = read_frag<B_T, 128>((img) + b_off, b_rc + 16 * j, 0, lane);     \
     fb[j][1] = read_frag<B_T, 128>((img) + b_off, b_rc + 16 * j, 1, lane);     \
+    }                                                                           \
   }
 #define PP_READ_A(img, I0)                                                      \
   _Pragma("unroll") for (int i = (I0); i < (I0) + MH; ++i) {                   \
+    if constexpr (W32) {                                                        \
+      _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) fa[i][ks] = frag32((img) + a_off, a_rc + 32 * i, ks);   \
+    } else {                                                                    \
     fa[i][0] = read_frag<A_T, 128>((img) + a_off, a_rc + 16 * i, 0, lane);     \
     fa[i][1] = read_frag<A_T, 128>((img) + a_off, a_rc + 16 * i, 1, lane);     \
+    }                                                                           \
   }
 #define PP_MFMA(I0)                                                             \
-  if constexpr (!F8) {                                                          \
+  if constexpr (W32) {                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                          \
+      _Pragma("unroll") for (int i = (I0); i < (I0) + MH; ++i)                 \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j)                         \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);  \
+  } else if constexpr (!F8) {                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                           \
       _Pragma("unroll") for (int i = (I0); i < (I0) + MH; ++i)                 \
         _Pragma("unroll") for (int j = 0; j < NI; ++j)                         \
@@ -235,7 +274,20 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
 #undef PP_MFMA
 
   // every fragment read of the ring has returned: park the accumulators and run the fused epilogue with all waves
-  park_acc<MI, NI, BN>(acc, smem, wm * TM, wn * TN, lane);
+  if constexpr (W32) {
+    // D = B_frag x A_frag (operands swapped as in the 16 x 16 form): lane l holds row l & 31 of the block and, in acc[4 q .. 4 q + 3],
+    // the four consecutive columns 8 q + 4 (l >> 5) .. + 3
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(smem + (wm * TM + 32 * i + (lane & 31)) * cpitch<BN>() + (wn * TN + 32 * j + 8 * q + 4 * (lane >> 5)) * 4) =
+              f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+  } else {
+    park_acc<MI, NI, BN>(acc, smem, wm * TM, wn * TN, lane);
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   epilogue_lds<EPI, BM, BN, PP_THREADS>(smem, g, m0, n0, tid);
@@ -245,6 +297,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
 template <int BM, int BN, int WM, int WN, bool A_T, bool B_T, int EPI>
 __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_kernel(const GemmArgs g) {
   gemm_pp_body<BM, BN, WM, WN, A_T, B_T, EPI>(g, xcd_remap(blockIdx.x, gridDim.x));
+}
+template <int EPI>
+__global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_w32_kernel(const GemmArgs g) {      // NT, bf16, 32 x 32 x 16 MFMAs
+  gemm_pp_body<PP_BM, PP_BN, 4, 2, false, false, EPI, 0, false, true>(g, xcd_remap(blockIdx.x, gridDim.x));
 }
 template <int EPI>
 __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_f8_kernel(const GemmArgs g) {
@@ -284,6 +340,25 @@ int launch_pp_t(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+int g_pp_w32 = 0;   // NT problems on the 32 x 32 x 16 MFMA form of the kernel (nv_gemm_set_tile(11, 0 | 1))
+template <int EPI>
+static int launch_pp_w32_t(const GemmArgs& a, hipStream_t s) {
+  constexpr int LDS = PP_S * (PP_BM / 128 + PP_BN / 128) * PP_SUB;
+  const int tiles = ((a.M + PP_BM - 1) / PP_BM) * ((a.N + PP_BN - 1) / PP_BN);
+  auto kern = gemm_pp_w32_kernel<EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int slot = nv_prof_begin(10, 2.0 * a.M * a.N * a.K, s);
+  nv_prof_bytes(slot, gemm_algo_bytes(a, EPI, 2));
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(PP_THREADS), LDS, s, a);
+  nv_prof_end(slot, s);
+  NV_CHECK_LAUNCH("nv_gemm_bf16/pp32");
+  return NV_OK;
+}
+
 int g_pp_dbg = 0;   // timing-only ablations of the NT / bf16-store kernel (tools/gemm_bench.py --dbg; results are wrong by design):
                     // 1 no DMA after the prologue, 2 every DMA from one L2-hot 48 KiB region, 4 fragments read once (5 = 1 + 4: MFMA only)
 template <int DBG>
@@ -303,6 +378,16 @@ int launch_pp(int layout, int epi, const GemmArgs& a, hipStream_t s) {
       case 2: return launch_pp_dbg<2>(a, s);
       case 4: return launch_pp_dbg<4>(a, s);
       case 5: return launch_pp_dbg<5>(a, s);
+      default: break;
+    }
+  }
+  if (g_pp_w32 && layout == 0) {
+    switch (epi) {
+      case EPI_STORE_BF16: return launch_pp_w32_t<EPI_STORE_BF16>(a, s);
+      case EPI_STORE_F32: return launch_pp_w32_t<EPI_STORE_F32>(a, s);
+      case EPI_BIAS_F32: return launch_pp_w32_t<EPI_BIAS_F32>(a, s);
+      case EPI_BIAS_GELU: return launch_pp_w32_t<EPI_BIAS_GELU>(a, s);
+      case EPI_BIAS_RESID: return launch_pp_w32_t<EPI_BIAS_RESID>(a, s);
       default: break;
     }
   }
@@ -348,9 +433,10 @@ int launch_pp_f8(int epi, const GemmArgs& a, hipStream_t s) {
     case EPI_STORE_F32: return launch_pp_f8_t<EPI_STORE_F32>(a, s);
     case EPI_BIAS_RESID: return launch_pp_f8_t<EPI_BIAS_RESID>(a, s);
     case EPI_BIAS_GELU_F8: return launch_pp_f8_t<EPI_BIAS_GELU_F8>(a, s);
+    case EPI_BIAS_GELU_F8T: return launch_pp_f8_t<EPI_BIAS_GELU_F8T>(a, s);
     default: break;
   }
-  nv_set_error("nv_gemm_f8: unsupported epilogue %d (0 bf16 store, 1 f32 store, 4 bias + residual, 7 bias + GELU -> fp8)", epi);
+  nv_set_error("nv_gemm_f8: unsupported epilogue %d (0 bf16 store, 1 f32 store, 4 bias + residual, 7 bias + GELU -> fp8, 8 the same + bf16 copies)", epi);
   return NV_ERR_ARG;
 }
 

@@ -238,6 +238,7 @@ int launch_pq_f8(int epi, const GemmArgs& a, hipStream_t s) {
     case EPI_STORE_F32: return launch_pq_t<false, false, EPI_STORE_F32, true>(a, s);
     case EPI_BIAS_RESID: return launch_pq_t<false, false, EPI_BIAS_RESID, true>(a, s);
     case EPI_BIAS_GELU_F8: return launch_pq_t<false, false, EPI_BIAS_GELU_F8, true>(a, s);
+    case EPI_BIAS_GELU_F8T: return launch_pq_t<false, false, EPI_BIAS_GELU_F8T, true>(a, s);
     default: break;
   }
   nv_set_error("nv_gemm_f8/pq: unsupported epilogue %d", epi);

@@ -175,18 +175,47 @@ class VitRuntime:
             scales.append(row)
         return scales
 
-    def quantize_fp8(self, params: torch.Tensor, act_scales):
-        """fp8 weight arena (bytes at the parameter arena's element offsets) + column scales for the given activation scales."""
+    def quantize_fp8(self, params: torch.Tensor, act_scales, reuse=None):
+        """fp8 weight arena (bytes at the parameter arena's element offsets) + column scales for the given activation scales.
+        reuse: a dict this function returned earlier - its device buffers are overwritten in place (the per-step re-quantisation of
+        an fp8 training run must not allocate and clear a parameter-sized arena every step)."""
         cnt = lib.nv_vit_fp8_scale_count(ctypes.byref(self.cfg))
         if cnt < 0:
             check(-1, "nv_vit_fp8_scale_count")
         flat = [float(v) for row in act_scales for v in row]
         host = (ctypes.c_float * len(flat))(*flat)
-        p8 = torch.zeros(params.numel(), dtype=torch.uint8, device=params.device)
-        cs = torch.empty(cnt, dtype=torch.float32, device=params.device)
+        if reuse is not None and reuse["params8"].numel() == params.numel() and reuse["params8"].device == params.device:
+            p8, cs = reuse["params8"], reuse["colscales"]
+        else:
+            p8 = torch.zeros(params.numel(), dtype=torch.uint8, device=params.device)
+            cs = torch.empty(cnt, dtype=torch.float32, device=params.device)
         check(lib.nv_vit_quantize_fp8(ctypes.byref(self.cfg), params.data_ptr(), ctypes.cast(host, ctypes.c_void_p), p8.data_ptr(), cs.data_ptr(),
                                       torch.cuda.current_stream().cuda_stream), "nv_vit_quantize_fp8")
         return dict(params8=p8, colscales=cs, act_scales=host, act_list=act_scales)
+
+    def forward_fp8_train(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, f8, dropout: Tuple[float, float, int] = (0.0, 0.0, 0),
+                          vol_sigma=None, rows_form: Optional[int] = None) -> torch.Tensor:
+        """TRAINING forward with qkv / FC1 / FC2 of every block on e4m3 operands (nv_vit_forward_fp8_train): fills the training
+        workspace exactly as forward(training=True) does, so backward() follows as usual (on bf16 operands).  Block dropout must be 0."""
+        if dropout[0] > 0:
+            raise NotImplementedError("neurovit_amd: the fp8 training forward has no block dropout (TRAINING_DROPOUT must be 0; the embedding "
+                                      "dropout is applied) - train with bf16 forwards (vit.fp8_training = False) to use dropout")
+        rows_form = self.rows_form if rows_form is None else int(rows_form)
+        B, inp = self._input_form(video, vol_sigma, 0, rows_form)
+        ws = self.workspace(B, True, video.device)
+        logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
+        check(lib.nv_vit_forward_fp8_train(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
+                                           None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p), params.data_ptr(),
+                                           params16.data_ptr(), f8["params8"].data_ptr(), f8["colscales"].data_ptr(),
+                                           ctypes.cast(f8["act_scales"], ctypes.c_void_p), ws.data_ptr(), ws.numel(), float(dropout[1]), int(dropout[2]),
+                                           logits.data_ptr(), torch.cuda.current_stream().cuda_stream), "nv_vit_forward_fp8_train")
+        self._keep = (vol_sigma, inp)
+        self._rows_form = rows_form
+        self._last = (B, True, ws, video)
+        self.generation += 1
+        self.backward_done = False
+        self._dropout = (0.0, dropout[1], dropout[2])
+        return logits
 
     def forward_fp8(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, f8, vol_sigma=None, time_points: int = 0) -> torch.Tensor:
         B, inp = self._input_form(video, vol_sigma, time_points, self.rows_form)

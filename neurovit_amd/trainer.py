@@ -119,6 +119,8 @@ class TrainStep:
         if not (torch.is_tensor(labels) and labels.is_cuda and labels.dtype == torch.int64 and labels.dim() == 1 and labels.shape[0] == fmri.shape[0]):
             return False
         vit = self._vit
+        if vit.fp8_training and vit._fp8 is not None:
+            return False                                                 # fp8 training forwards go through ViT._run_forward (general path)
         if not vit._arena_ok():
             vit._build_arena()
         # .grad tensors that are not views of the gradient arena (set by foreign code) need the general path's accumulate-and-copy;

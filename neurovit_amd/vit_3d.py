@@ -292,6 +292,7 @@ class ViT(nn.Module):
         self._last_logits = None   # most recent forward's logits (the Trainer shell reads them without a second forward)
         self._grad_sync = None     # parallel.GradSync: all-reduce gradient buckets while backward still runs
         self._fp8 = None           # enable_fp8(): e4m3 weights + scales for inference forwards
+        self.fp8_training = False  # enable_fp8(training=True): training forwards on e4m3 operands too
         self._param_generation = 0 # bumped whenever the fused optimizer rewrites the arena (FusedAdamW.step / step_range)
         # Arithmetic of eval-mode forwards that record no graph: "bf16" (bf16 MFMA operands, the training arithmetic) or "fp32"
         # (every operand fp32 on the fp32 MFMA: what the reference's validate computes, Trainer.py:101-118 - logits within 1e-5
@@ -382,19 +383,31 @@ class ViT(nn.Module):
             self._shadow_key = key
 
     # ------------------------------------------------------------------ fp8 inference (BASELINE.json configs[4])
-    def enable_fp8(self, calibration_video: torch.Tensor, headroom: float = 2.0, out_proj: bool = True):
+    def enable_fp8(self, calibration_video: torch.Tensor, headroom: float = 2.0, out_proj: bool = True, training: bool = False):
         """Switch inference forwards (no grad being recorded) to the fp8 path: qkv / out-projection / FC1 / FC2 of every block on OCP
         e4m3 MFMA operands (out_proj = False keeps the out-projection, 8 % of the linear FLOPs, on bf16).  `calibration_video` ([B, C, F, H, W] on the device) fixes the per-tensor activation scales; weights are
-        re-quantised from the fp32 master parameters (call again after training steps).  Training forwards keep using bf16."""
+        re-quantised from the fp32 master parameters whenever they have changed.
+        training = True additionally runs TRAINING forwards with qkv / FC1 / FC2 on e4m3 operands (nv_vit_forward_fp8_train; the
+        backward pass stays on bf16 operands and reads the bf16 activations the same forward kernels write): the weights are
+        re-quantised after every optimizer step (in place), the activation scales stay those of the calibration batch - call
+        enable_fp8 again to recalibrate.  Block dropout must be 0 in that mode.  Default: training forwards keep using bf16."""
         self.flat_parameters()
         self._refresh_shadow()
         scales = self._rt.calibrate_fp8(calibration_video.float(), self._arena, self._shadow, headroom, out_proj)
         self._fp8 = self._rt.quantize_fp8(self._arena, scales)
         self._fp8["key"] = self._param_key()
+        self.fp8_training = bool(training)
         return scales
 
     def disable_fp8(self):
         self._fp8 = None
+        self.fp8_training = False
+
+    def _fresh_fp8(self):
+        """the e4m3 weights of the current parameters (re-quantised in place when the stock or the fused optimizer changed them)"""
+        if self._fp8["key"] != self._param_key():
+            self._fp8 = dict(self._rt.quantize_fp8(self._arena, self._fp8["act_list"], reuse=self._fp8), key=self._param_key())
+        return self._fp8
 
     def precision(self, mode: str):
         """Context manager: eval-mode no-grad forwards inside it run in `mode` ("bf16" | "fp32")."""
@@ -435,9 +448,10 @@ class ViT(nn.Module):
             return self._last_logits
         self._refresh_shadow()
         if self._fp8 is not None and not need_grad and not self.training:
-            if self._fp8["key"] != self._param_key():      # parameters changed since quantisation (stock or fused optimizer)
-                self._fp8 = dict(self._rt.quantize_fp8(self._arena, self._fp8["act_list"]), key=self._param_key())
-            self._last_logits = self._rt.forward_fp8(video, self._arena, self._shadow, self._fp8, vol_sigma=vol_sigma, time_points=time_points)
+            self._last_logits = self._rt.forward_fp8(video, self._arena, self._shadow, self._fresh_fp8(), vol_sigma=vol_sigma, time_points=time_points)
+            return self._last_logits
+        if self._fp8 is not None and self.fp8_training and need_grad and not time_points:
+            self._last_logits = self._rt.forward_fp8_train(video, self._arena, self._shadow, self._fresh_fp8(), dropout=drop, vol_sigma=vol_sigma)
             return self._last_logits
         self._last_logits = self._rt.forward(video, self._arena, self._shadow, training=need_grad, dropout=drop, vol_sigma=vol_sigma,
                                              time_points=time_points)

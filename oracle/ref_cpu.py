@@ -91,14 +91,34 @@ def strip_prefix(sd: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Te
 CAST_OFF = set()
 
 
+class _Q8(torch.autograd.Function):
+    """OCP e4m3 quantise-dequantise with a straight-through gradient (identity inside the representable range, zero where the value
+    saturated).  A plain `.to(torch.float8_e4m3fn)` is NOT that under autograd: its backward casts the GRADIENT to e4m3 as well, which
+    flushes everything below 2^-9 to zero - a training step through it learns nothing the HIP path (bf16 backward over the unquantised
+    activations) computes."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        y = x * scale
+        ctx.save_for_backward(y.abs() <= 448.0)
+        return y.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) / scale
+
+    @staticmethod
+    def backward(ctx, g):
+        (inside,) = ctx.saved_tensors
+        return g * inside, None
+
+
 def _q8(x: torch.Tensor, scale) -> torch.Tensor:
     """OCP e4m3 quantise-dequantise (round to nearest even, saturating at +-448), fp32 storage: the fp8 path's cast points."""
-    return (x * scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) / scale
+    if not torch.is_tensor(scale):
+        scale = torch.tensor(float(scale))
+    return _Q8.apply(x, scale.detach())
 
 
 def _q8_rows(w: torch.Tensor) -> torch.Tensor:
-    """Per-output-row weight quantisation of csrc/quant.hip::quant_rows_f8_kernel."""
-    amax = w.abs().amax(dim=1, keepdim=True)
+    """Per-output-row weight quantisation of csrc/quant.hip::quant_rows_f8_kernel (the row scales are constants for autograd)."""
+    amax = w.detach().abs().amax(dim=1, keepdim=True)
     sw = torch.where(amax > 0, 448.0 / amax, torch.ones_like(amax))
     return _q8(w, sw)
 

@@ -53,10 +53,12 @@ class AdamW:
 
 
 def train_step(sd: Dict[str, torch.Tensor], cfg: ref_cpu.ViTCfg, opt: AdamW, video: torch.Tensor,
-               target: torch.Tensor, emulate_bf16: bool = False):
-    """One Trainer.py:65-79 iteration on a ViT-level state dict.  Returns (loss, logits, grads)."""
+               target: torch.Tensor, emulate_bf16: bool = False, fp8_scales=None):
+    """One Trainer.py:65-79 iteration on a ViT-level state dict.  Returns (loss, logits, grads).
+    fp8_scales: the forward restates the HIP path's fp8 training forward (e4m3 LayerNorm outputs / GELU output / per-row weights for
+    qkv, FC1, FC2; quantisation is a cast, i.e. a straight-through estimator for autograd)."""
     leaves = {k: v.detach().requires_grad_(True) for k, v in sd.items()}
-    logits = ref_cpu.vit_forward(leaves, cfg, video, emulate_bf16)
+    logits = ref_cpu.vit_forward(leaves, cfg, video, emulate_bf16, fp8_scales=fp8_scales)
     loss = cross_entropy(logits, target)
     gl = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
     grads = {k: g for k, g in zip(leaves.keys(), gl) if g is not None}

@@ -201,6 +201,43 @@ def test_gemm_ping_pong_kernel_forced(ops, M, N, K):
         lib.nv_gemm_set_tile(0, 0)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (257, 264, 192), (2052, 2304, 768), (2052, 768, 3072), (520, 392, 1024), (300, 8, 128)])
+def test_gemm_ping_pong_kernel_on_32x32x16_mfma(ops, M, N, K):
+    """The 256 x 128 kernel's NT problems on v_mfma_f32_32x32x16_bf16 (nv_gemm_set_tile(11, 1): 32-row fragments from an image with a
+    swizzle of its own, accumulators parked from the 32 x 32 register layout): every NT epilogue against fp64 at the gates of the
+    16 x 16 x 32 form, ragged M / N, one to forty-eight K tiles, run-to-run bit equality, and agreement with the 16 x 16 x 32 form to
+    fp32 rounding (the same products, accumulated 16 deep instead of 32 deep per instruction)."""
+    from neurovit_amd._cabi import lib
+    A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias, resid = rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = A.double() @ B.double().T
+    Ad, Bd = dev(A), dev(B)
+    lib.nv_gemm_set_tile(4, 0)
+    try:
+        narrow = ops.gemm(ops.NT, ops.EPI_BIAS_F32, Ad, Bd, bias=dev(bias)).clone()
+        lib.nv_gemm_set_tile(11, 1)
+        first = ops.gemm(ops.NT, ops.EPI_STORE_BF16, Ad, Bd)
+        assert_close_bf16(first, ref, "pp32.nt_bf16")
+        for _ in range(5):
+            assert torch.equal(ops.gemm(ops.NT, ops.EPI_STORE_BF16, Ad, Bd), first)
+        wide = ops.gemm(ops.NT, ops.EPI_BIAS_F32, Ad, Bd, bias=dev(bias))
+        assert_close_f32(wide, ref + bias.double(), "pp32.bias_f32", 1e-5)
+        assert rel_err(wide, narrow) < 2e-6
+        assert_close_f32(ops.gemm(ops.NT, ops.EPI_STORE_F32, Ad, Bd), ref, "pp32.f32", 1e-5)
+        assert_close_f32(ops.gemm(ops.NT, ops.EPI_BIAS_RESID, Ad, Bd, bias=dev(bias), aux_in=dev(resid)),
+                         ref + bias.double() + resid.double(), "pp32.nt_resid", 1e-5)
+        u = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        h = ops.gemm(ops.NT, ops.EPI_BIAS_GELU, Ad, Bd, bias=dev(bias), aux_out=u)
+        assert_close_bf16(u, ref + bias.double(), "pp32.gelu.u")
+        assert_close_bf16(h, F.gelu(ref + bias.double()), "pp32.gelu.h")
+        # the other layouts keep the 16 x 16 x 32 kernels under the switch
+        Bt = bf(rnd(K, N, seed=7, scale=K ** -0.5))
+        assert_close_f32(ops.gemm(ops.NN, ops.EPI_STORE_F32, Ad, dev(Bt)), A.double() @ Bt.double(), "pp32.nn_f32", 1e-5)
+    finally:
+        lib.nv_gemm_set_tile(11, 0)
+        lib.nv_gemm_set_tile(0, 0)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (257, 264, 192), (2052, 768, 768), (520, 776, 1024), (300, 8, 128)])
 def test_gemm_256x256_kernel_forced(ops, M, N, K):
     """gemm_pq.hip (256 x 256 tiles, DMA issued by the compute waves, two-stage ring, two-pass epilogue): every layout and fused

@@ -478,6 +478,46 @@ def test_gradient_accumulation_matches_one_big_step(nv):
     assert rel_err(pa, pb) < 1e-6
 
 
+def test_fp8_training_mode_of_the_module(nv):
+    """ViT.enable_fp8(training=True): training forwards run qkv / FC1 / FC2 on e4m3 operands (the TrainStep takes the autograd-driven
+    path, not the native one-call step), the weights are re-quantised in place after every optimizer step, the loss falls, eval
+    forwards use the same fp8 state, and block dropout is refused (the fp8 forward kernels carry no dropout)."""
+    from neurovit_amd.trainer import TrainStep
+    model = _micro_model(nv, lr=1e-3)
+    vit = model.volume_encoder.vit3d
+    x = W.make_volume((4, 32, 32, 32), 2).cuda()
+    y = torch.tensor([0, 1, 1, 0], device="cuda")
+    vit.enable_fp8(x.permute(0, 3, 1, 2).unsqueeze(1), out_proj=False, training=True)
+    assert vit.fp8_training
+    p8 = vit._fp8["params8"]
+    before = p8.clone()
+    step = TrainStep(model)
+    losses = [float(step(x, y)) for _ in range(6)]
+    assert step._native is None or not step._native_ok(x, y)
+    assert losses[-1] < losses[0] and all(np.isfinite(losses))
+    with torch.no_grad():
+        model.eval()
+        out = model(x)                                   # fp8 inference forward: re-quantises after the last step, in place
+        model.train()
+    assert vit._fp8["params8"].data_ptr() == p8.data_ptr() and not torch.equal(vit._fp8["params8"], before)
+    assert torch.isfinite(out).all()
+    # the same steps with bf16 forwards: the fp8 curve stays close (e4m3 operand noise, 3 mantissa bits)
+    ref = _micro_model(nv, lr=1e-3)
+    rstep = TrainStep(ref)
+    rl = [float(rstep(x, y)) for _ in range(6)]
+    report(f"fp8 training mode (micro): losses fp8-forward {[round(v, 4) for v in losses]} vs bf16 {[round(v, 4) for v in rl]}")
+    assert abs(losses[0] - rl[0]) < 3e-2 * max(1.0, abs(rl[0]))
+    vit.disable_fp8()
+    assert not vit.fp8_training and step._native_ok(x, y)
+    # dropout: refused, with a message that says what to do
+    cfg = W.neuro_config(32, 8, DEVICE="cuda", TRAINING_DROPOUT=0.1, TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
+    dm = nv.NeuroEncoder(cfg)
+    dm.train()
+    dm.volume_encoder.vit3d.enable_fp8(x.permute(0, 3, 1, 2).unsqueeze(1), out_proj=False, training=True)
+    with pytest.raises(NotImplementedError, match="no block dropout"):
+        dm(x)
+
+
 @pytest.mark.parametrize("B", [1, 3, 5])
 def test_ragged_batch_sizes_match_oracle(nv, B):
     """Batch sizes that are not a multiple of anything (last DataLoader batch of an epoch): loss, logits and the first AdamW

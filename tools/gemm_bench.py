@@ -44,11 +44,16 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--tile", default="", help="force tile, e.g. 64x128 (default: heuristic)")
+    ap.add_argument("--w32", action="store_true", help="NT problems of the 256x128 kernel on v_mfma_f32_32x32x16_bf16 (nv_gemm_set_tile(11, 1))")
     ap.add_argument("--dbg", type=int, default=0, help="256x128 kernel timing ablation (results wrong by design): 1 no DMA, 2 DMA from one L2-hot region, 4 fragments read once, 5 MFMA only")
     a = ap.parse_args()
     if a.dbg:
         from neurovit_amd._cabi import lib as _l
         _l.nv_gemm_set_tile(8, a.dbg)
+    if a.w32:
+        from neurovit_amd._cabi import lib as _l2
+        _l2.nv_gemm_set_tile(11, 1)
+        print("--- 32x32x16 MFMA form for NT problems on 256x128 tiles")
     if a.tile:
         from neurovit_amd._cabi import lib
         bm, bn = {"ws128x128": (1, 1), "ws64x128": (3, 1), "ws64x128k": (3, 3), "pp": (4, 0), "nopp": (5, 0), "pq": (9, 0)}.get(a.tile) or tuple(int(v) for v in a.tile.split("x"))
