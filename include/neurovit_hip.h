@@ -122,6 +122,10 @@ int nv_skinny_nt(int epi, int R, int N, int K, const void* A, long lda, const vo
                  long ldr, void* out, long ldo, void* u_out, long ldu, void* stream);
 int nv_skinny_nn(int epi, int R, int N, int K, const void* A, long lda, const void* W, long ldw, const void* u, long ldu, void* out, long ldo,
                  float* dcol, int accumulate, void* stream);
+/* out bf16 [total_rows, N] dense = zeros, except rows r * keep_every (r < R) = A[r, :] W: one launch (dAO of the last block under
+ * pool = 'cls', whose incoming gradient lives on the cls rows only - clearing the other rows used to be a memset node) */
+int nv_skinny_nn_sparse(int R, int N, int K, const void* A, long lda, const void* W, long ldw, void* out, long total_rows, int keep_every,
+                        void* stream);
 
 /* ---- LayerNorm of the residual stream (vit_3d.py:18,37): x f32 [M,d] -> y bf16, saves mean / rstd */
 int nv_ln_fwd(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, void* y, long ldy,

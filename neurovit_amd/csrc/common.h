@@ -190,6 +190,20 @@ __device__ __forceinline__ int fresh_lane() {
   return l;
 }
 
+// Zero rows [0, rows) of a dense [rows, row_bytes] matrix EXCEPT the rows whose index is a multiple of `keep_every` (another part of the
+// same launch writes those: the cls rows of a [B, n, d] tensor), as slice `part` of `nparts` workgroup-sized slices; row_bytes % 16 == 0.
+// Folded into the kernel that writes the kept rows, so that "everything else is zero" costs no launch (and no hipMemsetAsync node).
+__device__ __forceinline__ void zero_rows_except(char* base, long rows, long row_bytes, int keep_every, int part, int nparts) {
+  const long chunks_per_row = row_bytes >> 4, total = rows * chunks_per_row;
+  const long per = (total + nparts - 1) / nparts, lo = (long)part * per, hi = (lo + per < total) ? lo + per : total;
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (long c = lo + threadIdx.x; c < hi; c += blockDim.x) {
+    const long row = c / chunks_per_row;
+    if (keep_every > 0 && row % keep_every == 0) continue;
+    *reinterpret_cast<uint4*>(base + (c << 4)) = z;
+  }
+}
+
 // XCD-aware bijective remap of a 1-D block id: blocks b, b+8, ... share an XCD (round-robin dispatch),
 // so give each XCD a contiguous range of logical tiles (L2 locality of shared operand panels).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

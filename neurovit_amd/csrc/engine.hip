@@ -732,8 +732,7 @@ extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const f
                   W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream, ln_reduce));                                   // g += dLN2 -> g16b
     // ---- Attention backward (vit_3d.py:48-60)
     if (tail) {
-      if (hipMemsetAsync(ws + W.dao, 0, (size_t)M * D.inner * 2, S) != hipSuccess) { nv_set_error("nv_vit_backward: hipMemsetAsync failed"); return NV_ERR_HIP; }
-      RUN(nv_skinny_nn(2, B, D.inner, d, g16b, d * rs, p16 + q.wo, D.inner, nullptr, 0, ws + W.dao, D.inner * rs, nullptr, 0, stream));                 // dAO = g Wo, cls rows
+      RUN(nv_skinny_nn_sparse(B, D.inner, d, g16b, d * rs, p16 + q.wo, D.inner, ws + W.dao, M, D.n, stream));                       // dAO = g Wo on the cls rows, zeros elsewhere
     } else
     RUN(nv_gemm_bf16(1, 0, M, D.inner, d, g16b, d, p16 + q.wo, D.inner, ws + W.dao, D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));  // dAO = g Wo
     RUN(nv_attn_bwd(ws + w.qkv, 3 * D.inner, ws + w.ao, ws + W.dao, D.inner, (float*)(ws + w.lse), B, D.n, D.heads, D.dh, scale,

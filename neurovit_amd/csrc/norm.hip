@@ -889,10 +889,18 @@ __global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict
                                                          const float* __restrict__ x, long row_stride, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, int d, int n, float* __restrict__ g, long ldg,
                                                          bf16* __restrict__ g16, long ldg16, float* __restrict__ partials, DropCfg drop,
-                                                         int pool_mean) {
+                                                         int pool_mean, int nvol) {
   extern __shared__ __attribute__((aligned(16))) float sh[];   // dyh[d] + 8 scratch
   float* dys = sh;
   float* scratch = sh + d;
+  if ((int)blockIdx.x >= nvol) {
+    // pool = 'cls': the residual gradient is zero except for the cls rows the first nvol workgroups write - the rest of this grid
+    // clears the other rows of g (fp32) and g16 (bf16) in the same launch (were two hipMemsetAsync nodes in front of it)
+    const int part = blockIdx.x - nvol, nparts = gridDim.x - nvol;
+    zero_rows_except(reinterpret_cast<char*>(g), (long)nvol * n, (long)d * 4, n, part, nparts);
+    if (g16) zero_rows_except(reinterpret_cast<char*>(g16), (long)nvol * n, (long)d * 2, n, part, nparts);
+    return;
+  }
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float mean = stats[2 * b], rstd = stats[2 * b + 1];
   const float* row = x + (long)b * row_stride;
@@ -981,14 +989,13 @@ extern "C" int nv_head_bwd(const float* dlogits, int B, int C, const float* W, c
   NV_CHECK_ARG(ws_bytes >= nv_head_bwd_workspace_bytes(B, d), "nv_head_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   NV_CHECK_ARG(ldg == d && (!g16 || ldg16 == d), "nv_head_bwd: g / g16 must be dense [B*n, d]");
-  // the residual gradient is zero except for the cls rows (pool = 'cls'): wide memsets, then the cls rows
-  if (!pool_mean && (hipMemsetAsync(g, 0, (size_t)B * n * d * sizeof(float), s) != hipSuccess ||
-      (g16 && hipMemsetAsync(g16, 0, (size_t)B * n * d * 2, s) != hipSuccess))) {
-    nv_set_error("nv_head_bwd: hipMemsetAsync failed");
-    return NV_ERR_HIP;
-  }
-  hipLaunchKernelGGL(head_bwd_x_kernel, dim3(B), dim3(256), (d + 8) * sizeof(float), s, dlogits, C, W, x, row_stride, stats, gamma, d, n,
-                     g, ldg, (bf16*)g16, ldg16, (float*)workspace, make_drop(drop_seed, drop_p), pool_mean);
+  // the residual gradient is zero except for the cls rows (pool = 'cls'): B workgroups write those, the others clear the rest
+  NV_CHECK_ARG(pool_mean || ((d % 8) == 0 && nv_aligned16(g) && (!g16 || nv_aligned16(g16))), "nv_head_bwd: g / g16 must be 16-byte aligned, d a multiple of 8");
+  const long fill_bytes = pool_mean ? 0 : (long)B * n * d * (g16 ? 6 : 4);
+  int fill_blocks = (int)((fill_bytes + (1 << 16) - 1) >> 16);            // ~64 KiB per workgroup
+  if (fill_blocks > 1024) fill_blocks = 1024;
+  hipLaunchKernelGGL(head_bwd_x_kernel, dim3(B + fill_blocks), dim3(256), (d + 8) * sizeof(float), s, dlogits, C, W, x, row_stride, stats, gamma, d, n,
+                     g, ldg, (bf16*)g16, ldg16, (float*)workspace, make_drop(drop_seed, drop_p), pool_mean, B);
   NV_CHECK_LAUNCH("nv_head_bwd/x");
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 31) / 32), dim3(256), 0, s, (const float*)workspace, B, d, 3, dgamma, dbeta,
                      dcolsum, accumulate);

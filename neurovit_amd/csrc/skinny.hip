@@ -84,9 +84,15 @@ constexpr int NN_KK = 64 / (NN_COLS / 8);   // k-rows per wave-instruction: 32
 template <int EPI>
 __global__ __launch_bounds__(1024) void skinny_nn_kernel(const bf16* __restrict__ A, long lda, int R, const bf16* __restrict__ W, long ldw, int N, int K,
                                                          const bf16* __restrict__ u, long ldu, void* __restrict__ out, long ldo,
-                                                         float* __restrict__ dcol, int accumulate) {
+                                                         float* __restrict__ dcol, int accumulate, long fill_rows, int keep_every) {
   // LDS: every lane's partial sums [16 waves][32 k-row lanes][SK_R][16 columns] (128 KiB), then per-wave sums [16][SK_R][16]
   extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+  if (blockIdx.z == 1) {
+    // nv_skinny_nn_sparse: `out` is a dense bf16 [fill_rows, N] matrix of which this launch computes the rows r * keep_every; the
+    // z = 1 half of the grid clears all the others (was a hipMemsetAsync node in front of the launch)
+    zero_rows_except(reinterpret_cast<char*>(out), fill_rows, (long)N * 2, keep_every, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    return;
+  }
   float (*part)[NN_KK][SK_R][NN_COLS] = reinterpret_cast<float (*)[NN_KK][SK_R][NN_COLS]>(sk_lds);
   float (*red)[SK_R][NN_COLS] = reinterpret_cast<float (*)[SK_R][NN_COLS]>(sk_lds + 16 * NN_KK * SK_R * NN_COLS);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ng = lane & (NN_COLS / 8 - 1), kk = lane / (NN_COLS / 8);
@@ -211,9 +217,29 @@ extern "C" int nv_skinny_nn(int epi, int R, int N, int K, const void* A, long ld
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_nn_kernel<SK_NN_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, NN_LDS);
     attr = true;
   }
-#define SK_NN(E) hipLaunchKernelGGL(skinny_nn_kernel<E>, grid, block, NN_LDS, s, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, (const bf16*)u, ldu, out, ldo, dcol, accumulate)
+#define SK_NN(E) hipLaunchKernelGGL(skinny_nn_kernel<E>, grid, block, NN_LDS, s, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, (const bf16*)u, ldu, out, ldo, dcol, accumulate, 0L, 0)
   if (epi == SK_NN_DGELU) SK_NN(SK_NN_DGELU); else if (epi == SK_NN_F32) SK_NN(SK_NN_F32); else SK_NN(SK_NN_BF16);
 #undef SK_NN
   NV_CHECK_LAUNCH("nv_skinny_nn");
+  return NV_OK;
+}
+
+// out bf16 [total_rows, N] dense: rows r * keep_every (r < R) = A[r, :] W, every other row zero - ONE launch (the data gradient of a
+// Linear whose incoming gradient is non-zero on the cls rows only: dAO of the last block under pool = 'cls').  N % 8 == 0.
+extern "C" int nv_skinny_nn_sparse(int R, int N, int K, const void* A, long lda, const void* W, long ldw, void* out, long total_rows, int keep_every,
+                                   void* stream) {
+  NV_CHECK_ARG(R > 0 && N > 0 && K > 0 && (N % 8) == 0 && (ldw % 8) == 0 && A && W && out && nv_aligned16(W) && nv_aligned16(out) && keep_every >= 1 &&
+                   (long)(R - 1) * keep_every < total_rows,
+               "nv_skinny_nn_sparse: N, ldw multiples of 8; W, out 16-byte aligned; (R - 1) * keep_every < total_rows");
+  const dim3 grid((N + NN_COLS - 1) / NN_COLS, (R + SK_R - 1) / SK_R, 2), block(1024);
+  constexpr int NN_LDS = (16 * NN_KK * SK_R * NN_COLS + 16 * SK_R * NN_COLS) * (int)sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_nn_kernel<SK_NN_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, NN_LDS);
+    attr = true;
+  }
+  hipLaunchKernelGGL(skinny_nn_kernel<SK_NN_BF16>, grid, block, NN_LDS, (hipStream_t)stream, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, (const bf16*)nullptr, 0L,
+                     out, (long)N * keep_every, (float*)nullptr, 0, total_rows, keep_every);
+  NV_CHECK_LAUNCH("nv_skinny_nn_sparse");
   return NV_OK;
 }

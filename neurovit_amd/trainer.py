@@ -78,6 +78,8 @@ class TrainStep:
         self._outside = [p for p in model.parameters() if id(p) not in ids]
         self._inside = [p for p in model.parameters() if id(p) in ids]
         self._native = None                                            # decided at the first step (see _native_ok)
+        self._graphs_on = os.environ.get("NEUROVIT_GRAPH_STEP", "0") == "1"   # replay the native step from captured graphs (see _graph_step)
+        self._graphs, self._graph_seen, self._graph_warm = {}, {}, 0
         self._head = getattr(model, "_temporal_head", None)            # 4D: its 16 parameters are one arena (temporal.TemporalHead)
         self._head_ids = set()
         if self._head is not None:
@@ -131,7 +133,68 @@ class TrainStep:
                 return False
         return True
 
+    # ------------------------------------------------------------------ ... replayed from a captured graph
+    def _graph_step(self, fmri: torch.Tensor, labels: torch.Tensor):
+        """The native step's forward + loss + backward as a captured HIP graph, replayed with ONE host call (the ~225 launches of a step
+        cost the host 1.6 ms to enqueue one by one, ~20 us as a graph); the AdamW update, whose bias-correction constants change every
+        step, is launched behind it.  One graph per (input address, label address, shape): a loader that hands its batches over in a
+        few recycled device buffers (DevicePrefetcher: two) hits the cache after the first pass over them; an address seen for the
+        first time runs the step eagerly and is captured the NEXT time it shows up, so tensors that never repeat never pay a capture.
+        Only with dropout off (the masks' seeds are kernel arguments) and without accumulation.  Returns None when this step is not
+        for the graph.  The returned loss / logits tensors are the graph's own outputs: the next replay of the same graph overwrites
+        them (clone what must outlive the next step - as with any captured graph)."""
+        vit, opt = self._vit, self.optimizer
+        if not self._graphs_on or self.accumulation_steps != 1 or vit._dropout_p != (0.0, 0.0):
+            return None
+        key = (fmri.data_ptr(), labels.data_ptr(), tuple(fmri.shape), tuple(fmri.stride()), vit._arena.data_ptr())
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            if self._graph_seen[key] < 2 or len(self._graphs) >= 4 or self._graph_warm < 3:
+                self._graph_warm += 1
+                if len(self._graph_seen) > 64:
+                    self._graphs_on = False                              # addresses never repeat: stop looking
+                return None
+            video = fmri.permute(0, 3, 1, 2).unsqueeze(1)
+            vit.check_video(video, arena_checked=True)
+            if vit._grads is None:
+                vit._grads = torch.zeros_like(vit._arena)
+            m, v = opt.arena_state(vit)
+            g0 = opt.param_groups[0]
+            torch.cuda.synchronize(fmri.device)
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    loss, logits = vit._rt.train_step(video, labels, vit._arena, vit._shadow, vit._grads, m, v, step=1, lr=g0["lr"], betas=g0["betas"],
+                                                      eps=g0["eps"], weight_decay=g0["weight_decay"], accumulate=False, update=False)
+            except Exception as e:                                       # capture refused (an unsupported call inside it): eager from now on
+                self._graphs_on = False
+                import warnings
+                warnings.warn(f"neurovit_amd: the train step could not be captured as a graph ({e}); continuing with eager launches")
+                return None
+            ent = self._graphs[key] = (graph, loss, logits, fmri, labels)     # (the tensors are kept alive with the graph that reads them)
+            # the capture itself executed nothing: fall through to the replay below
+        graph, loss, logits = ent[0], ent[1], ent[2]
+        vit._refresh_shadow()
+        graph.replay()
+        rt = vit._rt
+        rt._last = (fmri.shape[0], True, rt.workspace(fmri.shape[0], True, fmri.device), fmri.permute(0, 3, 1, 2).unsqueeze(1))
+        rt.generation += 1
+        rt.backward_done = True
+        rt._dropout = (0.0, 0.0, 0)
+        opt._steps += 1
+        opt._step_arena(vit, 1.0)                                        # AdamW over the arena + bf16 shadow (mark_shadow_fresh inside)
+        vit._last_logits = logits
+        self.last_outputs = logits
+        if vit._plist[0].grad is None:
+            for i, p in enumerate(vit._plist):
+                p.grad = vit._grad_view(i)
+        return loss.reshape(())
+
     def _native_step(self, fmri: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        got = self._graph_step(fmri, labels)
+        if got is not None:
+            return got
         vit, opt = self._vit, self.optimizer
         last_micro = (self._micro + 1) % self.accumulation_steps == 0
         video = fmri.permute(0, 3, 1, 2).unsqueeze(1)                    # NeuroEncoder.py:200-202 as a VIEW (the gather kernel reads the strides)

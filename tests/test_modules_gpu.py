@@ -316,6 +316,27 @@ def test_native_train_step_equals_the_general_path_bitwise(nv, case):
     report(f"native train step [{case}] == general path (losses, logits, gradients, parameters, shadow: bitwise)")
 
 
+def test_graph_replayed_train_step_equals_eager_launches_bitwise(nv, monkeypatch):
+    """NEUROVIT_GRAPH_STEP=1: after three eager native steps the forward + loss + backward of a step is captured as a HIP graph per
+    (input address, label address) and replayed (AdamW launched behind it): eight steps alternating between TWO batches (two graphs)
+    must leave the losses, the gradient arena and the parameters of the eager native step, bit for bit."""
+    from neurovit_amd.trainer import TrainStep
+    xs = [W.make_volume((2, 32, 32, 32), 2).cuda(), W.make_volume((2, 32, 32, 32), 3).cuda()]
+    ys = [torch.tensor([1, 0], device="cuda"), torch.tensor([0, 0], device="cuda")]
+    runs = []
+    for graphs in ("1", "0"):
+        monkeypatch.setenv("NEUROVIT_GRAPH_STEP", graphs)
+        model = _micro_model(nv)
+        step = TrainStep(model)
+        losses = [step(xs[i % 2], ys[i % 2]).clone() for i in range(10)]
+        vit = model.volume_encoder.vit3d
+        runs.append((torch.stack(losses), vit.flat_gradients().clone(), vit.flat_parameters()[0].clone(), len(step._graphs), model.gradients))
+    (la, ga, pa, na, ha), (lb, gb, pb, nb, hb) = runs
+    assert na == 2 and nb == 0, (na, nb)
+    assert torch.equal(la, lb) and torch.equal(ga, gb) and torch.equal(pa, pb) and torch.equal(ha, hb)
+    report("graph-replayed train step == eager native step (10 steps, two graphs: losses, gradients, parameters, hook gradient bitwise)")
+
+
 def test_native_train_step_leaves_foreign_grads_to_the_general_path(nv):
     """.grad tensors that are not views of the gradient arena (foreign code put them there) need accumulate-and-copy: the step must
     not take the native call then, and must still add to them."""
