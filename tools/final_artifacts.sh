@@ -13,12 +13,13 @@ fi
 python bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
 cut -c1-300 $OUT/bench.json
 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1 || { tail $OUT/smoke.log; exit 1; }
-# secondary lines: inference forwards (bf16 / fp8 / fp32), batch 20, the large preset
+# secondary lines: inference forwards (bf16 / fp8 / fp32), batch 20 / 64, the large preset (bf16 and fp8-forward train step), dropout
 ( python bench.py --forward-only --steps 30 --warmup 5; python bench.py --forward-only --precise --steps 20 --warmup 3;
   python bench.py --forward-only --batch 20 --steps 20 --warmup 3; python bench.py --forward-only --batch 20 --fp8 --steps 20 --warmup 3;
   python bench.py --forward-only --batch 20 --precise --steps 10 --warmup 3;
   python bench.py --forward-only --batch 64 --steps 10 --warmup 3; python bench.py --forward-only --batch 64 --fp8 --steps 10 --warmup 3;
-  python bench.py --preset large --steps 8 --warmup 2 --no-cpu-baseline --no-extras; python bench.py --preset large --forward-only --steps 8 --warmup 2;
+  python bench.py --preset large --steps 8 --warmup 2 --no-cpu-baseline --no-extras; python bench.py --preset large --fp8 --steps 8 --warmup 2 --no-cpu-baseline --no-extras;
+  python bench.py --preset large --forward-only --steps 8 --warmup 2;
   python bench.py --preset large --forward-only --fp8 --steps 8 --warmup 2; python bench.py --dropout 0.1 --steps 30 --warmup 5 --no-cpu-baseline --no-extras ) > $OUT/bench_secondary.jsonl 2> $OUT/bench_secondary.err || true
 python tools/neuro4d_train_bench.py 2> /dev/null | tail -1 > $OUT/neuro4d_train.log || true
 cat $OUT/neuro4d_train.log
@@ -26,5 +27,6 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/stats_run.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f32 -- python3 $R/bench.py --forward-only --precise --steps 10 --warmup 3 > $OUT/stats_f32_run.log 2>&1
+T=$(find $OUT/stats -name "*kernel_trace.csv" | head -1)
+python3 $R/tools/trace_timeline.py $T 8 --summary > $OUT/timeline_summary.txt || true
 echo done
