@@ -76,7 +76,11 @@ int nv_gemm_f8(int epi, int M, int N, int K, const void* A8, long lda, const voi
 int nv_ln_fwd_f8_train(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, float out_scale, void* y8, long ldy8,
                        void* y16, long ldy16, float* mean, float* rstd, void* stream);
 int nv_gemm_f8_gelu_train(int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, const float* colscale, const float* bias,
-                          float out_scale, void* h8, long ldh8, void* h16, long ldh16, void* u16, long ldu16, void* stream);
+                          float out_scale, void* h8, long ldh8, void* h16, long ldh16, void* u16, long ldu16, unsigned long drop_seed,
+                          float drop_p, void* stream);      /* dropout (vit_3d.py:21) on gelu(u): h8 and h16 carry the same mask */
+/* nv_gemm_f8 epilogue 4 with the nn.Dropout of vit_3d.py:23 on (acc * colscale + bias) before the residual add (mask of nv_gemm_bf16 epilogue 4) */
+int nv_gemm_f8_resid_drop(int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc, const float* colscale,
+                          const float* bias, const void* aux_in, long ld_aux_in, unsigned long drop_seed, float drop_p, void* stream);
 
 /* ---- fp32 inference path ("precise" mode).  The reference validates in fp32 without autocast (src/Trainer.py:101-118) and the logits
  * are to match its CPU forward to 1e-3; bf16 MFMA operands cannot (weights rounded to bf16 alone cost 1e-3 ... 6e-3), so these entry
@@ -338,12 +342,13 @@ int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* video, cons
 /* fp8 TRAINING forward: as nv_vit_forward_in(training = 1) - every activation the backward pass reads is written, in bf16 / fp32, where
  * the bf16 forward writes it - with qkv, FC1 and FC2 of every block on e4m3 operands (params8 / colscales / act_scales as for
  * nv_vit_forward_fp8; act_scales[4 l + 3], the out-projection's, is ignored: that linear stays on bf16 operands, as do attention, the
- * patch embedding, the head and a last block in the cls-rows form).  The block dropout must be 0 (drop_p; emb_drop_p is free).
+ * patch embedding, the head and a last block in the cls-rows form).  drop_p / emb_drop_p / drop_seed as for nv_vit_forward_in (the masks
+ * of the four block sites are those of the bf16 forward: the backward pass recomputes them from the same arguments).
  * Follow it with nv_vit_backward[_stages16] exactly as after nv_vit_forward_in; re-quantise the weights (nv_vit_quantize_fp8) after
  * every optimizer step.  Workspace: the training layout (nv_vit_workspace_bytes(cfg, B, 1)). */
 int nv_vit_forward_fp8_train(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
                              const nv_vit_input* in, const float* params, const void* params16, const void* params8, const float* colscales,
-                             const float* act_scales, void* workspace, long ws_bytes, float emb_drop_p, unsigned long drop_seed,
+                             const float* act_scales, void* workspace, long ws_bytes, float drop_p, float emb_drop_p, unsigned long drop_seed,
                              float* logits, void* stream);
 int nv_vit_backward(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                     const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads,

@@ -554,7 +554,7 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
 // head by head out of the attention kernel, which would have to write a second copy; 8 % of the linear FLOPs).
 extern "C" int nv_vit_forward_fp8_train(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
                                         const float* params, const void* params16, const void* params8, const float* colscales, const float* act_scales,
-                                        void* workspace, long ws_bytes, float emb_drop_p, unsigned long drop_seed, float* logits, void* stream) {
+                                        void* workspace, long ws_bytes, float drop_p, float emb_drop_p, unsigned long drop_seed, float* logits, void* stream) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 1, W);
@@ -587,7 +587,7 @@ extern "C" int nv_vit_forward_fp8_train(const nv_vit_config* cfg, int B, const f
                           est + D.T, site_seed(drop_seed, 4 * D.L), emb_drop_p, stream));
   const float scale = 1.0f / sqrtf((float)D.dh);
   const float* xin = (float*)(ws + W.x0);
-  const bool tail = cls_tail_wanted(D, 1, 0.f, in ? in->rows_form : 0);
+  const bool tail = cls_tail_wanted(D, 1, drop_p, in ? in->rows_form : 0);
   void* x8 = ws + W.f8x;
   void* h8 = ws + W.f8h;
   for (int l = 0; l < D.L; ++l) {
@@ -602,7 +602,7 @@ extern "C" int nv_vit_forward_fp8_train(const nv_vit_config* cfg, int B, const f
     float* st2 = (float*)(ws + w.st2);
     RUN(nv_ln_fwd_f8_train(xin, d, M, d, p + q.n1g, p + q.n1b, eps, s_xn1, x8, d, ws + w.xn1, d, st1, st1 + M, stream));
     RUN(nv_gemm_f8(0, M, 3 * D.inner, d, x8, d, p8 + q.wqkv, d, ws + w.qkv, 3 * D.inner, cs, nullptr, nullptr, 0, 1.f, stream));
-    RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), 0, 0.f, stream));
+    RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), site_seed(drop_seed, 4 * l + 0), drop_p, stream));
     if (tail && l == D.L - 1) {       // the last block on its B cls rows: the bf16 weight-streaming kernels, as in nv_vit_forward_in
       const long rs = D.n;
       RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, stream));
@@ -612,10 +612,11 @@ extern "C" int nv_vit_forward_fp8_train(const nv_vit_config* cfg, int B, const f
       xin = x2;
       continue;
     }
-    RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+    RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 1), drop_p, stream));
     RUN(nv_ln_fwd_f8_train(x1, d, M, d, p + q.n2g, p + q.n2b, eps, s_xn2, x8, d, ws + w.xn2, d, st2, st2 + M, stream));
-    RUN(nv_gemm_f8_gelu_train(M, D.m, d, x8, d, p8 + q.w1, d, cs + 3L * D.inner, p + q.b1, s_h, h8, D.m, ws + w.h, D.m, ws + w.u, D.m, stream));
-    RUN(nv_gemm_f8(4, M, d, D.m, h8, D.m, p8 + q.w2, D.m, x2, d, cs + 3L * D.inner + D.m, p + q.b2, x1, d, 1.f, stream));
+    RUN(nv_gemm_f8_gelu_train(M, D.m, d, x8, d, p8 + q.w1, d, cs + 3L * D.inner, p + q.b1, s_h, h8, D.m, ws + w.h, D.m, ws + w.u, D.m,
+                              site_seed(drop_seed, 4 * l + 2), drop_p, stream));
+    RUN(nv_gemm_f8_resid_drop(M, d, D.m, h8, D.m, p8 + q.w2, D.m, x2, d, cs + 3L * D.inner + D.m, p + q.b2, x1, d, site_seed(drop_seed, 4 * l + 3), drop_p, stream));
     xin = x2;
   }
   const float* pooled = xin;

@@ -513,7 +513,8 @@ extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void
 // fp8 (OCP e4m3) operands, NT layout: C = epilogue((A8 . B8^T) * colscale[n]).  Eight-wave 256 x 128 kernel only (the path exists for
 // the large-M inference shapes of ViT3D-large); K % 128 == 0.
 static int gemm_f8_impl(int epi, int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc, const float* colscale,
-                        const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* u16, long ldu16, void* h16, long ldh16, void* stream);
+                        const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* u16, long ldu16, void* h16, long ldh16, void* stream,
+                        unsigned long drop_seed = 0, float drop_p = 0.f);
 
 extern "C" int nv_gemm_f8(int epi, int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc, const float* colscale,
                           const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* stream) {
@@ -524,14 +525,23 @@ extern "C" int nv_gemm_f8(int epi, int M, int N, int K, const void* A8, long lda
 // FC1 of a TRAINING forward on fp8 operands (vit_3d.py:19-20): h8 (e4m3) = sat(gelu(u) * out_scale) feeds the fp8 FC2; u16 = the
 // pre-activation (optional) and h16 = gelu(u), both bf16, are what the bf16 backward pass reads (GELU' and the FC2 weight gradient).
 extern "C" int nv_gemm_f8_gelu_train(int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, const float* colscale, const float* bias,
-                                     float out_scale, void* h8, long ldh8, void* h16, long ldh16, void* u16, long ldu16, void* stream) {
+                                     float out_scale, void* h8, long ldh8, void* h16, long ldh16, void* u16, long ldu16, unsigned long drop_seed,
+                                     float drop_p, void* stream) {
   NV_CHECK_ARG(h16 && nv_aligned16(h16) && (ldh16 % 4) == 0 && ldh16 >= N && (!u16 || (nv_aligned16(u16) && (ldu16 % 4) == 0 && ldu16 >= N)),
                "nv_gemm_f8_gelu_train: h16 (required) / u16 (optional) must be 16-byte aligned bf16 [M, ld >= N], ld a multiple of 4");
-  return gemm_f8_impl(EPI_BIAS_GELU_F8T, M, N, K, A8, lda, B8, ldb, h8, ldh8, colscale, bias, nullptr, 0, out_scale, u16, ldu16, h16, ldh16, stream);
+  return gemm_f8_impl(EPI_BIAS_GELU_F8T, M, N, K, A8, lda, B8, ldb, h8, ldh8, colscale, bias, nullptr, 0, out_scale, u16, ldu16, h16, ldh16, stream, drop_seed, drop_p);
+}
+
+// nv_gemm_f8 epilogue 4 (f32 = aux_in + (acc * colscale + bias) * mask) with the nn.Dropout of a training forward (vit_3d.py:23): FC2 of
+// nv_vit_forward_fp8_train; the mask is the one nv_gemm_bf16's epilogue 4 applies for the same (seed, p) - the backward pass recomputes it.
+extern "C" int nv_gemm_f8_resid_drop(int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc, const float* colscale,
+                                     const float* bias, const void* aux_in, long ld_aux_in, unsigned long drop_seed, float drop_p, void* stream) {
+  return gemm_f8_impl(EPI_BIAS_RESID, M, N, K, A8, lda, B8, ldb, C, ldc, colscale, bias, aux_in, ld_aux_in, 1.f, nullptr, 0, nullptr, 0, stream, drop_seed, drop_p);
 }
 
 static int gemm_f8_impl(int epi, int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc, const float* colscale,
-                        const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* u16, long ldu16, void* h16, long ldh16, void* stream) {
+                        const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* u16, long ldu16, void* h16, long ldh16, void* stream,
+                        unsigned long drop_seed, float drop_p) {
   NV_CHECK_ARG(M > 0 && N > 0 && K > 0 && A8 && B8 && C && colscale, "nv_gemm_f8: null operand / empty problem");
   NV_CHECK_ARG((K % 128) == 0 && (N % 8) == 0 && (lda % 16) == 0 && (ldb % 16) == 0 && lda >= K && ldb >= K && ldc >= N && (ldc % 4) == 0,
                "nv_gemm_f8: K must be a multiple of 128, N of 8, lda / ldb of 16, ldc of 4");
@@ -545,7 +555,7 @@ static int gemm_f8_impl(int epi, int M, int N, int K, const void* A8, long lda, 
   a.aux_out2 = h16; a.ld_aux_out2 = ldh16;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ld_aux_in = ld_aux_in; a.ld_aux_out = ldu16;
   a.M = M; a.N = N; a.K = K; a.accumulate = 0; a.alpha = out_scale;
-  a.drop = make_drop(0, 0.f);
+  a.drop = make_drop(drop_seed, drop_p);
   a.colscale = colscale;
   a.col_order = 0;
   const long tpq = (long)((M + PQ_BM - 1) / PQ_BM) * ((N + PQ_BN - 1) / PQ_BN);

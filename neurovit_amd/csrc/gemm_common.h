@@ -186,7 +186,7 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, in
   if (g.colscale) v *= *reinterpret_cast<const f32x4*>(g.colscale + n);
   if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_GELU_F8 || EPI == EPI_BIAS_GELU_F8T) v += *reinterpret_cast<const f32x4*>(g.bias + n);
   f32x4 keep = f32x4{1.f, 1.f, 1.f, 1.f};
-  if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_DGELU || EPI == EPI_DGELU_COLSUM) {
+  if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_DGELU || EPI == EPI_DGELU_COLSUM || EPI == EPI_BIAS_GELU_F8T) {
     if (g.drop.thresh) {
       keep = drop_factor4(g.drop, (unsigned long long)m * g.N + n);      // N % 8 == 0, n % 4 == 0
     }
@@ -212,7 +212,7 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, in
     const f32x4 h = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])} * g.alpha;
     *reinterpret_cast<unsigned*>((char*)g.C + (long)m * g.ldc + n) = pack_fp8x4(h);
   } else if constexpr (EPI == EPI_BIAS_GELU_F8T) {
-    const f32x4 h = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+    const f32x4 h = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])} * keep;      // nn.Dropout behind the GELU (vit_3d.py:21): h16 and h8 carry the same mask
     if (g.aux_out) __builtin_nontemporal_store(cvt4(v[0], v[1], v[2], v[3]), reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n));
     *reinterpret_cast<bf16x4*>((bf16*)g.aux_out2 + (long)m * g.ld_aux_out2 + n) = cvt4(h[0], h[1], h[2], h[3]);
     *reinterpret_cast<unsigned*>((char*)g.C + (long)m * g.ldc + n) = pack_fp8x4(h * g.alpha);

@@ -196,10 +196,7 @@ class VitRuntime:
     def forward_fp8_train(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, f8, dropout: Tuple[float, float, int] = (0.0, 0.0, 0),
                           vol_sigma=None, rows_form: Optional[int] = None) -> torch.Tensor:
         """TRAINING forward with qkv / FC1 / FC2 of every block on e4m3 operands (nv_vit_forward_fp8_train): fills the training
-        workspace exactly as forward(training=True) does, so backward() follows as usual (on bf16 operands).  Block dropout must be 0."""
-        if dropout[0] > 0:
-            raise NotImplementedError("neurovit_amd: the fp8 training forward has no block dropout (TRAINING_DROPOUT must be 0; the embedding "
-                                      "dropout is applied) - train with bf16 forwards (vit.fp8_training = False) to use dropout")
+        workspace exactly as forward(training=True) does, so backward() follows as usual (on bf16 operands); dropout as in forward()."""
         rows_form = self.rows_form if rows_form is None else int(rows_form)
         B, inp = self._input_form(video, vol_sigma, 0, rows_form)
         ws = self.workspace(B, True, video.device)
@@ -207,14 +204,14 @@ class VitRuntime:
         check(lib.nv_vit_forward_fp8_train(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
                                            None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p), params.data_ptr(),
                                            params16.data_ptr(), f8["params8"].data_ptr(), f8["colscales"].data_ptr(),
-                                           ctypes.cast(f8["act_scales"], ctypes.c_void_p), ws.data_ptr(), ws.numel(), float(dropout[1]), int(dropout[2]),
+                                           ctypes.cast(f8["act_scales"], ctypes.c_void_p), ws.data_ptr(), ws.numel(), float(dropout[0]), float(dropout[1]), int(dropout[2]),
                                            logits.data_ptr(), torch.cuda.current_stream().cuda_stream), "nv_vit_forward_fp8_train")
         self._keep = (vol_sigma, inp)
         self._rows_form = rows_form
         self._last = (B, True, ws, video)
         self.generation += 1
         self.backward_done = False
-        self._dropout = (0.0, dropout[1], dropout[2])
+        self._dropout = dropout
         return logits
 
     def forward_fp8(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, f8, vol_sigma=None, time_points: int = 0) -> torch.Tensor:

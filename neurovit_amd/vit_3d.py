@@ -390,7 +390,7 @@ class ViT(nn.Module):
         training = True additionally runs TRAINING forwards with qkv / FC1 / FC2 on e4m3 operands (nv_vit_forward_fp8_train; the
         backward pass stays on bf16 operands and reads the bf16 activations the same forward kernels write): the weights are
         re-quantised after every optimizer step (in place), the activation scales stay those of the calibration batch - call
-        enable_fp8 again to recalibrate.  Block dropout must be 0 in that mode.  Default: training forwards keep using bf16."""
+        enable_fp8 again to recalibrate.  Dropout works as in the bf16 forward (same masks).  Default: training forwards keep using bf16."""
         self.flat_parameters()
         self._refresh_shadow()
         scales = self._rt.calibrate_fp8(calibration_video.float(), self._arena, self._shadow, headroom, out_proj)

@@ -374,10 +374,12 @@ def feed_forward(sd, pre, x, emulate=False, drop=None, f8=None):
     hmask = drop_mask(drop[1], drop[0], (rows, sd[pre + "net.1.weight"].shape[0])).reshape(x.shape[0], x.shape[1], -1) if drop else None
     omask = drop_mask(drop[2], drop[0], (rows, d)).reshape(x.shape) if drop else None
     xn = F.layer_norm(x, (d,), sd[pre + "net.0.weight"], sd[pre + "net.0.bias"], LN_EPS)
-    if f8 is not None:          # fp8 path: f8 = (scale of the LN output, scale of the GELU output)
+    if f8 is not None:          # fp8 path: f8 = (scale of the LN output, scale of the GELU output); train mode: the two dropout masks as below
         u = F.linear(_q8(xn, f8[0]), _q8_rows(sd[pre + "net.1.weight"])) + sd[pre + "net.1.bias"]
-        h = _q8(F.gelu(u), f8[1])
-        return F.linear(h, _q8_rows(sd[pre + "net.4.weight"])) + sd[pre + "net.4.bias"]
+        gl = F.gelu(u)
+        h = _q8(gl if hmask is None else gl * hmask, f8[1])
+        y = F.linear(h, _q8_rows(sd[pre + "net.4.weight"])) + sd[pre + "net.4.bias"]
+        return y if omask is None else y * omask
     if emulate:
         u = _linear(_r(xn, "xn2"), sd[pre + "net.1.weight"], sd[pre + "net.1.bias"], True, "xn2")
         h = _GeluEmu.apply(u, torch.ones(()) if hmask is None else hmask)

@@ -485,6 +485,23 @@ def test_fp8_training_forward_equals_the_inference_forward_and_fills_the_workspa
     cos = torch.nn.functional.cosine_similarity(g8.flatten(), g_bf.flatten(), dim=0).item()
     report(f"fp8 training forward (micro, depth 3): logits == fp8 inference forward (bitwise); gradient arena vs bf16 step: cosine {cos:.4f}, rel L2 {rel_l2(g8, g_bf):.3e}")
     assert cos > 0.98
+    # train-mode dropout: the four block sites carry the bf16 path's masks (attention probabilities, out-projection, GELU output in BOTH
+    # its e4m3 and its bf16 copy, FC2 output) - three-way on the logits against the oracle that restates masks and e4m3 cast points
+    drop = (0.1, 0.1, 0x5eed)
+    rt.rows_form = 1
+    d8 = rt.forward_fp8_train(video, params, p16, f8, dropout=drop).clone()
+    assert torch.equal(d8, rt.forward_fp8_train(video, params, p16, f8, dropout=drop)) and not torch.equal(d8, trn)
+    with torch.no_grad():
+        ocfg = ref_cpu.ViTCfg(**cfgdict)
+        v = ref_cpu.fmri_to_video(fmri)
+        ref32 = ref_cpu.vit_forward(sd, ocfg, v, dropout=drop)
+        emu8 = ref_cpu.vit_forward(sd, ocfg, v, emulate_bf16=True, fp8_scales=scales, dropout=drop)
+    e_hip, e_emu, e_pair = rel_err(d8, ref32), rel_err(emu8, ref32), rel_err(d8, emu8)
+    report(f"fp8 training forward with dropout 0.1 (micro, depth 3): HIP vs fp32 {e_hip:.3e}; fp8 emulation vs fp32 {e_emu:.3e}; HIP vs emulation {e_pair:.3e}")
+    assert e_hip <= RATIO * e_emu + 5e-3 and e_pair < 6e-2
+    gd = torch.zeros_like(params)
+    rt.backward(dlog, params, p16, gd, accumulate=False)          # the backward recomputes the same masks from the forward's arguments
+    assert torch.isfinite(gd).all() and gd.abs().sum() > 0
 
 
 def test_fp8_train_step_large_geometry_depth2_vs_fp8_emulating_oracle(eng):

@@ -502,7 +502,7 @@ def test_gradient_accumulation_matches_one_big_step(nv):
 def test_fp8_training_mode_of_the_module(nv):
     """ViT.enable_fp8(training=True): training forwards run qkv / FC1 / FC2 on e4m3 operands (the TrainStep takes the autograd-driven
     path, not the native one-call step), the weights are re-quantised in place after every optimizer step, the loss falls, eval
-    forwards use the same fp8 state, and block dropout is refused (the fp8 forward kernels carry no dropout)."""
+    forwards use the same fp8 state, and dropout works (the bf16 path's masks, applied in the fp8 epilogues)."""
     from neurovit_amd.trainer import TrainStep
     model = _micro_model(nv, lr=1e-3)
     vit = model.volume_encoder.vit3d
@@ -530,13 +530,22 @@ def test_fp8_training_mode_of_the_module(nv):
     assert abs(losses[0] - rl[0]) < 3e-2 * max(1.0, abs(rl[0]))
     vit.disable_fp8()
     assert not vit.fp8_training and step._native_ok(x, y)
-    # dropout: refused, with a message that says what to do
-    cfg = W.neuro_config(32, 8, DEVICE="cuda", TRAINING_DROPOUT=0.1, TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
+    # with TRAINING_DROPOUT > 0: stochastic, reproducible under torch.manual_seed, trainable (the masks of the bf16 path, in the fp8 epilogues)
+    cfg = W.neuro_config(32, 8, DEVICE="cuda", TRAINING_DROPOUT=0.1, TRAINING_LEARNING_RATE=1e-3, TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2,
+                         TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
     dm = nv.NeuroEncoder(cfg)
+    dm.load_state_dict(W.make_tensors(W.vit_param_spec(**W.MICRO), 1, prefix="volume_encoder.vit3d."), strict=True)
     dm.train()
     dm.volume_encoder.vit3d.enable_fp8(x.permute(0, 3, 1, 2).unsqueeze(1), out_proj=False, training=True)
-    with pytest.raises(NotImplementedError, match="no block dropout"):
-        dm(x)
+    torch.manual_seed(7)
+    a = dm(x).detach().clone()
+    b = dm(x).detach().clone()
+    torch.manual_seed(7)
+    c = dm(x).detach().clone()
+    assert not torch.equal(a, b) and torch.equal(a, c)
+    dstep = TrainStep(dm)
+    dl = [float(dstep(x, y)) for _ in range(8)]
+    assert all(np.isfinite(dl)) and min(dl[4:]) < dl[0]
 
 
 @pytest.mark.parametrize("B", [1, 3, 5])
