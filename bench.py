@@ -587,7 +587,7 @@ def main():
     g_bytes = sum(kinds[k].get("bytes", 0.0) for k in gk)
     roofline = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family: gemm_pp_kernel / gemm_pp_grouped_tn_kernel (256x128 tiles) + gemm_ws_kernel (64x128 tiles), all fused epilogues",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "bytes/launch of FABRIC traffic (L2 memory-side read + write requests, rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE: Infinity-Cache hits are counted, so this is an upper bound of the HBM bytes, not the HBM bytes), mean over the launches of `achieved`", "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_unit": "bytes/launch of FABRIC traffic (L2 memory-side read + write requests, rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE: Infinity-Cache hits are counted, so this is an upper bound of the HBM bytes, not the HBM bytes; none of the 688 counters `rocprofv3 -L` lists on the MI355X box is a memory-side-cache or memory-controller counter, so the split cannot be measured), mean over the launches of `achieved`", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(g_bytes / max(g_n, 1), 1),
                 "traffic_over_algorithmic": None if not (traffic and g_bytes) else round(traffic / (g_bytes / g_n), 2),
                 "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches_per_step": g_n // prof_steps,
