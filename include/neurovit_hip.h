@@ -110,6 +110,27 @@ typedef struct nv_gemm_problem {
 } nv_gemm_problem;
 int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gemm_problem* problems, void* stream);
 
+/* ---- AdamW applied where the gradient is produced (Trainer.py:75 optimizer.step() folded into loss.backward() for the Linear
+ * weights: torch's "optimizer in backward" pattern).  The five arenas share element offsets: element i of `grads` is the gradient of
+ * params[i], whose optimizer state is adam_m[i] / adam_v[i] and whose bf16 shadow is params16[i].
+ * nv_gemm_bf16_grouped_adamw: the TN problems of nv_gemm_bf16_grouped (every C inside `grads`, accumulate = 0, no C16) whose epilogue
+ *   runs the update of nv_adamw_step on the tile it holds instead of storing it - the same arithmetic on the same fp32 gradient, so
+ *   parameters, state and shadow come out bit-identical to nv_gemm_bf16_grouped + nv_adamw_step; the gradient itself is stored only
+ *   when keep_grads = 1.  26 B/param of memory traffic instead of 34, and no second pass over these weights.
+ *   The caller orders every reader of the weights' bf16 shadow (the data-gradient GEMMs of the same layer) BEFORE this launch.
+ * nv_adamw_ranges: the plain update (nv_adamw_step arithmetic, fp32 gradients) over `count` element ranges (HOST arrays; begins and
+ *   lens multiples of 4) in one launch - the rest of the arena (biases, LayerNorm, embeddings, head) behind a fused backward. */
+typedef struct nv_adamw_arena {
+  int struct_size;            /* sizeof(nv_adamw_arena) */
+  int step;                   /* >= 1 */
+  double lr, beta1, beta2, eps, weight_decay;
+  float grad_scale;           /* the update reads grad * grad_scale */
+  int keep_grads;             /* nv_gemm_bf16_grouped_adamw: 1 = also store the gradient to C */
+  float* params; float* grads; float* adam_m; float* adam_v; void* params16;
+} nv_adamw_arena;
+int nv_gemm_bf16_grouped_adamw(int count, const nv_gemm_problem* problems, const nv_adamw_arena* opt, void* stream);
+int nv_adamw_ranges(const nv_adamw_arena* opt, const long* begins, const long* lens, int count, void* stream);
+
 /* tuning aid: force the workgroup tile ((64,64), (64,128), (128,128): the general small-tile kernel); bm = 0 restores the built-in
  * heuristic; bm = 1 / 3 forces the warp-specialised 128 x 128 / 64 x 128 tile (bn: ring, 0 = heuristic, 1 = 3 x 64-deep, (3,3) =
  * 3 x 128-deep), bm = 4 the eight-wave 256 x 128 ping-pong kernel, bm = 5 forbids it, bm = 9 the 256 x 256 kernel; (6, n) sets the ping-pong
@@ -396,6 +417,10 @@ typedef struct nv_train_hparams {
   double lr, beta1, beta2, eps, weight_decay;
   float grad_scale;         /* the update reads grad * grad_scale */
   int accumulate, update;
+  int fuse_update;          /* (revision 5) with update = 1, accumulate = 0: 1 = the Linear weights of the transformer layers are updated by
+                             * their weight-gradient GEMMs (nv_gemm_bf16_grouped_adamw), the rest by nv_adamw_ranges; the gradients of
+                             * those weights are then NOT left in `grads`; 2 = the same and they are; 0 = one nv_adamw_step at the end.
+                             * Parameters, optimizer state and loss are bit-identical in all three */
 } nv_train_hparams;
 int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
                       float* params, void* params16, float* grads, float* adam_m, float* adam_v, void* workspace, long ws_bytes,
@@ -409,7 +434,7 @@ int nv_cu_census(unsigned* out, int blocks, int threads, int lds_bytes, int hold
 
 /* ABI revision of this header: bumped whenever a struct gains a field or an entry point changes its argument list (the list is in
  * INTEGRATION.md "ABI revisions").  A caller built against revision R must refuse a library whose nv_abi_version() != R. */
-#define NV_ABI_VERSION 4
+#define NV_ABI_VERSION 5
 int nv_abi_version(void);
 /* dst[b .. b + len) = bf16(src[b .. b + len)) for `count` element ranges (HOST arrays begins / lens; any count) */
 int nv_cast_ranges_bf16(const float* src, void* dst, const long* begins, const long* lens, int count, void* stream);

@@ -36,10 +36,18 @@ class TrainHparams(ctypes.Structure):
     """struct nv_train_hparams (neurovit_hip.h): optimizer constants and accumulation flags of nv_vit_train_step."""
     _fields_ = [("struct_size", ctypes.c_int), ("step", ctypes.c_int), ("lr", ctypes.c_double), ("beta1", ctypes.c_double),
                 ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double), ("grad_scale", ctypes.c_float),
-                ("accumulate", ctypes.c_int), ("update", ctypes.c_int)]
+                ("accumulate", ctypes.c_int), ("update", ctypes.c_int), ("fuse_update", ctypes.c_int)]
 
 
-ABI_VERSION = 4      # NV_ABI_VERSION of the header this binding was written against (checked at load time)
+class AdamwArena(ctypes.Structure):
+    """struct nv_adamw_arena (neurovit_hip.h): AdamW constants + the five arenas that share element offsets."""
+    _fields_ = [("struct_size", ctypes.c_int), ("step", ctypes.c_int), ("lr", ctypes.c_double), ("beta1", ctypes.c_double),
+                ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double), ("grad_scale", ctypes.c_float),
+                ("keep_grads", ctypes.c_int), ("params", ctypes.c_void_p), ("grads", ctypes.c_void_p), ("adam_m", ctypes.c_void_p),
+                ("adam_v", ctypes.c_void_p), ("params16", ctypes.c_void_p)]
+
+
+ABI_VERSION = 5      # NV_ABI_VERSION of the header this binding was written against (checked at load time)
 
 
 def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 
 typedef __bf16 bf16;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -151,6 +152,31 @@ __device__ __forceinline__ float drop_factor(const DropCfg& d, unsigned long lon
   const uint64_t h = nv_hash64(d.seed, idx >> 2);
   const unsigned field = (unsigned)(h >> (16 * (unsigned)(idx & 3))) & 0xFFFFu;
   return (field >= d.thresh) ? d.scale : 0.f;
+}
+
+// ---- AdamW (torch.optim.AdamW, Trainer.py:31,75), shared by the streaming kernel (optim.hip) and the weight-gradient GEMM epilogue
+// that applies the update in place (gemm_common.h EPI_ADAMW): ONE definition, so both forms produce the same bits.
+// Every derived constant is formed in double on the host, as torch does, then rounded once.
+struct AdamArgs {
+  float decay, one_minus_b1, beta2, one_minus_b2, eps, step_size, bc2_sqrt, grad_scale;
+};
+static inline AdamArgs make_adam_args(int step, double lr, double beta1, double beta2, double eps, double weight_decay, float grad_scale) {
+  AdamArgs a;
+  a.decay = (float)(1.0 - lr * weight_decay);
+  a.one_minus_b1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.one_minus_b2 = (float)(1.0 - beta2);
+  a.eps = (float)eps; a.grad_scale = grad_scale;
+  a.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+  a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+  return a;
+}
+// Same operation order as torch's single-tensor AdamW (param.mul_; exp_avg.lerp_; exp_avg_sq.mul_.addcmul_;
+// denom = sqrt(v)/bc2_sqrt + eps; param.addcdiv_) so results track the reference optimizer to fp32 rounding.  gv = grad * grad_scale.
+__device__ __forceinline__ void adamw_update4(f32x4& pv, const f32x4 gv, f32x4& mv, f32x4& vv, const AdamArgs& a) {
+  pv *= a.decay;
+  mv += (gv - mv) * a.one_minus_b1;
+  vv = vv * a.beta2 + (gv * a.one_minus_b2) * gv;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pv[j] -= a.step_size * (mv[j] / (sqrtf(vv[j]) / a.bc2_sqrt + a.eps));
 }
 
 // LDS-DMA issued by the waves that also read the tiles.  Two things the builtin form costs here:

@@ -642,11 +642,28 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
                                   last_stage, drop_p, emb_drop_p, drop_seed, stream, aux_stream, join_aux, 0);
 }
 
+// fuse != null (nv_vit_train_step, fuse_update): the four Linear weights of every layer are updated by their weight-gradient GEMMs
+// (nv_gemm_bf16_grouped_adamw).  That launch rewrites the bf16 shadow of W_qkv, which the layer's last data-gradient GEMM
+// (dxn1 = dqkv W_qkv) reads: in this mode that GEMM is queued BEFORE the main stream signals the auxiliary one.
+static int backward_impl(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
+                         const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads, void* grads16,
+                         int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
+                         unsigned long drop_seed, void* stream, void* aux_stream, int join_aux, int rows_form, const nv_adamw_arena* fuse);
+
 extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                                         const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads, void* grads16,
                                         int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
                                         unsigned long drop_seed, void* stream, void* aux_stream, int join_aux, int rows_form) {
+  return backward_impl(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, grads16, accumulate, first_stage, last_stage,
+                       drop_p, emb_drop_p, drop_seed, stream, aux_stream, join_aux, rows_form, nullptr);
+}
+
+static int backward_impl(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
+                         const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads, void* grads16,
+                         int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
+                         unsigned long drop_seed, void* stream, void* aux_stream, int join_aux, int rows_form, const nv_adamw_arena* fuse) {
   Dims D; RUN(make_dims(cfg, B, D));
+  NV_CHECK_ARG(!fuse || (!accumulate && !grads16 && fuse->grads == grads), "nv_vit_backward: the fused optimizer update needs accumulate = 0, no bf16 mirror, and its own gradient arena");
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 1, W);
   NV_CHECK_ARG(video && strides5 && params && params16 && workspace && dlogits && grads, "nv_vit_backward: null pointer");
@@ -738,6 +755,9 @@ extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const f
     RUN(nv_gemm_bf16(1, 0, M, D.inner, d, g16b, d, p16 + q.wo, D.inner, ws + W.dao, D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));  // dAO = g Wo
     RUN(nv_attn_bwd(ws + w.qkv, 3 * D.inner, ws + w.ao, ws + W.dao, D.inner, (float*)(ws + w.lse), B, D.n, D.heads, D.dh, scale,
                     (float*)(ws + W.delta), dqkv, 3 * D.inner, site_seed(drop_seed, 4 * l + 0), drop_p, stream));
+    float* dxn1 = (l == D.L - 1) ? (float*)(ws + W.hookg) : dxn;    // gradient of the last block's attention-LN output is kept (Grad-CAM hook)
+    if (fuse)      // the last reader of this layer's bf16 weights, ahead of the launch that rewrites them (see above)
+      RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
     // ---- [A] everything of this layer that only finishes parameter gradients
     if (forked) RUN(stream_sync(S, A));                                                                                        // dU, g16b, dqkv (and the LN partials) ready
     {
@@ -764,12 +784,13 @@ extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const f
       pr[1] = {D.m, d, Mr, du, D.m * rs, ws + w.xn2, d * rs, gr + q.w1, d, acc, M16(q.w1), d};                        // dW1 = dU^T xn2
       pr[2] = {d, D.inner, Mr, g16b, d * rs, ws + w.ao, D.inner * rs, gr + q.wo, D.inner, acc, M16(q.wo), D.inner};   // dWo = g^T ao
       pr[3] = {3 * D.inner, d, M, dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, acc, M16(q.wqkv), d};  // dWqkv = dqkv^T xn1
-      RUN(nv_gemm_bf16_grouped(2, 1, 4, pr, sA));
+      if (fuse) RUN(nv_gemm_bf16_grouped_adamw(4, pr, fuse, sA));
+      else RUN(nv_gemm_bf16_grouped(2, 1, 4, pr, sA));
     }
     hipEvent_t done = nullptr;
     if (forked) { done = deferred_event(); if (!done || hipEventRecord(done, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; } }
-    float* dxn1 = (l == D.L - 1) ? (float*)(ws + W.hookg) : dxn;    // gradient of the last block's attention-LN output is kept (Grad-CAM hook)
-    RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+    if (!fuse)
+      RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
     // LN1 backward writes the residual gradient of layer l-1 into the buffer copy layer l+1 used (and layer l-1 then rewrites
     // the rest of that copy): the auxiliary work of layer l+1 - a whole layer behind by now - must have finished with it.
     if (forked && prev_done && hipStreamWaitEvent(S, prev_done, 0) != hipSuccess) { nv_set_error("nv_vit_backward: event wait failed"); return NV_ERR_HIP; }
@@ -856,11 +877,30 @@ extern "C" int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* v
   NV_CHECK_ARG(!(in && in->time_points > 0), "nv_vit_train_step: the fused 4D input form is forward-only (the 4D model's encoder is frozen, NeuroEncoder.py:34-36)");
   RUN(nv_vit_forward_in(cfg, B, video, shape5, strides5, in, params, params16, workspace, ws_bytes, 1, drop_p, emb_drop_p, drop_seed, logits, stream));
   RUN(nv_ce_loss(logits, labels, B, cfg->num_classes, 1.f, loss, dlogits, stream));
-  RUN(nv_vit_backward_stages16(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, nullptr, hp->accumulate ? 1 : 0, 0, cfg->depth + 1,
-                               drop_p, emb_drop_p, drop_seed, stream, aux_stream, 1, in ? in->rows_form : 0));
-  if (hp->update) {
+  const bool fused = hp->update && !hp->accumulate && hp->fuse_update;
+  nv_adamw_arena opt;
+  opt.struct_size = (int)sizeof(opt); opt.step = hp->step; opt.lr = hp->lr; opt.beta1 = hp->beta1; opt.beta2 = hp->beta2; opt.eps = hp->eps;
+  opt.weight_decay = hp->weight_decay; opt.grad_scale = hp->grad_scale; opt.keep_grads = hp->fuse_update == 2;
+  opt.params = params; opt.grads = grads; opt.adam_m = adam_m; opt.adam_v = adam_v; opt.params16 = params16;
+  RUN(backward_impl(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, nullptr, hp->accumulate ? 1 : 0, 0, cfg->depth + 1,
+                    drop_p, emb_drop_p, drop_seed, stream, aux_stream, 1, in ? in->rows_form : 0, fused ? &opt : nullptr));
+  if (hp->update && !fused) {
     const long total = nv_vit_param_count(cfg);
     RUN(nv_adamw_step(params, grads, 0, adam_m, adam_v, params16, total, hp->step, hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, hp->grad_scale, 0, stream));
+  } else if (fused) {
+    // what the weight-gradient GEMMs did not update: the arena minus the four Linear weights of every layer (arena order:
+    // ... n1b | wqkv | wo | bo n2g n2b | w1 | b1 | w2 | b2 n1g' ...), one launch
+    Dims D; RUN(make_dims(cfg, B, D));
+    ParamTab T; make_params(D, T);
+    std::vector<long> begins, lens;
+    long cur = 0;
+    auto skip = [&](long off, long numel) { if (off > cur) { begins.push_back(cur); lens.push_back(off - cur); } cur = align_up(off + numel, 8); };
+    for (int l = 0; l < D.L; ++l) {
+      const LayerP& q = T.layer[l];
+      skip(q.wqkv, 3L * D.inner * D.d); skip(q.wo, (long)D.d * D.inner); skip(q.w1, (long)D.m * D.d); skip(q.w2, (long)D.d * D.m);
+    }
+    if (T.total > cur) { begins.push_back(cur); lens.push_back(T.total - cur); }
+    RUN(nv_adamw_ranges(&opt, begins.data(), lens.data(), (int)begins.size(), stream));
   }
   return NV_OK;
 }

@@ -564,9 +564,17 @@ static int gemm_f8_impl(int epi, int M, int N, int K, const void* A8, long lda, 
 }
 
 // Grouped weight-gradient GEMMs (layout 2 / TN, fp32 store or accumulate): see gemm_ws_grouped_kernel.
-extern "C" int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gemm_problem* pr, void* stream) {
-  NV_CHECK_ARG(layout == 2 && epi == EPI_STORE_F32, "nv_gemm_bf16_grouped: only layout 2 (TN) with epilogue 1 (fp32 store) is provided");
+static int grouped_tn_impl(int count, const nv_gemm_problem* pr, const nv_adamw_arena* opt, void* stream) {
   NV_CHECK_ARG(pr && count >= 1 && count <= GROUP_MAX, "nv_gemm_bf16_grouped: 1..%d problems", GROUP_MAX);
+  AdamArgs adam = {};
+  if (opt) {
+    NV_CHECK_ARG(opt->struct_size == (int)sizeof(nv_adamw_arena), "nv_gemm_bf16_grouped_adamw: nv_adamw_arena.struct_size = %d, this library expects %d (ABI revision %d)",
+                 opt->struct_size, (int)sizeof(nv_adamw_arena), NV_ABI_VERSION);
+    NV_CHECK_ARG(opt->params && opt->grads && opt->adam_m && opt->adam_v && opt->params16 && opt->step >= 1, "nv_gemm_bf16_grouped_adamw: null arena or step < 1");
+    NV_CHECK_ARG(nv_aligned16(opt->params) && nv_aligned16(opt->grads) && nv_aligned16(opt->adam_m) && nv_aligned16(opt->adam_v) && nv_aligned16(opt->params16),
+                 "nv_gemm_bf16_grouped_adamw: arenas must be 16-byte aligned");
+    adam = make_adam_args(opt->step, opt->lr, opt->beta1, opt->beta2, opt->eps, opt->weight_decay, opt->grad_scale);
+  }
   constexpr int BM = 64, BN = 128;
   GemmGroup G;
   G.count = count;
@@ -588,12 +596,18 @@ extern "C" int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gem
     a.drop = make_drop(0, 0.f);
     a.colscale = nullptr;
     a.col_order = (q.N > q.M) ? 1 : 0;
+    if (opt) {
+      const long off = (const float*)q.C - opt->grads;
+      NV_CHECK_ARG(!q.accumulate && !q.C16 && off >= 0 && (off % 4) == 0, "nv_gemm_bf16_grouped_adamw: problem %d: C must lie in opt->grads (16-byte aligned offset), accumulate = 0, no C16", i);
+      a.opt.p = opt->params + off; a.opt.m = opt->adam_m + off; a.opt.v = opt->adam_v + off; a.opt.p16 = (bf16*)opt->params16 + off;
+      a.opt.a = adam; a.opt.keep_grad = opt->keep_grads ? 1 : 0;
+    }
     tiles += ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN);
     G.tile_end[i] = tiles;
     flops += 2.0 * q.M * q.N * q.K;
   }
   for (int i = count; i < GROUP_MAX; ++i) { G.p[i] = G.p[0]; G.tile_end[i] = tiles; }
-  if (g_tile_override == 4 || (g_tile_override == 0 && g_pp_grouped)) {
+  if (opt || g_tile_override == 4 || (g_tile_override == 0 && g_pp_grouped)) {      // (the fused update exists on this kernel only)
     // 256 x 128 ping-pong tiles: the four problems of a ViT3D-base layer are 216 tiles - one round on 256 CUs
     int tpp = 0;
     for (int i = 0; i < count; ++i) {
@@ -601,7 +615,7 @@ extern "C" int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gem
       G.tile_end[i] = tpp;
     }
     for (int i = count; i < GROUP_MAX; ++i) G.tile_end[i] = tpp;
-    return launch_pp_grouped_tn(G, tpp, flops, (hipStream_t)stream);
+    return launch_pp_grouped_tn(G, tpp, flops, (hipStream_t)stream, opt != nullptr);
   }
   constexpr int LDS = 3 * (BM + BN) * BK * 2;
   auto kern = gemm_ws_grouped_kernel<BM, BN, 3, 1, true, true, EPI_STORE_F32>;
@@ -621,4 +635,14 @@ extern "C" int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gem
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_bf16_grouped");
   return NV_OK;
+}
+
+extern "C" int nv_gemm_bf16_grouped(int layout, int epi, int count, const nv_gemm_problem* pr, void* stream) {
+  NV_CHECK_ARG(layout == 2 && epi == EPI_STORE_F32, "nv_gemm_bf16_grouped: only layout 2 (TN) with epilogue 1 (fp32 store) is provided");
+  return grouped_tn_impl(count, pr, nullptr, stream);
+}
+
+extern "C" int nv_gemm_bf16_grouped_adamw(int count, const nv_gemm_problem* pr, const nv_adamw_arena* opt, void* stream) {
+  NV_CHECK_ARG(opt, "nv_gemm_bf16_grouped_adamw: null optimizer block");
+  return grouped_tn_impl(count, pr, opt, stream);
 }

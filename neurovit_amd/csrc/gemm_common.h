@@ -15,6 +15,15 @@ enum {
                         // pre-activation u, aux_out2(bf16) = gelu(u) - out of the same epilogue (one pass over the tile instead of a quantise pass)
   EPI_DGELU_COLSUM = 6, // EPI_DGELU + aux_out(f32)[tile_row, n] = column sums of the stored bf16 values over the tile's rows: the bias
                         // gradient of the Linear in front of the GELU, produced where the tile already is (large-tile kernels only)
+  EPI_ADAMW = 9,        // weight-gradient GEMM that applies torch.optim.AdamW to the weight it differentiates: acc is the gradient of
+                        // opt.p[m, n] (same leading dimension as C); p, m, v are updated in place, p16 = bf16(p); C is only written when
+                        // opt.keep_grad.  Saves the 4-byte store and the 4-byte re-read of every gradient (8 of 34 B/param per step)
+};
+
+struct OptFuse {        // EPI_ADAMW: element (m, n) of the problem is p[m * ldc + n] (the arenas share element offsets with the gradient arena)
+  float* p = nullptr; float* m = nullptr; float* v = nullptr; bf16* p16 = nullptr;
+  AdamArgs a = {};
+  int keep_grad = 0;
 };
 
 struct GemmArgs {
@@ -32,6 +41,7 @@ struct GemmArgs {
   int col_order;   // 1: consecutive workgroups walk DOWN a tile column (keeps the B panel in the XCD's L2), 0: along a tile row
   float alpha;
   const float* colscale;   // fp8 operands: acc *= colscale[n] (1 / (activation scale * weight-row scale)) before the epilogue; null otherwise
+  OptFuse opt;             // EPI_ADAMW only
 };
 
 // algorithmic bytes of one GEMM launch: both operands read once, every output written once, epilogue inputs read once
@@ -47,6 +57,7 @@ static inline double gemm_algo_bytes(const GemmArgs& a, int epi, int operand_byt
     case EPI_DGELU: case EPI_DGELU_COLSUM: b += mn * 4; break;
     case EPI_BIAS_GELU_F8: b += mn; break;
     case EPI_BIAS_GELU_F8T: b += mn * 5; break;
+    case EPI_ADAMW: b += mn * (26 + (a.opt.keep_grad ? 4 : 0)); break;      // p, m, v read and written, bf16 shadow written
     default: break;
   }
   return b;
@@ -200,6 +211,18 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, in
     // optional bf16 mirror of what was stored (data-parallel gradient messages: the weight gradient leaves its GEMM already in the
     // wire format, no cast pass over the arena afterwards)
     if (g.aux_out) *reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n) = cvt4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (EPI == EPI_ADAMW) {
+    // the arithmetic of adamw_kernel (optim.hip) on the gradient the fp32-store epilogue would have written: same bits
+    const long off = (long)m * g.ldc + n;
+    if (g.opt.keep_grad) *reinterpret_cast<f32x4*>((float*)g.C + off) = v;
+    f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.opt.p + off));
+    f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.opt.m + off));
+    f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.opt.v + off));
+    adamw_update4(pv, v * g.opt.a.grad_scale, mv, vv, g.opt.a);
+    __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(g.opt.p + off));
+    __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(g.opt.m + off));
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(g.opt.v + off));
+    *reinterpret_cast<bf16x4*>(g.opt.p16 + off) = cvt4(pv[0], pv[1], pv[2], pv[3]);
   } else if constexpr (EPI == EPI_BIAS_F32) {
     *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
   } else if constexpr (EPI == EPI_BIAS_GELU) {
@@ -261,8 +284,47 @@ __device__ __forceinline__ void park_acc(const f32x4 (&acc)[MI][NI], char* ctile
       *reinterpret_cast<f32x4*>(ctile + (rb + 16 * i + lr) * cpitch<BN>() + (cb + 16 * j + 4 * lg) * 4) = acc[i][j];
 }
 template <int BM, int BN, int NT> constexpr int colsum_scratch_bytes() { return (NT / 64) * BN * 4; }   // behind the parked C tile
+// EPI_ADAMW: the update reads three arrays and writes four per element, and the compiler cannot move the loads of one chunk above the
+// stores of the one before (the arenas are not `restrict` to it): issued chunk by chunk every wave would sit out one full memory
+// latency per chunk.  Loads of ADAM_U chunks are issued together, as the streaming kernel does (optim.hip).
+constexpr int ADAM_U = 4;
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void epilogue_lds_adamw(const char* ctile, const GemmArgs& g, int m0, int n0, int tid) {
+  constexpr int CPR = BN / 4, TOT = BM * CPR;
+  for (int c0 = tid; c0 < TOT; c0 += NT * ADAM_U) {
+    f32x4 pv[ADAM_U], mv[ADAM_U], vv[ADAM_U];
+    long off[ADAM_U];
+    bool ok[ADAM_U];
+#pragma unroll
+    for (int u = 0; u < ADAM_U; ++u) {
+      const int c = c0 + u * NT, row = c / CPR, col = (c % CPR) * 4;
+      ok[u] = c < TOT && m0 + row < g.M && n0 + col < g.N;
+      off[u] = (long)(m0 + row) * g.ldc + n0 + col;
+      if (ok[u]) {
+        pv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.opt.p + off[u]));
+        mv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.opt.m + off[u]));
+        vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.opt.v + off[u]));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < ADAM_U; ++u) {
+      if (ok[u]) {
+        const int c = c0 + u * NT, row = c / CPR, col = (c % CPR) * 4;
+        const f32x4 gr = *reinterpret_cast<const f32x4*>(ctile + row * cpitch<BN>() + col * 4);
+        if (g.opt.keep_grad) *reinterpret_cast<f32x4*>((float*)g.C + off[u]) = gr;
+        adamw_update4(pv[u], gr * g.opt.a.grad_scale, mv[u], vv[u], g.opt.a);
+        __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(g.opt.p + off[u]));
+        __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(g.opt.m + off[u]));
+        __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(g.opt.v + off[u]));
+        *reinterpret_cast<bf16x4*>(g.opt.p16 + off[u]) = cvt4(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
+      }
+    }
+  }
+}
+
 template <int EPI, int BM, int BN, int NT>
 __device__ __forceinline__ void epilogue_lds(char* ctile, const GemmArgs& g, int m0, int n0, int tid) {
+  if constexpr (EPI == EPI_ADAMW) { epilogue_lds_adamw<BM, BN, NT>(ctile, g, m0, n0, tid); return; }
   constexpr int CPR = BN / 4;                 // 16-byte chunks per row
   static_assert(NT % CPR == 0 && 64 % CPR == 0, "every thread keeps one column group");
   f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -8,6 +8,6 @@ int launch_pq(int layout, int epi, const GemmArgs& a, hipStream_t s);
 int launch_pq_f8(int epi, const GemmArgs& a, hipStream_t s);
 int launch_pp(int layout, int epi, const GemmArgs& a, hipStream_t s);
 int launch_pp_f8(int epi, const GemmArgs& a, hipStream_t s);
-int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_t s);
+int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_t s, bool adamw = false);
 extern int g_pp_dbg;
 extern int g_pp_w32;

@@ -319,6 +319,14 @@ __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_grouped_tn_kernel(const
   gemm_pp_body<PP_BM, PP_BN, 4, 2, true, true, EPI_STORE_F32>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
 }
 
+// the same with the AdamW update of the differentiated weights in the epilogue (EPI_ADAMW)
+__global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_grouped_tn_adamw_kernel(const GemmGroup G) {
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int p = 0;
+  while (p + 1 < G.count && bid >= G.tile_end[p]) ++p;
+  gemm_pp_body<PP_BM, PP_BN, 4, 2, true, true, EPI_ADAMW>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
+}
+
 template <bool A_T, bool B_T, int EPI>
 int launch_pp_t(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = PP_BM, BN = PP_BN;
@@ -441,19 +449,19 @@ int launch_pp_f8(int epi, const GemmArgs& a, hipStream_t s) {
 }
 
 // grouped weight-gradient GEMMs (TN, fp32 store / accumulate) on 256 x 128 tiles
-int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_t s) {
+int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_t s, bool adamw) {
   constexpr int BM = PP_BM, BN = PP_BN;
   constexpr int LDS = PP_S * (BM / 128 + BN / 128) * PP_SUB;
-  auto kern = gemm_pp_grouped_tn_kernel;
-  static bool attr_set = false;
-  if (!attr_set) {
+  auto kern = adamw ? gemm_pp_grouped_tn_adamw_kernel : gemm_pp_grouped_tn_kernel;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[adamw]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
+    attr_set[adamw] = true;
   }
   const int slot = nv_prof_begin(13, flops, s);
   if (slot >= 0) {
     double bytes = 0.0;
-    for (int i = 0; i < G.count; ++i) bytes += gemm_algo_bytes(G.p[i], EPI_STORE_F32, 2);
+    for (int i = 0; i < G.count; ++i) bytes += gemm_algo_bytes(G.p[i], adamw ? EPI_ADAMW : EPI_STORE_F32, 2);
     nv_prof_bytes(slot, bytes);
   }
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(PP_THREADS), LDS, s, G);

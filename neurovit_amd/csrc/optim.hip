@@ -7,14 +7,9 @@
 //   ce_loss        nn.CrossEntropyLoss() (mean) forward + d(loss)/d(logits) in one tiny kernel
 #include "common.h"
 
-struct AdamArgs {   // every derived constant is formed in double on the host, as torch does, then rounded once
-  float decay, one_minus_b1, beta2, one_minus_b2, eps, step_size, bc2_sqrt, grad_scale;
-};
-
 // Streaming kernel: every byte is touched once per step, so loads and stores carry the non-temporal hint (5.8 vs 5.4 TB/s
 // back to back on MI355X); the bf16 shadow is stored normally - the next forward pass reads it.
-// Same operation order as torch's single-tensor AdamW (param.mul_; exp_avg.lerp_; exp_avg_sq.mul_.addcmul_;
-// denom = sqrt(v)/bc2_sqrt + eps; param.addcdiv_) so results track the reference optimizer to fp32 rounding.
+// The update itself is adamw_update4 (common.h).
 // G16: the gradient is read from a bf16 buffer (the data-parallel all-reduce ran on bf16 messages; reading them here saves the
 // cast back to fp32 - a full extra pass over the arena - and 2 of the 16 bytes this kernel reads per parameter)
 #ifndef NV_ADAMW_UNROLL
@@ -48,11 +43,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     for (int u = 0; u < U; ++u) {
       const long i = i0 + (long)u * blockDim.x;
       if (i < n4) {
-        pv[u] *= a.decay;
-        mv[u] += (gv[u] - mv[u]) * a.one_minus_b1;
-        vv[u] = vv[u] * a.beta2 + (gv[u] * a.one_minus_b2) * gv[u];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pv[u][j] -= a.step_size * (mv[u][j] / (sqrtf(vv[u][j]) / a.bc2_sqrt + a.eps));
+        adamw_update4(pv[u], gv[u], mv[u], vv[u], a);
         __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(p) + i);
         __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(m) + i);
         __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v) + i);
@@ -69,18 +60,77 @@ extern "C" int nv_adamw_step(float* p, const void* grad, int grad_bf16, float* m
   NV_CHECK_ARG(nv_aligned16(p) && (grad_bf16 ? ((uintptr_t)grad & 7) == 0 : nv_aligned16(grad)) && nv_aligned16(m) && nv_aligned16(v) &&
                    (!p16 || ((uintptr_t)p16 & 7) == 0),
                "nv_adamw_step: alignment");
-  AdamArgs a;
-  a.decay = (float)(1.0 - lr * weight_decay);
-  a.one_minus_b1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.one_minus_b2 = (float)(1.0 - beta2);
-  a.eps = (float)eps; a.grad_scale = grad_scale;
-  a.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
-  a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+  const AdamArgs a = make_adam_args(step, lr, beta1, beta2, eps, weight_decay, grad_scale);
   const long n4 = count / 4;
   long blocks = (n4 + 256L * NV_ADAMW_UNROLL - 1) / (256L * NV_ADAMW_UNROLL);
   if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
   if (grad_bf16) hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (bf16*)p16, n4, a);
   else hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (bf16*)p16, n4, a);
   NV_CHECK_LAUNCH("nv_adamw_step");
+  return NV_OK;
+}
+
+// The same update over a list of element ranges in ONE launch: what is left of the arena when the Linear weights were updated by
+// their weight-gradient GEMMs (EPI_ADAMW) - biases, LayerNorm affine parameters, embeddings, head: ~45 ranges of a few hundred
+// elements and the patch-embedding weight.  A workgroup owns one 2048-element chunk of one range (chunk_end = running chunk counts).
+constexpr int ADAM_MAX_RANGES = 64, ADAM_CHUNK = 2048;
+struct AdamRanges { long begin[ADAM_MAX_RANGES]; long len[ADAM_MAX_RANGES]; int chunk_end[ADAM_MAX_RANGES]; int count; };
+__global__ __launch_bounds__(256) void adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
+                                                           float* __restrict__ v, bf16* __restrict__ p16, const AdamRanges R, AdamArgs a) {
+  int r = 0;
+  while (r + 1 < R.count && (int)blockIdx.x >= R.chunk_end[r]) ++r;       // workgroup-uniform
+  const long c0 = (long)((int)blockIdx.x - (r ? R.chunk_end[r - 1] : 0)) * ADAM_CHUNK;
+  const long base = R.begin[r] + c0, n4 = min((long)ADAM_CHUNK, R.len[r] - c0) / 4;
+  constexpr int U = ADAM_CHUNK / (256 * 4);
+  f32x4 pv[U], gv[U], mv[U], vv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long i = threadIdx.x + 256 * u;
+    if (i < n4) {
+      pv[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p + base) + i);
+      gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grad + base) + i) * a.grad_scale;
+      mv[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m + base) + i);
+      vv[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v + base) + i);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long i = threadIdx.x + 256 * u;
+    if (i < n4) {
+      adamw_update4(pv[u], gv[u], mv[u], vv[u], a);
+      __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(p + base) + i);
+      __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(m + base) + i);
+      __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v + base) + i);
+      reinterpret_cast<bf16x4*>(p16 + base)[i] = cvt4(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
+    }
+  }
+}
+
+extern "C" int nv_adamw_ranges(const nv_adamw_arena* opt, const long* begins, const long* lens, int count, void* stream) {
+  NV_CHECK_ARG(opt && opt->struct_size == (int)sizeof(nv_adamw_arena), "nv_adamw_ranges: nv_adamw_arena.struct_size = %d, this library expects %d (ABI revision %d)",
+               opt ? opt->struct_size : -1, (int)sizeof(nv_adamw_arena), NV_ABI_VERSION);
+  NV_CHECK_ARG(opt->params && opt->grads && opt->adam_m && opt->adam_v && opt->params16 && opt->step >= 1 && count >= 0 && (count == 0 || (begins && lens)),
+               "nv_adamw_ranges: null arena / range list or step < 1");
+  NV_CHECK_ARG(nv_aligned16(opt->params) && nv_aligned16(opt->grads) && nv_aligned16(opt->adam_m) && nv_aligned16(opt->adam_v) && nv_aligned16(opt->params16),
+               "nv_adamw_ranges: arenas must be 16-byte aligned");
+  const AdamArgs a = make_adam_args(opt->step, opt->lr, opt->beta1, opt->beta2, opt->eps, opt->weight_decay, opt->grad_scale);
+  for (int first = 0; first < count; first += ADAM_MAX_RANGES) {
+    AdamRanges R;
+    int n = 0, chunks = 0;
+    for (int i = first; i < count && i < first + ADAM_MAX_RANGES; ++i) {
+      NV_CHECK_ARG(begins[i] >= 0 && lens[i] >= 0 && (begins[i] % 4) == 0 && (lens[i] % 4) == 0, "nv_adamw_ranges: range %d = [%ld, +%ld) must be non-negative multiples of 4", i, begins[i], lens[i]);
+      if (lens[i] == 0) continue;
+      R.begin[n] = begins[i]; R.len[n] = lens[i];
+      chunks += (int)((lens[i] + ADAM_CHUNK - 1) / ADAM_CHUNK);
+      R.chunk_end[n++] = chunks;
+    }
+    if (!n) continue;
+    R.count = n;
+    for (int i = n; i < ADAM_MAX_RANGES; ++i) { R.begin[i] = 0; R.len[i] = 0; R.chunk_end[i] = chunks; }
+    hipLaunchKernelGGL(adamw_ranges_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, opt->params, opt->grads, opt->adam_m, opt->adam_v,
+                       (bf16*)opt->params16, R, a);
+    NV_CHECK_LAUNCH("nv_adamw_ranges");
+  }
   return NV_OK;
 }
 

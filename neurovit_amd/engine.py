@@ -252,11 +252,13 @@ class VitRuntime:
 
     def train_step(self, video: torch.Tensor, labels: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, grads: torch.Tensor,
                    adam_m: torch.Tensor, adam_v: torch.Tensor, *, step: int, lr: float, betas, eps: float, weight_decay: float,
-                   grad_scale: float = 1.0, accumulate: bool = False, update: bool = True,
+                   grad_scale: float = 1.0, accumulate: bool = False, update: bool = True, fuse_update: int = 0,
                    dropout: Tuple[float, float, int] = (0.0, 0.0, 0), vol_sigma=None, rows_form: Optional[int] = None):
         """The reference's whole train step (Trainer.py:65-79) as ONE native call (nv_vit_train_step): forward, CrossEntropyLoss,
         backward of every stage, AdamW over the arena + bf16 shadow refresh.  Returns (loss [1], logits [B, C]) on the device.
-        Same launches, streams and arithmetic as forward() + ops.ce_loss + backward() + ops.adamw_step."""
+        Same launches, streams and arithmetic as forward() + ops.ce_loss + backward() + ops.adamw_step.
+        fuse_update (only with update and not accumulate): 1 = the transformer layers' Linear weights are updated by their
+        weight-gradient GEMMs (their gradients are then not left in `grads`), 2 = the same but they are; same bits either way."""
         rows_form = self.rows_form if rows_form is None else int(rows_form)
         B, inp = self._input_form(video, vol_sigma, 0, rows_form)
         ws = self.workspace(B, True, video.device)
@@ -266,7 +268,7 @@ class VitRuntime:
         self._dlogits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=dev)
         assert labels.is_cuda and labels.dtype == torch.int64 and labels.numel() == B and labels.is_contiguous()
         hp = TrainHparams(ctypes.sizeof(TrainHparams), int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
-                          float(grad_scale), int(bool(accumulate)), int(bool(update)))
+                          float(grad_scale), int(bool(accumulate)), int(bool(update)), int(fuse_update))
         check(lib.nv_vit_train_step(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
                                     None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p),
                                     params.data_ptr(), params16.data_ptr(), grads.data_ptr(), adam_m.data_ptr(), adam_v.data_ptr(),

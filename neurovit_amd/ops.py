@@ -168,6 +168,38 @@ def gemm_tn_grouped(problems) -> None:
     check(lib.nv_gemm_bf16_grouped(TN, EPI_STORE_F32, len(problems), ctypes.cast(arr, ctypes.c_void_p), _stream()), "nv_gemm_bf16_grouped")
 
 
+def adamw_arena(params, grads, adam_m, adam_v, params16, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0, keep_grads=False):
+    """struct nv_adamw_arena over five flat tensors that share element offsets (fp32 x 4, bf16 shadow)."""
+    from ._cabi import AdamwArena
+    n = params.numel()
+    assert all(t.is_cuda and t.is_contiguous() and t.numel() == n for t in (params, grads, adam_m, adam_v, params16))
+    assert params16.dtype == torch.bfloat16 and all(t.dtype == torch.float32 for t in (params, grads, adam_m, adam_v))
+    return AdamwArena(ctypes.sizeof(AdamwArena), int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(grad_scale),
+                      int(bool(keep_grads)), params.data_ptr(), grads.data_ptr(), adam_m.data_ptr(), adam_v.data_ptr(), params16.data_ptr())
+
+
+def gemm_tn_grouped_adamw(problems, opt) -> None:
+    """problems: up to four (A[K, M] bf16, B[K, N] bf16, C[M, N] f32 VIEW INTO opt's gradient arena): the gradient C = A^T B is consumed by
+    the AdamW update of the parameters at the same arena offsets inside the GEMM's epilogue (nv_gemm_bf16_grouped_adamw)."""
+    arr = (GemmProblem * len(problems))()
+    for i, pr in enumerate(problems):
+        A, B, C = pr[:3]
+        _need_cuda(A)
+        K, M = A.shape
+        N = B.shape[1]
+        assert B.shape[0] == K and C.shape == (M, N) and C.dtype == torch.float32
+        arr[i] = GemmProblem(M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0), 0, None, 0)
+    check(lib.nv_gemm_bf16_grouped_adamw(len(problems), ctypes.cast(arr, ctypes.c_void_p), ctypes.byref(opt), _stream()), "nv_gemm_bf16_grouped_adamw")
+
+
+def adamw_ranges(opt, ranges) -> None:
+    """AdamW (nv_adamw_step arithmetic) over [(begin, len)] element ranges of opt's arenas, one launch."""
+    n = len(ranges)
+    b = (ctypes.c_long * max(n, 1))(*[int(r[0]) for r in ranges])
+    l = (ctypes.c_long * max(n, 1))(*[int(r[1]) for r in ranges])
+    check(lib.nv_adamw_ranges(ctypes.byref(opt), b, l, n, _stream()), "nv_adamw_ranges")
+
+
 def ln_fwd(x: torch.Tensor, gamma, beta, eps: float = 1e-5):
     _need_cuda(x)
     M, d = x.shape

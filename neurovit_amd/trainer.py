@@ -25,8 +25,15 @@ from .parallel import GradSync, broadcast_parameters
 class TrainStep:
     def __init__(self, model: NeuroEncoder, lr: Optional[float] = None, weight_decay: Optional[float] = None, process_group=None,
                  n_buckets: int = 4, accumulation_steps: int = 1, overlap_optimizer: bool = False,
-                 grad_comm_dtype: torch.dtype = torch.float32, grad_comm_algo: Optional[str] = None):
+                 grad_comm_dtype: torch.dtype = torch.float32, grad_comm_algo: Optional[str] = None, fuse_update: Optional[int] = None):
         cfg = model.config
+        # native step only: 1 = AdamW of the layers' Linear weights inside their weight-gradient GEMMs (p.grad of those weights is then
+        # NOT refreshed - torch's optimizer-in-backward trade; nothing on the reference path reads it: Trainer.py:72 clears the
+        # gradients at the start of the next step), 2 = the same with the gradients still stored, 0 = one AdamW launch at the end
+        # Default 1: +1.6 % on the batch-4 step (profiles/r04_adamw_in_wgrad_epilogue.log).  The .grad of those weights is set to None
+        # in that mode (never a stale tensor); set 2 (or NEUROVIT_FUSE_UPDATE=2) to read gradients after the step
+        self.fuse_update = int(os.environ.get("NEUROVIT_FUSE_UPDATE", "1")) if fuse_update is None else int(fuse_update)
+        assert self.fuse_update in (0, 1, 2), "fuse_update: 0, 1 or 2"
         self.model = model
         self.criterion = CrossEntropyLoss()
         lr = cfg.get("TRAINING_LEARNING_RATE", 1e-4) if lr is None else lr
@@ -210,13 +217,24 @@ class TrainStep:
         if last_micro:
             opt._steps += 1
         g0 = opt.param_groups[0]
+        # the update inside the weight-gradient GEMMs: only a step that overwrites its gradients AND updates (no accumulation window)
+        fuse = self.fuse_update if (self.accumulation_steps == 1 and not vit._phantom) else 0
         accumulate = self._micro > 0        # the first micro-step of a window overwrites (zero_grad(set_to_none=True), Trainer.py:72), the others add
         loss, logits = vit._rt.train_step(video, labels.contiguous(), arena, shadow, grads, m, v, step=max(opt._steps, 1), lr=g0["lr"], betas=g0["betas"],
                                           eps=g0["eps"], weight_decay=g0["weight_decay"], grad_scale=1.0, accumulate=accumulate, update=last_micro,
-                                          dropout=vit.draw_dropout())
+                                          fuse_update=fuse, dropout=vit.draw_dropout())
         vit._last_logits = logits
         self.last_outputs = logits
         if vit._plist[0].grad is None:                                   # .grad = views of the gradient arena (once; they stay valid)
+            for i, p in enumerate(vit._plist):
+                p.grad = vit._grad_view(i)
+        if fuse == 1 and vit._plist[10].grad is not None:
+            # the layers' Linear weights were updated inside their gradient GEMMs and their gradients never written: no .grad rather
+            # than a stale one (entries 8 + 11 l + {2, 3, 7, 9} of the parameter table: to_qkv, to_out, FC1, FC2 weights of block l)
+            for l in range(vit._cfg.depth):
+                for k in (2, 3, 7, 9):
+                    vit._plist[8 + 11 * l + k].grad = None
+        elif fuse != 1 and vit._plist[10].grad is None:
             for i, p in enumerate(vit._plist):
                 p.grad = vit._grad_view(i)
         self._micro += 1

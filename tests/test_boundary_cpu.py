@@ -216,13 +216,13 @@ def test_flops_formula_in_package_equals_survey_numbers():
     assert abs(engine.flops_forward(engine.make_config(**{k: v for k, v in W.BASE.items() if k != "pool"})) / 1e9 - 100.07) < 0.01
 
 def test_ctypes_structs_match_the_header_layout(tmp_path):
-    """The ctypes mirrors of the header's structs (nv_vit_config, nv_vit_input, nv_gemm_problem, nv_reduce_job, nv_train_hparams) against what a C
+    """The ctypes mirrors of the header's structs (nv_vit_config, nv_vit_input, nv_gemm_problem, nv_reduce_job, nv_train_hparams, nv_adamw_arena) against what a C
     compiler makes of include/neurovit_hip.h: same size, same offset for every field (the header is plain C: gcc compiles it)."""
     import subprocess
     from neurovit_amd import ops
-    from neurovit_amd._cabi import HEADER, TrainHparams, VitConfig, VitInput
+    from neurovit_amd._cabi import HEADER, AdamwArena, TrainHparams, VitConfig, VitInput
     structs = {"nv_vit_config": VitConfig, "nv_vit_input": VitInput, "nv_gemm_problem": ops.GemmProblem, "nv_reduce_job": ops.ReduceJob,
-               "nv_train_hparams": TrainHparams}
+               "nv_train_hparams": TrainHparams, "nv_adamw_arena": AdamwArena}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')

@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 
 import weights as W
-from conftest import rel_err, rel_l2
+from conftest import rel_err, rel_l2, report
 from oracle import ref_cpu, train_step
 
 pytestmark = pytest.mark.gpu
@@ -808,6 +808,63 @@ def test_adamw_reads_bf16_gradients(ops):
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("keep", [False, True])
+def test_weight_gradient_gemm_with_the_adamw_update_in_its_epilogue(ops, keep):
+    """nv_gemm_bf16_grouped_adamw: the four weight gradients of a ViT3D-base layer (K = 2052 rows) whose epilogue applies AdamW to the
+    weights at the same arena offsets, against nv_gemm_bf16_grouped + nv_adamw_step on the same arenas: parameters, both moments
+    and the bf16 shadow bit for bit, over two steps (bias corrections differ); the gradient is only stored when asked; what lies
+    between the weights in the arena is not touched.  nv_adamw_ranges finishes the rest: whole arena == one nv_adamw_step."""
+    K = 2052
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    gap = 776                                                  # a bias + padding between two weights (multiple of 8)
+    offs, cur = [], 8
+    for Mo, N in shapes:
+        offs.append(cur)
+        cur += Mo * N + gap
+    total = cur
+    p0 = rnd(total, seed=1) * 0.05
+    A = [dev(bf(rnd(K, Mo, seed=20 + i))) for i, (Mo, N) in enumerate(shapes)]
+    Bm = [dev(bf(rnd(K, N, seed=30 + i, scale=K ** -0.5))) for i, (Mo, N) in enumerate(shapes)]
+    small = dev(rnd(total, seed=9) * 0.01)                     # gradients of everything that is not one of the four weights
+
+    def arenas():
+        return dev(p0.clone()), small.clone(), torch.zeros(total, device="cuda"), torch.zeros(total, device="cuda"), dev(p0.clone()).bfloat16()
+
+    def views(g):
+        return [g[o:o + Mo * N].view(Mo, N) for o, (Mo, N) in zip(offs, shapes)]
+
+    hyper = dict(lr=1e-3, weight_decay=1e-2, grad_scale=0.5)
+    ref, fus = arenas(), arenas()
+    sentinel = 123.0
+    for step in (1, 2):
+        # reference: store the gradients, then one AdamW over the arena
+        ops.gemm_tn_grouped([(a, b, c, False) for a, b, c in zip(A, Bm, views(ref[1]))])
+        ops.adamw_step(ref[0], ref[1], ref[2], ref[3], ref[4], step, **hyper)
+        # fused: the GEMM updates the weights, nv_adamw_ranges the rest
+        opt = ops.adamw_arena(*fus, step, keep_grads=keep, **hyper)
+        for c in views(fus[1]):
+            c.fill_(sentinel)
+        ops.gemm_tn_grouped_adamw(list(zip(A, Bm, views(fus[1]))), opt)
+        rest, cur = [], 0
+        for o, (Mo, N) in zip(offs, shapes):
+            rest.append((cur, o - cur))
+            cur = o + Mo * N
+        rest.append((cur, total - cur))
+        if step == 1:                                          # before the ranges ran: nothing outside the four weights has moved
+            for b, n in rest:
+                assert torch.equal(fus[0][b:b + n].cpu(), p0[b:b + n]) and not fus[2][b:b + n].any()
+        ops.adamw_ranges(opt, rest + [(0, 0)])                 # (an empty range is skipped)
+        for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "bf16 shadow"), (ref[0], ref[2], ref[3], ref[4]), (fus[0], fus[2], fus[3], fus[4])):
+            assert torch.equal(x, y), f"step {step}: {name} differ between the fused epilogue and GEMM + AdamW"
+        for c_ref, c_fus in zip(views(ref[1]), views(fus[1])):
+            if keep:
+                assert torch.equal(c_ref, c_fus)
+            else:
+                assert bool((c_fus == sentinel).all()), "keep_grads = 0 must not write the gradient"
+    assert float((ref[0].cpu() - p0).abs().max()) > 1e-4       # the update did something
+    report(f"weight-gradient GEMM + AdamW epilogue (keep_grads={int(keep)}) == GEMM then AdamW: p, m, v, bf16 shadow bitwise over 2 steps")
 
 
 # ------------------------------------------------------------------------------------------ input contract (A0 / F3)
