@@ -374,7 +374,7 @@ def test_graph_replayed_train_step_equals_eager_launches_bitwise(nv, monkeypatch
     for graphs in ("1", "0"):
         monkeypatch.setenv("NEUROVIT_GRAPH_STEP", graphs)
         model = _micro_model(nv)
-        step = TrainStep(model)
+        step = TrainStep(model, fuse_update=2)      # (eager steps: update inside the gradient GEMMs, gradients still stored - the arena is compared)
         losses = [step(xs[i % 2], ys[i % 2]).clone() for i in range(10)]
         vit = model.volume_encoder.vit3d
         runs.append((torch.stack(losses), vit.flat_gradients().clone(), vit.flat_parameters()[0].clone(), len(step._graphs), model.gradients))
