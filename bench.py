@@ -34,8 +34,9 @@ KIND_NAMES = {0: "gemm_ws_kernel<64,128,...,false,false,*> (NT: out-proj, FC2, p
               5: "gemm_pp_f8_kernel / gemm_pq_kernel<...,true> (fp8 e4m3 operands: qkv, FC1, FC2 of an --fp8 run; priced against the bf16 peak here)",
               10: "gemm_pp_kernel<256,128,4,2,false,false,*> (NT: qkv, FC1)", 11: "gemm_pp_kernel<256,128,4,2,false,true,*> (NN: dU with fused GELU' and bias column sums)",
               12: "gemm_pp_kernel<256,128,4,2,true,true,1> (TN)", 13: "gemm_pp_grouped_tn_kernel (four weight gradients of a layer, auxiliary stream)",
+              14: "gemm_pp_grouped_tn_adamw_kernel (the same + AdamW of those weights in the epilogue: 26 B/param of optimizer traffic inside the launch)",
               20: "gemm_pq_kernel<false,false,*> (NT, 256x256 tiles)", 21: "gemm_pq_kernel<false,true,*> (NN, 256x256 tiles)", 22: "gemm_pq_kernel<true,true,*> (TN, 256x256 tiles)"}
-GEMM_KINDS = (0, 1, 2, 5, 10, 11, 12, 13, 20, 21, 22)
+GEMM_KINDS = (0, 1, 2, 5, 10, 11, 12, 13, 14, 20, 21, 22)
 
 
 def parse():
@@ -550,6 +551,18 @@ def main():
     _, s_ms, s_fl, _ = prof_leg()
     rt.use_aux_stream = was
     achieved_serial = s_fl / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
+    # (3) the step as timed updates the layers' Linear weights INSIDE their weight-gradient GEMMs (TrainStep.fuse_update: AdamW's 26 B/param
+    #     ride in those launches, which makes them HBM-bound and lowers the family's TFLOP/s although the step is faster).  The
+    #     same family with the update as one launch of its own (the definition of rounds 1-3), for comparison:
+    achieved_unfused = None
+    fused_was = getattr(step, "fuse_update", 0)
+    if fused_was and 14 in kinds:
+        step.fuse_update = 0
+        step(x, y)
+        _, u_ms, u_fl, _ = prof_leg()
+        step.fuse_update = fused_was
+        step(x, y)
+        achieved_unfused = u_fl / (u_ms * 1e-3) / 1e12 if u_ms > 0 else None
     # HBM-side check.  PMC counters cannot be read in-process: they come from rocprofv3 --pmc passes of THIS command on an MI355X
     # (tools/pmc_traffic_summary.py -> profiles/rNN_pmc_traffic.json, per nv_prof kind); the algorithmic bytes beside them are
     # counted live, per launch, by the launchers (operands read once + outputs written once).  traffic / algorithmic = the waste.
@@ -592,7 +605,11 @@ def main():
                 "traffic_over_algorithmic": None if not (traffic and g_bytes) else round(traffic / (g_bytes / g_n), 2),
                 "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches_per_step": g_n // prof_steps,
                 "achieved_single_stream": round(achieved_serial, 2), "frac_single_stream": round(achieved_serial / PEAK_BF16_TFLOPS, 4),
-                "note": "achieved = per-launch hipEvent durations inside the concurrent two-stream step (agrees with rocprofv3 of this command); "
+                "achieved_update_unfused": None if achieved_unfused is None else round(achieved_unfused, 2),
+                "frac_update_unfused": None if achieved_unfused is None else round(achieved_unfused / PEAK_BF16_TFLOPS, 4),
+                "note": "achieved = per-launch hipEvent durations inside the concurrent two-stream step (agrees with rocprofv3 of this command); the weight-gradient "
+                        "launches of this step carry the AdamW update of their weights in the epilogue (184 MB of optimizer traffic per launch), "
+                        "achieved_update_unfused = the same family when AdamW is one launch of its own (rounds 1-3's definition; that step is 1.6 % slower); "
                         "achieved_single_stream = same kernels, same shapes, engine run on one stream (kernels alone on the chip); traffic = PMC "
                         "counters of a rocprofv3 run of this command (not readable in-process), algorithmic bytes counted live per launch",
                 "by_kernel": by_kernel}
@@ -614,7 +631,9 @@ def main():
            "dtype": "fp8 forward (e4m3 qkv/FC1/FC2 operands, fp32 accumulate), bf16 backward" if a.fp8 else "bf16", "data": "synthetic",
            "config": {"workload": f"ViT3D-{a.preset} {S}^3 patch {p}, train step (fwd+bwd+AdamW), batch {B}/GPU, dropout {a.dropout:g}",
                       "global_batch": B * world, "parallelism": f"dp{world}", "grad_buckets": a.buckets,
-                      "grad_allreduce": ("none (1 GPU)" if world == 1 else f"{a.grad_comm} messages, sum, overlapped with backward")},
+                      "grad_allreduce": ("none (1 GPU)" if world == 1 else f"{a.grad_comm} messages, sum, overlapped with backward"),
+                      "adamw": ("layers' Linear weights updated in their weight-gradient GEMM epilogues, the rest in one launch" if (getattr(step, "fuse_update", 0) and step._native)
+                                else "one launch over the arena behind the backward pass" if world == 1 else "per arena range behind the gradient all-reduce")},
            "mfma_frac_step": round(value / world * f_step / (PEAK_BF16_TFLOPS * 1e12), 4),
            # the last block runs on its B cls rows (pool='cls': the other rows never reach the head; tests prove identical logits and
            # gradients), so ~5 % of the ALGORITHMIC FLOPs above are not executed: this is the fraction over the FLOPs the step's MFMA

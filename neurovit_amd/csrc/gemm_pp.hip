@@ -458,7 +458,7 @@ int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set[adamw] = true;
   }
-  const int slot = nv_prof_begin(13, flops, s);
+  const int slot = nv_prof_begin(adamw ? 14 : 13, flops, s);
   if (slot >= 0) {
     double bytes = 0.0;
     for (int i = 0; i < G.count; ++i) bytes += gemm_algo_bytes(G.p[i], adamw ? EPI_ADAMW : EPI_STORE_F32, 2);

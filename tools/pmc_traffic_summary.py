@@ -55,6 +55,8 @@ def kind_of(key: str):
         return 5 if m.group(4) == "true" else tn(m, 10)
     if key.startswith("gemm_pp_f8_kernel"):
         return 5
+    if key.startswith("gemm_pp_grouped_tn_adamw_kernel"):
+        return 14
     if key.startswith("gemm_pp_grouped_tn_kernel"):
         return 13
     m = re.match(r"gemm_pq_kernel<(true|false), (true|false), \d+(, (true|false))?>", key)
@@ -115,11 +117,11 @@ def main():
         d["fetch_MB_per_launch"] = round(d.pop("fetch_MB") / d["launches"], 3)
         d["write_MB_per_launch"] = round(d.pop("write_MB") / d["launches"], 3)
         d["launches_per_step"] = None if not steps else round(d["launches"] / steps, 2)
-    gem = [d for kd, d in by_kind.items() if kd in (0, 1, 2, 10, 11, 12, 13, 20, 21, 22)]
+    gem = [d for kd, d in by_kind.items() if kd in (0, 1, 2, 10, 11, 12, 13, 14, 20, 21, 22)]
     n = sum(d["launches"] for d in gem)
     fm = sum(d["fetch_MB_per_launch"] * d["launches"] for d in gem) / max(n, 1)
     wm = sum(d["write_MB_per_launch"] * d["launches"] for d in gem) / max(n, 1)
-    js = {"kernel": "bf16 MFMA GEMM family (nv_prof kinds 0-2, 10-13, 20-22): gemm_ws_kernel<...>, gemm_pp_kernel<...>, gemm_pp_grouped_tn_kernel, gemm_pq_kernel<...>",
+    js = {"kernel": "bf16 MFMA GEMM family (nv_prof kinds 0-2, 10-14, 20-22): gemm_ws_kernel<...>, gemm_pp_kernel<...>, gemm_pp_grouped_tn_kernel / gemm_pp_grouped_tn_adamw_kernel, gemm_pq_kernel<...>",
           "steps_profiled": steps, "launches": n, "launches_per_step": None if not steps else round(n / steps, 2),
           "fetch_MB_per_launch": round(fm, 2), "write_MB_per_launch": round(wm, 2), "traffic_MB_per_launch": round(fm + wm, 2),
           "by_kind": {str(k): v for k, v in sorted(by_kind.items())},

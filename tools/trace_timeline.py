@@ -2,7 +2,7 @@
 """Timeline of ONE train step from a rocprofv3 --kernel-trace CSV: every dispatch in start order with its stream / queue, duration,
 the gap to the previous dispatch's end on the same queue and the idle time of the whole device in front of it.
 usage: trace_timeline.py <kernel_trace.csv> [step-index-from-the-end = 2] [--summary]
-A step is delimited by the adamw_kernel dispatches."""
+A step is delimited by the optimizer launch that ends it (adamw_kernel, or adamw_ranges_kernel behind a fused backward)."""
 import csv
 import sys
 
@@ -13,7 +13,7 @@ rows = list(csv.DictReader(open(path)))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-ends = [i for i, r in enumerate(rows) if "adamw_kernel" in r["Kernel_Name"]]
+ends = [i for i, r in enumerate(rows) if "adamw_kernel<" in r["Kernel_Name"] or "adamw_ranges_kernel" in r["Kernel_Name"]]      # (not the GEMM with the update in its epilogue)
 if len(ends) < back + 1:
     sys.exit(f"only {len(ends)} optimizer launches in the trace")
 lo, hi = ends[-back - 1] + 1, ends[-back]
