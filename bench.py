@@ -556,7 +556,7 @@ def main():
     #     same family with the update as one launch of its own (the definition of rounds 1-3), for comparison:
     achieved_unfused = None
     fused_was = getattr(step, "fuse_update", 0)
-    if fused_was and 14 in kinds:
+    if 14 in kinds:
         step.fuse_update = 0
         step(x, y)
         _, u_ms, u_fl, _ = prof_leg()
@@ -632,7 +632,7 @@ def main():
            "config": {"workload": f"ViT3D-{a.preset} {S}^3 patch {p}, train step (fwd+bwd+AdamW), batch {B}/GPU, dropout {a.dropout:g}",
                       "global_batch": B * world, "parallelism": f"dp{world}", "grad_buckets": a.buckets,
                       "grad_allreduce": ("none (1 GPU)" if world == 1 else f"{a.grad_comm} messages, sum, overlapped with backward"),
-                      "adamw": ("layers' Linear weights updated in their weight-gradient GEMM epilogues, the rest in one launch" if (getattr(step, "fuse_update", 0) and step._native)
+                      "adamw": ("layers' Linear weights updated in their weight-gradient GEMM epilogues, the rest in one launch" if 14 in kinds
                                 else "one launch over the arena behind the backward pass" if world == 1 else "per arena range behind the gradient all-reduce")},
            "mfma_frac_step": round(value / world * f_step / (PEAK_BF16_TFLOPS * 1e12), 4),
            # the last block runs on its B cls rows (pool='cls': the other rows never reach the head; tests prove identical logits and

@@ -93,6 +93,8 @@ class _Lib:
                                    "(make -C neurovit_amd/csrc); see INTEGRATION.md 'ABI revisions'")
             if os.environ.get("NEUROVIT_ATTN_MODE"):           # A/B aid: nv_attn_set_mode for the whole process (see the header)
                 dll.nv_attn_set_mode(int(os.environ["NEUROVIT_ATTN_MODE"]))
+            if os.environ.get("NEUROVIT_ADAMW_WGS"):           # A/B aid: workgroups of the weight-gradient launch with the AdamW epilogue
+                dll.nv_gemm_set_tile(12, int(os.environ["NEUROVIT_ADAMW_WGS"]))
             self._dll = dll
         return self._dll
 

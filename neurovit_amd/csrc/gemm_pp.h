@@ -11,3 +11,4 @@ int launch_pp_f8(int epi, const GemmArgs& a, hipStream_t s);
 int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_t s, bool adamw = false);
 extern int g_pp_dbg;
 extern int g_pp_w32;
+extern int g_pp_adamw_wgs;

@@ -320,11 +320,17 @@ __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_grouped_tn_kernel(const
 }
 
 // the same with the AdamW update of the differentiated weights in the epilogue (EPI_ADAMW)
+// A workgroup walks tiles bid, bid + grid, ...: with fewer workgroups than tiles (g_pp_adamw_wgs) the HBM-bound epilogues - 26 B per
+// weight, during which the workgroup's CU computes nothing - occupy that many CUs instead of one per tile, and the rest of the
+// chip stays with the other stream's kernels.
 __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_grouped_tn_adamw_kernel(const GemmGroup G) {
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  int p = 0;
-  while (p + 1 < G.count && bid >= G.tile_end[p]) ++p;
-  gemm_pp_body<PP_BM, PP_BN, 4, 2, true, true, EPI_ADAMW>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
+  const int total = G.tile_end[GROUP_MAX - 1];
+  for (int bid = xcd_remap(blockIdx.x, gridDim.x); bid < total; bid += gridDim.x) {
+    int p = 0;
+    while (p + 1 < G.count && bid >= G.tile_end[p]) ++p;
+    gemm_pp_body<PP_BM, PP_BN, 4, 2, true, true, EPI_ADAMW>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
+    __syncthreads();      // the parked tile has been consumed before the next tile's first DMA lands on it
+  }
 }
 
 template <bool A_T, bool B_T, int EPI>
@@ -348,6 +354,10 @@ int launch_pp_t(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// workgroups of the weight-gradient launch with the AdamW epilogue (0 = one per tile); nv_gemm_set_tile(12, n).  Half the chip: ViT3D-base,
+// batch 4, same box, volumes/s of the train step - one per tile (216) 1107, 144: 1082, 136: 1108, 128: 1122, 120: 1123, 112: 1124,
+// 108: 1133 against 1140 for 128 on another box, 96: 1055, 72: 1078; update unfused 1094 (profiles/r04_adamw_in_wgrad_epilogue.log)
+int g_pp_adamw_wgs = 128;
 int g_pp_w32 = 0;   // NT problems on the 32 x 32 x 16 MFMA form of the kernel (nv_gemm_set_tile(11, 0 | 1))
 template <int EPI>
 static int launch_pp_w32_t(const GemmArgs& a, hipStream_t s) {
@@ -464,7 +474,8 @@ int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_
     for (int i = 0; i < G.count; ++i) bytes += gemm_algo_bytes(G.p[i], adamw ? EPI_ADAMW : EPI_STORE_F32, 2);
     nv_prof_bytes(slot, bytes);
   }
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(PP_THREADS), LDS, s, G);
+  const int wgs = (adamw && g_pp_adamw_wgs > 0 && g_pp_adamw_wgs < tiles) ? g_pp_adamw_wgs : tiles;
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(PP_THREADS), LDS, s, G);
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_bf16_grouped/pp");
   return NV_OK;
