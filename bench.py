@@ -609,7 +609,7 @@ def main():
                 "frac_update_unfused": None if achieved_unfused is None else round(achieved_unfused / PEAK_BF16_TFLOPS, 4),
                 "note": "achieved = per-launch hipEvent durations inside the concurrent two-stream step (agrees with rocprofv3 of this command); the weight-gradient "
                         "launches of this step carry the AdamW update of their weights in the epilogue (184 MB of optimizer traffic per launch), "
-                        "achieved_update_unfused = the same family when AdamW is one launch of its own (rounds 1-3's definition; that step is 1.6 % slower); "
+                        "achieved_update_unfused = the same family when AdamW is one launch of its own (rounds 1-3's definition; that step is 2.6 % slower at batch 4, profiles/r04_adamw_in_wgrad_epilogue.log); "
                         "achieved_single_stream = same kernels, same shapes, engine run on one stream (kernels alone on the chip); traffic = PMC "
                         "counters of a rocprofv3 run of this command (not readable in-process), algorithmic bytes counted live per launch",
                 "by_kernel": by_kernel}
