@@ -551,12 +551,14 @@ def main():
     _, s_ms, s_fl, _ = prof_leg()
     rt.use_aux_stream = was
     achieved_serial = s_fl / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
-    # (3) the step as timed updates the layers' Linear weights INSIDE their weight-gradient GEMMs (TrainStep.fuse_update: AdamW's 26 B/param
-    #     ride in those launches, which makes them HBM-bound and lowers the family's TFLOP/s although the step is faster).  The
-    #     same family with the update as one launch of its own (the definition of rounds 1-3), for comparison:
+    # (3) the step as timed updates the layers' Linear weights DURING the backward pass (TrainStep.fuse_update: per-layer AdamW launches on
+    #     the auxiliary stream, or the update inside the weight-gradient GEMMs): the GEMMs then share the chip with that HBM-bound
+    #     work and their event-bracketed durations grow although the step is faster.  The same family with the whole update as
+    #     one launch behind the backward pass (the definition of rounds 1-3), for comparison:
     achieved_unfused = None
     fused_was = getattr(step, "fuse_update", 0)
-    if 14 in kinds:
+    fuse_mode = getattr(step, "last_fuse_update", 0)
+    if fuse_mode:
         step.fuse_update = 0
         step(x, y)
         _, u_ms, u_fl, _ = prof_leg()
@@ -607,9 +609,10 @@ def main():
                 "achieved_single_stream": round(achieved_serial, 2), "frac_single_stream": round(achieved_serial / PEAK_BF16_TFLOPS, 4),
                 "achieved_update_unfused": None if achieved_unfused is None else round(achieved_unfused, 2),
                 "frac_update_unfused": None if achieved_unfused is None else round(achieved_unfused / PEAK_BF16_TFLOPS, 4),
-                "note": "achieved = per-launch hipEvent durations inside the concurrent two-stream step (agrees with rocprofv3 of this command); the weight-gradient "
-                        "launches of this step carry the AdamW update of their weights in the epilogue (184 MB of optimizer traffic per launch), "
-                        "achieved_update_unfused = the same family when AdamW is one launch of its own (rounds 1-3's definition; that step is 2.6 % slower at batch 4, profiles/r04_adamw_in_wgrad_epilogue.log); "
+                "note": "achieved = per-launch hipEvent durations inside the concurrent two-stream step (agrees with rocprofv3 of this command); in this step AdamW of the "
+                        "layers' weights runs during the backward pass (config.adamw), sharing the chip with these launches; "
+                        "achieved_update_unfused = the same family when the whole update is one launch behind the backward pass (rounds 1-3's definition; that step is "
+                        "2.8-3.7 % slower at batch 4, profiles/r04_adamw_in_wgrad_epilogue.log); "
                         "achieved_single_stream = same kernels, same shapes, engine run on one stream (kernels alone on the chip); traffic = PMC "
                         "counters of a rocprofv3 run of this command (not readable in-process), algorithmic bytes counted live per launch",
                 "by_kernel": by_kernel}
@@ -632,8 +635,10 @@ def main():
            "config": {"workload": f"ViT3D-{a.preset} {S}^3 patch {p}, train step (fwd+bwd+AdamW), batch {B}/GPU, dropout {a.dropout:g}",
                       "global_batch": B * world, "parallelism": f"dp{world}", "grad_buckets": a.buckets,
                       "grad_allreduce": ("none (1 GPU)" if world == 1 else f"{a.grad_comm} messages, sum, overlapped with backward"),
-                      "adamw": ("layers' Linear weights updated in their weight-gradient GEMM epilogues, the rest in one launch" if 14 in kinds
-                                else "one launch over the arena behind the backward pass" if world == 1 else "per arena range behind the gradient all-reduce")},
+                      "adamw": ({1: "layers' Linear weights updated in their weight-gradient GEMM epilogues, the rest in one launch",
+                                 2: "layers' Linear weights updated in their weight-gradient GEMM epilogues (gradients kept), the rest in one launch",
+                                 3: "layers' Linear weights updated per layer on the auxiliary stream behind their weight-gradient GEMMs, the rest in one launch"}.get(
+                                     fuse_mode, "one launch over the arena behind the backward pass" if world == 1 else "per arena range behind the gradient all-reduce"))},
            "mfma_frac_step": round(value / world * f_step / (PEAK_BF16_TFLOPS * 1e12), 4),
            # the last block runs on its B cls rows (pool='cls': the other rows never reach the head; tests prove identical logits and
            # gradients), so ~5 % of the ALGORITHMIC FLOPs above are not executed: this is the fraction over the FLOPs the step's MFMA

@@ -135,7 +135,8 @@ int nv_adamw_ranges(const nv_adamw_arena* opt, const long* begins, const long* l
  * heuristic; bm = 1 / 3 forces the warp-specialised 128 x 128 / 64 x 128 tile (bn: ring, 0 = heuristic, 1 = 3 x 64-deep, (3,3) =
  * 3 x 128-deep), bm = 4 the eight-wave 256 x 128 ping-pong kernel, bm = 5 forbids it, bm = 9 the 256 x 256 kernel; (6, n) sets the ping-pong
  * kernel's minimum tile count, (7, 0|1) switches the grouped weight-gradient launch between the two kernel families, (11, 0|1) runs
- * the NT problems of the 256 x 128 kernel on v_mfma_f32_32x32x16_bf16 instead of 16x16x32 */
+ * the NT problems of the 256 x 128 kernel on v_mfma_f32_32x32x16_bf16 instead of 16x16x32, (12, n) = workgroups of nv_gemm_bf16_grouped_adamw (walking its
+ * tiles; 0 = one per tile; default 128), (13, n) = at most n workgroups per nv_adamw_ranges launch (0 = one per 2048-element chunk) */
 int nv_gemm_set_tile(int bm, int bn);
 
 /* ---- Linear layers on a few rows (the cls rows of the last block under pool='cls'): weight-streaming kernels, rows addressed through
@@ -417,10 +418,13 @@ typedef struct nv_train_hparams {
   double lr, beta1, beta2, eps, weight_decay;
   float grad_scale;         /* the update reads grad * grad_scale */
   int accumulate, update;
-  int fuse_update;          /* (revision 5) with update = 1, accumulate = 0: 1 = the Linear weights of the transformer layers are updated by
-                             * their weight-gradient GEMMs (nv_gemm_bf16_grouped_adamw), the rest by nv_adamw_ranges; the gradients of
-                             * those weights are then NOT left in `grads`; 2 = the same and they are; 0 = one nv_adamw_step at the end.
-                             * Parameters, optimizer state and loss are bit-identical in all three */
+  int fuse_update;          /* (revision 5) with update = 1, accumulate = 0: where the Linear weights of the transformer layers (96 % of the
+                             * parameters) are updated.  0 = with everything else, one nv_adamw_step behind the backward pass.
+                             * 3 = per layer, by an AdamW launch on the auxiliary stream behind that layer's weight-gradient GEMMs, while
+                             * the main stream is already in the next layer (gradients stay in `grads`).  1 = by the weight-gradient GEMMs
+                             * themselves (nv_gemm_bf16_grouped_adamw; the gradients of those weights are then NOT left in `grads`),
+                             * 2 = the same and they are.  In 1 .. 3 the rest of the arena is updated by one nv_adamw_ranges launch.
+                             * Parameters, optimizer state and losses are bit-identical in all four */
 } nv_train_hparams;
 int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
                       float* params, void* params16, float* grads, float* adam_m, float* adam_v, void* workspace, long ws_bytes,

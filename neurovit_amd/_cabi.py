@@ -95,6 +95,8 @@ class _Lib:
                 dll.nv_attn_set_mode(int(os.environ["NEUROVIT_ATTN_MODE"]))
             if os.environ.get("NEUROVIT_ADAMW_WGS"):           # A/B aid: workgroups of the weight-gradient launch with the AdamW epilogue
                 dll.nv_gemm_set_tile(12, int(os.environ["NEUROVIT_ADAMW_WGS"]))
+            if os.environ.get("NEUROVIT_ADAMW_CAP"):
+                dll.nv_gemm_set_tile(13, int(os.environ["NEUROVIT_ADAMW_CAP"]))
             self._dll = dll
         return self._dll
 

@@ -642,26 +642,28 @@ extern "C" int nv_vit_backward_stages(const nv_vit_config* cfg, int B, const flo
                                   last_stage, drop_p, emb_drop_p, drop_seed, stream, aux_stream, join_aux, 0);
 }
 
-// fuse != null (nv_vit_train_step, fuse_update): the four Linear weights of every layer are updated by their weight-gradient GEMMs
-// (nv_gemm_bf16_grouped_adamw).  That launch rewrites the bf16 shadow of W_qkv, which the layer's last data-gradient GEMM
-// (dxn1 = dqkv W_qkv) reads: in this mode that GEMM is queued BEFORE the main stream signals the auxiliary one.
+// fuse != null (nv_vit_train_step, fuse_update): the four Linear weights of every layer are updated on the auxiliary stream while the
+// backward pass is still running - fuse_mode 3: by an AdamW launch over those weights queued behind the layer's weight-gradient
+// GEMMs; fuse_mode 1 / 2: by those GEMMs themselves (nv_gemm_bf16_grouped_adamw).  Either rewrites the bf16 shadow of W_qkv, which
+// the layer's last data-gradient GEMM (dxn1 = dqkv W_qkv) reads: in these modes that GEMM is queued BEFORE the main stream signals
+// the auxiliary one.
 static int backward_impl(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                          const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads, void* grads16,
                          int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
-                         unsigned long drop_seed, void* stream, void* aux_stream, int join_aux, int rows_form, const nv_adamw_arena* fuse);
+                         unsigned long drop_seed, void* stream, void* aux_stream, int join_aux, int rows_form, const nv_adamw_arena* fuse, int fuse_mode);
 
 extern "C" int nv_vit_backward_stages16(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                                         const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads, void* grads16,
                                         int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
                                         unsigned long drop_seed, void* stream, void* aux_stream, int join_aux, int rows_form) {
   return backward_impl(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, grads16, accumulate, first_stage, last_stage,
-                       drop_p, emb_drop_p, drop_seed, stream, aux_stream, join_aux, rows_form, nullptr);
+                       drop_p, emb_drop_p, drop_seed, stream, aux_stream, join_aux, rows_form, nullptr, 0);
 }
 
 static int backward_impl(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const float* params,
                          const void* params16, void* workspace, long ws_bytes, const float* dlogits, float* grads, void* grads16,
                          int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
-                         unsigned long drop_seed, void* stream, void* aux_stream, int join_aux, int rows_form, const nv_adamw_arena* fuse) {
+                         unsigned long drop_seed, void* stream, void* aux_stream, int join_aux, int rows_form, const nv_adamw_arena* fuse, int fuse_mode) {
   Dims D; RUN(make_dims(cfg, B, D));
   NV_CHECK_ARG(!fuse || (!accumulate && !grads16 && fuse->grads == grads), "nv_vit_backward: the fused optimizer update needs accumulate = 0, no bf16 mirror, and its own gradient arena");
   ParamTab T; make_params(D, T);
@@ -784,7 +786,12 @@ static int backward_impl(const nv_vit_config* cfg, int B, const float* video, co
       pr[1] = {D.m, d, Mr, du, D.m * rs, ws + w.xn2, d * rs, gr + q.w1, d, acc, M16(q.w1), d};                        // dW1 = dU^T xn2
       pr[2] = {d, D.inner, Mr, g16b, d * rs, ws + w.ao, D.inner * rs, gr + q.wo, D.inner, acc, M16(q.wo), D.inner};   // dWo = g^T ao
       pr[3] = {3 * D.inner, d, M, dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, acc, M16(q.wqkv), d};  // dWqkv = dqkv^T xn1
-      if (fuse) RUN(nv_gemm_bf16_grouped_adamw(4, pr, fuse, sA));
+      if (fuse && fuse_mode == 3) {      // gradients stored as ever; the layer's update as a launch of its own behind the GEMMs, beside the main stream's chain
+        RUN(nv_gemm_bf16_grouped(2, 1, 4, pr, sA));
+        const long b[3] = {q.wqkv, q.w1, q.w2};
+        const long n[3] = {align_up(3L * D.inner * d, 8) + (long)d * D.inner, (long)D.m * d, (long)d * D.m};
+        RUN(nv_adamw_ranges(fuse, b, n, 3, sA));
+      } else if (fuse) RUN(nv_gemm_bf16_grouped_adamw(4, pr, fuse, sA));
       else RUN(nv_gemm_bf16_grouped(2, 1, 4, pr, sA));
     }
     hipEvent_t done = nullptr;
@@ -877,18 +884,19 @@ extern "C" int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* v
   NV_CHECK_ARG(!(in && in->time_points > 0), "nv_vit_train_step: the fused 4D input form is forward-only (the 4D model's encoder is frozen, NeuroEncoder.py:34-36)");
   RUN(nv_vit_forward_in(cfg, B, video, shape5, strides5, in, params, params16, workspace, ws_bytes, 1, drop_p, emb_drop_p, drop_seed, logits, stream));
   RUN(nv_ce_loss(logits, labels, B, cfg->num_classes, 1.f, loss, dlogits, stream));
+  NV_CHECK_ARG(hp->fuse_update >= 0 && hp->fuse_update <= 3, "nv_vit_train_step: fuse_update = %d (0 .. 3)", hp->fuse_update);
   const bool fused = hp->update && !hp->accumulate && hp->fuse_update;
   nv_adamw_arena opt;
   opt.struct_size = (int)sizeof(opt); opt.step = hp->step; opt.lr = hp->lr; opt.beta1 = hp->beta1; opt.beta2 = hp->beta2; opt.eps = hp->eps;
   opt.weight_decay = hp->weight_decay; opt.grad_scale = hp->grad_scale; opt.keep_grads = hp->fuse_update == 2;
   opt.params = params; opt.grads = grads; opt.adam_m = adam_m; opt.adam_v = adam_v; opt.params16 = params16;
   RUN(backward_impl(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, nullptr, hp->accumulate ? 1 : 0, 0, cfg->depth + 1,
-                    drop_p, emb_drop_p, drop_seed, stream, aux_stream, 1, in ? in->rows_form : 0, fused ? &opt : nullptr));
+                    drop_p, emb_drop_p, drop_seed, stream, aux_stream, 1, in ? in->rows_form : 0, fused ? &opt : nullptr, hp->fuse_update));
   if (hp->update && !fused) {
     const long total = nv_vit_param_count(cfg);
     RUN(nv_adamw_step(params, grads, 0, adam_m, adam_v, params16, total, hp->step, hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, hp->grad_scale, 0, stream));
   } else if (fused) {
-    // what the weight-gradient GEMMs did not update: the arena minus the four Linear weights of every layer (arena order:
+    // what was not updated during the backward pass: the arena minus the four Linear weights of every layer (arena order:
     // ... n1b | wqkv | wo | bo n2g n2b | w1 | b1 | w2 | b2 n1g' ...), one launch
     Dims D; RUN(make_dims(cfg, B, D));
     ParamTab T; make_params(D, T);

@@ -77,36 +77,43 @@ constexpr int ADAM_MAX_RANGES = 64, ADAM_CHUNK = 2048;
 struct AdamRanges { long begin[ADAM_MAX_RANGES]; long len[ADAM_MAX_RANGES]; int chunk_end[ADAM_MAX_RANGES]; int count; };
 __global__ __launch_bounds__(256) void adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
                                                            float* __restrict__ v, bf16* __restrict__ p16, const AdamRanges R, AdamArgs a) {
+  const int chunks = R.chunk_end[ADAM_MAX_RANGES - 1];
   int r = 0;
-  while (r + 1 < R.count && (int)blockIdx.x >= R.chunk_end[r]) ++r;       // workgroup-uniform
-  const long c0 = (long)((int)blockIdx.x - (r ? R.chunk_end[r - 1] : 0)) * ADAM_CHUNK;
-  const long base = R.begin[r] + c0, n4 = min((long)ADAM_CHUNK, R.len[r] - c0) / 4;
-  constexpr int U = ADAM_CHUNK / (256 * 4);
-  f32x4 pv[U], gv[U], mv[U], vv[U];
+  for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {      // (a capped grid walks the chunks: few CUs for an HBM-bound pass)
+    while (r + 1 < R.count && chunk >= R.chunk_end[r]) ++r;                // workgroup-uniform
+    const long c0 = (long)(chunk - (r ? R.chunk_end[r - 1] : 0)) * ADAM_CHUNK;
+    const long base = R.begin[r] + c0, n4 = min((long)ADAM_CHUNK, R.len[r] - c0) / 4;
+    constexpr int U = ADAM_CHUNK / (256 * 4);
+    f32x4 pv[U], gv[U], mv[U], vv[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const long i = threadIdx.x + 256 * u;
-    if (i < n4) {
-      pv[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p + base) + i);
-      gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grad + base) + i) * a.grad_scale;
-      mv[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m + base) + i);
-      vv[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v + base) + i);
+    for (int u = 0; u < U; ++u) {
+      const long i = threadIdx.x + 256 * u;
+      if (i < n4) {
+        pv[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p + base) + i);
+        gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grad + base) + i) * a.grad_scale;
+        mv[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m + base) + i);
+        vv[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v + base) + i);
+      }
     }
-  }
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const long i = threadIdx.x + 256 * u;
-    if (i < n4) {
-      adamw_update4(pv[u], gv[u], mv[u], vv[u], a);
-      __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(p + base) + i);
-      __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(m + base) + i);
-      __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v + base) + i);
-      reinterpret_cast<bf16x4*>(p16 + base)[i] = cvt4(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
+    for (int u = 0; u < U; ++u) {
+      const long i = threadIdx.x + 256 * u;
+      if (i < n4) {
+        adamw_update4(pv[u], gv[u], mv[u], vv[u], a);
+        __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(p + base) + i);
+        __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(m + base) + i);
+        __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v + base) + i);
+        reinterpret_cast<bf16x4*>(p16 + base)[i] = cvt4(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
+      }
     }
   }
 }
 
+int g_adamw_ranges_cap = 0;      // tuning aid (nv_gemm_set_tile(13, n)): at most n workgroups per nv_adamw_ranges launch, walking the chunks (0 = one per chunk).
+                                 // ViT3D-base batch 4, per-layer launches of fuse_update = 3: 16 -> 502 volumes/s, 32 -> 754, 64 -> 1000, 128 -> 1110,
+                                 // 256 ... 2048 and uncapped (3456) 1140 ... 1170: the update must not become the auxiliary stream's critical path
 extern "C" int nv_adamw_ranges(const nv_adamw_arena* opt, const long* begins, const long* lens, int count, void* stream) {
+  const int max_blocks = g_adamw_ranges_cap;
   NV_CHECK_ARG(opt && opt->struct_size == (int)sizeof(nv_adamw_arena), "nv_adamw_ranges: nv_adamw_arena.struct_size = %d, this library expects %d (ABI revision %d)",
                opt ? opt->struct_size : -1, (int)sizeof(nv_adamw_arena), NV_ABI_VERSION);
   NV_CHECK_ARG(opt->params && opt->grads && opt->adam_m && opt->adam_v && opt->params16 && opt->step >= 1 && count >= 0 && (count == 0 || (begins && lens)),
@@ -127,7 +134,8 @@ extern "C" int nv_adamw_ranges(const nv_adamw_arena* opt, const long* begins, co
     if (!n) continue;
     R.count = n;
     for (int i = n; i < ADAM_MAX_RANGES; ++i) { R.begin[i] = 0; R.len[i] = 0; R.chunk_end[i] = chunks; }
-    hipLaunchKernelGGL(adamw_ranges_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, opt->params, opt->grads, opt->adam_m, opt->adam_v,
+    const int blocks = (max_blocks > 0 && max_blocks < chunks) ? max_blocks : chunks;
+    hipLaunchKernelGGL(adamw_ranges_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, opt->params, opt->grads, opt->adam_m, opt->adam_v,
                        (bf16*)opt->params16, R, a);
     NV_CHECK_LAUNCH("nv_adamw_ranges");
   }

@@ -23,22 +23,25 @@ from .parallel import GradSync, broadcast_parameters
 
 
 class TrainStep:
-    FUSE_MAX_ROWS = 4096      # fuse_update=None: token rows (batch x tokens) up to which the update runs inside the weight-gradient GEMMs
+    FUSE_MAX_ROWS = 4096      # fuse_update=None: token rows (batch x tokens) up to which the layers' weights are updated during the backward pass
 
     def __init__(self, model: NeuroEncoder, lr: Optional[float] = None, weight_decay: Optional[float] = None, process_group=None,
                  n_buckets: int = 4, accumulation_steps: int = 1, overlap_optimizer: bool = False,
                  grad_comm_dtype: torch.dtype = torch.float32, grad_comm_algo: Optional[str] = None, fuse_update: Optional[int] = None):
         cfg = model.config
-        # native step only: 1 = AdamW of the layers' Linear weights inside their weight-gradient GEMMs (p.grad of those weights is then
-        # None, never a stale tensor - torch's optimizer-in-backward trade; nothing on the reference path reads it: Trainer.py:72 clears
-        # the gradients at the start of the next step), 2 = the same with the gradients still stored, 0 = one AdamW launch behind the
-        # backward pass.  None (default; NEUROVIT_FUSE_UPDATE unset) = by batch: 1 up to FUSE_MAX_ROWS token rows per step, 0 above -
-        # ViT3D-base, same box, volumes/s unfused -> fused: batch 2 644 -> 696 (+8 %), 4: 1094 -> 1124 (+2.7 %), 8: 1429 -> 1425,
-        # 16: 1824 -> 1783 (-2.3 %), 32: 1987 -> 1932; ViT3D-large batch 4 (16 388 rows) 52.1 -> 51.9: small batches leave CUs idle
-        # beside the HBM-bound epilogues, large ones do not (profiles/r04_adamw_in_wgrad_epilogue.log)
+        # native step only - where AdamW runs for the layers' Linear weights (96 % of the parameters); same bits in every mode:
+        #   0  with the rest of the arena, one launch behind the backward pass
+        #   3  per layer on the auxiliary stream, behind that layer's weight-gradient GEMMs, beside the main stream's chain
+        #   1  inside those GEMMs' epilogues (nv_gemm_bf16_grouped_adamw; .grad of those weights is then None - torch's
+        #      optimizer-in-backward trade), 2 = the same with the gradients still stored
+        # None (default; NEUROVIT_FUSE_UPDATE unset) = by batch: 3 up to FUSE_MAX_ROWS token rows per step, 0 above.  ViT3D-base, same
+        # box, volumes/s mode 0 -> 3: batch 2 641 -> 655 (+2.3 %), 4: 1126 -> 1157 (+2.8 ... +3.7 %), 8: 1390 -> 1382, 16: 1780 -> 1749,
+        # 32: 1940 -> 1923; ViT3D-large 53.8 -> 53.3 - small batches leave wave slots and memory bandwidth idle beside the chain, large
+        # ones do not.  Mode 1 at batch 2 / 4: +8 % / +2.5 % (profiles/r04_adamw_in_wgrad_epilogue.log)
         env = os.environ.get("NEUROVIT_FUSE_UPDATE")
         self.fuse_update = (int(env) if env is not None else None) if fuse_update is None else int(fuse_update)
-        assert self.fuse_update in (None, 0, 1, 2), "fuse_update: None (by batch), 0, 1 or 2"
+        assert self.fuse_update in (None, 0, 1, 2, 3), "fuse_update: None (by batch), 0, 1, 2 or 3"
+        self.last_fuse_update = 0          # what the most recent native step did
         self.model = model
         self.criterion = CrossEntropyLoss()
         lr = cfg.get("TRAINING_LEARNING_RATE", 1e-4) if lr is None else lr
@@ -225,9 +228,10 @@ class TrainStep:
         # the update inside the weight-gradient GEMMs: only a step that overwrites its gradients AND updates (no accumulation window)
         fuse = self.fuse_update
         if fuse is None:
-            fuse = 1 if fmri.shape[0] * vit.pos_embedding.shape[1] <= self.FUSE_MAX_ROWS else 0
+            fuse = 3 if fmri.shape[0] * vit.pos_embedding.shape[1] <= self.FUSE_MAX_ROWS else 0
         if self.accumulation_steps != 1 or vit._phantom:
             fuse = 0
+        self.last_fuse_update = fuse
         accumulate = self._micro > 0        # the first micro-step of a window overwrites (zero_grad(set_to_none=True), Trainer.py:72), the others add
         loss, logits = vit._rt.train_step(video, labels.contiguous(), arena, shadow, grads, m, v, step=max(opt._steps, 1), lr=g0["lr"], betas=g0["betas"],
                                           eps=g0["eps"], weight_decay=g0["weight_decay"], grad_scale=1.0, accumulate=accumulate, update=last_micro,

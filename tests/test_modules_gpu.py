@@ -299,7 +299,7 @@ def test_native_train_step_equals_the_general_path_bitwise(nv, case):
         model = nv.NeuroEncoder(cfg)
         model.load_state_dict(W.make_tensors(W.vit_param_spec(**W.MICRO), 1, prefix="volume_encoder.vit3d."), strict=True)
         model.train()
-        step = TrainStep(model, accumulation_steps=acc, fuse_update=0)     # (the gradient arena is compared: the fused update, tested below, does not write all of it)
+        step = TrainStep(model, accumulation_steps=acc)
         if not native:
             step._native = False
         torch.manual_seed(11)
@@ -317,21 +317,23 @@ def test_native_train_step_equals_the_general_path_bitwise(nv, case):
 
 
 @pytest.mark.parametrize("case", ["plain", "accumulate2", "dropout"])
-def test_native_train_step_with_adamw_inside_the_weight_gradient_gemms_bitwise(nv, case):
-    """TrainStep(fuse_update = 1 | 2): the four Linear weights of every layer are updated by the epilogue of their weight-gradient
-    GEMMs (nv_gemm_bf16_grouped_adamw; the layer's dxn1 GEMM, last reader of the bf16 weights, is queued ahead of it) and the rest
-    of the arena by nv_adamw_ranges - against the native step with one AdamW launch at the end: losses, logits, parameters, bf16
-    shadow, both moments and the Grad-CAM hook gradient bit for bit over three steps; mode 2 also leaves the same gradient arena,
-    mode 1 leaves the same gradients outside those weights.  (accumulate2: a window's last micro-step ADDS to the gradients, so
-    it keeps the separate update - the switch must then change nothing.)"""
+def test_native_train_step_with_adamw_during_the_backward_pass_bitwise(nv, case):
+    """TrainStep(fuse_update = 3 | 1 | 2): the four Linear weights of every layer are updated while the backward pass is still running -
+    3: by a per-layer AdamW launch on the auxiliary stream behind the layer's weight-gradient GEMMs; 1 / 2: by the epilogue of those
+    GEMMs (nv_gemm_bf16_grouped_adamw); the layer's dxn1 GEMM, last reader of the bf16 weights, is queued ahead either way, and the
+    rest of the arena is updated by nv_adamw_ranges - against the native step with one AdamW launch at the end (0): losses, logits,
+    parameters, bf16 shadow, both moments and the Grad-CAM hook gradient bit for bit over three steps; modes 2 and 3 also leave
+    the same gradient arena, mode 1 the same gradients outside those weights (and no .grad on them).  (accumulate2: a window's
+    last micro-step ADDS to the gradients, so it keeps the separate update - the switch must then change nothing.)  The default
+    (None) picks mode 3 for a batch this small."""
     from neurovit_amd.trainer import TrainStep
     drop = 0.1 if case == "dropout" else 0.0
     acc = 2 if case == "accumulate2" else 1
     size = dict(TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
     x = W.make_volume((2, 32, 32, 32), 2).cuda()
     y = torch.tensor([1, 0], device="cuda")
-    runs = []
-    for fuse in (0, 1, 2):
+    runs = {}
+    for fuse in (0, 1, 2, 3, None):
         cfg = W.neuro_config(32, 8, DEVICE="cuda", TRAINING_DROPOUT=drop, TRAINING_LEARNING_RATE=1e-3, TRAINING_WEIGHT_DECAY=1e-2, **size)
         model = nv.NeuroEncoder(cfg)
         model.load_state_dict(W.make_tensors(W.vit_param_spec(**W.MICRO), 1, prefix="volume_encoder.vit3d."), strict=True)
@@ -340,27 +342,24 @@ def test_native_train_step_with_adamw_inside_the_weight_gradient_gemms_bitwise(n
         torch.manual_seed(11)
         losses = [step(x, y).clone() for _ in range(3 * acc)]
         assert step._native, "the 3D single-process step must take the native call"
+        assert step.last_fuse_update == (0 if acc > 1 else (3 if fuse is None else fuse))
         vit = model.volume_encoder.vit3d
         m, v = step.optimizer.arena_state(vit)
-        runs.append((torch.stack(losses), step.last_outputs.clone(), vit.flat_parameters()[0].clone(), vit.flat_parameters()[1].clone(), m.clone(), v.clone(),
-                     model.gradients.clone(), vit.flat_gradients().clone()))
+        runs[fuse] = (torch.stack(losses), step.last_outputs.clone(), vit.flat_parameters()[0].clone(), vit.flat_parameters()[1].clone(), m.clone(), v.clone(),
+                      model.gradients.clone(), vit.flat_gradients().clone(), [i for i, p in enumerate(vit._plist) if p.grad is None])
     names = ("losses", "logits", "parameters", "bf16 shadow", "exp_avg", "exp_avg_sq", "hook gradient")
-    for fuse in (1, 2):
+    for fuse in (1, 2, 3, None):
         for i, name in enumerate(names):
             assert torch.equal(runs[0][i], runs[fuse][i]), f"{case}: fuse_update={fuse}: {name} differ from the separate update"
-    assert torch.equal(runs[0][7], runs[2][7]), "fuse_update=2 must leave the gradient arena of the separate update"
-    vit = model.volume_encoder.vit3d
+    for fuse in (2, 3, None):
+        assert torch.equal(runs[0][7], runs[fuse][7]), f"fuse_update={fuse} must leave the gradient arena of the separate update"
+        assert runs[fuse][8] == []
     off, num, _ = vit._layout
-    small = [i for i, p in enumerate(vit._plist) if p.dim() < 2]
-    for i in small:
+    for i in [i for i, p in enumerate(vit._plist) if p.dim() < 2]:
         assert torch.equal(runs[0][7][off[i]:off[i] + num[i]], runs[1][7][off[i]:off[i] + num[i]])
-    if acc == 1:      # the model of the last run (fuse_update=2) has every .grad; a fuse_update=1 step has none for the fused weights, all others
-        assert all(p.grad is not None for p in vit._plist)
-        step1 = TrainStep(model, fuse_update=1)
-        step1(x, y)
-        none = [i for i, p in enumerate(vit._plist) if p.grad is None]
-        assert none == sorted(8 + 11 * l + k for l in range(2) for k in (2, 3, 7, 9)) and all(vit._plist[i].dim() == 2 for i in none)
-    report(f"native train step, AdamW inside the weight-gradient GEMMs [{case}] == separate AdamW (losses, logits, p, shadow, m, v: bitwise)")
+    fused_weights = sorted(8 + 11 * l + k for l in range(2) for k in (2, 3, 7, 9))
+    assert runs[1][8] == ([] if acc > 1 else fused_weights) and all(vit._plist[i].dim() == 2 for i in fused_weights)
+    report(f"native train step, AdamW of the layers' weights during the backward pass [{case}] == separate AdamW (losses, logits, p, shadow, m, v: bitwise; modes 1, 2, 3)")
 
 
 def test_graph_replayed_train_step_equals_eager_launches_bitwise(nv, monkeypatch):
@@ -374,7 +373,7 @@ def test_graph_replayed_train_step_equals_eager_launches_bitwise(nv, monkeypatch
     for graphs in ("1", "0"):
         monkeypatch.setenv("NEUROVIT_GRAPH_STEP", graphs)
         model = _micro_model(nv)
-        step = TrainStep(model, fuse_update=2)      # (eager steps: update inside the gradient GEMMs, gradients still stored - the arena is compared)
+        step = TrainStep(model)
         losses = [step(xs[i % 2], ys[i % 2]).clone() for i in range(10)]
         vit = model.volume_encoder.vit3d
         runs.append((torch.stack(losses), vit.flat_gradients().clone(), vit.flat_parameters()[0].clone(), len(step._graphs), model.gradients))
