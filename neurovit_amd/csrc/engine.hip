@@ -665,7 +665,8 @@ static int backward_impl(const nv_vit_config* cfg, int B, const float* video, co
                          int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
                          unsigned long drop_seed, void* stream, void* aux_stream, int join_aux, int rows_form, const nv_adamw_arena* fuse, int fuse_mode) {
   Dims D; RUN(make_dims(cfg, B, D));
-  NV_CHECK_ARG(!fuse || (!accumulate && !grads16 && fuse->grads == grads), "nv_vit_backward: the fused optimizer update needs accumulate = 0, no bf16 mirror, and its own gradient arena");
+  NV_CHECK_ARG(!fuse || (!accumulate && !grads16 && fuse->grads == grads && first_stage == 0 && last_stage == D.L + 1),
+               "nv_vit_backward: the optimizer update during the backward pass needs accumulate = 0, no bf16 mirror, its own gradient arena and every stage in one call");
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 1, W);
   NV_CHECK_ARG(video && strides5 && params && params16 && workspace && dlogits && grads, "nv_vit_backward: null pointer");
@@ -716,6 +717,14 @@ static int backward_impl(const nv_vit_config* cfg, int B, const float* video, co
   hipEvent_t prev_done = carry_take(workspace);     // everything the previous (higher) layer queued on [A] - in the previous, unjoined call
   bool layers_here = false;
   int pending_ln1 = -1;               // layer whose LN1-backward partials still wait for their reduction
+  int pending_adam = -1;              // fuse_mode 3: layer whose weights are updated at the NEXT signal - the main stream orders a layer's dxn1 GEMM (last
+                                      // reader of its bf16 weights) behind the signal of that layer, so the update waits for the one after it
+  auto layer_update = [&](int lu) -> int {
+    const LayerP& qu = T.layer[lu];
+    const long b[3] = {qu.wqkv, qu.w1, qu.w2};
+    const long n[3] = {align_up(3L * D.inner * d, 8) + (long)d * D.inner, (long)D.m * d, (long)d * D.m};
+    return nv_adamw_ranges(fuse, b, n, 3, sA);
+  };
   auto reduce_ln1 = [&](int lp) -> int {
     const LayerP& qp = T.layer[lp];
     return nv_ln_bwd_reduce(RED3(lp), M, d, gr + qp.n1g, gr + qp.n1b, (lp > 0) ? gr + T.layer[lp - 1].b2 : nullptr, acc, sA);
@@ -758,10 +767,12 @@ static int backward_impl(const nv_vit_config* cfg, int B, const float* video, co
     RUN(nv_attn_bwd(ws + w.qkv, 3 * D.inner, ws + w.ao, ws + W.dao, D.inner, (float*)(ws + w.lse), B, D.n, D.heads, D.dh, scale,
                     (float*)(ws + W.delta), dqkv, 3 * D.inner, site_seed(drop_seed, 4 * l + 0), drop_p, stream));
     float* dxn1 = (l == D.L - 1) ? (float*)(ws + W.hookg) : dxn;    // gradient of the last block's attention-LN output is kept (Grad-CAM hook)
-    if (fuse)      // the last reader of this layer's bf16 weights, ahead of the launch that rewrites them (see above)
+    const bool dxn1_first = fuse && fuse_mode != 3;
+    if (dxn1_first)      // the last reader of this layer's bf16 weights, ahead of the launch that rewrites them (see above)
       RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
     // ---- [A] everything of this layer that only finishes parameter gradients
     if (forked) RUN(stream_sync(S, A));                                                                                        // dU, g16b, dqkv (and the LN partials) ready
+    if (pending_adam >= 0) { RUN(layer_update(pending_adam)); pending_adam = -1; }      // [A] fuse_mode 3: the layer above, whose last reader (its dxn1 GEMM) ran before this signal
     {
       // [A] ONE launch for every small parameter gradient that is final by now: db1 (column sums of dU), dLN2 affine + dbo
       // (= colsum(g)), and dLN1 affine + db2 of the layer above (whose partials were written after that layer's block ran)
@@ -786,17 +797,15 @@ static int backward_impl(const nv_vit_config* cfg, int B, const float* video, co
       pr[1] = {D.m, d, Mr, du, D.m * rs, ws + w.xn2, d * rs, gr + q.w1, d, acc, M16(q.w1), d};                        // dW1 = dU^T xn2
       pr[2] = {d, D.inner, Mr, g16b, d * rs, ws + w.ao, D.inner * rs, gr + q.wo, D.inner, acc, M16(q.wo), D.inner};   // dWo = g^T ao
       pr[3] = {3 * D.inner, d, M, dqkv, 3 * D.inner, ws + w.xn1, d, gr + q.wqkv, d, acc, M16(q.wqkv), d};  // dWqkv = dqkv^T xn1
-      if (fuse && fuse_mode == 3) {      // gradients stored as ever; the layer's update as a launch of its own behind the GEMMs, beside the main stream's chain
+      if (fuse && fuse_mode == 3) {      // gradients stored as ever; the layer's update follows as a launch of its own, one signal later
         RUN(nv_gemm_bf16_grouped(2, 1, 4, pr, sA));
-        const long b[3] = {q.wqkv, q.w1, q.w2};
-        const long n[3] = {align_up(3L * D.inner * d, 8) + (long)d * D.inner, (long)D.m * d, (long)d * D.m};
-        RUN(nv_adamw_ranges(fuse, b, n, 3, sA));
+        pending_adam = l;
       } else if (fuse) RUN(nv_gemm_bf16_grouped_adamw(4, pr, fuse, sA));
       else RUN(nv_gemm_bf16_grouped(2, 1, 4, pr, sA));
     }
     hipEvent_t done = nullptr;
     if (forked) { done = deferred_event(); if (!done || hipEventRecord(done, A) != hipSuccess) { nv_set_error("nv_vit_backward: event record failed"); return NV_ERR_HIP; } }
-    if (!fuse)
+    if (!dxn1_first)
       RUN(nv_gemm_bf16(1, 1, M, d, 3 * D.inner, dqkv, 3 * D.inner, p16 + q.wqkv, d, dxn1, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
     // LN1 backward writes the residual gradient of layer l-1 into the buffer copy layer l+1 used (and layer l-1 then rewrites
     // the rest of that copy): the auxiliary work of layer l+1 - a whole layer behind by now - must have finished with it.
@@ -836,6 +845,7 @@ static int backward_impl(const nv_vit_config* cfg, int B, const float* video, co
   // the main stream meanwhile produces the patch-embedding weight gradient
   if (forked) RUN(stream_sync(S, A));                                                                                          // dt16 and layer 0's LN1 partials ready
   if (pending_ln1 >= 0) RUN(reduce_ln1(pending_ln1));
+  if (pending_adam >= 0) { RUN(layer_update(pending_adam)); pending_adam = -1; }                                                // [A] layer 0's weights
   RUN(nv_gemm_bf16(1, 1, D.T, D.Ppad, d, ws + W.dt16, d, wpe, D.Ppad, ws + W.dxp, D.Ppad, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, sA));              // [A] dxp = dt Wpe
   RUN(nv_patch_ln_bwd(video, strides5, B, cfg->channels, cfg->frames, cfg->image_size, img_w(cfg), cfg->image_patch_size,
                       pat_w(cfg), cfg->frame_patch_size, (float*)(ws + W.dxp), D.Ppad, pst, pst + D.T, gr + T.pe_g, gr + T.pe_b, acc, redA,

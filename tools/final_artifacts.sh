@@ -28,5 +28,5 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1
 T=$(find $OUT/stats -name "*kernel_trace.csv" | head -1)
-python3 $R/tools/trace_timeline.py $T 8 --summary > $OUT/timeline_summary.txt || true
+python3 $R/tools/trace_timeline.py $T 18 --summary > $OUT/timeline_summary.txt || true
 echo done

@@ -2,7 +2,7 @@
 """Timeline of ONE train step from a rocprofv3 --kernel-trace CSV: every dispatch in start order with its stream / queue, duration,
 the gap to the previous dispatch's end on the same queue and the idle time of the whole device in front of it.
 usage: trace_timeline.py <kernel_trace.csv> [step-index-from-the-end = 2] [--summary]
-A step is delimited by the optimizer launch that ends it (adamw_kernel, or adamw_ranges_kernel behind a fused backward)."""
+A step starts at its patch_ln_fwd_kernel dispatch and ends in front of the next one."""
 import csv
 import sys
 
@@ -13,14 +13,14 @@ rows = list(csv.DictReader(open(path)))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-ends = [i for i, r in enumerate(rows) if "adamw_kernel<" in r["Kernel_Name"] or "adamw_ranges_kernel" in r["Kernel_Name"]]      # (not the GEMM with the update in its epilogue)
-if len(ends) < back + 1:
-    sys.exit(f"only {len(ends)} optimizer launches in the trace")
-lo, hi = ends[-back - 1] + 1, ends[-back]
+starts = [i for i, r in enumerate(rows) if "patch_ln_fwd_kernel" in r["Kernel_Name"]]      # first kernel of a (training or inference) forward
+if len(starts) < back + 2:
+    sys.exit(f"only {len(starts)} forward passes in the trace")
+lo, hi = starts[-back - 1], starts[-back] - 1
 step = rows[lo:hi + 1]
 t0 = step[0]["s"]
 qkey = "Queue_Id" if "Queue_Id" in step[0] else ("Stream_Id" if "Stream_Id" in step[0] else None)
-last_end_q, dev_end = {}, rows[lo - 1]["e"]
+last_end_q, dev_end = {}, rows[lo - 1]["e"] if lo > 0 else rows[lo]["s"]
 busy, gaps, n = 0, 0, 0
 per = {}
 union = 0
@@ -38,7 +38,7 @@ for r in step:
     last_end_q[q] = r["e"]
     dev_end = max(dev_end, r["e"])
     gaps += idle; n += 1
-span = (step[-1]["e"] - rows[lo - 1]["e"]) / 1e3
+span = (max(r["e"] for r in step) - (rows[lo - 1]["e"] if lo > 0 else step[0]["s"])) / 1e3
 print(f"# step: {n} dispatches, span {span:.1f} us, device busy (union) {union / 1e3:.1f} us, device idle {gaps:.1f} us, sum of durations {sum(v[1] for v in per.values()):.1f} us")
 for name, (c, d, i) in sorted(per.items(), key=lambda kv: -kv[1][1]):
     print(f"# {d:9.1f} us  {c:4d} x {d / c:8.2f} us   idle before {i:7.1f} us   {name}")
