@@ -254,6 +254,15 @@ int nv_head_bwd(const float* dlogits, int B, int C, const float* W, const float*
                 const float* xh, const float* gamma, int d, int n, float* g, long ldg, void* g16, long ldg16, float* dgamma,
                 float* dbeta, float* dW, float* dbias, float* dcolsum, int accumulate, void* workspace, long ws_bytes,
                 unsigned long drop_seed, float drop_p, int pool_mean, void* stream);
+/* nv_head_fwd + nv_ce_loss + nv_head_bwd (pool = 'cls') in TWO launches instead of five, every output bit-identical to the three calls
+ * (launch 1: one workgroup per volume runs the bodies of their per-volume kernels back to back, the other workgroups clear g / g16
+ * outside the cls rows; launch 2: every sum over the volumes): mlp_head forward, nn.CrossEntropyLoss (mean) and their backward,
+ * vit_3d.py:118-123,128-130 + Trainer.py:70,74.  workspace: nv_head_step_workspace_bytes(B, d). */
+long nv_head_step_workspace_bytes(int B, int d);
+int nv_head_step(const float* x, long row_stride, int B, int d, const float* gamma, const float* beta, float eps, const float* W,
+                 const float* bias, int C, const long* labels, float grad_scale, float* xh, float* stats, float* logits, float* loss,
+                 float* dlogits, int n, float* g, long ldg, void* g16, long ldg16, float* dgamma, float* dbeta, float* dW, float* dbias,
+                 float* dcolsum, int accumulate, void* workspace, long ws_bytes, unsigned long drop_seed, float drop_p, void* stream);
 /* pool='mean' (vit_3d.py:127): out[b,:] = mean_t x[b,t,:]; feed it to nv_head_fwd / nv_head_bwd with row_stride = d
    and pool_mean = 1 (every row of g then receives dx / n) */
 int nv_token_mean(const float* x, int B, int n, int d, float* out, void* stream);
@@ -403,6 +412,7 @@ int nv_vit_stage_param_range(const nv_vit_config* cfg, int stage, long* begin, l
  * are not produced.  The form is chosen PER CALL by rows_form (nv_vit_input / nv_vit_backward_stages16); this sets the process
  * default used by rows_form = 0 and by the entry points without that argument: 1 (initial) = cls rows, 0 = every row. */
 int nv_vit_set_cls_tail(int on);
+int nv_vit_set_head_step(int on);   /* A/B aid: 0 = nv_vit_train_step runs the head as nv_head_fwd + nv_ce_loss + nv_head_bwd (same bits), 1 (default) = nv_head_step */
 
 /* ---- the reference's whole train step (src/Trainer.py:65-79) as ONE call: ViT forward (training layout) -> nn.CrossEntropyLoss
  * (mean) -> backward of every stage -> torch.optim.AdamW update of the whole arena (+ bf16 shadow refresh).  ~225 kernel launches

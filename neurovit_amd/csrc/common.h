@@ -154,6 +154,35 @@ __device__ __forceinline__ float drop_factor(const DropCfg& d, unsigned long lon
   return (field >= d.thresh) ? d.scale : 0.f;
 }
 
+// ---- nn.CrossEntropyLoss of ONE row (256 threads, every thread returns the row's loss term): shared by ce_loss_kernel (optim.hip) and the
+// fused head step (norm.hip) so that both produce the same bits.  red: 4 floats of LDS.  dl (optional): d(loss)/d(logits) of the row.
+// torch raises a device-side assert for a label outside [0, C); here nothing may read out of bounds or abort the stream: the term is
+// NaN (visible at the first .item()) and the row's gradient is that of no target.
+__device__ __forceinline__ float ce_row_term(const float* __restrict__ row, long tl, int C, float gscale_over_B, float* red, float* __restrict__ dl) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float mx = -INFINITY;
+  for (int c = tid; c < C; c += 256) mx = fmaxf(mx, row[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) red[wid] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int c = tid; c < C; c += 256) se += expf(row[c] - mx);
+  se = wave_sum(se);
+  if (lane == 0) red[wid] = se;
+  __syncthreads();
+  se = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  const bool t_ok = tl >= 0 && tl < (long)C;
+  const int t = t_ok ? (int)tl : -1;
+  const float term = t_ok ? (mx + logf(se)) - row[t] : __builtin_nanf("");
+  if (dl)
+    for (int c = tid; c < C; c += 256) dl[c] = (expf(row[c] - mx) / se - (c == t ? 1.f : 0.f)) * gscale_over_B;
+  return term;
+}
+
 // ---- AdamW (torch.optim.AdamW, Trainer.py:31,75), shared by the streaming kernel (optim.hip) and the weight-gradient GEMM epilogue
 // that applies the update in place (gemm_common.h EPI_ADAMW): ONE definition, so both forms produce the same bits.
 // Every derived constant is formed in double on the host, as torch does, then rounded once.

@@ -35,6 +35,8 @@ struct Dims {
 // that records no graph (the frozen encoder of the 4D model under Trainer.train, config4D.yaml TRAINING_DROPOUT 0.2).
 static int g_cls_tail = 1;
 extern "C" int nv_vit_set_cls_tail(int on) { g_cls_tail = on ? 1 : 0; return 0; }
+static int g_head_step = 1;      // nv_vit_train_step: head forward + loss + head backward as one launch (nv_head_step) where it exists
+extern "C" int nv_vit_set_head_step(int on) { g_head_step = on ? 1 : 0; return 0; }
 static bool cls_tail_wanted(const Dims& D, int training, float drop_p, int rows_form) {
   const bool want = rows_form == 1 ? false : (rows_form == 2 ? true : g_cls_tail != 0);
   return want && !D.pool_mean && drop_p == 0.f && (!training || D.B <= 4);
@@ -128,7 +130,7 @@ void make_ws(const Dims& D, int training, WS& W) {
     W.dt = add(T * d * 4); W.dt16 = add(T * d * 2); W.dxp = add(T * D.Ppad * 4);
     W.dwpe = (D.P != D.Ppad) ? add(d * D.Ppad * 4) : -1;
     long r = nv_ln_bwd_workspace_bytes(D.M, D.d);
-    const long r2 = nv_patch_ln_bwd_workspace_bytes(D.T, D.P), r3 = nv_head_bwd_workspace_bytes(D.B, D.d),
+    const long r2 = nv_patch_ln_bwd_workspace_bytes(D.T, D.P), r3 = nv_head_step_workspace_bytes(D.B, D.d),
                r4 = nv_colsum_workspace_bytes(D.M, D.m);
     r = r > r2 ? r : r2; r = r > r3 ? r : r3; r = r > r4 ? r : r4;
     W.red_bytes = r; W.red = add(r);
@@ -280,9 +282,20 @@ extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* vide
   return nv_vit_forward_in(cfg, B, video, shape5, strides5, nullptr, params, params16, workspace, ws_bytes, training, drop_p, emb_drop_p, drop_seed, logits, stream);
 }
 
+static int forward_in_impl(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
+                           const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
+                           unsigned long drop_seed, float* logits, void* stream, bool skip_head);
+
 extern "C" int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
                                  const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
                                  unsigned long drop_seed, float* logits, void* stream) {
+  return forward_in_impl(cfg, B, video, shape5, strides5, in, params, params16, workspace, ws_bytes, training, drop_p, emb_drop_p, drop_seed, logits, stream, false);
+}
+
+// skip_head: everything up to the last block's output; the caller runs the head itself (nv_vit_train_step: nv_head_step)
+static int forward_in_impl(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
+                           const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
+                           unsigned long drop_seed, float* logits, void* stream, bool skip_head) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, training, W);
@@ -348,6 +361,7 @@ extern "C" int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* v
     RUN(nv_gemm_bf16(0, 4, M, d, D.m, ws + w.h, D.m, p16 + q.w2, D.m, x2, d, p + q.b2, x1, d, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 3), drop_p, stream));
     xin = x2;
   }
+  if (skip_head) return NV_OK;
   // A9: cls pooling + LayerNorm + Linear(dim, C)
   const float* pooled = xin;
   long pooled_stride = (long)D.n * d;
@@ -665,7 +679,7 @@ static int backward_impl(const nv_vit_config* cfg, int B, const float* video, co
                          int accumulate, int first_stage, int last_stage, float drop_p, float emb_drop_p,
                          unsigned long drop_seed, void* stream, void* aux_stream, int join_aux, int rows_form, const nv_adamw_arena* fuse, int fuse_mode) {
   Dims D; RUN(make_dims(cfg, B, D));
-  NV_CHECK_ARG(!fuse || (!accumulate && !grads16 && fuse->grads == grads && first_stage == 0 && last_stage == D.L + 1),
+  NV_CHECK_ARG(!fuse || (!accumulate && !grads16 && fuse->grads == grads && first_stage <= 1 && last_stage == D.L + 1),
                "nv_vit_backward: the optimizer update during the backward pass needs accumulate = 0, no bf16 mirror, its own gradient arena and every stage in one call");
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 1, W);
@@ -700,7 +714,7 @@ static int backward_impl(const nv_vit_config* cfg, int B, const float* video, co
   hipStream_t A = aux_stream ? (hipStream_t)aux_stream : S;       // weight-gradient stream (== S: fully serial)
   void* sA = (void*)A;
   const bool forked = (A != S);
-  if (forked) RUN(stream_sync(S, A));                              // everything before this call is visible to A
+  // (no S -> A ordering here: everything the auxiliary stream does in this call is queued behind a signal of the main stream below)
 
   NV_CHECK_ARG(first_stage >= 0 && last_stage <= D.L + 1 && first_stage <= last_stage, "nv_vit_backward_stages: bad stage range [%d, %d]", first_stage, last_stage);
   // head: writes g (zeros + cls rows) and the last layer's FC2 bias gradient (colsum of g)
@@ -892,15 +906,29 @@ extern "C" int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* v
                hp ? hp->struct_size : -1, (int)sizeof(nv_train_hparams), NV_ABI_VERSION);
   NV_CHECK_ARG(labels && loss && dlogits && grads && (!hp->update || (adam_m && adam_v && hp->step >= 1)), "nv_vit_train_step: null pointer (labels / loss / dlogits / grads / optimizer state) or step < 1");
   NV_CHECK_ARG(!(in && in->time_points > 0), "nv_vit_train_step: the fused 4D input form is forward-only (the 4D model's encoder is frozen, NeuroEncoder.py:34-36)");
-  RUN(nv_vit_forward_in(cfg, B, video, shape5, strides5, in, params, params16, workspace, ws_bytes, 1, drop_p, emb_drop_p, drop_seed, logits, stream));
-  RUN(nv_ce_loss(logits, labels, B, cfg->num_classes, 1.f, loss, dlogits, stream));
+  // the head's forward, the loss and the head's backward as two launches instead of five (nv_head_step: bit-identical to the three calls)
+  const bool head_fused = g_head_step && !cfg->pool_mean;
+  RUN(forward_in_impl(cfg, B, video, shape5, strides5, in, params, params16, workspace, ws_bytes, 1, drop_p, emb_drop_p, drop_seed, logits, stream, head_fused));
+  if (head_fused) {
+    Dims D; RUN(make_dims(cfg, B, D));
+    ParamTab T; make_params(D, T);
+    WS W; make_ws(D, 1, W);
+    char* ws = (char*)workspace;
+    const int Ll = D.L - 1;
+    RUN(nv_head_step((const float*)(ws + W.layer[Ll].x2), (long)D.n * D.d, B, D.d, params + T.hg, params + T.hb, cfg->ln_eps, params + T.hw, params + T.hbias, D.C,
+                     labels, 1.f, (float*)(ws + W.xh), (float*)(ws + W.hst), logits, loss, dlogits, D.n, (float*)(ws + W.g), D.d,
+                     ws + ((Ll & 1) ? W.alt[0] : W.g16), D.d, grads + T.hg, grads + T.hb, grads + T.hw, grads + T.hbias, grads + T.layer[Ll].b2,
+                     hp->accumulate ? 1 : 0, ws + W.red, W.red_bytes, site_seed(drop_seed, 4 * Ll + 3), drop_p, stream));
+  } else {
+    RUN(nv_ce_loss(logits, labels, B, cfg->num_classes, 1.f, loss, dlogits, stream));
+  }
   NV_CHECK_ARG(hp->fuse_update >= 0 && hp->fuse_update <= 3, "nv_vit_train_step: fuse_update = %d (0 .. 3)", hp->fuse_update);
   const bool fused = hp->update && !hp->accumulate && hp->fuse_update;
   nv_adamw_arena opt;
   opt.struct_size = (int)sizeof(opt); opt.step = hp->step; opt.lr = hp->lr; opt.beta1 = hp->beta1; opt.beta2 = hp->beta2; opt.eps = hp->eps;
   opt.weight_decay = hp->weight_decay; opt.grad_scale = hp->grad_scale; opt.keep_grads = hp->fuse_update == 2;
   opt.params = params; opt.grads = grads; opt.adam_m = adam_m; opt.adam_v = adam_v; opt.params16 = params16;
-  RUN(backward_impl(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, nullptr, hp->accumulate ? 1 : 0, 0, cfg->depth + 1,
+  RUN(backward_impl(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, nullptr, hp->accumulate ? 1 : 0, head_fused ? 1 : 0, cfg->depth + 1,
                     drop_p, emb_drop_p, drop_seed, stream, aux_stream, 1, in ? in->rows_form : 0, fused ? &opt : nullptr, hp->fuse_update));
   if (hp->update && !fused) {
     const long total = nv_vit_param_count(cfg);

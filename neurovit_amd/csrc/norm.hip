@@ -836,14 +836,14 @@ extern "C" int nv_embed_finish_bwd(const float* g, long ldg, const float* t, lon
 
 // --------------------------------------------------------------------------------------- classification head (A9)
 // One workgroup per volume: xh = LN(x[b, 0, :]); logits[b, c] = xh . W[c, :] + bias[c].  All fp32 (VALU).
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, long row_stride, int d, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float eps, const float* __restrict__ Wt,
-                                                       const float* __restrict__ bias, int C, float* __restrict__ xh_out,
-                                                       float* __restrict__ stats_out, float* __restrict__ logits) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];   // d floats + 8 scratch
-  float* xs = sh;
+// (body shared with head_step_kernel below: one definition, the same bits)
+__device__ __forceinline__ void head_fwd_row(int b, float* sh, const float* __restrict__ x, long row_stride, int d, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, float eps, const float* __restrict__ Wt,
+                                             const float* __restrict__ bias, int C, float* __restrict__ xh_out,
+                                             float* __restrict__ stats_out, float* __restrict__ logits) {
+  float* xs = sh;              // d floats + 8 scratch
   float* scratch = sh + d;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float* row = x + (long)b * row_stride;
   float s = 0.f;
   for (int c = tid; c < d; c += 256) { xs[c] = row[c]; s += xs[c]; }
@@ -872,6 +872,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   }
 }
 
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, long row_stride, int d, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, const float* __restrict__ Wt,
+                                                       const float* __restrict__ bias, int C, float* __restrict__ xh_out,
+                                                       float* __restrict__ stats_out, float* __restrict__ logits) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];   // d floats + 8 scratch
+  head_fwd_row(blockIdx.x, sh, x, row_stride, d, gamma, beta, eps, Wt, bias, C, xh_out, stats_out, logits);
+}
+
 extern "C" int nv_head_fwd(const float* x, long row_stride, int B, int d, const float* gamma, const float* beta, float eps,
                            const float* W, const float* bias, int C, float* xh, float* stats, float* logits, void* stream) {
   NV_CHECK_ARG(B > 0 && d > 0 && C > 0, "nv_head_fwd: bad dims");
@@ -885,23 +893,13 @@ extern "C" int nv_head_fwd(const float* x, long row_stride, int B, int d, const 
 // token mean when pool_mean: then x is the [B, d] pooled matrix and every row of g gets dx / n);
 // writes g[b, 0, :] = dx (fp32 + bf16; the other rows were zeroed by a memset node in front) and per-volume
 // partials [b][3][d] = (dgamma, dbeta, dx) reduced afterwards.
-__global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict__ dlogits, int C, const float* __restrict__ Wt,
-                                                         const float* __restrict__ x, long row_stride, const float* __restrict__ stats,
-                                                         const float* __restrict__ gamma, int d, int n, float* __restrict__ g, long ldg,
-                                                         bf16* __restrict__ g16, long ldg16, float* __restrict__ partials, DropCfg drop,
-                                                         int pool_mean, int nvol) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];   // dyh[d] + 8 scratch
-  float* dys = sh;
+__device__ __forceinline__ void head_bwd_x_row(int b, float* sh, const float* __restrict__ dlogits, int C, const float* __restrict__ Wt,
+                                               const float* __restrict__ x, long row_stride, const float* __restrict__ stats,
+                                               const float* __restrict__ gamma, int d, int n, float* __restrict__ g, long ldg,
+                                               bf16* __restrict__ g16, long ldg16, float* __restrict__ partials, const DropCfg& drop, int pool_mean) {
+  float* dys = sh;             // dyh[d] + 8 scratch
   float* scratch = sh + d;
-  if ((int)blockIdx.x >= nvol) {
-    // pool = 'cls': the residual gradient is zero except for the cls rows the first nvol workgroups write - the rest of this grid
-    // clears the other rows of g (fp32) and g16 (bf16) in the same launch (were two hipMemsetAsync nodes in front of it)
-    const int part = blockIdx.x - nvol, nparts = gridDim.x - nvol;
-    zero_rows_except(reinterpret_cast<char*>(g), (long)nvol * n, (long)d * 4, n, part, nparts);
-    if (g16) zero_rows_except(reinterpret_cast<char*>(g16), (long)nvol * n, (long)d * 2, n, part, nparts);
-    return;
-  }
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float mean = stats[2 * b], rstd = stats[2 * b + 1];
   const float* row = x + (long)b * row_stride;
   float s1 = 0.f, s2 = 0.f;
@@ -942,6 +940,23 @@ __global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict
     if (g16) g16[(long)b * n * ldg16 + c] = (bf16)dxm;
     partials[((long)b * 3 + 2) * d + c] = dxm;
   }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict__ dlogits, int C, const float* __restrict__ Wt,
+                                                         const float* __restrict__ x, long row_stride, const float* __restrict__ stats,
+                                                         const float* __restrict__ gamma, int d, int n, float* __restrict__ g, long ldg,
+                                                         bf16* __restrict__ g16, long ldg16, float* __restrict__ partials, DropCfg drop,
+                                                         int pool_mean, int nvol) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];   // dyh[d] + 8 scratch
+  if ((int)blockIdx.x >= nvol) {
+    // pool = 'cls': the residual gradient is zero except for the cls rows the first nvol workgroups write - the rest of this grid
+    // clears the other rows of g (fp32) and g16 (bf16) in the same launch (were two hipMemsetAsync nodes in front of it)
+    const int part = blockIdx.x - nvol, nparts = gridDim.x - nvol;
+    zero_rows_except(reinterpret_cast<char*>(g), (long)nvol * n, (long)d * 4, n, part, nparts);
+    if (g16) zero_rows_except(reinterpret_cast<char*>(g16), (long)nvol * n, (long)d * 2, n, part, nparts);
+    return;
+  }
+  head_bwd_x_row(blockIdx.x, sh, dlogits, C, Wt, x, row_stride, stats, gamma, d, n, g, ldg, g16, ldg16, partials, drop, pool_mean);
 }
 
 // dW[c, k] = sum_b dlogits[b, c] * xh[b, k];  dbias[c] = sum_b dlogits[b, c]
@@ -1003,6 +1018,110 @@ extern "C" int nv_head_bwd(const float* dlogits, int B, int C, const float* W, c
   const long tot = (long)C * d;
   hipLaunchKernelGGL(head_bwd_w_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, dlogits, xh, B, C, d, dW, dbias, accumulate);
   NV_CHECK_LAUNCH("nv_head_bwd/w");
+  return NV_OK;
+}
+
+// ---- the head's forward, nn.CrossEntropyLoss and the head's backward in TWO launches instead of five (the train step as one call,
+// Trainer.py:69-74: dependent launches of a few microseconds of work each).  Launch 1: one workgroup per volume runs head_fwd_row,
+// ce_row_term and head_bwd_x_row - the bodies of head_fwd_kernel, ce_loss_kernel and head_bwd_x_kernel - while the other workgroups
+// clear the rows of g / g16 outside the cls rows; launch 2: everything that sums over the volumes, in the order of ce_loss_kernel,
+// reduce_partials_kernel and head_bwd_w_kernel.  Every output bit-identical to the five launches.  pool = 'cls' only.
+// (One launch with a single workgroup walking the volumes was measured first: 1.1 % SLOWER than the five launches - 4 x ~10 us in a row.)
+struct HeadStep {
+  const float* x; long row_stride; int B, d, C, n; const float* gamma; const float* beta; float eps; const float* W; const float* bias;
+  const long* labels; float grad_scale; float* xh; float* stats; float* logits; float* loss; float* dlogits;
+  float* g; long ldg; bf16* g16; long ldg16; float* dgamma; float* dbeta; float* dW; float* dbias; float* dcolsum; int accumulate;
+  float* partials; float* terms; DropCfg drop;
+};
+// sum over the R rows of column i of part[R][stride], in reduce_partials_kernel's order (8 row groups, four interleaved accumulators each)
+__device__ __forceinline__ float partial_column_sum(const float* part, int R, long stride, int i) {
+  float grp[8];
+#pragma unroll
+  for (int rg = 0; rg < 8; ++rg) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = rg;
+    for (; r + 24 < R; r += 32) {
+      s0 += part[(long)r * stride + i];
+      s1 += part[(long)(r + 8) * stride + i];
+      s2 += part[(long)(r + 16) * stride + i];
+      s3 += part[(long)(r + 24) * stride + i];
+    }
+    for (; r < R; r += 8) s0 += part[(long)r * stride + i];
+    grp[rg] = (s0 + s1) + (s2 + s3);
+  }
+  return ((grp[0] + grp[1]) + (grp[2] + grp[3])) + ((grp[4] + grp[5]) + (grp[6] + grp[7]));
+}
+// launch 1: workgroup b = volume b (forward, loss term, backward to the cls row of g), the others clear g / g16 outside the cls rows
+__global__ __launch_bounds__(256) void head_rows_kernel(const HeadStep a) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];   // d floats + 8 scratch + 4 (loss reductions)
+  if ((int)blockIdx.x >= a.B) {
+    const int part = blockIdx.x - a.B, nparts = gridDim.x - a.B;
+    zero_rows_except(reinterpret_cast<char*>(a.g), (long)a.B * a.n, (long)a.d * 4, a.n, part, nparts);
+    if (a.g16) zero_rows_except(reinterpret_cast<char*>(a.g16), (long)a.B * a.n, (long)a.d * 2, a.n, part, nparts);
+    return;
+  }
+  const int b = blockIdx.x;
+  head_fwd_row(b, sh, a.x, a.row_stride, a.d, a.gamma, a.beta, a.eps, a.W, a.bias, a.C, a.xh, a.stats, a.logits);
+  __syncthreads();                                   // logits[b], stats[b] (global, written by this workgroup) are visible to all of it
+  const float term = ce_row_term(a.logits + (long)b * a.C, a.labels[b], a.C, a.grad_scale / (float)a.B, sh + a.d + 8, a.dlogits + (long)b * a.C);
+  if (threadIdx.x == 0) a.terms[b] = term;
+  __syncthreads();
+  head_bwd_x_row(b, sh, a.dlogits, a.C, a.W, a.x, a.row_stride, a.stats, a.gamma, a.d, a.n, a.g, a.ldg, a.g16, a.ldg16, a.partials, a.drop, 0);
+}
+// launch 2: everything that sums over the volumes - the loss, (dgamma, dbeta, column sum of the cls-row gradient), dW, dbias
+__global__ __launch_bounds__(256) void head_sums_kernel(const HeadStep a) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx == 0) {
+    float total = 0.f;
+    for (int b = 0; b < a.B; ++b) total += a.terms[b];
+    a.loss[0] = total / (float)a.B;
+  }
+  if (idx < 3L * a.d) {
+    const int i = (int)idx;
+    const float s = partial_column_sum(a.partials, a.B, 3L * a.d, i);
+    const int seg = i / a.d, c = i - seg * a.d;
+    float* o = seg == 0 ? a.dgamma : (seg == 1 ? a.dbeta : a.dcolsum);
+    if (o) o[c] = a.accumulate ? o[c] + s : s;
+    return;
+  }
+  const long j = idx - 3L * a.d;
+  if (j < (long)a.C * a.d) {
+    const int c = (int)(j / a.d), k = (int)(j - (long)c * a.d);
+    float s = 0.f;
+    for (int b = 0; b < a.B; ++b) s += a.dlogits[(long)b * a.C + c] * a.xh[(long)b * a.d + k];
+    a.dW[j] = a.accumulate ? a.dW[j] + s : s;
+    if (j < a.C) {
+      float t = 0.f;
+      for (int b = 0; b < a.B; ++b) t += a.dlogits[(long)b * a.C + j];
+      a.dbias[j] = a.accumulate ? a.dbias[j] + t : t;
+    }
+  }
+}
+
+extern "C" long nv_head_step_workspace_bytes(int B, int d) { return nv_head_bwd_workspace_bytes(B, d) + (long)((B + 3) / 4 * 4) * sizeof(float); }
+
+extern "C" int nv_head_step(const float* x, long row_stride, int B, int d, const float* gamma, const float* beta, float eps, const float* W,
+                            const float* bias, int C, const long* labels, float grad_scale, float* xh, float* stats, float* logits, float* loss,
+                            float* dlogits, int n, float* g, long ldg, void* g16, long ldg16, float* dgamma, float* dbeta, float* dW, float* dbias,
+                            float* dcolsum, int accumulate, void* workspace, long ws_bytes, unsigned long drop_seed, float drop_p, void* stream) {
+  NV_CHECK_ARG(B > 0 && d > 0 && C > 0 && C <= d && n > 0, "nv_head_step: B = %d, d = %d, C = %d, n = %d", B, d, C, n);
+  NV_CHECK_ARG(x && gamma && beta && W && bias && labels && xh && stats && logits && loss && dlogits && g && dgamma && dbeta && dW && dbias && workspace,
+               "nv_head_step: null pointer");
+  NV_CHECK_ARG(ws_bytes >= nv_head_step_workspace_bytes(B, d), "nv_head_step: workspace too small");
+  NV_CHECK_ARG(ldg == d && (!g16 || ldg16 == d) && (d % 8) == 0 && nv_aligned16(g) && (!g16 || nv_aligned16(g16)), "nv_head_step: g / g16 must be dense [B*n, d], 16-byte aligned, d a multiple of 8");
+  HeadStep a;
+  a.x = x; a.row_stride = row_stride; a.B = B; a.d = d; a.C = C; a.n = n; a.gamma = gamma; a.beta = beta; a.eps = eps; a.W = W; a.bias = bias;
+  a.labels = labels; a.grad_scale = grad_scale; a.xh = xh; a.stats = stats; a.logits = logits; a.loss = loss; a.dlogits = dlogits;
+  a.g = g; a.ldg = ldg; a.g16 = (bf16*)g16; a.ldg16 = ldg16; a.dgamma = dgamma; a.dbeta = dbeta; a.dW = dW; a.dbias = dbias; a.dcolsum = dcolsum;
+  a.accumulate = accumulate; a.partials = (float*)workspace; a.terms = (float*)workspace + (long)B * 3 * d; a.drop = make_drop(drop_seed, drop_p);
+  const long fill_bytes = (long)B * n * d * (g16 ? 6 : 4);
+  int fill_blocks = (int)((fill_bytes + (1 << 16) - 1) >> 16);            // ~64 KiB per workgroup
+  if (fill_blocks > 1024) fill_blocks = 1024;
+  hipLaunchKernelGGL(head_rows_kernel, dim3(B + fill_blocks), dim3(256), (d + 12) * sizeof(float), (hipStream_t)stream, a);
+  NV_CHECK_LAUNCH("nv_head_step/rows");
+  const long outs = 3L * d + (long)C * d;
+  hipLaunchKernelGGL(head_sums_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  NV_CHECK_LAUNCH("nv_head_step");
   return NV_OK;
 }
 

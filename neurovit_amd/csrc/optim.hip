@@ -238,35 +238,10 @@ extern "C" int nv_dropout_apply(const float* x, long ldx, int M, int N, unsigned
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const long* __restrict__ target, int B, int C,
                                                       float grad_scale, float* __restrict__ loss, float* __restrict__ dlogits) {
   __shared__ float red[4];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float total = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float* row = logits + (long)b * C;
-    float mx = -INFINITY;
-    for (int c = tid; c < C; c += 256) mx = fmaxf(mx, row[c]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if (lane == 0) red[wid] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float se = 0.f;
-    for (int c = tid; c < C; c += 256) se += expf(row[c] - mx);
-    se = wave_sum(se);
-    if (lane == 0) red[wid] = se;
-    __syncthreads();
-    se = (red[0] + red[1]) + (red[2] + red[3]);
-    __syncthreads();
-    // torch raises a device-side assert for a label outside [0, C); here nothing may read out of bounds or abort the
-    // stream: the loss is poisoned with NaN (visible at the first .item()) and the row's gradient is that of no target
-    const long tl = target[b];
-    const bool t_ok = tl >= 0 && tl < (long)C;
-    const int t = t_ok ? (int)tl : -1;
-    total += t_ok ? (mx + logf(se)) - row[t] : __builtin_nanf("");
-    if (dlogits)
-      for (int c = tid; c < C; c += 256) dlogits[(long)b * C + c] = (expf(row[c] - mx) / se - (c == t ? 1.f : 0.f)) * (grad_scale / (float)B);
-  }
-  if (tid == 0) loss[0] = total / (float)B;
+  for (int b = 0; b < B; ++b)
+    total += ce_row_term(logits + (long)b * C, target[b], C, grad_scale / (float)B, red, dlogits ? dlogits + (long)b * C : nullptr);
+  if (threadIdx.x == 0) loss[0] = total / (float)B;
 }
 
 extern "C" int nv_ce_loss(const float* logits, const long* target, int B, int C, float grad_scale, float* loss, float* dlogits, void* stream) {

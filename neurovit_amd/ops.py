@@ -325,6 +325,24 @@ def head_bwd(dlogits, W, x, st, xh, gamma, drop_seed=0, drop_p=0.0):
     return g, g16, dgamma, dbeta, dW, db, dcol
 
 
+def head_step(x, gamma, beta, W, bias, labels, eps=1e-5, drop_seed=0, drop_p=0.0):
+    """nv_head_step: head forward + CrossEntropyLoss + head backward in two launches.  Returns what head_fwd, ce_loss and head_bwd return together:
+    (logits, xh, st, loss, dlogits, g, g16, dgamma, dbeta, dW, db, dcol)."""
+    B, n, d = x.shape
+    C = W.shape[0]
+    dev = x.device
+    xh = torch.empty((B, d), device=dev); st = torch.empty((B, 2), device=dev)
+    logits = torch.empty((B, C), device=dev); dl = torch.empty((B, C), device=dev); loss = torch.empty(1, device=dev)
+    g = torch.full((B, n, d), float("nan"), device=dev); g16 = torch.full((B, n, d), float("nan"), dtype=torch.bfloat16, device=dev)
+    dgamma, dbeta, dcol = (torch.empty(d, device=dev) for _ in range(3))
+    dW = torch.empty((C, d), device=dev); db = torch.empty(C, device=dev)
+    nb = lib.nv_head_step_workspace_bytes(B, d)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    check(lib.nv_head_step(_p(x), n * d, B, d, _p(gamma), _p(beta), eps, _p(W), _p(bias), C, _p(labels), 1.0, _p(xh), _p(st), _p(logits), _p(loss), _p(dl),
+                           n, _p(g), d, _p(g16), d, _p(dgamma), _p(dbeta), _p(dW), _p(db), _p(dcol), 0, _p(ws), nb, drop_seed, drop_p, _stream()), "nv_head_step")
+    return logits, xh, st, loss, dl, g, g16, dgamma, dbeta, dW, db, dcol
+
+
 def colsum_bf16(X: torch.Tensor, accumulate=False, out=None):
     M, N = X.shape
     out = torch.empty(N, device=X.device) if out is None else out

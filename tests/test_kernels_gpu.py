@@ -810,6 +810,29 @@ def test_adamw_reads_bf16_gradients(ops):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,drop", [(4, 0.0), (1, 0.0), (8, 0.1), (37, 0.0)])
+def test_head_step_equals_head_forward_loss_and_head_backward_bitwise(ops, B, drop):
+    """nv_head_step (the train step's head forward + nn.CrossEntropyLoss + head backward as two launches instead of five) against nv_head_fwd, nv_ce_loss and
+    nv_head_bwd: every output - logits, normalised row, statistics, loss, dlogits, the residual gradient (fp32 and bf16, zeros outside the
+    cls rows included), dgamma, dbeta, dW, dbias, the column sum - bit for bit; a label outside [0, C) poisons the loss with NaN in both."""
+    n, d, C = 65, 768, 2
+    x = dev(rnd(B, n, d, seed=1))
+    gamma, beta = dev(1.0 + 0.1 * rnd(d, seed=2)), dev(0.1 * rnd(d, seed=3))
+    Wh, bh = dev(rnd(C, d, seed=4) * d ** -0.5), dev(0.1 * rnd(C, seed=5))
+    y = torch.tensor([i % C for i in range(B)], device="cuda")
+    logits, xh, st = ops.head_fwd(x, gamma, beta, Wh, bh)
+    loss, dl = ops.ce_loss(logits, y)
+    sep = (logits, xh, st, loss, dl) + tuple(ops.head_bwd(dl, Wh, x, st, xh, gamma, drop_seed=77, drop_p=drop))
+    one = ops.head_step(x, gamma, beta, Wh, bh, y, drop_seed=77, drop_p=drop)
+    names = ("logits", "xh", "stats", "loss", "dlogits", "g", "g16", "dgamma", "dbeta", "dW", "dbias", "dcolsum")
+    for name, a, b in zip(names, sep, one):
+        assert torch.equal(a, b), f"{name} differ between the fused head step and the three launches"
+    assert float(one[5].abs().sum()) > 0 and not one[5][:, 1:].any() and not one[6][:, 1:].any()
+    bad = y.clone(); bad[0] = C
+    assert torch.isnan(ops.head_step(x, gamma, beta, Wh, bh, bad)[3]).all() and torch.isnan(ops.ce_loss(logits, bad)[0]).all()
+    report(f"head step, two launches == head forward + CE + head backward (B={B}, dropout {drop}): 12 outputs bitwise")
+
+
 @pytest.mark.parametrize("keep", [False, True])
 def test_weight_gradient_gemm_with_the_adamw_update_in_its_epilogue(ops, keep):
     """nv_gemm_bf16_grouped_adamw: the four weight gradients of a ViT3D-base layer (K = 2052 rows) whose epilogue applies AdamW to the
