@@ -750,6 +750,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
+// Dropout factors of THIS lane's key for the four query rows q0 .. q0 + 3 (the dK/dV pass holds S^T: a lane's four values are four QUERY rows of one
+// key, while the mask is hashed in groups of four consecutive KEYS of one query row).  The four lanes of a DPP quad hold the keys 4a .. 4a + 3
+// (key0 is a multiple of 16, r = lane & 15): one hash group per query row - so lane i of the quad hashes row q0 + i only, and the quad exchanges the
+// 16-bit fields with quad broadcasts: one 64-bit hash (three 64-bit multiplies) + 8 DPP moves per four values instead of four hashes.
+// (ViT3D-base batch 4, dropout 0.1: the dK/dV kernel 29.7 us with four hashes per lane against 15.0 us without dropout.)
+template <int J>
+__device__ __forceinline__ unsigned quad_bcast(unsigned v) {
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xF, 0xF, true);
+}
+__device__ __forceinline__ f32x4 drop_factor_rows4(const DropCfg& d, unsigned long long row0_idx, unsigned long long row_stride) {
+  const unsigned c = (unsigned)(row0_idx & 3);              // this lane's key within its group of four = its place in the quad
+  const uint64_t h = nv_hash64(d.seed, (row0_idx + c * row_stride) >> 2);
+  const unsigned lo = (unsigned)h, hi = (unsigned)(h >> 32);
+  const unsigned l0 = quad_bcast<0>(lo), l1 = quad_bcast<1>(lo), l2 = quad_bcast<2>(lo), l3 = quad_bcast<3>(lo);
+  const unsigned h0 = quad_bcast<0>(hi), h1 = quad_bcast<1>(hi), h2 = quad_bcast<2>(hi), h3 = quad_bcast<3>(hi);
+  const unsigned w[4] = {(c & 2) ? h0 : l0, (c & 2) ? h1 : l1, (c & 2) ? h2 : l2, (c & 2) ? h3 : l3};
+  f32x4 f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned field = (c & 1) ? (w[j] >> 16) : (w[j] & 0xFFFFu);
+    f[j] = (field >= d.thresh) ? d.scale : 0.f;
+  }
+  return f;
+}
+
 // one 64-query tile of the dK/dV pass for one wave (16 keys); sL / sDl hold this tile's 64 log2-domain lse and delta values
 template <bool DROP>
 __device__ __forceinline__ void dkv_softmax_grad(const f32x4 (&sc)[4], const f32x4 (&dp)[4], f32x4 (&p)[4], f32x4 (&ds)[4], const float* sL,
@@ -761,11 +786,8 @@ __device__ __forceinline__ void dkv_softmax_grad(const f32x4 (&sc)[4], const f32
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 16 * t + 4 * g);
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + 16 * t + 4 * g);
       f32x4 f = {1.f, 1.f, 1.f, 1.f};
-      if constexpr (DROP) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          f[j] = drop_factor(drop, (((unsigned long long)bh * n + (qt * TQ + 16 * t + 4 * g + j)) * ((n + 3) & ~3)) + keyabs);
-      }
+      if constexpr (DROP)
+        f = drop_factor_rows4(drop, (((unsigned long long)bh * n + (qt * TQ + 16 * t + 4 * g)) * ((n + 3) & ~3)) + keyabs, (unsigned long long)((n + 3) & ~3));
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         f32x2 x = {sc[t][2 * hh], sc[t][2 * hh + 1]};
@@ -1142,11 +1164,8 @@ __device__ __forceinline__ void dkv_softmax_grad_inplace(f32x4 (&sc)[4], f32x4 (
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLraw + 16 * t + 4 * g) * 1.44269504088896340736f;
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + 16 * t + 4 * g);
       f32x4 f = {1.f, 1.f, 1.f, 1.f};
-      if constexpr (DROP) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          f[j] = drop_factor(drop, (((unsigned long long)bh * n + (qt * TQ + 16 * t + 4 * g + j)) * ((n + 3) & ~3)) + keyabs);
-      }
+      if constexpr (DROP)
+        f = drop_factor_rows4(drop, (((unsigned long long)bh * n + (qt * TQ + 16 * t + 4 * g)) * ((n + 3) & ~3)) + keyabs, (unsigned long long)((n + 3) & ~3));
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         f32x2 x = {sc[t][2 * hh], sc[t][2 * hh + 1]};
