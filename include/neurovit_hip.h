@@ -144,10 +144,13 @@ int nv_gemm_set_tile(int bm, int bn);
  * nv_skinny_nt: W [N, K] row-major.  epi 0: out f32 [R, N] = resid + (bias + A W^T)   epi 1: u = bias + A W^T (bf16, optional), out bf16 = gelu(u)
  * nv_skinny_nn: W [K, N] row-major.  epi 0: out bf16 = (A W) * gelu'(u), dcol[n] (+)= column sums of the stored values (optional, R <= 4)
  *                                    epi 1: out f32 = A W     epi 2: out bf16 = A W */
+/* (revision 5) drop_seed / drop_p: the nn.Dropout of the site (vit_3d.py:21,23,45), as in nv_gemm_bf16 - nt epi 0 on (bias + A W^T), epi 1 on gelu(u),
+ * nn epi 0 on A W (the mask of the GELU output the gradient flows back through).  The mask is the one of the DENSE [M, N] tensor `out` is a
+ * row-strided view of (ldo a multiple of N): element (r, n) of the view hashes at its offset r * ldo + n. */
 int nv_skinny_nt(int epi, int R, int N, int K, const void* A, long lda, const void* W, long ldw, const float* bias, const float* resid,
-                 long ldr, void* out, long ldo, void* u_out, long ldu, void* stream);
+                 long ldr, void* out, long ldo, void* u_out, long ldu, unsigned long drop_seed, float drop_p, void* stream);
 int nv_skinny_nn(int epi, int R, int N, int K, const void* A, long lda, const void* W, long ldw, const void* u, long ldu, void* out, long ldo,
-                 float* dcol, int accumulate, void* stream);
+                 float* dcol, int accumulate, unsigned long drop_seed, float drop_p, void* stream);
 /* out bf16 [total_rows, N] dense = zeros, except rows r * keep_every (r < R) = A[r, :] W: one launch (dAO of the last block under
  * pool = 'cls', whose incoming gradient lives on the cls rows only - clearing the other rows used to be a memset node) */
 int nv_skinny_nn_sparse(int R, int N, int K, const void* A, long lda, const void* W, long ldw, void* out, long total_rows, int keep_every,

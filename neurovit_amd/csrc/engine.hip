@@ -39,7 +39,8 @@ static int g_head_step = 1;      // nv_vit_train_step: head forward + loss + hea
 extern "C" int nv_vit_set_head_step(int on) { g_head_step = on ? 1 : 0; return 0; }
 static bool cls_tail_wanted(const Dims& D, int training, float drop_p, int rows_form) {
   const bool want = rows_form == 1 ? false : (rows_form == 2 ? true : g_cls_tail != 0);
-  return want && !D.pool_mean && drop_p == 0.f && (!training || D.B <= 4);
+  (void)drop_p;      // (round 4: the cls-row kernels carry the nn.Dropout masks of the dense tensors, skinny.hip)
+  return want && !D.pool_mean && (!training || D.B <= 4);
 }
 
 // image width / width of a patch: nv_vit_config.image_width / patch_width, 0 = square (vit_3d.py:80-81 takes pairs)
@@ -348,10 +349,10 @@ static int forward_in_impl(const nv_vit_config* cfg, int B, const float* video, 
     if (tail && l == D.L - 1) {
       // cls rows only (row b of the small problem = row b * n of the buffers); LN2 statistics land at st2[0 .. B) / st2[M .. M + B)
       const long rs = D.n;
-      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, stream));
+      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, site_seed(drop_seed, 4 * l + 1), drop_p, stream));
       RUN(nv_ln_fwd(x1, d * rs, B, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d * rs, st2, st2 + M, stream));
-      RUN(nv_skinny_nt(1, B, D.m, d, ws + w.xn2, d * rs, p16 + q.w1, d, p + q.b1, nullptr, 0, ws + w.h, D.m * rs, training ? ws + w.u : nullptr, D.m * rs, stream));
-      RUN(nv_skinny_nt(0, B, d, D.m, ws + w.h, D.m * rs, p16 + q.w2, D.m, p + q.b2, x1, d * rs, x2, d * rs, nullptr, 0, stream));
+      RUN(nv_skinny_nt(1, B, D.m, d, ws + w.xn2, d * rs, p16 + q.w1, d, p + q.b1, nullptr, 0, ws + w.h, D.m * rs, training ? ws + w.u : nullptr, D.m * rs, site_seed(drop_seed, 4 * l + 2), drop_p, stream));
+      RUN(nv_skinny_nt(0, B, d, D.m, ws + w.h, D.m * rs, p16 + q.w2, D.m, p + q.b2, x1, d * rs, x2, d * rs, nullptr, 0, site_seed(drop_seed, 4 * l + 3), drop_p, stream));
       xin = x2;
       continue;
     }
@@ -536,10 +537,10 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
       // weight-streaming kernels - these few rows gain nothing from fp8 and lose nothing by staying in bf16
       const long rs = D.n;
       float* st = (float*)(ws + w.st2);
-      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, stream));
+      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, 0, 0.f, stream));
       RUN(nv_ln_fwd(x1, d * rs, B, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d * rs, st, st + M, stream));
-      RUN(nv_skinny_nt(1, B, D.m, d, ws + w.xn2, d * rs, p16 + q.w1, d, p + q.b1, nullptr, 0, ws + w.h, D.m * rs, nullptr, 0, stream));
-      RUN(nv_skinny_nt(0, B, d, D.m, ws + w.h, D.m * rs, p16 + q.w2, D.m, p + q.b2, x1, d * rs, x2, d * rs, nullptr, 0, stream));
+      RUN(nv_skinny_nt(1, B, D.m, d, ws + w.xn2, d * rs, p16 + q.w1, d, p + q.b1, nullptr, 0, ws + w.h, D.m * rs, nullptr, 0, 0, 0.f, stream));
+      RUN(nv_skinny_nt(0, B, d, D.m, ws + w.h, D.m * rs, p16 + q.w2, D.m, p + q.b2, x1, d * rs, x2, d * rs, nullptr, 0, 0, 0.f, stream));
       xin = x2;
       continue;
     }
@@ -619,10 +620,10 @@ extern "C" int nv_vit_forward_fp8_train(const nv_vit_config* cfg, int B, const f
     RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), site_seed(drop_seed, 4 * l + 0), drop_p, stream));
     if (tail && l == D.L - 1) {       // the last block on its B cls rows: the bf16 weight-streaming kernels, as in nv_vit_forward_in
       const long rs = D.n;
-      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, stream));
+      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, site_seed(drop_seed, 4 * l + 1), drop_p, stream));
       RUN(nv_ln_fwd(x1, d * rs, B, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d * rs, st2, st2 + M, stream));
-      RUN(nv_skinny_nt(1, B, D.m, d, ws + w.xn2, d * rs, p16 + q.w1, d, p + q.b1, nullptr, 0, ws + w.h, D.m * rs, ws + w.u, D.m * rs, stream));
-      RUN(nv_skinny_nt(0, B, d, D.m, ws + w.h, D.m * rs, p16 + q.w2, D.m, p + q.b2, x1, d * rs, x2, d * rs, nullptr, 0, stream));
+      RUN(nv_skinny_nt(1, B, D.m, d, ws + w.xn2, d * rs, p16 + q.w1, d, p + q.b1, nullptr, 0, ws + w.h, D.m * rs, ws + w.u, D.m * rs, site_seed(drop_seed, 4 * l + 2), drop_p, stream));
+      RUN(nv_skinny_nt(0, B, d, D.m, ws + w.h, D.m * rs, p16 + q.w2, D.m, p + q.b2, x1, d * rs, x2, d * rs, nullptr, 0, site_seed(drop_seed, 4 * l + 3), drop_p, stream));
       xin = x2;
       continue;
     }
@@ -764,8 +765,8 @@ static int backward_impl(const nv_vit_config* cfg, int B, const float* video, co
     const long rs = tail ? (long)D.n : 1;
     // ---- FeedForward backward (vit_3d.py:16-26)
     if (tail) {
-      RUN(nv_skinny_nn(0, B, D.m, d, g16, d * rs, p16 + q.w2, D.m, ws + w.u, D.m * rs, du, D.m * rs, gr + q.b1, acc, stream));       // dU = (g W2) * gelu'(u), db1 = column sums
-      RUN(nv_skinny_nn(1, B, d, D.m, du, D.m * rs, p16 + q.w1, d, nullptr, 0, dxn, d * rs, nullptr, 0, stream));                     // dxn2 = dU W1
+      RUN(nv_skinny_nn(0, B, D.m, d, g16, d * rs, p16 + q.w2, D.m, ws + w.u, D.m * rs, du, D.m * rs, gr + q.b1, acc, site_seed(drop_seed, 4 * l + 2), drop_p, stream));   // dU = (g W2 * mask) * gelu'(u), db1 = column sums
+      RUN(nv_skinny_nn(1, B, d, D.m, du, D.m * rs, p16 + q.w1, d, nullptr, 0, dxn, d * rs, nullptr, 0, 0, 0.f, stream));             // dxn2 = dU W1
     } else {
     RUN(nv_gemm_bf16(1, du_tile_rows ? 6 : 5, M, D.m, d, g16, d, p16 + q.w2, D.m, du, D.m, nullptr, ws + w.u, D.m, du_tile_rows ? CS1(l) : nullptr, D.m, 0, 1.f,
                      site_seed(drop_seed, 4 * l + 2), drop_p, stream));   // dU = (g W2 * mask) * gelu'(u)  [+ per-tile column sums -> db1]

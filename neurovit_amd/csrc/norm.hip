@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             *reinterpret_cast<f32x4*>(g_out + (long)row * ldg + c) = o;
             // g16 / colsum feed the backward of the Linear whose (dropped-out) output was added to this residual stream
             if (drop.thresh) {
-              o *= drop_factor4(drop, (unsigned long long)row * d + c);
+              o *= drop_factor4(drop, (unsigned long long)row * ldg + c);      // element index of the DENSE [M, d] tensor g is a (row-strided) view of: ldg = d x row spacing
             }
             if (g16) *reinterpret_cast<bf16x4*>(g16 + (long)row * ldg16 + c) = cvt4(o[0], o[1], o[2], o[3]);
             a_c[v] += o;
@@ -325,6 +325,7 @@ static int ln_bwd_launch(const float* dy, long lddy, const float* x, long ldx, c
                          float* dcolsum, int accumulate, void* workspace, long ws_bytes, unsigned long drop_seed, float drop_p,
                          void* stream, void* reduce_stream, int seg_rows, int seg_skip) {
   NV_CHECK_ARG(M > 0 && d > 0 && (d % 4) == 0 && d <= 2048, "nv_ln_bwd: d=%d must be a multiple of 4 and <= 2048", d);
+  NV_CHECK_ARG(drop_p == 0.f || (ldg % d) == 0, "nv_ln_bwd: with dropout g must be a (row-strided) view of a dense [*, d] tensor (ldg a multiple of d)");
   const DropCfg drop = make_drop(drop_seed, drop_p);
   NV_CHECK_ARG(ws_bytes >= nv_ln_bwd_workspace_bytes(M, d), "nv_ln_bwd: workspace too small");
   NV_CHECK_ARG((lddy % 4) == 0 && (ldx % 4) == 0 && (ldg % 4) == 0 && (ldg16 % 4) == 0, "nv_ln_bwd: leading dims must be multiples of 4");

@@ -9,8 +9,8 @@
 //   NN (backward, W [K, N] row-major): one 1024-thread workgroup per 16 output columns (48-192 workgroups); a wave reads 32 k-rows
 //      x 16 columns per instruction, sixteen waves split K, partial sums meet in LDS in a fixed order.
 // Rows are addressed through leading dimensions, so the cls rows of a [B, n, d] tensor are a view (ld = n * d), never a copy.
-// Cast points and epilogue arithmetic are those of the tiled kernels (gemm_common.h::epilogue4); no dropout (the engine takes this
-// path only when the block's dropout is off).
+// Cast points and epilogue arithmetic are those of the tiled kernels (gemm_common.h::epilogue4), nn.Dropout masks included: the mask of the
+// dense tensor, hashed at the element offset of the strided view.
 #include "common.h"
 
 namespace {
@@ -23,7 +23,7 @@ enum { SK_NN_DGELU = 0, SK_NN_F32 = 1, SK_NN_BF16 = 2 };
 template <int EPI>
 __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16* __restrict__ A, long lda, int R, const bf16* __restrict__ W, long ldw, int N, int K,
                                                         const float* __restrict__ bias, const float* __restrict__ resid, long ldr,
-                                                        void* __restrict__ out, long ldo, bf16* __restrict__ u_out, long ldu) {
+                                                        void* __restrict__ out, long ldo, bf16* __restrict__ u_out, long ldu, DropCfg drop) {
   const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int r0 = blockIdx.y * SK_R, rows = (R - r0 < SK_R) ? R - r0 : SK_R;
   if (n >= N) return;
@@ -69,11 +69,14 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16* __restrict__
   if (lane < rows) {
     const long row = r0 + lane;
     const float v = mine + bias[n];
+    // nn.Dropout of the site (vit_3d.py:21,23,45): the mask of the DENSE [M, N] tensor this launch writes a few rows of - `out` is a strided view of it
+    // (ldo = N x row spacing), so the element offset row * ldo + n IS the dense element index the tiled epilogues hash (gemm_common.h::epilogue4)
+    const float keep = drop.thresh ? drop_factor(drop, (unsigned long long)(row * ldo + n)) : 1.f;
     if constexpr (EPI == SK_NT_RESID) {
-      ((float*)out)[row * ldo + n] = v + resid[row * ldr + n];
+      ((float*)out)[row * ldo + n] = v * keep + resid[row * ldr + n];
     } else {
       if (u_out) u_out[row * ldu + n] = (bf16)v;
-      ((bf16*)out)[row * ldo + n] = (bf16)gelu_f(v);
+      ((bf16*)out)[row * ldo + n] = (bf16)(gelu_f(v) * keep);
     }
   }
 }
@@ -84,7 +87,7 @@ constexpr int NN_KK = 64 / (NN_COLS / 8);   // k-rows per wave-instruction: 32
 template <int EPI>
 __global__ __launch_bounds__(1024) void skinny_nn_kernel(const bf16* __restrict__ A, long lda, int R, const bf16* __restrict__ W, long ldw, int N, int K,
                                                          const bf16* __restrict__ u, long ldu, void* __restrict__ out, long ldo,
-                                                         float* __restrict__ dcol, int accumulate, long fill_rows, int keep_every) {
+                                                         float* __restrict__ dcol, int accumulate, long fill_rows, int keep_every, DropCfg drop) {
   // LDS: every lane's partial sums [16 waves][32 k-row lanes][SK_R][16 columns] (128 KiB), then per-wave sums [16][SK_R][16]
   extern __shared__ __attribute__((aligned(16))) float sk_lds[];
   if (blockIdx.z == 1) {
@@ -159,7 +162,8 @@ __global__ __launch_bounds__(1024) void skinny_nn_kernel(const bf16* __restrict_
     const long row = r0 + r;
     const int n = n0 + c;
     if constexpr (EPI == SK_NN_DGELU) {
-      const bf16 o = (bf16)(v * gelu_grad_f((float)u[row * ldu + n]));
+      const float keep = drop.thresh ? drop_factor(drop, (unsigned long long)(row * ldo + n)) : 1.f;      // the mask of the GELU output this gradient flows back through
+      const bf16 o = (bf16)(v * keep * gelu_grad_f((float)u[row * ldu + n]));
       ((bf16*)out)[row * ldo + n] = o;
       stored = (float)o;                                         // what the weight-gradient product will read: summed as stored
     } else if constexpr (EPI == SK_NN_F32) {
@@ -187,16 +191,18 @@ __global__ __launch_bounds__(1024) void skinny_nn_kernel(const bf16* __restrict_
 
 // out[r, n] = resid[r, n] + (bias[n] + sum_k A[r, k] W[n, k])   (epi 0, out f32)   |   u = bias + sum; out = gelu(u) (epi 1, out / u bf16)
 extern "C" int nv_skinny_nt(int epi, int R, int N, int K, const void* A, long lda, const void* W, long ldw, const float* bias, const float* resid,
-                            long ldr, void* out, long ldo, void* u_out, long ldu, void* stream) {
+                            long ldr, void* out, long ldo, void* u_out, long ldu, unsigned long drop_seed, float drop_p, void* stream) {
+  NV_CHECK_ARG(drop_p == 0.f || (ldo % N) == 0, "nv_skinny_nt: with dropout `out` must be a row-strided view of a dense [M, N] tensor (ldo a multiple of N)");
+  const DropCfg drop = make_drop(drop_seed, drop_p);
   NV_CHECK_ARG(R > 0 && N > 0 && K > 0 && (K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && A && W && bias && out && nv_aligned16(A) && nv_aligned16(W),
                "nv_skinny_nt: K, lda, ldw must be multiples of 8, operands 16-byte aligned");
   NV_CHECK_ARG(epi == SK_NT_GELU || (epi == SK_NT_RESID && resid), "nv_skinny_nt: epilogue 0 needs resid; epilogues are 0 (bias + residual, f32) and 1 (bias + GELU, bf16)");
   const dim3 grid((N + 3) / 4, (R + SK_R - 1) / SK_R), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (epi == SK_NT_RESID)
-    hipLaunchKernelGGL(skinny_nt_kernel<SK_NT_RESID>, grid, block, 0, s, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, bias, resid, ldr, out, ldo, (bf16*)nullptr, 0L);
+    hipLaunchKernelGGL(skinny_nt_kernel<SK_NT_RESID>, grid, block, 0, s, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, bias, resid, ldr, out, ldo, (bf16*)nullptr, 0L, drop);
   else
-    hipLaunchKernelGGL(skinny_nt_kernel<SK_NT_GELU>, grid, block, 0, s, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, bias, resid, ldr, out, ldo, (bf16*)u_out, ldu);
+    hipLaunchKernelGGL(skinny_nt_kernel<SK_NT_GELU>, grid, block, 0, s, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, bias, resid, ldr, out, ldo, (bf16*)u_out, ldu, drop);
   NV_CHECK_LAUNCH("nv_skinny_nt");
   return NV_OK;
 }
@@ -204,7 +210,9 @@ extern "C" int nv_skinny_nt(int epi, int R, int N, int K, const void* A, long ld
 // out[r, n] = epilogue(sum_k A[r, k] W[k, n]): epi 0 bf16 out = sum * gelu'(u[r, n]) (+ dcol[n] (+)= column sums of the stored values, R <= 4),
 // 1 f32 store, 2 bf16 store.  N % 8 == 0.
 extern "C" int nv_skinny_nn(int epi, int R, int N, int K, const void* A, long lda, const void* W, long ldw, const void* u, long ldu, void* out, long ldo,
-                            float* dcol, int accumulate, void* stream) {
+                            float* dcol, int accumulate, unsigned long drop_seed, float drop_p, void* stream) {
+  NV_CHECK_ARG(drop_p == 0.f || (epi == SK_NN_DGELU && (ldo % N) == 0), "nv_skinny_nn: dropout only with epilogue 0, `out` a row-strided view of a dense [M, N] tensor");
+  const DropCfg drop = make_drop(drop_seed, drop_p);
   NV_CHECK_ARG(R > 0 && N > 0 && K > 0 && (N % 8) == 0 && (ldw % 8) == 0 && A && W && out && nv_aligned16(W), "nv_skinny_nn: N, ldw must be multiples of 8, W 16-byte aligned");
   NV_CHECK_ARG(epi >= 0 && epi <= 2 && (epi != SK_NN_DGELU || u) && (!dcol || (epi == SK_NN_DGELU && R <= SK_R)), "nv_skinny_nn: epilogue 0 needs u; column sums only with epilogue 0 and R <= 4");
   const dim3 grid((N + NN_COLS - 1) / NN_COLS, (R + SK_R - 1) / SK_R), block(1024);
@@ -217,7 +225,7 @@ extern "C" int nv_skinny_nn(int epi, int R, int N, int K, const void* A, long ld
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_nn_kernel<SK_NN_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, NN_LDS);
     attr = true;
   }
-#define SK_NN(E) hipLaunchKernelGGL(skinny_nn_kernel<E>, grid, block, NN_LDS, s, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, (const bf16*)u, ldu, out, ldo, dcol, accumulate, 0L, 0)
+#define SK_NN(E) hipLaunchKernelGGL(skinny_nn_kernel<E>, grid, block, NN_LDS, s, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, (const bf16*)u, ldu, out, ldo, dcol, accumulate, 0L, 0, drop)
   if (epi == SK_NN_DGELU) SK_NN(SK_NN_DGELU); else if (epi == SK_NN_F32) SK_NN(SK_NN_F32); else SK_NN(SK_NN_BF16);
 #undef SK_NN
   NV_CHECK_LAUNCH("nv_skinny_nn");
@@ -239,7 +247,7 @@ extern "C" int nv_skinny_nn_sparse(int R, int N, int K, const void* A, long lda,
     attr = true;
   }
   hipLaunchKernelGGL(skinny_nn_kernel<SK_NN_BF16>, grid, block, NN_LDS, (hipStream_t)stream, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, (const bf16*)nullptr, 0L,
-                     out, (long)N * keep_every, (float*)nullptr, 0, total_rows, keep_every);
+                     out, (long)N * keep_every, (float*)nullptr, 0, total_rows, keep_every, make_drop(0, 0.f));
   NV_CHECK_LAUNCH("nv_skinny_nn_sparse");
   return NV_OK;
 }

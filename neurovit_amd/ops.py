@@ -48,25 +48,26 @@ def cast_ranges_bf16(src: torch.Tensor, dst: torch.Tensor, ranges) -> None:
 
 
 def skinny_nt(epi: int, A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, resid: Optional[torch.Tensor] = None,
-              u_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              u_out: Optional[torch.Tensor] = None, drop_seed: int = 0, drop_p: float = 0.0) -> torch.Tensor:
     """out[r] = epilogue(A[r] @ W.T) on a few rows; A / resid / out / u_out may be row-strided 2-D views (e.g. x[::n]).
-    epi 0: out f32 = resid + (bias + A W^T); epi 1: u = bias + A W^T (bf16, optional), out bf16 = gelu(u)."""
+    epi 0: out f32 = resid + (bias + A W^T) * mask; epi 1: u = bias + A W^T (bf16, optional), out bf16 = gelu(u) * mask.
+    mask: nn.Dropout of the dense tensor `out` is a view of (element offsets are hashed), drop_p = 0: none."""
     _need_cuda(A, W)
     R, K = A.shape
     N = W.shape[0]
     check(lib.nv_skinny_nt(epi, R, N, K, _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(resid), 0 if resid is None else resid.stride(0),
-                           _p(out), out.stride(0), _p(u_out), 0 if u_out is None else u_out.stride(0), _stream()), "nv_skinny_nt")
+                           _p(out), out.stride(0), _p(u_out), 0 if u_out is None else u_out.stride(0), int(drop_seed), float(drop_p), _stream()), "nv_skinny_nt")
     return out
 
 
 def skinny_nn(epi: int, A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, u: Optional[torch.Tensor] = None,
-              dcol: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    """out[r] = epilogue(A[r] @ W) on a few rows (W [K, N]); epi 0: bf16 (A W) * gelu'(u) (+ column sums into dcol), 1: f32, 2: bf16."""
+              dcol: Optional[torch.Tensor] = None, accumulate: bool = False, drop_seed: int = 0, drop_p: float = 0.0) -> torch.Tensor:
+    """out[r] = epilogue(A[r] @ W) on a few rows (W [K, N]); epi 0: bf16 (A W * mask) * gelu'(u) (+ column sums into dcol), 1: f32, 2: bf16."""
     _need_cuda(A, W)
     R, K = A.shape
     N = W.shape[1]
     check(lib.nv_skinny_nn(epi, R, N, K, _p(A), A.stride(0), _p(W), W.stride(0), _p(u), 0 if u is None else u.stride(0), _p(out), out.stride(0),
-                           _p(dcol), int(accumulate), _stream()), "nv_skinny_nn")
+                           _p(dcol), int(accumulate), int(drop_seed), float(drop_p), _stream()), "nv_skinny_nn")
     return out
 
 

@@ -290,11 +290,12 @@ def test_inference_mode_matches_training_forward(eng):
     assert torch.equal(b, c)           # run-to-run deterministic
 
 
-def test_cls_rows_form_is_never_taken_with_dropout(eng):
-    """The weight-streaming kernels of the cls-rows form apply no dropout.  A train-mode forward that records no graph still runs
-    with the block dropout on (the frozen encoder of the 4D model under Trainer.train: Trainer.py:59, config4D.yaml TRAINING_DROPOUT
-    0.2), so it must take the all-rows path whatever form is asked for: bit-identical logits for rows_form 1 and 2, with dropout,
-    training workspace or not - and different from the dropout-free logits (the masks really are applied at every site)."""
+def test_cls_rows_form_under_dropout_applies_the_masks_of_the_dense_tensors(eng):
+    """Round 4: the weight-streaming kernels of the cls-rows form carry the nn.Dropout masks (the mask of the dense tensor, hashed at the element
+    offset of the strided view), so the form is taken under dropout too - a train-mode forward that records no graph still runs with the block
+    dropout on (the frozen encoder of the 4D model under Trainer.train: Trainer.py:59, config4D.yaml TRAINING_DROPOUT 0.2).  Logits of
+    rows_form 1 (every row) and 2 (cls rows) agree to fp32 rounding WITH dropout, training workspace or not - one differing mask bit would show
+    as a difference of the order of the logits - and differ from the dropout-free logits (the masks really are applied); so do the gradients."""
     cfgdict = dict(W.MICRO)
     sd = W.make_tensors(W.vit_param_spec(**cfgdict), 1)
     cfg, off, num, arena = load_arena(eng, cfgdict, sd)
@@ -306,9 +307,21 @@ def test_cls_rows_form_is_never_taken_with_dropout(eng):
     for training in (False, True):
         a = rt.forward(video, params, p16, training=training, dropout=drop, rows_form=1).clone()
         b = rt.forward(video, params, p16, training=training, dropout=drop, rows_form=2).clone()
-        assert torch.equal(a, b), training
+        assert rel_l2(b, a) < 1e-5, (training, rel_l2(b, a))
+        assert torch.equal(b, rt.forward(video, params, p16, training=training, dropout=drop, rows_form=2))      # deterministic
     clean = rt.forward(video, params, p16, training=False, rows_form=2)
-    assert not torch.equal(clean, a)
+    assert rel_l2(clean, a) > 1e-3
+    # gradients of both forms under dropout
+    dlogits = torch.tensor([[0.3, -0.3], [-0.2, 0.2], [0.1, -0.1]], device="cuda")
+    grads = []
+    for form in (1, 2):
+        rt.forward(video, params, p16, training=True, dropout=drop, rows_form=form)
+        g = torch.zeros_like(params)
+        rt.backward(dlogits, params, p16, g, accumulate=False)
+        grads.append(g.clone())
+    e = rel_l2(grads[1], grads[0])
+    report(f"cls-rows form under dropout 0.2 vs every row: gradient arena {e:.2e}")
+    assert e < 2e-5, e
     # and without dropout the two forms agree to fp32 rounding, training or not
     for training in (False, True):
         a = rt.forward(video, params, p16, training=training, rows_form=1).clone()

@@ -362,6 +362,42 @@ def test_skinny_linear_kernels_on_strided_rows(ops, R, n):
     assert torch.equal(again, o16)
 
 
+def test_skinny_linear_kernels_carry_the_dropout_masks_of_the_dense_tensors(ops):
+    """The cls rows of the last block under dropout: nv_skinny_nt / nv_skinny_nn on every n-th row of a dense [B * n, .] tensor must apply the SAME
+    nn.Dropout mask the tiled GEMM epilogues apply to those rows of the dense tensor (the element offset of the strided view is the dense element
+    index): all three dropout sites of a block - out-projection / FC2 (bias + residual), FC1 (GELU), and dU in the backward pass - against the
+    tiled kernels run on the whole dense problem with the same seed: same zeros, same values."""
+    R, n, d, m, p = 4, 513, 768, 3072, 0.25
+    M = R * n
+    x = dev(bf(rnd(M, d, seed=1)))
+    W1, W2 = dev(bf(rnd(m, d, seed=2, scale=d ** -0.5))), dev(bf(rnd(d, m, seed=3, scale=m ** -0.5)))
+    b1, b2 = dev(rnd(m, seed=4)), dev(rnd(d, seed=5))
+    res = dev(rnd(M, d, seed=6))
+    # FC1 + GELU + dropout
+    u_t = torch.empty((M, m), dtype=torch.bfloat16, device="cuda")
+    h_t = ops.gemm(ops.NT, ops.EPI_BIAS_GELU, x, W1, bias=b1, aux_out=u_t, drop_seed=11, drop_p=p)
+    h_s = torch.zeros((M, m), dtype=torch.bfloat16, device="cuda"); u_s = torch.zeros_like(h_s)
+    ops.skinny_nt(1, x[::n], W1, b1, h_s[::n], u_out=u_s[::n], drop_seed=11, drop_p=p)
+    zeros_t = h_t[::n] == 0
+    assert 0.2 < float(zeros_t.float().mean()) < 0.3 and torch.equal(zeros_t, h_s[::n] == 0)
+    assert rel_l2(h_s[::n].float(), h_t[::n].float()) < 4e-3 and rel_l2(u_s[::n].float(), u_t[::n].float()) < 4e-3
+    # FC2 + bias + dropout + residual
+    y_t = ops.gemm(ops.NT, ops.EPI_BIAS_RESID, h_t, W2, bias=b2, aux_in=res, drop_seed=12, drop_p=p)
+    y_s = torch.zeros((M, d), device="cuda")
+    ops.skinny_nt(0, h_t[::n], W2, b2, y_s[::n], resid=res[::n], drop_seed=12, drop_p=p)
+    dropped_t = y_t[::n] == res[::n]
+    assert 0.2 < float(dropped_t.float().mean()) < 0.3 and torch.equal(dropped_t, y_s[::n] == res[::n])
+    assert rel_l2(y_s[::n], y_t[::n]) < 1e-5
+    # dU = (g W2 * mask) * gelu'(u)
+    g = dev(bf(rnd(M, d, seed=7)))
+    du_t = ops.gemm(ops.NN, ops.EPI_DGELU, g, W2, aux_in=u_t, drop_seed=11, drop_p=p)
+    du_s = torch.zeros((M, m), dtype=torch.bfloat16, device="cuda")
+    ops.skinny_nn(0, g[::n], W2, du_s[::n], u=u_t[::n], drop_seed=11, drop_p=p)
+    assert torch.equal(du_t[::n] == 0, du_s[::n] == 0) and torch.equal(du_t[::n] == 0, zeros_t | (du_t[::n] == 0))
+    assert rel_l2(du_s[::n].float(), du_t[::n].float()) < 4e-3
+    report("skinny cls-row kernels under dropout 0.25: masks identical to the tiled epilogues on the dense tensors (FC1, FC2 + residual, dU)")
+
+
 def test_gemm_ping_pong_grouped_equals_single_launches(ops):
     """Grouped weight gradients on the ping-pong tiles: bit-identical to single launches of the same kernel."""
     from neurovit_amd._cabi import lib
