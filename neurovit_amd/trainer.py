@@ -35,7 +35,7 @@ class TrainStep:
         #   1  inside those GEMMs' epilogues (nv_gemm_bf16_grouped_adamw; .grad of those weights is then None - torch's
         #      optimizer-in-backward trade), 2 = the same with the gradients still stored
         # None (default; NEUROVIT_FUSE_UPDATE unset) = by batch: 3 up to FUSE_MAX_ROWS token rows per step, 0 above.  ViT3D-base, same
-        # box, volumes/s mode 0 -> 3: batch 2 641 -> 655 (+2.3 %), 4: 1126 -> 1157 (+2.8 ... +3.7 %), 8: 1390 -> 1382, 16: 1780 -> 1749,
+        # box, volumes/s mode 0 -> 3: batch 2 641 -> 655 (+2.3 %), 4: 1113 -> 1165 (+4.8 %), 5: 1055 -> 1132, 6: 1152 -> 1191, 7: 1268 -> 1322, 8: 1390 -> 1382, 16: 1780 -> 1749,
         # 32: 1940 -> 1923; ViT3D-large 53.8 -> 53.3 - small batches leave wave slots and memory bandwidth idle beside the chain, large
         # ones do not.  Mode 1 at batch 2 / 4: +8 % / +2.5 % (profiles/r04_adamw_in_wgrad_epilogue.log)
         env = os.environ.get("NEUROVIT_FUSE_UPDATE")
