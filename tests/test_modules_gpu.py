@@ -362,6 +362,40 @@ def test_native_train_step_with_adamw_during_the_backward_pass_bitwise(nv, case)
     report(f"native train step, AdamW of the layers' weights during the backward pass [{case}] == separate AdamW (losses, logits, p, shadow, m, v: bitwise; modes 1, 2, 3)")
 
 
+def test_base_size_train_steps_are_bit_identical_in_every_update_mode(nv):
+    """BASELINE.json configs[1] at full size (ViT3D-base 128^3 p16, batch 4), ten train steps over three batches in every fuse_update mode: the
+    per-layer update (3) and the update inside the weight-gradient GEMMs (1, 2) rewrite the bf16 weights while the backward pass is still running -
+    a reader ordered wrongly shows up where the kernels take their real time, not on the micro model.  Losses, parameters, bf16 shadow and both
+    moments must equal those of the single update behind the backward pass (0) bit for bit (tools/mode_race_check.py runs 30 steps, with and
+    without dropout)."""
+    from neurovit_amd import config as nvcfg
+    from neurovit_amd.trainer import TrainStep
+    size = nvcfg.preset("base")
+    S = size["TRAINING_VIT_INPUT_SIZE"]
+    config = dict(DEVICE="cuda:0", TRAINING_DIM=3, TRAINING_DROPOUT=0.0, GRADCAM_CUBE_SIZE=8, DATASET_NAME="adni", TRAINING_LEARNING_RATE=1e-4,
+                  TRAINING_WEIGHT_DECAY=1e-2, **size)
+    batches = [(W.make_volume((4, S, S, S), 50 + i).cuda(), torch.tensor([i % 2, 1, 0, (i + 1) % 2], device="cuda")) for i in range(3)]
+    ref = None
+    for mode in (0, 3, 1):
+        torch.manual_seed(42)
+        model = nv.NeuroEncoder(config)
+        model.train()
+        step = TrainStep(model, fuse_update=mode)
+        losses = torch.stack([step(*batches[i % 3]).clone() for i in range(10)])
+        assert step._native and step.last_fuse_update == mode
+        vit = model.volume_encoder.vit3d
+        m, v = step.optimizer.arena_state(vit)
+        got = (losses, vit.flat_parameters()[0].clone(), vit.flat_parameters()[1].clone(), m.clone(), v.clone())
+        del model, step
+        if ref is None:
+            ref = got
+            assert torch.isfinite(losses).all() and float(losses[-1]) < float(losses[0])
+            continue
+        for name, a, b in zip(("losses", "parameters", "bf16 shadow", "exp_avg", "exp_avg_sq"), ref, got):
+            assert torch.equal(a, b), f"fuse_update={mode}: {name} differ from the single update behind the backward pass"
+    report("ViT3D-base batch 4, 10 train steps: update modes 3 and 1 == mode 0 (losses, parameters, shadow, moments: bitwise)")
+
+
 def test_graph_replayed_train_step_equals_eager_launches_bitwise(nv, monkeypatch):
     """NEUROVIT_GRAPH_STEP=1: after three eager native steps the forward + loss + backward of a step is captured as a HIP graph per
     (input address, label address) and replayed (AdamW launched behind it): eight steps alternating between TWO batches (two graphs)
