@@ -75,12 +75,13 @@ __device__ __forceinline__ bf16x8 cvt8(f32x4 a, f32x4 b) {
 }
 
 // exact-erf GELU (nn.GELU() default, vit_3d.py:20) and its derivative.  erf by Abramowitz-Stegun 7.1.26
-// (|error| <= 1.5e-7 absolute - three orders below the bf16 resolution of the values these feed), ~15 VALU ops
+// (|error| <= 1.5e-7 absolute - three orders below the bf16 resolution of the values these feed), ~16 VALU ops
 // instead of the ~40 of libm's erff: the GELU epilogues run on the four consumer waves only.
 // Both return through one shared exp(-u^2/2).
 __device__ __forceinline__ void erf_parts(float u, float& erf_v, float& gauss) {
   const float x = fabsf(u) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);   // v_rcp_f32 (1 ulp): __frcp_rn is the ten-instruction IEEE division - a third of this function's VALU time, for a
+                                                                    // correctly rounded t whose last bit is 1e-7 of an erf that is itself good to 1.5e-7 and feeds bf16 values
   gauss = __expf(-x * x);                                   // = exp(-u^2 / 2)
   const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
   erf_v = copysignf(1.0f - poly * gauss, u);

@@ -65,15 +65,29 @@ def run_case(engine, tag, cfgdict, seeds, B=2, dropout=(0.0, 0.0, 0)):
     does), then once more in the product's default form - the last block's out-projection / FeedForward on the cls rows only
     (rows_form = 2; the form is an argument of each call) - which must reproduce the logits and every gradient."""
     out = _run_case_full_rows(engine, tag, cfgdict, seeds, B, dropout)
-    logits, rt, gcpu, (cfg, params, params16, video, dlogits) = out
+    logits, rt, gcpu, (cfg, params, params16, video, dlogits), (names, off, num, ref_grads, grads32) = out
     rt2 = engine.VitRuntime(cfg)
     logits2 = rt2.forward(video, params, params16, training=True, dropout=dropout, rows_form=2)
     grads2 = torch.zeros_like(params)
     rt2.backward(dlogits, params, params16, grads2, accumulate=False)
     assert rel_l2(logits2, logits) < 1e-5, (tag, "cls-rows form: logits")
-    e = rel_l2(grads2.cpu(), gcpu)
-    report(f"{tag} cls-rows form of the last block vs all rows: logits {rel_l2(logits2, logits):.2e}, gradient arena {e:.2e}")
-    assert e < 2e-5, (tag, "cls-rows form: gradients", e)
+    # The two forms are the same arithmetic up to the summation order of the last block's Linear layers on the cls rows (weight-streaming
+    # against tiled kernels): fp32-rounding differences (~1e-6) in that block.  Whether they STAY there is luck: every layer of the backward pass
+    # rounds the residual gradient to bf16, and one flipped rounding is a 4e-3 change of that element which the layers below inherit - the
+    # gradient arenas of the two forms then differ by 1e-8 (no flip: most seeds) or by up to ~2e-3 (flips; base(B=1): 1.6e-3 after an
+    # unrelated 1-ulp change of the GELU's reciprocal moved one bf16 value of u).  So the cls-rows form is held to the SAME gates against the
+    # two oracles as the every-row form (every parameter, three-way), and to the every-row form itself at the size of those gates.
+    g2 = grads2.cpu()
+    fails = []
+    for k, o, nn in zip(names, off, num):
+        hip = g2[o:o + nn].reshape(ref_grads[k].shape)
+        e_he, e_h32, e_e32 = rel_l2(hip, ref_grads[k]), rel_l2(hip, grads32[k]), rel_l2(ref_grads[k], grads32[k])
+        if not (e_h32 <= RATIO * e_e32 + SLACK and e_he <= GRAD_REL):
+            fails.append((k, e_he, e_h32, e_e32))
+    assert not fails, (tag, "cls-rows form: gradients against the oracles", fails)
+    e = rel_l2(g2, gcpu)
+    report(f"{tag} cls-rows form of the last block vs all rows: logits {rel_l2(logits2, logits):.2e}, gradient arena {e:.2e} (every parameter inside the oracle gates)")
+    assert e < 5e-3, (tag, "cls-rows form: gradients", e)
     return logits, rt, None
 
 
@@ -128,7 +142,7 @@ def _run_case_full_rows(engine, tag, cfgdict, seeds, B, dropout):
     # accumulate=True doubles every gradient
     rt.backward(dlogits.cuda(), params, params16, grads, accumulate=True)
     assert rel_err(grads.cpu(), 2 * gcpu) < 1e-5
-    return logits, rt, gcpu, (cfg, params, params16, video, dlogits.cuda())
+    return logits, rt, gcpu, (cfg, params, params16, video, dlogits.cuda()), (names, off, num, ref_grads, grads32)
 
 
 G4_GATE = {"micro": 3.0e-3, "tiny": 2.4e-3}     # 1.5 x measured (1.92e-3, 1.49e-3): see the module docstring
@@ -321,7 +335,7 @@ def test_cls_rows_form_under_dropout_applies_the_masks_of_the_dense_tensors(eng)
         grads.append(g.clone())
     e = rel_l2(grads[1], grads[0])
     report(f"cls-rows form under dropout 0.2 vs every row: gradient arena {e:.2e}")
-    assert e < 2e-5, e
+    assert e < 5e-3, e        # (a differing mask bit would be a difference of order 0.1-1; fp32-rounding differences can reach 1e-3 through bf16 flips, see run_case)
     # and without dropout the two forms agree to fp32 rounding, training or not
     for training in (False, True):
         a = rt.forward(video, params, p16, training=training, rows_form=1).clone()
