@@ -32,6 +32,17 @@ int nv_version(void);
 int nv_arch_ok(void);                 /* 1 iff the current HIP device is gfx950 */
 const char* nv_last_error(void);
 
+/* ---- 16-bit operand format (process-wide, like the nv_*_set_* tuning switches): what every `void*` buffer this header calls
+ * "bf16" holds, and which MFMA instruction contracts it.  NV_OPERAND_BF16 (default; BASELINE.json's dtype) or NV_OPERAND_FP16 - the
+ * reference's own training arithmetic (torch.autocast(float16) + GradScaler, src/Trainer.py:29,68,74-76): same MFMA rate, 11 instead
+ * of 8 significand bits (logits within 1e-3 of the reference's fp32 CPU forward), 5 instead of 8 exponent bits (train with a loss
+ * scale: nv_train_hparams.loss_scale).  The fp8 entry points require NV_OPERAND_BF16.  Set it before the calls of a model; buffers
+ * written under one format must be read under the same one. */
+#define NV_OPERAND_BF16 0
+#define NV_OPERAND_FP16 1
+int nv_set_operand_format(int fmt);
+int nv_operand_format(void);
+
 /* ---- optional per-launch hipEvent profiler (bench.py roofline leg).  kind: warp-specialised GEMM kernels 0 NT, 1 NN, 2 TN;
  * 3 attention fwd, 4 attention bwd; 5 fp8 GEMM; eight-wave 256 x 128 GEMM kernel 10 NT, 11 NN, 12 TN, 13 grouped TN; 256 x 256 kernel 20 NT,
  * 21 NN, 22 TN; fp32 path: 30 GEMM, 31 attention.  nv_prof_summary synchronises; call it outside timed regions. */
@@ -280,6 +291,31 @@ int nv_ce_loss(const float* logits, const long* target, int B, int C, float grad
                void* stream);
 int nv_adamw_step(float* p, const void* grad, int grad_bf16, float* m, float* v, void* p16, long count, int step, double lr,
                   double beta1, double beta2, double eps, double weight_decay, float grad_scale, int max_blocks, void* stream);
+/* ---- dynamic loss scale for NV_OPERAND_FP16 training: torch.amp.GradScaler (src/Trainer.py:29,74-76) kept on the device - no
+ * found_inf read-back per step.  `state`: NV_LOSS_SCALE_FLOATS floats of device memory owned by the caller; [0] = current scale,
+ * [5] = optimizer updates applied so far, [11] = updates skipped (the rest: common.h LS_*).  Per optimizer step:
+ *   nv_ce_loss_scaled / nv_head_step_scaled   d(loss)/d(logits) is multiplied by state[0] (the reported loss is not)
+ *   nv_loss_scale_check(grads, count, state)  found_inf |= any inf / NaN in grads[0 .. count)   (after the backward pass / all-reduce)
+ *   nv_loss_scale_update(state, lr, b1, b2)   decides skip or step: backoff / growth of the scale, AdamW's step count and bias
+ *                                             corrections (double arithmetic, as torch forms them), 1 / scale for the update
+ *   nv_adamw_step_scaled(..., state, stream)  nv_adamw_step that does nothing when the step is skipped and un-scales the gradients
+ *                                             (its `step` argument is ignored: the state's own count of applied updates is used)
+ * GradScaler defaults: init_scale 65536, growth_factor 2, backoff_factor 0.5, growth_interval 2000.  start_step = updates already
+ * applied to the optimizer state. */
+#define NV_LOSS_SCALE_FLOATS 16
+int nv_loss_scale_init(float* state, float init_scale, float growth_factor, float backoff_factor, int growth_interval, int start_step, void* stream);
+int nv_loss_scale_check(const float* grads, long count, float* state, void* stream);
+int nv_loss_scale_update(float* state, double lr, double beta1, double beta2, void* stream);
+int nv_ce_loss_scaled(const float* logits, const long* target, int B, int C, float grad_scale, const float* scale_state, float* loss,
+                      float* dlogits, void* stream);
+int nv_adamw_step_scaled(float* p, const void* grad, int grad_bf16, float* m, float* v, void* p16, long count, int step, double lr,
+                         double beta1, double beta2, double eps, double weight_decay, float grad_scale, int max_blocks,
+                         const float* scale_state, void* stream);
+int nv_head_step_scaled(const float* x, long row_stride, int B, int d, const float* gamma, const float* beta, float eps, const float* W,
+                        const float* bias, int C, const long* labels, float grad_scale, const float* scale_state, float* xh, float* stats,
+                        float* logits, float* loss, float* dlogits, int n, float* g, long ldg, void* g16, long ldg16, float* dgamma,
+                        float* dbeta, float* dW, float* dbias, float* dcolsum, int accumulate, void* workspace, long ws_bytes,
+                        unsigned long drop_seed, float drop_p, void* stream);
 /* grad_bf16 = 1: `grad` is a bf16 buffer (the gradient all-reduce ran on bf16 messages): no cast back to fp32 is needed. */
 /* max_blocks > 0 caps the grid (256-thread workgroups, grid-stride): used when the update of one gradient bucket runs on a
    side stream beside the backward pass, so that it takes a slice of the chip instead of queueing ahead of the GEMMs. */
@@ -438,6 +474,13 @@ typedef struct nv_train_hparams {
                              * themselves (nv_gemm_bf16_grouped_adamw; the gradients of those weights are then NOT left in `grads`),
                              * 2 = the same and they are.  In 1 .. 3 the rest of the arena is updated by one nv_adamw_ranges launch.
                              * Parameters, optimizer state and losses are bit-identical in all four */
+  float loss_scale;         /* (revision 6) static loss scale: d(loss)/d(logits) is multiplied by it and the update divides it out again
+                             * (0 or 1 = none) - what keeps the 16-bit gradient tensors of NV_OPERAND_FP16 away from the subnormals; a power
+                             * of two changes no bit of a finite result.  No overflow check: use loss_scale_state for GradScaler semantics */
+  float* loss_scale_state;  /* (revision 6) device block of nv_loss_scale_init or NULL: dynamic loss scale (torch.amp.GradScaler, Trainer.py:29,
+                             * 74-76) - the step is scaled by its current value, every gradient is checked for inf / NaN after the backward
+                             * pass, and the update is applied or skipped on the device (requires fuse_update = 0; with accumulate / update
+                             * = 0 micro-steps only the scaling happens) */
 } nv_train_hparams;
 int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
                       float* params, void* params16, float* grads, float* adam_m, float* adam_v, void* workspace, long ws_bytes,
@@ -451,7 +494,7 @@ int nv_cu_census(unsigned* out, int blocks, int threads, int lds_bytes, int hold
 
 /* ABI revision of this header: bumped whenever a struct gains a field or an entry point changes its argument list (the list is in
  * INTEGRATION.md "ABI revisions").  A caller built against revision R must refuse a library whose nv_abi_version() != R. */
-#define NV_ABI_VERSION 5
+#define NV_ABI_VERSION 6
 int nv_abi_version(void);
 /* dst[b .. b + len) = bf16(src[b .. b + len)) for `count` element ranges (HOST arrays begins / lens; any count) */
 int nv_cast_ranges_bf16(const float* src, void* dst, const long* begins, const long* lens, int count, void* stream);

@@ -19,41 +19,41 @@ import torch.nn.functional as F
 from .vit_3d import ViT
 
 
+def _encoder_weights_of(checkpoint: dict, prefix: str = "volume_encoder.") -> dict:
+    """The entries of a 3D NeuroEncoder checkpoint that belong to its ViT3DEncoder, re-keyed for that sub-module: the 4D model is
+    built around the encoder of a trained 3D model (NeuroEncoder.py:23-31) and nothing else of that file is used."""
+    wanted = prefix + "vit3d."
+    return {key[len(prefix):]: tensor for key, tensor in checkpoint.items() if key.startswith(wanted)}
+
+
 class NeuroEncoder(nn.Module):
-    """3D or 4D encoder for MRI / fMRI volumes (NeuroEncoder.py:15-68)."""
+    """3D or 4D encoder for MRI / fMRI volumes (NeuroEncoder.py:15-68).  Attribute names and the ORDER in which sub-modules are created
+    are the contract (state_dict keys; the RNG stream of a seeded construction) - tests/test_boundary_cpu.py pins both."""
 
     def __init__(self, config):
         super().__init__()
         self.config = config
         self.device = config['DEVICE']
-
         self.volume_encoder = ViT3DEncoder(config)
-
-        if config['TRAINING_DIM'] == 4:
-            # Extract only ViT3D weights by filtering keys (NeuroEncoder.py:23-36)
-            best_model_path = os.path.join(config['GLOBAL_BASE_PATH'], config['BEST_MODEL_PATH'])
-            full_state_dict = torch.load(best_model_path, map_location='cpu', weights_only=True)
-            vit3d_state_dict = {
-                k.replace("volume_encoder.vit3d.", "vit3d."): v
-                for k, v in full_state_dict.items()
-                if k.startswith("volume_encoder.vit3d.")
-            }
-            self.volume_encoder.load_state_dict(vit3d_state_dict, strict=True)
-
-            for param in self.volume_encoder.parameters():
-                param.requires_grad = False
-            self.volume_encoder.eval()
-
+        four_d = config['TRAINING_DIM'] == 4
+        if four_d:
+            self._adopt_trained_encoder(os.path.join(config['GLOBAL_BASE_PATH'], config['BEST_MODEL_PATH']))
             self.temporal_transformer = TemporalTransformer(config)
             self.projection_head = ProjectionHead(config)
             # the two modules above hold the parameters (reference classes, keys and initialisation); the computation
             # transformer -> mean over time -> projection is one native launch per direction (temporal.py, csrc/temporal.hip)
             from .temporal import TemporalHead
             self._temporal_head = TemporalHead(self.temporal_transformer, self.projection_head)
-
-        self.to(self.device)  # Move entire model to device
-
+        self.to(self.device)
         self.register_hooks()
+
+    def _adopt_trained_encoder(self, checkpoint_path: str) -> None:
+        """4D model (NeuroEncoder.py:23-36): the spatial encoder is the ViT3D of a trained 3D checkpoint - loaded strictly, frozen and
+        kept in eval mode; only the temporal head trains.  The file is read with weights_only=True (a plain state_dict, Trainer.py:54-55)."""
+        saved = torch.load(checkpoint_path, map_location='cpu', weights_only=True)
+        self.volume_encoder.load_state_dict(_encoder_weights_of(saved), strict=True)
+        self.volume_encoder.requires_grad_(False)
+        self.volume_encoder.eval()
 
     def forward(self, fmri):
         if self.config['TRAINING_DIM'] == 3:
@@ -80,8 +80,14 @@ class NeuroEncoder(nn.Module):
         return self.projection_head(pooled)
 
     def precision(self, mode: str):
-        """Context manager: eval-mode no-grad forwards of the ViT3D encoder inside it run in `mode` ("bf16" | "fp32")."""
+        """Context manager: eval-mode no-grad forwards of the ViT3D encoder inside it run in `mode` ("bf16" / "fp16": the 16-bit
+        operand path in the encoder's operand format, or "fp32")."""
         return self.volume_encoder.vit3d.precision(mode)
+
+    def set_operands(self, fmt: str):
+        """16-bit MFMA operand format of the ViT3D encoder: "bf16" (default) or "fp16" (the reference's autocast arithmetic)."""
+        self.volume_encoder.vit3d.set_operands(fmt)
+        return self
 
     def forward_raw(self, raw, crop=None):
         """3D model fed RAW scanner volumes [B, X, Y, Z] float32 on the device: the dataset's crop (DatasetADNI.py:212) is a strided
@@ -175,6 +181,10 @@ class NeuroEncoder(nn.Module):
 class ViT3DEncoder(nn.Module):
     """NeuroEncoder.py:171-205: config -> ViT, and the [B,H,W,D] -> [B,1,D,H,W] input view."""
 
+    # the transformer size the reference hard-codes (NeuroEncoder.py:187-190); optional TRAINING_VIT_* keys override it
+    REFERENCE_SIZE = {'TRAINING_VIT_DIM': 1024, 'TRAINING_VIT_DEPTH': 6, 'TRAINING_VIT_HEADS': 8, 'TRAINING_VIT_DIM_HEAD': 64,
+                      'TRAINING_VIT_MLP_DIM': 2048}
+
     def __init__(self, config):
         super().__init__()
         self.device = config['DEVICE']
@@ -182,27 +192,21 @@ class ViT3DEncoder(nn.Module):
         self.grid_size = config['TRAINING_VIT_INPUT_SIZE']
         self.cube_size = config['GRADCAM_CUBE_SIZE']
         self.patch_size = config['TRAINING_VIT_PATCH_SIZE']
-        number_classes = (self.grid_size // self.cube_size) ** 3 if config['DATASET_NAME'] == 'gradcam' else 2
-
-        self.vit3d = ViT(
-            channels=1,
-            image_size=self.grid_size,
-            image_patch_size=self.patch_size,
-            frames=self.grid_size,
-            frame_patch_size=self.patch_size,
-            num_classes=number_classes,
-            dim=config.get('TRAINING_VIT_DIM', 1024),
-            depth=config.get('TRAINING_VIT_DEPTH', 6),
-            heads=config.get('TRAINING_VIT_HEADS', 8),
-            dim_head=config.get('TRAINING_VIT_DIM_HEAD', 64),
-            mlp_dim=config.get('TRAINING_VIT_MLP_DIM', 2048),
-            dropout=self.dropout,
-            emb_dropout=self.dropout,
-            pool='cls'
-        ).to(self.device)
+        size = {key: config.get(key, default) for key, default in self.REFERENCE_SIZE.items()}
+        # the synthetic cube-localisation task has one class per cube position (NeuroEncoder.py:179); everything else is binary
+        cubes_per_axis = self.grid_size // self.cube_size
+        classes = cubes_per_axis ** 3 if config['DATASET_NAME'] == 'gradcam' else 2
+        # a cubic single-channel volume: frames (depth) and image sides share one extent and one patch edge
+        self.vit3d = ViT(image_size=self.grid_size, image_patch_size=self.patch_size, frames=self.grid_size, frame_patch_size=self.patch_size,
+                         channels=1, num_classes=classes, dim=size['TRAINING_VIT_DIM'], depth=size['TRAINING_VIT_DEPTH'],
+                         heads=size['TRAINING_VIT_HEADS'], dim_head=size['TRAINING_VIT_DIM_HEAD'], mlp_dim=size['TRAINING_VIT_MLP_DIM'],
+                         pool='cls', dropout=self.dropout, emb_dropout=self.dropout).to(self.device)
         # arithmetic of eval-mode no-grad forwards: "bf16" (default; the training arithmetic) or "fp32" (the reference's validate,
         # Trainer.py:101-118).  The Trainer shell's validate / evaluate_samples use VALIDATION_PRECISION (default "fp32").
         self.vit3d.eval_precision = config.get('TRAINING_VIT_EVAL_PRECISION', 'bf16')
+        # 16-bit MFMA operand format of the training arithmetic: "bf16" (default) or "fp16" - what the reference's autocast(float16)
+        # computes in (Trainer.py:68); TrainStep then scales the loss as its GradScaler does (Trainer.py:29,74-76)
+        self.vit3d.set_operands(config.get('TRAINING_VIT_OPERANDS', 'bf16'))
 
     def forward_raw(self, raw, crop=None):
         from .preprocess import ADNI_CROP, crop_view, volume_sigma
@@ -218,21 +222,21 @@ class ViT3DEncoder(nn.Module):
     def forward(self, x):
         # x: (batch, H, W, D).  The permuted tensor is only a VIEW: the patch-gather kernel reads the original
         # [B,H,W,D] memory through its strides, so the reference's permute never costs a copy.
-        timepoint = x.to(self.device)
-        timepoint = timepoint.permute(0, 3, 1, 2)
-        timepoint = timepoint.unsqueeze(1)
-        return self.vit3d(timepoint)
+        volume = x.to(self.device)
+        return self.vit3d(volume.permute(0, 3, 1, 2).unsqueeze(1))      # (batch, channel = 1, frames = D, height = H, width = W)
 
 
 class TemporalTransformer(nn.Module):
     """NeuroEncoder.py:207-217.  d_model = 2 (the frozen ViT3D emits 2 logits): 10 274 parameters.  The stock module is the
     parameter holder (reference state_dict keys and initialisation); NeuroEncoder.forward computes it through temporal.TemporalHead."""
 
+    D_MODEL, HEADS, LAYERS = 2, 2, 1      # NeuroEncoder.py:210-211: the sequence elements are the encoder's two logits
+
     def __init__(self, config):
         super().__init__()
         self.device = config['DEVICE']
-        encoder_layer = nn.TransformerEncoderLayer(d_model=2, nhead=2, batch_first=True)
-        self.transformer = nn.TransformerEncoder(encoder_layer, num_layers=1).to(self.device)
+        block = nn.TransformerEncoderLayer(d_model=self.D_MODEL, nhead=self.HEADS, batch_first=True)
+        self.transformer = nn.TransformerEncoder(block, num_layers=self.LAYERS).to(self.device)
 
     def forward(self, x):
         return self.transformer(x)

@@ -36,7 +36,8 @@ class TrainHparams(ctypes.Structure):
     """struct nv_train_hparams (neurovit_hip.h): optimizer constants and accumulation flags of nv_vit_train_step."""
     _fields_ = [("struct_size", ctypes.c_int), ("step", ctypes.c_int), ("lr", ctypes.c_double), ("beta1", ctypes.c_double),
                 ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double), ("grad_scale", ctypes.c_float),
-                ("accumulate", ctypes.c_int), ("update", ctypes.c_int), ("fuse_update", ctypes.c_int)]
+                ("accumulate", ctypes.c_int), ("update", ctypes.c_int), ("fuse_update", ctypes.c_int),
+                ("loss_scale", ctypes.c_float), ("loss_scale_state", ctypes.c_void_p)]
 
 
 class AdamwArena(ctypes.Structure):
@@ -47,7 +48,7 @@ class AdamwArena(ctypes.Structure):
                 ("adam_v", ctypes.c_void_p), ("params16", ctypes.c_void_p)]
 
 
-ABI_VERSION = 5      # NV_ABI_VERSION of the header this binding was written against (checked at load time)
+ABI_VERSION = 6      # NV_ABI_VERSION of the header this binding was written against (checked at load time)
 
 
 def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
@@ -107,6 +108,26 @@ class _Lib:
 
 
 lib = _Lib()
+
+
+OPERAND_FORMATS = {"bf16": 0, "fp16": 1}      # NV_OPERAND_BF16 / NV_OPERAND_FP16
+_operand_format = "bf16"                      # what the library is set to (its own default)
+
+
+def set_operand_format(fmt: str) -> None:
+    """Select what every 16-bit buffer of the following calls holds and which MFMA contracts it (nv_set_operand_format): "bf16" (default)
+    or "fp16" - the reference's autocast arithmetic (src/Trainer.py:68).  Process-wide in the library; modules set their own format
+    in front of their calls, so models of both formats can live in one process.  Costs a C call only when the format changes."""
+    global _operand_format
+    if fmt != _operand_format:
+        if fmt not in OPERAND_FORMATS:
+            raise ValueError(f"neurovit_amd: operand format must be 'bf16' or 'fp16', got {fmt!r}")
+        check(lib.nv_set_operand_format(OPERAND_FORMATS[fmt]), "nv_set_operand_format")
+        _operand_format = fmt
+
+
+def operand_format() -> str:
+    return _operand_format
 
 
 def last_error() -> str:

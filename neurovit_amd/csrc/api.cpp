@@ -20,6 +20,19 @@ extern "C" int nv_version(void) { return 1; }
 #include "../../include/neurovit_hip.h"
 extern "C" int nv_abi_version(void) { return NV_ABI_VERSION; }   // see INTEGRATION.md "ABI revisions"
 
+// ---- 16-bit operand format of this process: what every `void*` "16-bit" buffer of the C-ABI holds and which MFMA the contractions
+// issue (common.h: kernels are templates over the element type; every launcher reads this switch).  bf16 is the default and what
+// BASELINE.json's metric names; fp16 is the reference's own training arithmetic (autocast(float16) + GradScaler, src/Trainer.py:29,68,
+// 74-76): 3 more mantissa bits (logits within 1e-3 of the fp32 CPU forward) at the same MFMA rate, 5 instead of 8 exponent bits
+// (the train step then scales the loss: nv_loss_scale_*).  A caller that mixes models of both formats sets it before each call.
+static int g_operand_format = NV_OPERAND_BF16;
+extern "C" int nv_operand_format(void) { return g_operand_format; }
+extern "C" int nv_set_operand_format(int fmt) {
+  if (fmt != NV_OPERAND_BF16 && fmt != NV_OPERAND_FP16) { nv_set_error("nv_set_operand_format: %d is neither NV_OPERAND_BF16 (0) nor NV_OPERAND_FP16 (1)", fmt); return NV_ERR_ARG; }
+  g_operand_format = fmt;
+  return NV_OK;
+}
+
 // 1 when the current HIP device is gfx950 (MI355X), 0 otherwise, negative on HIP error.
 extern "C" int nv_arch_ok(void) {
   int dev = 0;

@@ -29,7 +29,7 @@ constexpr int TK = 64;            // keys per LDS tile
 constexpr int IMG = TK * DH * 2;  // 8 KiB image
 
 // stage one [64 rows][64 bf16] tile: rows row0.. of X (row stride ld), zero-fill rows >= nrows
-__device__ __forceinline__ void tile_gload(const bf16* X, long ld, int row0, int nrows, int tid, uint4 (&reg)[2]) {
+__device__ __forceinline__ void tile_gload(const r16* X, long ld, int row0, int nrows, int tid, uint4 (&reg)[2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int c = tid + 256 * i, row = row0 + (c >> 3);
@@ -46,15 +46,15 @@ __device__ __forceinline__ void tile_swrite(char* img, int tid, const uint4 (&re
   }
 }
 // row-read fragment: lane (r,g) <- X[16t + r][32ks + 8g .. +7]
-__device__ __forceinline__ bf16x8 frag_row(const char* img, int t, int ks, int r, int g) {
-  return *reinterpret_cast<const bf16x8*>(img + img128_off(16 * t + r, 4 * ks + g));
+__device__ __forceinline__ r16x8 frag_row(const char* img, int t, int ks, int r, int g) {
+  return *reinterpret_cast<const r16x8*>(img + img128_off(16 * t + r, 4 * ks + g));
 }
 // transposed fragment: lane (r,g) <- { X[32ks + 4g + j][16t + r] (j<4), X[32ks + 16 + 4g + j-4][16t + r] (j>=4) }
-__device__ __forceinline__ bf16x8 frag_tr(const char* img, int t, int ks, int r, int g) {
+__device__ __forceinline__ r16x8 frag_tr(const char* img, int t, int ks, int r, int g) {
   const int q = r >> 2, p = r & 3;
   const int ch = 2 * t + (p >> 1), sub = (p & 1) << 3;
-  const bf16x4 lo = lds_read_tr(img + img128_off(32 * ks + 4 * g + q, ch) + sub);
-  const bf16x4 hi = lds_read_tr(img + img128_off(32 * ks + 16 + 4 * g + q, ch) + sub);
+  const r16x4 lo = lds_read_tr(img + img128_off(32 * ks + 4 * g + q, ch) + sub);
+  const r16x4 hi = lds_read_tr(img + img128_off(32 * ks + 16 + 4 * g + q, ch) + sub);
   return cat4(lo, hi);
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -109,7 +109,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // pieces back to back (identical arithmetic, bit-identical results).
 // The softmax is VALU-bound (head dim 64: 16 MFMAs per tile against ~16 scores per lane), so it is written for the
 // packed fp32 pipe (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32), v_max3_f32 and the bare v_exp_f32.
-struct RowFrags { bf16x8 f[2][4]; };    // [ks][t]: fragments of one 64-row operand tile
+struct RowFrags { r16x8 f[2][4]; };    // [ks][t]: fragments of one 64-row operand tile
 __device__ __forceinline__ void load_row_frags(const char* img, int r, int g, RowFrags& F) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
@@ -123,7 +123,8 @@ __device__ __forceinline__ void load_tr_frags(const char* img, int r, int g, Row
     for (int t = 0; t < 4; ++t) F.f[ks][t] = frag_tr(img, t, ks, r, g);
 }
 // acc[t] (+)= X_tile[16t.., :] . y   (ks outer: four independent accumulators between dependent MFMAs)
-__device__ __forceinline__ void mfma_rows(const RowFrags& F, const bf16x8 (&y)[2], f32x4 (&acc)[4], bool zero) {
+template <typename T>
+__device__ __forceinline__ void mfma_rows(const RowFrags& F, const r16x8 (&y)[2], f32x4 (&acc)[4], bool zero) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if (zero) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -131,7 +132,7 @@ __device__ __forceinline__ void mfma_rows(const RowFrags& F, const bf16x8 (&y)[2
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.f[ks][t], y[ks], acc[t], 0, 0, 0);
+    for (int t = 0; t < 4; ++t) acc[t] = mfma16<T>(F.f[ks][t], y[ks], acc[t]);
 }
 // online softmax of one tile's raw scores s (in place -> probabilities, dropout applied), running max m / sum l, rescale of o
 template <bool DROP>
@@ -187,20 +188,21 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4], int kt, bool last, in
     }
 }
 // o[t] += V_tile^T[16t.., :] . P^T   (the probability accumulators are the MFMA B operand)
+template <typename T>
 __device__ __forceinline__ void fwd_pv(const RowFrags& V, const f32x4 (&s)[4], f32x4 (&o)[4]) {
-  const bf16x8 pf[2] = {cvt8(s[0], s[1]), cvt8(s[2], s[3])};
-  mfma_rows(V, pf, o, false);
+  const r16x8 pf[2] = {cvt8<T>(s[0], s[1]), cvt8<T>(s[2], s[3])};
+  mfma_rows<T>(V, pf, o, false);
 }
-template <bool DROP>
-__device__ __forceinline__ void fwd_tile(const char* sK, const char* sV, int kt, bool last, int n, const bf16x8 (&qf)[2], f32x4 (&o)[4],
+template <bool DROP, typename T>
+__device__ __forceinline__ void fwd_tile(const char* sK, const char* sV, int kt, bool last, int n, const r16x8 (&qf)[2], f32x4 (&o)[4],
                                          float& m, float& l, float scale_log2e, const DropCfg& drop, int bh, int qabs, int r, int g) {
   RowFrags F;
   f32x4 s[4];
   load_row_frags(sK, r, g, F);
-  mfma_rows(F, qf, s, true);
+  mfma_rows<T>(F, qf, s, true);
   fwd_softmax<DROP>(s, kt, last, n, o, m, l, scale_log2e, drop, bh, qabs, g);
   load_tr_frags(sV, r, g, F);
-  fwd_pv(F, s, o);
+  fwd_pv<T>(F, s, o);
 }
 
 // merge of two online-softmax states of the same rows (key range split in two): shared by the streaming kernel (which keeps
@@ -220,37 +222,38 @@ __device__ __forceinline__ int attn_half_tiles(int nkt) { return (nkt + 1) >> 1;
 
 // One query row's 64 outputs of this lane (4 x 4 consecutive columns): bf16, or - o8 > 0, the fp8 inference path's out-projection
 // operand - OCP e4m3 bytes of (value * o8) at the same ELEMENT offsets of a byte buffer.
-__device__ __forceinline__ void store_out_row(bf16* out, long off, const f32x4 (&o)[4], float inv, float o8, int g) {
+template <typename T>
+__device__ __forceinline__ void store_out_row(r16* out, long off, const f32x4 (&o)[4], float inv, float o8, int g) {
   if (o8 > 0.f) {
     unsigned char* row = reinterpret_cast<unsigned char*>(out) + off;
     const float sc = inv * o8;
 #pragma unroll
     for (int t = 0; t < 4; ++t) *reinterpret_cast<unsigned*>(row + 16 * t + 4 * g) = pack_fp8x4(o[t] * sc);
   } else {
-    bf16* row = out + off;
+    r16* row = out + off;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x4*>(row + 16 * t + 4 * g) = cvt4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<r16x4*>(row + 16 * t + 4 * g) = cvt4<T>(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
   }
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
-                                                       bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop, float o8) {
+template <bool DROP, typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const r16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
+                                                       r16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop, float o8) {
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
   char* sK = smem;
   char* sV = smem + IMG;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 15, g = lane >> 4;
   const Grid2 gb = grid2d_xcd((n + TQ - 1) / TQ);                  // 1-D launch: whole heads per XCD
   const int b = gb.by / heads, h = gb.by - b * heads, inner = heads * DH;
-  const bf16* Q = qkv + (long)b * n * ld + h * DH;
-  const bf16* K = Q + inner;
-  const bf16* V = Q + 2 * inner;
+  const r16* Q = qkv + (long)b * n * ld + h * DH;
+  const r16* K = Q + inner;
+  const r16* V = Q + 2 * inner;
   const int q0 = gb.bx * TQ + 16 * wid;
   const int qrow = min(q0 + r, n - 1);
 
-  bf16x8 qf[2];
+  r16x8 qf[2];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const r16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
 
   f32x4 o[4], o0[4];
 #pragma unroll
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
       for (int t = 0; t < 4; ++t) { o0[t] = o[t]; o[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
-    fwd_tile<DROP>(sK, sV, kt, kt == nkt - 1, n, qf, o, m, l, scale_log2e, drop, gb.by, q0 + r, r, g);
+    fwd_tile<DROP, T>(sK, sV, kt, kt == nkt - 1, n, qf, o, m, l, scale_log2e, drop, gb.by, q0 + r, r, g);
   }
   if (nkt <= nh) {                       // single tile: the (empty) second state is merged all the same
     m0 = m; l0 = l; m = -INFINITY; l = 0.f;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const float inv = 1.0f / ltot;
   const int q = q0 + r;
   if (q < n) {
-    store_out_row(out, ((long)b * n + q) * ldo + h * DH, o, inv, o8, g);
+    store_out_row<T>(out, ((long)b * n + q) * ldo + h * DH, o, inv, o8, g);
     if (g == 0 && lse) lse[((long)b * heads + h) * n + q] = (m + log2f(ltot)) * 0.69314718055994530942f;
   }
 }
@@ -311,7 +314,7 @@ constexpr int RES_MAX_TILES = 9;
 
 // (LDS-DMA helpers - uniform_rsrc / lds_dma, issued from inline asm - are in common.h)
 // all eight waves: DMA rows 0 .. 64*nt-1 of X (row stride ld elements, 64 bf16 per row) into nt swizzled 8 KiB images
-__device__ __forceinline__ void res_dma(const bf16* X, long ld, int n, int nt, char* img, int wid, int lane) {
+__device__ __forceinline__ void res_dma(const r16* X, long ld, int n, int nt, char* img, int wid, int lane) {
   const unsigned bytes = (unsigned)((((long)n - 1) * ld + DH) * 2);
   const dma_desc rs = uniform_rsrc(X, bytes);
   const int row = lane >> 3;                                          // 8 rows x 8 chunks per wave-instruction
@@ -344,9 +347,9 @@ __device__ __forceinline__ ResBlock res_block(int n) {
 
 // SPLIT = 2: sixteen waves; waves w and w + 8 share a row group and take one half of the key tiles each (four waves per
 // SIMD instead of two hide the softmax's dependent-instruction latency), then merge (m, l, o) through LDS.
-template <int SPLIT, bool DROP>
-__global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads,
-                                                                           float scale_log2e, bf16* __restrict__ out, long ldo,
+template <int SPLIT, bool DROP, typename T>
+__global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const r16* __restrict__ qkv, long ld, int n, int heads,
+                                                                           float scale_log2e, r16* __restrict__ out, long ldo,
                                                                            float* __restrict__ lse, DropCfg drop, float o8) {
   extern __shared__ __attribute__((aligned(16))) char rsmem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
@@ -354,16 +357,16 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
   const int slot = wid & 7, half = wid >> 3;          // half is 0 when SPLIT == 1
   const ResBlock rb = res_block(n);
   const int b = rb.by / heads, h = rb.by - b * heads, inner = heads * DH;
-  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const r16* Q = qkv + (long)b * n * ld + h * DH;
   const int nkt = (n + TK - 1) / TK;
   char* sK = rsmem;
   char* sV = rsmem + nkt * IMG;
   const int grp = res_group(n, slot, rb.bx, rb.nblk);
   const int q0 = (grp < 0 ? 0 : grp) * 16;
   const int qrow = min(q0 + r, n - 1);
-  bf16x8 qf[2];
+  r16x8 qf[2];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const r16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
   if (SPLIT == 1 || half == 0) res_dma(Q + inner, ld, n, nkt, sK, slot, lane);
   if (SPLIT == 1 || half == 1) res_dma(Q + 2 * inner, ld, n, nkt, sV, slot, lane);
   // (taking the tiles one by one as they land - a counted wait and a barrier per tile - measured 16.1 us against 14.5: the
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
       // four waves per SIMD hide the LDS latency by themselves; the plain tile step keeps the kernel within 128 VGPRs
       if (grp >= 0)
         for (int kt = k0; kt < k1; ++kt)
-          fwd_tile<DROP>(sK + kt * IMG, sV + kt * IMG, kt, kt == nkt - 1, n, qf, o1, m1, l1, scale_log2e, drop, rb.by, q0 + r, r, g);
+          fwd_tile<DROP, T>(sK + kt * IMG, sV + kt * IMG, kt, kt == nkt - 1, n, qf, o1, m1, l1, scale_log2e, drop, rb.by, q0 + r, r, g);
     } else if (grp >= 0 && k0 < k1) {
       // software pipeline: the V fragments of this tile and the K fragments of the next one are requested from LDS before the
       // softmax arithmetic, so the ds_read latency sits under ~130 VALU instructions instead of in front of the MFMAs
@@ -396,14 +399,14 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
       f32x4 sc[4];
       load_row_frags(sK + k0 * IMG, r, g, KF);
       for (int kt = k0; kt < k1; ++kt) {
-        mfma_rows(KF, qf, sc, true);
+        mfma_rows<T>(KF, qf, sc, true);
         __builtin_amdgcn_sched_barrier(0);
         load_tr_frags(sV + kt * IMG, r, g, VF);
         load_row_frags(sK + (kt + 1 < k1 ? kt + 1 : kt) * IMG, r, g, KF);
         __builtin_amdgcn_sched_barrier(0);
         fwd_softmax<DROP>(sc, kt, kt == nkt - 1, n, o1, m1, l1, scale_log2e, drop, rb.by, q0 + r, g);
         __builtin_amdgcn_sched_barrier(0);
-        fwd_pv(VF, sc, o1);
+        fwd_pv<T>(VF, sc, o1);
       }
     }
     if (SPLIT == 1) {
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(RES_THREADS * SPLIT) void attn_fwd_res_kernel(const
   const float inv = 1.0f / ltot;
   const int q = q0 + r;
   if (q < n) {
-    store_out_row(out, ((long)b * n + q) * ldo + h * DH, o, inv, o8, g);
+    store_out_row<T>(out, ((long)b * n + q) * ldo + h * DH, o, inv, o8, g);
     if (g == 0 && lse) lse[((long)b * heads + h) * n + q] = (m + log2f(ltot)) * 0.69314718055994530942f;
   }
 }
@@ -461,23 +464,23 @@ constexpr int WIDE_ROWS = 128;     // query rows per workgroup (4 waves x 32)
 #define NV_WIDE_FWD_BLOCKS 3       // workgroups per CU the register budget is set for.  3 = 168 VGPRs (10 spilled, 44 B of scratch) against 178 at 2:
                                    // same-box A/B, ViT3D-large forward 161.9 / 162.4 -> 167.3 / 167.5 volumes/s, base batch 64 6113 / 6119 -> 6181 / 6174
 #endif
-template <bool DROP>
-__global__ __launch_bounds__(256, NV_WIDE_FWD_BLOCKS) void attn_fwd_wide_kernel(const bf16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
-                                                               bf16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop, float o8) {
+template <bool DROP, typename T>
+__global__ __launch_bounds__(256, NV_WIDE_FWD_BLOCKS) void attn_fwd_wide_kernel(const r16* __restrict__ qkv, long ld, int n, int heads, float scale_log2e,
+                                                               r16* __restrict__ out, long ldo, float* __restrict__ lse, DropCfg drop, float o8) {
   __shared__ __attribute__((aligned(16))) char wsmem[2 * 2 * IMG];      // [stage][K image | V image]
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Grid2 gb = grid2d_xcd((n + WIDE_ROWS - 1) / WIDE_ROWS);                  // 1-D launch: whole heads per XCD
   const int b = gb.by / heads, h = gb.by - b * heads, inner = heads * DH;
-  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const r16* Q = qkv + (long)b * n * ld + h * DH;
   const int q0 = gb.bx * WIDE_ROWS + 32 * wid;
 
-  bf16x8 qf[2][2];
+  r16x8 qf[2][2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int qrow = min(q0 + 16 * u + r, n - 1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[u][ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+    for (int ks = 0; ks < 2; ++ks) qf[u][ks] = *reinterpret_cast<const r16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
   }
 
   // LDS-DMA of one K and one V tile: 8 + 8 pieces of 1 KiB (8 rows x 128 B), pieces wid and wid + 4 of each per wave
@@ -521,16 +524,16 @@ __global__ __launch_bounds__(256, NV_WIDE_FWD_BLOCKS) void attn_fwd_wide_kernel(
     RowFrags F;
     f32x4 s[2][4];
     load_row_frags(cur, r, g, F);
-    mfma_rows(F, qf[0], s[0], true);
-    mfma_rows(F, qf[1], s[1], true);
+    mfma_rows<T>(F, qf[0], s[0], true);
+    mfma_rows<T>(F, qf[1], s[1], true);
     __builtin_amdgcn_sched_barrier(0);
     load_tr_frags(cur + IMG, r, g, F);                    // V fragments requested before the softmax arithmetic
     __builtin_amdgcn_sched_barrier(0);
     fwd_softmax<DROP>(s[0], kt, kt == nkt - 1, n, o[0], m[0], l[0], scale_log2e, drop, gb.by, q0 + r, g);
     fwd_softmax<DROP>(s[1], kt, kt == nkt - 1, n, o[1], m[1], l[1], scale_log2e, drop, gb.by, q0 + 16 + r, g);
     __builtin_amdgcn_sched_barrier(0);
-    fwd_pv(F, s[0], o[0]);
-    fwd_pv(F, s[1], o[1]);
+    fwd_pv<T>(F, s[0], o[0]);
+    fwd_pv<T>(F, s[1], o[1]);
   };
   // two loops, one per half of the key range (the split point every forward kernel uses), the first state parked in between:
   // as ONE loop with the parking under `if (kt == nh)` the compiler copied all 34 state registers on every pass
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(256, NV_WIDE_FWD_BLOCKS) void attn_fwd_wide_kernel(
     const float inv = 1.0f / ltot;
     const int q = q0 + 16 * u + r;
     if (q < n) {
-      store_out_row(out, ((long)b * n + q) * ldo + h * DH, o0[u], inv, o8, g);
+      store_out_row<T>(out, ((long)b * n + q) * ldo + h * DH, o0[u], inv, o8, g);
       if (g == 0 && lse) lse[((long)b * heads + h) * n + q] = (m0[u] + log2f(ltot)) * 0.69314718055994530942f;
     }
   }
@@ -579,6 +582,27 @@ static void attn_res_attr(Kern kern, int lds) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
+// One launch of kernel family K for the run-time (dropout, operand format) pair: K(D, T) names the instantiation (two per kernel and
+// format: the dropout code under a runtime branch cost register copies - and, in one kernel, spills - on the path without it).
+#define ATTN_LAUNCH(K, ...)                                                                                      \
+  do {                                                                                                           \
+    if (fp16) { if (dropping) hipLaunchKernelGGL((K(true, fp16_t)), __VA_ARGS__); else hipLaunchKernelGGL((K(false, fp16_t)), __VA_ARGS__); } \
+    else { if (dropping) hipLaunchKernelGGL((K(true, bf16_t)), __VA_ARGS__); else hipLaunchKernelGGL((K(false, bf16_t)), __VA_ARGS__); }       \
+  } while (0)
+#define ATTN_ATTR(K, lds)                                                                                        \
+  do { attn_res_attr(K(false, bf16_t), lds); attn_res_attr(K(true, bf16_t), lds); attn_res_attr(K(false, fp16_t), lds); attn_res_attr(K(true, fp16_t), lds); } while (0)
+#define K_FWD_RES1(D, T) attn_fwd_res_kernel<1, D, T>
+#define K_FWD_RES2(D, T) attn_fwd_res_kernel<2, D, T>
+#define K_FWD_WIDE(D, T) attn_fwd_wide_kernel<D, T>
+#define K_FWD(D, T) attn_fwd_kernel<D, T>
+#define K_DQ_RES(D, T) attn_bwd_dq_res_kernel<D, T>
+#define K_DKV_RES(D, T) attn_bwd_dkv_res_kernel<D, T>
+#define K_BWD_RES(D, T) attn_bwd_res_kernel<D, T>
+#define K_DQ_WIDE(D, T) attn_bwd_dq_wide_kernel<D, T>
+#define K_DKV_WIDE(D, T) attn_bwd_dkv_wide_kernel<D, T>
+#define K_DQ(D, T) attn_bwd_dq_kernel<D, T>
+#define K_DKV(D, T) attn_bwd_dkv_kernel<D, T>
+
 static int attn_fwd_impl(const void* qkv, long ld_qkv, int B, int n, int heads, int dim_head, float scale, void* out, long ld_out,
                          float* lse, unsigned long drop_seed, float drop_p, float o8, void* stream) {
   NV_CHECK_ARG(attn_generic_supported(dim_head), "nv_attn_fwd: dim_head=%d unsupported (multiples of 8 up to 128)", dim_head);
@@ -587,8 +611,10 @@ static int attn_fwd_impl(const void* qkv, long ld_qkv, int B, int n, int heads, 
   NV_CHECK_ARG(nv_aligned16(qkv) && nv_aligned16(out), "nv_attn_fwd: alignment");
   if (dim_head != DH)      // the MFMA kernels below are built for the reference's default head dim (vit_3d.py:29); any other one: attention_generic.hip
     return launch_attn_generic_fwd(qkv, ld_qkv, B, n, heads, dim_head, scale, out, ld_out, lse, make_drop(drop_seed, drop_p), (hipStream_t)stream);
-  const bool dropping = make_drop(drop_seed, drop_p).thresh != 0;      // two instantiations of every kernel: the dropout code under a runtime
-                                                                         // branch cost register copies (and, in one kernel, spills) on the path without it
+  const DropCfg drop = make_drop(drop_seed, drop_p);
+  const bool dropping = drop.thresh != 0, fp16 = nv_operand_format() == NV_OPERAND_FP16;
+  const float sl2 = scale * 1.44269504088896340736f;
+  hipStream_t s = (hipStream_t)stream;
   const int slot = nv_prof_begin(3, 4.0 * B * heads * (double)n * n * DH, stream);
   // LDS-resident K / V (one 144 KiB workgroup per CU) pays when there are few row groups (ViT3D-base at batch 4: 240 workgroups);
   // with thousands of row groups the wide streaming kernel keeps several workgroups per CU and reads half the fragments
@@ -599,32 +625,18 @@ static int attn_fwd_impl(const void* qkv, long ld_qkv, int B, int n, int heads, 
     const int lds = 2 * ((n + TK - 1) / TK) * IMG;
     static bool attr = false;
     if (!attr) {
-      attn_res_attr(attn_fwd_res_kernel<1, false>, 2 * RES_MAX_TILES * IMG);
-      attn_res_attr(attn_fwd_res_kernel<1, true>, 2 * RES_MAX_TILES * IMG);
-      attn_res_attr(attn_fwd_res_kernel<2, false>, 2 * RES_MAX_TILES * IMG);
-      attn_res_attr(attn_fwd_res_kernel<2, true>, 2 * RES_MAX_TILES * IMG);
+      ATTN_ATTR(K_FWD_RES1, 2 * RES_MAX_TILES * IMG);
+      ATTN_ATTR(K_FWD_RES2, 2 * RES_MAX_TILES * IMG);
       attr = true;
     }
-    if (g_attn_split == 2)
-      { if (dropping) hipLaunchKernelGGL((attn_fwd_res_kernel<2, true>), dim3(attn_res_blocks(n) * B * heads), dim3(2 * RES_THREADS), lds, (hipStream_t)stream,
-                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8);
-    else hipLaunchKernelGGL((attn_fwd_res_kernel<2, false>), dim3(attn_res_blocks(n) * B * heads), dim3(2 * RES_THREADS), lds, (hipStream_t)stream,
-                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8); }
-    else
-      { if (dropping) hipLaunchKernelGGL((attn_fwd_res_kernel<1, true>), dim3(attn_res_blocks(n) * B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
-                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8);
-    else hipLaunchKernelGGL((attn_fwd_res_kernel<1, false>), dim3(attn_res_blocks(n) * B * heads), dim3(RES_THREADS), lds, (hipStream_t)stream,
-                         (const bf16*)qkv, ld_qkv, n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8); }
+    const dim3 grid(attn_res_blocks(n) * B * heads);
+    if (g_attn_split == 2) ATTN_LAUNCH(K_FWD_RES2, grid, dim3(2 * RES_THREADS), lds, s, (const r16*)qkv, ld_qkv, n, heads, sl2, (r16*)out, ld_out, lse, drop, o8);
+    else ATTN_LAUNCH(K_FWD_RES1, grid, dim3(RES_THREADS), lds, s, (const r16*)qkv, ld_qkv, n, heads, sl2, (r16*)out, ld_out, lse, drop, o8);
   } else if (g_attn_mode != 1 && (long)n * ld_qkv < (1L << 30)) {
-    { if (dropping) hipLaunchKernelGGL((attn_fwd_wide_kernel<true>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv,
-                       n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8);
-    else hipLaunchKernelGGL((attn_fwd_wide_kernel<false>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv,
-                       n, heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8); }
-  } else
-  { if (dropping) hipLaunchKernelGGL((attn_fwd_kernel<true>), dim3(((n + TQ - 1) / TQ) * B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
-                     heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8);
-    else hipLaunchKernelGGL((attn_fwd_kernel<false>), dim3(((n + TQ - 1) / TQ) * B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, n,
-                     heads, scale * 1.44269504088896340736f, (bf16*)out, ld_out, lse, make_drop(drop_seed, drop_p), o8); }
+    ATTN_LAUNCH(K_FWD_WIDE, dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, s, (const r16*)qkv, ld_qkv, n, heads, sl2, (r16*)out, ld_out, lse, drop, o8);
+  } else {
+    ATTN_LAUNCH(K_FWD, dim3(((n + TQ - 1) / TQ) * B * heads), dim3(256), 0, s, (const r16*)qkv, ld_qkv, n, heads, sl2, (r16*)out, ld_out, lse, drop, o8);
+  }
   nv_prof_end(slot, stream);
   NV_CHECK_LAUNCH("nv_attn_fwd");
   return NV_OK;
@@ -672,26 +684,26 @@ __device__ __forceinline__ void dq_softmax_grad(const f32x4 (&sc)[4], f32x4 (&dp
       }
     }
 }
-template <bool DROP>
-__device__ __forceinline__ void dq_tile(const char* sK, const char* sV, int kt, int n, const bf16x8 (&qf)[2], const bf16x8 (&dof)[2],
+template <bool DROP, typename T>
+__device__ __forceinline__ void dq_tile(const char* sK, const char* sV, int kt, int n, const r16x8 (&qf)[2], const r16x8 (&dof)[2],
                                         f32x4 (&dq)[4], float dl, float lse2, float scale_log2e, const DropCfg& drop, int bh, int qabs,
                                         int r, int g) {
   RowFrags F;
   f32x4 sc[4], dp[4], ds[4];
   load_row_frags(sK, r, g, F);
-  mfma_rows(F, qf, sc, true);
+  mfma_rows<T>(F, qf, sc, true);
   load_row_frags(sV, r, g, F);
-  mfma_rows(F, dof, dp, true);
+  mfma_rows<T>(F, dof, dp, true);
   dq_softmax_grad<DROP>(sc, dp, ds, kt, n, dl, lse2, scale_log2e, drop, bh, qabs, g);
   load_tr_frags(sK, r, g, F);
-  const bf16x8 dsf[2] = {cvt8(ds[0], ds[1]), cvt8(ds[2], ds[3])};
-  mfma_rows(F, dsf, dq, false);
+  const r16x8 dsf[2] = {cvt8<T>(ds[0], ds[1]), cvt8<T>(ds[2], ds[3])};
+  mfma_rows<T>(F, dsf, dq, false);
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
-                                                          const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse, int n,
-                                                          int heads, float scale, float* __restrict__ delta, bf16* __restrict__ dqkv,
+template <bool DROP, typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const r16* __restrict__ qkv, long ld, const r16* __restrict__ out,
+                                                          const r16* __restrict__ dout, long ldo, const float* __restrict__ lse, int n,
+                                                          int heads, float scale, float* __restrict__ delta, r16* __restrict__ dqkv,
                                                           long ldd, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
   char* sK = smem;
@@ -699,23 +711,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 15, g = lane >> 4;
   const Grid2 gb = grid2d_xcd((n + TQ - 1) / TQ);                  // 1-D launch: whole heads per XCD
   const int b = gb.by / heads, h = gb.by - b * heads, inner = heads * DH;
-  const bf16* Q = qkv + (long)b * n * ld + h * DH;
-  const bf16* K = Q + inner;
-  const bf16* V = Q + 2 * inner;
+  const r16* Q = qkv + (long)b * n * ld + h * DH;
+  const r16* K = Q + inner;
+  const r16* V = Q + 2 * inner;
   const int q0 = gb.bx * TQ + 16 * wid;
   const int qrow = min(q0 + r, n - 1);
   const float scale_log2e = scale * 1.44269504088896340736f;
 
-  bf16x8 qf[2], dof[2];
+  r16x8 qf[2], dof[2];
   float dl = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+    qf[ks] = *reinterpret_cast<const r16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
     const long off = ((long)b * n + qrow) * ldo + h * DH + 32 * ks + 8 * g;
-    dof[ks] = *reinterpret_cast<const bf16x8*>(dout + off);
-    const bf16x8 of = *reinterpret_cast<const bf16x8*>(out + off);
+    dof[ks] = *reinterpret_cast<const r16x8*>(dout + off);
+    const r16x8 of = *reinterpret_cast<const r16x8*>(out + off);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[j];
+    for (int j = 0; j < 8; ++j) dl += dec1<T>(dof[ks][j]) * dec1<T>(of[j]);
   }
   dl = group_sum(dl);
   const float lse2 = lse[((long)b * heads + h) * n + qrow] * 1.44269504088896340736f;
@@ -738,14 +750,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       tile_gload(K, ld, (kt + 1) * TK, n, tid, rk);
       tile_gload(V, ld, (kt + 1) * TK, n, tid, rv);
     }
-    dq_tile<DROP>(sK, sV, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, gb.by, q0 + r, r, g);
+    dq_tile<DROP, T>(sK, sV, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, gb.by, q0 + r, r, g);
   }
   const int q = q0 + r;
   if (q < n) {
-    bf16* drow = dqkv + ((long)b * n + q) * ldd + h * DH;
+    r16* drow = dqkv + ((long)b * n + q) * ldd + h * DH;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      *reinterpret_cast<bf16x4*>(drow + 16 * t + 4 * g) = cvt4(dq[t][0] * scale, dq[t][1] * scale, dq[t][2] * scale, dq[t][3] * scale);
+      *reinterpret_cast<r16x4*>(drow + 16 * t + 4 * g) = cvt4<T>(dq[t][0] * scale, dq[t][1] * scale, dq[t][2] * scale, dq[t][3] * scale);
   }
 }
 
@@ -802,29 +814,29 @@ __device__ __forceinline__ void dkv_softmax_grad(const f32x4 (&sc)[4], const f32
       }
     }
 }
-template <bool DROP>
+template <bool DROP, typename T>
 __device__ __forceinline__ void dkv_tile(const char* sQ, const char* sD, const float* sL, const float* sDl, int qt, int n,
-                                         const bf16x8 (&kf)[2], const bf16x8 (&vf)[2], f32x4 (&dk)[4], f32x4 (&dv)[4], float scale_log2e,
+                                         const r16x8 (&kf)[2], const r16x8 (&vf)[2], f32x4 (&dk)[4], f32x4 (&dv)[4], float scale_log2e,
                                          const DropCfg& drop, int bh, int keyabs, int r, int g) {
   RowFrags F, G;
   f32x4 sc[4], dp[4], p[4], ds[4];
   load_row_frags(sQ, r, g, F);
   load_row_frags(sD, r, g, G);
-  mfma_rows(F, kf, sc, true);
-  mfma_rows(G, vf, dp, true);
+  mfma_rows<T>(F, kf, sc, true);
+  mfma_rows<T>(G, vf, dp, true);
   dkv_softmax_grad<DROP>(sc, dp, p, ds, sL, sDl, qt, n, scale_log2e, drop, bh, keyabs, g);
   load_tr_frags(sD, r, g, G);
   load_tr_frags(sQ, r, g, F);
-  const bf16x8 pf[2] = {cvt8(p[0], p[1]), cvt8(p[2], p[3])};
-  const bf16x8 dsf[2] = {cvt8(ds[0], ds[1]), cvt8(ds[2], ds[3])};
-  mfma_rows(G, pf, dv, false);
-  mfma_rows(F, dsf, dk, false);
+  const r16x8 pf[2] = {cvt8<T>(p[0], p[1]), cvt8<T>(p[2], p[3])};
+  const r16x8 dsf[2] = {cvt8<T>(ds[0], ds[1]), cvt8<T>(ds[2], ds[3])};
+  mfma_rows<T>(G, pf, dv, false);
+  mfma_rows<T>(F, dsf, dk, false);
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout, long ldo,
+template <bool DROP, typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const r16* __restrict__ qkv, long ld, const r16* __restrict__ dout, long ldo,
                                                            const float* __restrict__ lse, const float* __restrict__ delta, int n,
-                                                           int heads, float scale, bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
+                                                           int heads, float scale, r16* __restrict__ dqkv, long ldd, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) char smem[2 * IMG + 2 * TQ * 4];
   char* sQ = smem;
   char* sD = smem + IMG;
@@ -833,21 +845,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 15, g = lane >> 4;
   const Grid2 gb = grid2d_xcd((n + TK - 1) / TK);                  // 1-D launch: whole heads per XCD
   const int b = gb.by / heads, h = gb.by - b * heads, inner = heads * DH;
-  const bf16* Q = qkv + (long)b * n * ld + h * DH;
-  const bf16* K = Q + inner;
-  const bf16* V = Q + 2 * inner;
-  const bf16* dO = dout + (long)b * n * ldo + h * DH;
+  const r16* Q = qkv + (long)b * n * ld + h * DH;
+  const r16* K = Q + inner;
+  const r16* V = Q + 2 * inner;
+  const r16* dO = dout + (long)b * n * ldo + h * DH;
   const float* L = lse + ((long)b * heads + h) * n;
   const float* Dl = delta + ((long)b * heads + h) * n;
   const int key0 = gb.bx * TK + 16 * wid;
   const int krow = min(key0 + r, n - 1);
   const float scale_log2e = scale * 1.44269504088896340736f;
 
-  bf16x8 kf[2], vf[2];
+  r16x8 kf[2], vf[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    kf[ks] = *reinterpret_cast<const bf16x8*>(K + (long)krow * ld + 32 * ks + 8 * g);
-    vf[ks] = *reinterpret_cast<const bf16x8*>(V + (long)krow * ld + 32 * ks + 8 * g);
+    kf[ks] = *reinterpret_cast<const r16x8*>(K + (long)krow * ld + 32 * ks + 8 * g);
+    vf[ks] = *reinterpret_cast<const r16x8*>(V + (long)krow * ld + 32 * ks + 8 * g);
   }
   f32x4 dk[4], dv[4];
 #pragma unroll
@@ -877,15 +889,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
       tile_gload(dO, ldo, (qt + 1) * TQ, n, tid, rd);
       stats_load(qt + 1);
     }
-    dkv_tile<DROP>(sQ, sD, sL, sDl, qt, n, kf, vf, dk, dv, scale_log2e, drop, gb.by, key0 + r, r, g);
+    dkv_tile<DROP, T>(sQ, sD, sL, sDl, qt, n, kf, vf, dk, dv, scale_log2e, drop, gb.by, key0 + r, r, g);
   }
   const int key = key0 + r;
   if (key < n) {
-    bf16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
+    r16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      *reinterpret_cast<bf16x4*>(drow + inner + 16 * t + 4 * g) = cvt4(dk[t][0] * scale, dk[t][1] * scale, dk[t][2] * scale, dk[t][3] * scale);
-      *reinterpret_cast<bf16x4*>(drow + 2 * inner + 16 * t + 4 * g) = cvt4(dv[t][0], dv[t][1], dv[t][2], dv[t][3]);
+      *reinterpret_cast<r16x4*>(drow + inner + 16 * t + 4 * g) = cvt4<T>(dk[t][0] * scale, dk[t][1] * scale, dk[t][2] * scale, dk[t][3] * scale);
+      *reinterpret_cast<r16x4*>(drow + 2 * inner + 16 * t + 4 * g) = cvt4<T>(dv[t][0], dv[t][1], dv[t][2], dv[t][3]);
     }
   }
 }
@@ -893,28 +905,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 // ------------------------------------------------------------------------------------------------ resident backward kernels
 // delta of one query row (16 lanes r, 4 lane groups g): rowsum(dO . O) over the head's 64 columns.  ONE function for every place that
 // needs it, so the value is the same to the last bit wherever it is computed (the dQ pass, or - merged launch - the dK/dV pass itself).
-__device__ __forceinline__ float row_delta(const bf16* __restrict__ dout, const bf16* __restrict__ out, long off, int g, bf16x8 (&dof)[2]) {
+template <typename T>
+__device__ __forceinline__ float row_delta(const r16* __restrict__ dout, const r16* __restrict__ out, long off, int g, r16x8 (&dof)[2]) {
   float dl = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    dof[ks] = *reinterpret_cast<const bf16x8*>(dout + off + 32 * ks + 8 * g);
-    const bf16x8 of = *reinterpret_cast<const bf16x8*>(out + off + 32 * ks + 8 * g);
+    dof[ks] = *reinterpret_cast<const r16x8*>(dout + off + 32 * ks + 8 * g);
+    const r16x8 of = *reinterpret_cast<const r16x8*>(out + off + 32 * ks + 8 * g);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[j];
+    for (int j = 0; j < 8; ++j) dl += dec1<T>(dof[ks][j]) * dec1<T>(of[j]);
   }
   return group_sum(dl);
 }
 
 // body of the dQ pass for workgroup (bx of nblk) of (batch, head) pair `by`
-template <bool DROP>
-__device__ __forceinline__ void attn_bwd_dq_res_body(char* rsmem, int by, int bx, int nblk, const bf16* __restrict__ qkv, long ld,
-                                                     const bf16* __restrict__ out, const bf16* __restrict__ dout, long ldo,
+template <bool DROP, typename T>
+__device__ __forceinline__ void attn_bwd_dq_res_body(char* rsmem, int by, int bx, int nblk, const r16* __restrict__ qkv, long ld,
+                                                     const r16* __restrict__ out, const r16* __restrict__ dout, long ldo,
                                                      const float* __restrict__ lse, int n, int heads, float scale, float* __restrict__ delta,
-                                                     bf16* __restrict__ dqkv, long ldd, const DropCfg& drop) {
+                                                     r16* __restrict__ dqkv, long ldd, const DropCfg& drop) {
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = by / heads, h = by - b * heads, inner = heads * DH;
-  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const r16* Q = qkv + (long)b * n * ld + h * DH;
   const int nkt = (n + TK - 1) / TK;
   char* sK = rsmem;
   char* sV = rsmem + nkt * IMG;
@@ -925,10 +938,10 @@ __device__ __forceinline__ void attn_bwd_dq_res_body(char* rsmem, int by, int bx
   const int qrow = min(q0 + r, n - 1);
   const float scale_log2e = scale * 1.44269504088896340736f;
 
-  bf16x8 qf[2], dof[2];
+  r16x8 qf[2], dof[2];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
-  const float dl = row_delta(dout, out, ((long)b * n + qrow) * ldo + h * DH, g, dof);
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const r16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+  const float dl = row_delta<T>(dout, out, ((long)b * n + qrow) * ldo + h * DH, g, dof);
   const float lse2 = lse[((long)b * heads + h) * n + qrow] * 1.44269504088896340736f;
   __syncthreads();                                   // drains the DMA (vmcnt(0)) of every wave
   if (grp < 0) return;
@@ -939,31 +952,31 @@ __device__ __forceinline__ void attn_bwd_dq_res_body(char* rsmem, int by, int bx
   for (int t = 0; t < 4; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   // (software-pipelining the fragment reads as in the forward kernel measured slower inside the train step: 901 vs 923 volumes/s)
   for (int kt = 0; kt < nkt; ++kt)
-    dq_tile<DROP>(sK + kt * IMG, sV + kt * IMG, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, by, q0 + r, r, g);
+    dq_tile<DROP, T>(sK + kt * IMG, sV + kt * IMG, kt, n, qf, dof, dq, dl, lse2, scale_log2e, drop, by, q0 + r, r, g);
   const int q = q0 + r;
   if (q < n) {
-    bf16* drow = dqkv + ((long)b * n + q) * ldd + h * DH;
+    r16* drow = dqkv + ((long)b * n + q) * ldd + h * DH;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      *reinterpret_cast<bf16x4*>(drow + 16 * t + 4 * g) = cvt4(dq[t][0] * scale, dq[t][1] * scale, dq[t][2] * scale, dq[t][3] * scale);
+      *reinterpret_cast<r16x4*>(drow + 16 * t + 4 * g) = cvt4<T>(dq[t][0] * scale, dq[t][1] * scale, dq[t][2] * scale, dq[t][3] * scale);
   }
 }
 
 // body of the dK / dV pass.  OWN_DELTA: delta = rowsum(dO . O) of every query row of the head is computed HERE (from `out`), with
 // row_delta - the dQ pass's own function - instead of being read from what a preceding dQ launch wrote: that dependency was the only
 // reason for two launches.  48 KiB of dO / O re-read per workgroup out of L2, under the wait for the resident tiles.
-template <bool DROP, bool OWN_DELTA>
-__device__ __forceinline__ void attn_bwd_dkv_res_body(char* rsmem, int by, int bx, int nblk, const bf16* __restrict__ qkv, long ld,
-                                                      const bf16* __restrict__ out, const bf16* __restrict__ dout, long ldo,
+template <bool DROP, bool OWN_DELTA, typename T>
+__device__ __forceinline__ void attn_bwd_dkv_res_body(char* rsmem, int by, int bx, int nblk, const r16* __restrict__ qkv, long ld,
+                                                      const r16* __restrict__ out, const r16* __restrict__ dout, long ldo,
                                                       const float* __restrict__ lse, const float* __restrict__ delta, int n, int heads,
-                                                      float scale, bf16* __restrict__ dqkv, long ldd, const DropCfg& drop) {
+                                                      float scale, r16* __restrict__ dqkv, long ldd, const DropCfg& drop) {
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = by / heads, h = by - b * heads, inner = heads * DH;
-  const bf16* Q = qkv + (long)b * n * ld + h * DH;
-  const bf16* K = Q + inner;
-  const bf16* V = Q + 2 * inner;
-  const bf16* dO = dout + (long)b * n * ldo + h * DH;
+  const r16* Q = qkv + (long)b * n * ld + h * DH;
+  const r16* K = Q + inner;
+  const r16* V = Q + 2 * inner;
+  const r16* dO = dout + (long)b * n * ldo + h * DH;
   const float* L = lse + ((long)b * heads + h) * n;
   const int nqt = (n + TQ - 1) / TQ;
   char* sQ = rsmem;
@@ -974,11 +987,11 @@ __device__ __forceinline__ void attn_bwd_dkv_res_body(char* rsmem, int by, int b
   res_dma(dO, ldo, n, nqt, sD, wid, lane);
   if constexpr (OWN_DELTA) {
     for (int q = tid; q < nqt * TQ; q += RES_THREADS) sL[q] = (q < n) ? L[q] * 1.44269504088896340736f : INFINITY;   // exp2(x - inf) = 0 masks padded query rows
-    const bf16* O = out + (long)b * n * ldo + h * DH;
+    const r16* O = out + (long)b * n * ldo + h * DH;
     for (int q0 = 16 * wid; q0 < nqt * TQ; q0 += 16 * (RES_THREADS / 64)) {
-      bf16x8 scratch[2];
+      r16x8 scratch[2];
       const int q = q0 + r;
-      const float dl = row_delta(dO, O, (long)min(q, n - 1) * ldo, g, scratch);
+      const float dl = row_delta<T>(dO, O, (long)min(q, n - 1) * ldo, g, scratch);
       if (g == 0) sDl[q] = (q < n) ? dl : 0.f;
     }
   } else {
@@ -992,11 +1005,11 @@ __device__ __forceinline__ void attn_bwd_dkv_res_body(char* rsmem, int by, int b
   const int key0 = (grp < 0 ? 0 : grp) * 16;
   const int krow = min(key0 + r, n - 1);
   const float scale_log2e = scale * 1.44269504088896340736f;
-  bf16x8 kf[2], vf[2];
+  r16x8 kf[2], vf[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    kf[ks] = *reinterpret_cast<const bf16x8*>(K + (long)krow * ld + 32 * ks + 8 * g);
-    vf[ks] = *reinterpret_cast<const bf16x8*>(V + (long)krow * ld + 32 * ks + 8 * g);
+    kf[ks] = *reinterpret_cast<const r16x8*>(K + (long)krow * ld + 32 * ks + 8 * g);
+    vf[ks] = *reinterpret_cast<const r16x8*>(V + (long)krow * ld + 32 * ks + 8 * g);
   }
   __syncthreads();                                   // DMA drained, sL / sDl written
   if (grp < 0) return;
@@ -1005,36 +1018,36 @@ __device__ __forceinline__ void attn_bwd_dkv_res_body(char* rsmem, int by, int b
 #pragma unroll
   for (int t = 0; t < 4; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int qt = 0; qt < nqt; ++qt)
-    dkv_tile<DROP>(sQ + qt * IMG, sD + qt * IMG, sL + qt * TQ, sDl + qt * TQ, qt, n, kf, vf, dk, dv, scale_log2e, drop, by, key0 + r, r, g);
+    dkv_tile<DROP, T>(sQ + qt * IMG, sD + qt * IMG, sL + qt * TQ, sDl + qt * TQ, qt, n, kf, vf, dk, dv, scale_log2e, drop, by, key0 + r, r, g);
   const int key = key0 + r;
   if (key < n) {
-    bf16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
+    r16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      *reinterpret_cast<bf16x4*>(drow + inner + 16 * t + 4 * g) = cvt4(dk[t][0] * scale, dk[t][1] * scale, dk[t][2] * scale, dk[t][3] * scale);
-      *reinterpret_cast<bf16x4*>(drow + 2 * inner + 16 * t + 4 * g) = cvt4(dv[t][0], dv[t][1], dv[t][2], dv[t][3]);
+      *reinterpret_cast<r16x4*>(drow + inner + 16 * t + 4 * g) = cvt4<T>(dk[t][0] * scale, dk[t][1] * scale, dk[t][2] * scale, dk[t][3] * scale);
+      *reinterpret_cast<r16x4*>(drow + 2 * inner + 16 * t + 4 * g) = cvt4<T>(dv[t][0], dv[t][1], dv[t][2], dv[t][3]);
     }
   }
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
-                                                                      const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse,
+template <bool DROP, typename T>
+__global__ __launch_bounds__(RES_THREADS) void attn_bwd_dq_res_kernel(const r16* __restrict__ qkv, long ld, const r16* __restrict__ out,
+                                                                      const r16* __restrict__ dout, long ldo, const float* __restrict__ lse,
                                                                       int n, int heads, float scale, float* __restrict__ delta,
-                                                                      bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
+                                                                      r16* __restrict__ dqkv, long ldd, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char rsmem[];
   const ResBlock rb = res_block(n);
-  attn_bwd_dq_res_body<DROP>(rsmem, rb.by, rb.bx, rb.nblk, qkv, ld, out, dout, ldo, lse, n, heads, scale, delta, dqkv, ldd, drop);
+  attn_bwd_dq_res_body<DROP, T>(rsmem, rb.by, rb.bx, rb.nblk, qkv, ld, out, dout, ldo, lse, n, heads, scale, delta, dqkv, ldd, drop);
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout,
+template <bool DROP, typename T>
+__global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const r16* __restrict__ qkv, long ld, const r16* __restrict__ dout,
                                                                        long ldo, const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                       int n, int heads, float scale, bf16* __restrict__ dqkv, long ldd,
+                                                                       int n, int heads, float scale, r16* __restrict__ dqkv, long ldd,
                                                                        DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char rsmem[];
   const ResBlock rb = res_block(n);
-  attn_bwd_dkv_res_body<DROP, false>(rsmem, rb.by, rb.bx, rb.nblk, qkv, ld, nullptr, dout, ldo, lse, delta, n, heads, scale, dqkv, ldd, drop);
+  attn_bwd_dkv_res_body<DROP, false, T>(rsmem, rb.by, rb.bx, rb.nblk, qkv, ld, nullptr, dout, ldo, lse, delta, n, heads, scale, dqkv, ldd, drop);
 }
 
 // dQ and dK / dV of the resident form as ONE grid of 2 x nblk workgroups per (batch, head): logical ids [0, nblk)
@@ -1042,17 +1055,17 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_dkv_res_kernel(const bf1
 // consecutive logical ids, i.e. one XCD (xcd_remap).  Results are those of the two launches bit for bit (same bodies, same delta
 // arithmetic: tests/test_kernels_gpu.py).  NOT the default: ViT3D-base at batch 4 is 480 workgroups of 144 KiB on 256 CUs - two
 // uneven rounds - and measured 36.3 us per layer against 16.3 + 15.5 for the two launches (nv_attn_set_mode(+100) selects it).
-template <bool DROP>
-__global__ __launch_bounds__(RES_THREADS) void attn_bwd_res_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
-                                                                   const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse,
+template <bool DROP, typename T>
+__global__ __launch_bounds__(RES_THREADS) void attn_bwd_res_kernel(const r16* __restrict__ qkv, long ld, const r16* __restrict__ out,
+                                                                   const r16* __restrict__ dout, long ldo, const float* __restrict__ lse,
                                                                    int n, int heads, float scale, float* __restrict__ delta,
-                                                                   bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
+                                                                   r16* __restrict__ dqkv, long ldd, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char rsmem[];
   const int nblk = attn_res_blocks(n);
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int by = lid / (2 * nblk), rem = lid - by * 2 * nblk;
-  if (rem < nblk) attn_bwd_dkv_res_body<DROP, true>(rsmem, by, rem, nblk, qkv, ld, out, dout, ldo, lse, nullptr, n, heads, scale, dqkv, ldd, drop);
-  else attn_bwd_dq_res_body<DROP>(rsmem, by, rem - nblk, nblk, qkv, ld, out, dout, ldo, lse, n, heads, scale, delta, dqkv, ldd, drop);
+  if (rem < nblk) attn_bwd_dkv_res_body<DROP, true, T>(rsmem, by, rem, nblk, qkv, ld, out, dout, ldo, lse, nullptr, n, heads, scale, dqkv, ldd, drop);
+  else attn_bwd_dq_res_body<DROP, T>(rsmem, by, rem - nblk, nblk, qkv, ld, out, dout, ldo, lse, n, heads, scale, delta, dqkv, ldd, drop);
 }
 
 // ------------------------------------------------------------------------------------------------ wide streaming backward
@@ -1060,21 +1073,21 @@ __global__ __launch_bounds__(RES_THREADS) void attn_bwd_res_kernel(const bf16* _
 // (query rows in the dQ pass, keys in the dK / dV pass), so one set of LDS fragment reads feeds twice the MFMAs; the streamed
 // operand tiles arrive by LDS-DMA into a two-stage ring with one barrier per tile.  Per-group arithmetic is that of the
 // streaming kernels (shared __device__ pieces).
-template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ out,
-                                                                  const bf16* __restrict__ dout, long ldo, const float* __restrict__ lse, int n,
-                                                                  int heads, float scale, float* __restrict__ delta, bf16* __restrict__ dqkv,
+template <bool DROP, typename T>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const r16* __restrict__ qkv, long ld, const r16* __restrict__ out,
+                                                                  const r16* __restrict__ dout, long ldo, const float* __restrict__ lse, int n,
+                                                                  int heads, float scale, float* __restrict__ delta, r16* __restrict__ dqkv,
                                                                   long ldd, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) char wsmem[2 * 2 * IMG];      // [stage][K image | V image]
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Grid2 gb = grid2d_xcd((n + WIDE_ROWS - 1) / WIDE_ROWS);                  // 1-D launch: whole heads per XCD
   const int b = gb.by / heads, h = gb.by - b * heads, inner = heads * DH;
-  const bf16* Q = qkv + (long)b * n * ld + h * DH;
+  const r16* Q = qkv + (long)b * n * ld + h * DH;
   const int q0 = gb.bx * WIDE_ROWS + 32 * wid;
   const float scale_log2e = scale * 1.44269504088896340736f;
 
-  bf16x8 qf[2][2], dof[2][2];
+  r16x8 qf[2][2], dof[2][2];
   float dl[2], lse2[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -1082,12 +1095,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const bf16* __
     float d = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      qf[u][ks] = *reinterpret_cast<const bf16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
+      qf[u][ks] = *reinterpret_cast<const r16x8*>(Q + (long)qrow * ld + 32 * ks + 8 * g);
       const long off = ((long)b * n + qrow) * ldo + h * DH + 32 * ks + 8 * g;
-      dof[u][ks] = *reinterpret_cast<const bf16x8*>(dout + off);
-      const bf16x8 of = *reinterpret_cast<const bf16x8*>(out + off);
+      dof[u][ks] = *reinterpret_cast<const r16x8*>(dout + off);
+      const r16x8 of = *reinterpret_cast<const r16x8*>(out + off);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) d += (float)dof[u][ks][j] * (float)of[j];
+      for (int j = 0; j < 8; ++j) d += dec1<T>(dof[u][ks][j]) * dec1<T>(of[j]);
     }
     dl[u] = group_sum(d);
     lse2[u] = lse[((long)b * heads + h) * n + qrow] * 1.44269504088896340736f;
@@ -1127,28 +1140,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_wide_kernel(const bf16* __
     RowFrags F;
     f32x4 sc[2][4], dp[2][4], ds[2][4];
     load_row_frags(cur, r, g, F);
-    mfma_rows(F, qf[0], sc[0], true);
-    mfma_rows(F, qf[1], sc[1], true);
+    mfma_rows<T>(F, qf[0], sc[0], true);
+    mfma_rows<T>(F, qf[1], sc[1], true);
     load_row_frags(cur + IMG, r, g, F);
-    mfma_rows(F, dof[0], dp[0], true);
-    mfma_rows(F, dof[1], dp[1], true);
+    mfma_rows<T>(F, dof[0], dp[0], true);
+    mfma_rows<T>(F, dof[1], dp[1], true);
     dq_softmax_grad<DROP>(sc[0], dp[0], ds[0], kt, n, dl[0], lse2[0], scale_log2e, drop, gb.by, q0 + r, g);
     dq_softmax_grad<DROP>(sc[1], dp[1], ds[1], kt, n, dl[1], lse2[1], scale_log2e, drop, gb.by, q0 + 16 + r, g);
     load_tr_frags(cur, r, g, F);                          // (after the exponentials: requesting them earlier spills registers)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const bf16x8 dsf[2] = {cvt8(ds[u][0], ds[u][1]), cvt8(ds[u][2], ds[u][3])};
-      mfma_rows(F, dsf, dq[u], false);
+      const r16x8 dsf[2] = {cvt8<T>(ds[u][0], ds[u][1]), cvt8<T>(ds[u][2], ds[u][3])};
+      mfma_rows<T>(F, dsf, dq[u], false);
     }
   }
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int q = q0 + 16 * u + r;
     if (q < n) {
-      bf16* drow = dqkv + ((long)b * n + q) * ldd + h * DH;
+      r16* drow = dqkv + ((long)b * n + q) * ldd + h * DH;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        *reinterpret_cast<bf16x4*>(drow + 16 * t + 4 * g) = cvt4(dq[u][t][0] * scale, dq[u][t][1] * scale, dq[u][t][2] * scale, dq[u][t][3] * scale);
+        *reinterpret_cast<r16x4*>(drow + 16 * t + 4 * g) = cvt4<T>(dq[u][t][0] * scale, dq[u][t][1] * scale, dq[u][t][2] * scale, dq[u][t][3] * scale);
     }
   }
 }
@@ -1182,10 +1195,10 @@ __device__ __forceinline__ void dkv_softmax_grad_inplace(f32x4 (&sc)[4], f32x4 (
 }
 
 // (two workgroups per CU: at three - 168 VGPRs, 38 spilled - the ViT3D-large train step drops from 50.5 to 45.6 volumes/s, same box)
-template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* __restrict__ qkv, long ld, const bf16* __restrict__ dout, long ldo,
+template <bool DROP, typename T>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const r16* __restrict__ qkv, long ld, const r16* __restrict__ dout, long ldo,
                                                                    const float* __restrict__ lse, const float* __restrict__ delta, int n,
-                                                                   int heads, float scale, bf16* __restrict__ dqkv, long ldd, DropCfg drop) {
+                                                                   int heads, float scale, r16* __restrict__ dqkv, long ldd, DropCfg drop) {
   // [stage][Q image | dO image | 64 lse | 64 delta].  Query rows beyond n arrive as zeros everywhere (buffer bounds): Q = dO = 0 makes
   // their scores, dP and delta zero, so their (unmasked) probabilities multiply zeros - the same exact zeros the streaming kernel adds
   constexpr int STG = 2 * IMG + 2 * TQ * 4;
@@ -1194,21 +1207,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* _
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Grid2 gb = grid2d_xcd((n + WIDE_ROWS - 1) / WIDE_ROWS);                  // 1-D launch: whole heads per XCD
   const int b = gb.by / heads, h = gb.by - b * heads, inner = heads * DH;
-  const bf16* Q = qkv + (long)b * n * ld + h * DH;
-  const bf16* K = Q + inner;
-  const bf16* V = Q + 2 * inner;
-  const bf16* dO = dout + (long)b * n * ldo + h * DH;
+  const r16* Q = qkv + (long)b * n * ld + h * DH;
+  const r16* K = Q + inner;
+  const r16* V = Q + 2 * inner;
+  const r16* dO = dout + (long)b * n * ldo + h * DH;
   const int key0 = gb.bx * WIDE_ROWS + 32 * wid;
   const float scale_log2e = scale * 1.44269504088896340736f;
 
-  bf16x8 kf[2][2], vf[2][2];
+  r16x8 kf[2][2], vf[2][2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int krow = min(key0 + 16 * u + r, n - 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      kf[u][ks] = *reinterpret_cast<const bf16x8*>(K + (long)krow * ld + 32 * ks + 8 * g);
-      vf[u][ks] = *reinterpret_cast<const bf16x8*>(V + (long)krow * ld + 32 * ks + 8 * g);
+      kf[u][ks] = *reinterpret_cast<const r16x8*>(K + (long)krow * ld + 32 * ks + 8 * g);
+      vf[u][ks] = *reinterpret_cast<const r16x8*>(V + (long)krow * ld + 32 * ks + 8 * g);
     }
   }
   const dma_desc rsQ = uniform_rsrc(Q, (unsigned)((((long)n - 1) * ld + DH) * 2));
@@ -1256,59 +1269,59 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_wide_kernel(const bf16* _
       for (int u = 0; u < 2; ++u) {
         f32x4 sc1[4], dp1[4];
         load_row_frags(cur, r, g, F);
-        mfma_rows(F, kf[u], sc1, true);
+        mfma_rows<T>(F, kf[u], sc1, true);
         __builtin_amdgcn_sched_barrier(0);
         load_row_frags(cur + IMG, r, g, F);
-        mfma_rows(F, vf[u], dp1, true);
+        mfma_rows<T>(F, vf[u], dp1, true);
         __builtin_amdgcn_sched_barrier(0);
         dkv_softmax_grad_inplace<DROP>(sc1, dp1, sL, sDl, qt, n, scale_log2e, drop, gb.by, key0 + 16 * u + r, g);
-        bf16x8 pf1[2], dsf1[2];
-        pf1[0] = cvt8(sc1[0], sc1[1]); pf1[1] = cvt8(sc1[2], sc1[3]);
-        dsf1[0] = cvt8(dp1[0], dp1[1]); dsf1[1] = cvt8(dp1[2], dp1[3]);
+        r16x8 pf1[2], dsf1[2];
+        pf1[0] = cvt8<T>(sc1[0], sc1[1]); pf1[1] = cvt8<T>(sc1[2], sc1[3]);
+        dsf1[0] = cvt8<T>(dp1[0], dp1[1]); dsf1[1] = cvt8<T>(dp1[2], dp1[3]);
         __builtin_amdgcn_sched_barrier(0);
         load_tr_frags(cur + IMG, r, g, F);
-        mfma_rows(F, pf1, dv[u], false);
+        mfma_rows<T>(F, pf1, dv[u], false);
         __builtin_amdgcn_sched_barrier(0);
         load_tr_frags(cur, r, g, F);
-        mfma_rows(F, dsf1, dk[u], false);
+        mfma_rows<T>(F, dsf1, dk[u], false);
         __builtin_amdgcn_sched_barrier(0);
       }
       continue;
     }
     f32x4 sc[2][4], dp[2][4];
     load_row_frags(cur, r, g, F);
-    mfma_rows(F, kf[0], sc[0], true);
-    mfma_rows(F, kf[1], sc[1], true);
+    mfma_rows<T>(F, kf[0], sc[0], true);
+    mfma_rows<T>(F, kf[1], sc[1], true);
     __builtin_amdgcn_sched_barrier(0);                    // (keeps one fragment set live at a time: the kernel is at the register limit)
     load_row_frags(cur + IMG, r, g, F);
-    mfma_rows(F, vf[0], dp[0], true);
-    mfma_rows(F, vf[1], dp[1], true);
+    mfma_rows<T>(F, vf[0], dp[0], true);
+    mfma_rows<T>(F, vf[1], dp[1], true);
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 pf[2][2], dsf[2][2];                           // rounded at once: 16 registers per group instead of 32
+    r16x8 pf[2][2], dsf[2][2];                           // rounded at once: 16 registers per group instead of 32
     dkv_softmax_grad_inplace<DROP>(sc[0], dp[0], sL, sDl, qt, n, scale_log2e, drop, gb.by, key0 + r, g);
-    pf[0][0] = cvt8(sc[0][0], sc[0][1]); pf[0][1] = cvt8(sc[0][2], sc[0][3]);
-    dsf[0][0] = cvt8(dp[0][0], dp[0][1]); dsf[0][1] = cvt8(dp[0][2], dp[0][3]);
+    pf[0][0] = cvt8<T>(sc[0][0], sc[0][1]); pf[0][1] = cvt8<T>(sc[0][2], sc[0][3]);
+    dsf[0][0] = cvt8<T>(dp[0][0], dp[0][1]); dsf[0][1] = cvt8<T>(dp[0][2], dp[0][3]);
     dkv_softmax_grad_inplace<DROP>(sc[1], dp[1], sL, sDl, qt, n, scale_log2e, drop, gb.by, key0 + 16 + r, g);
-    pf[1][0] = cvt8(sc[1][0], sc[1][1]); pf[1][1] = cvt8(sc[1][2], sc[1][3]);
-    dsf[1][0] = cvt8(dp[1][0], dp[1][1]); dsf[1][1] = cvt8(dp[1][2], dp[1][3]);
+    pf[1][0] = cvt8<T>(sc[1][0], sc[1][1]); pf[1][1] = cvt8<T>(sc[1][2], sc[1][3]);
+    dsf[1][0] = cvt8<T>(dp[1][0], dp[1][1]); dsf[1][1] = cvt8<T>(dp[1][2], dp[1][3]);
     __builtin_amdgcn_sched_barrier(0);
     load_tr_frags(cur + IMG, r, g, F);
-    mfma_rows(F, pf[0], dv[0], false);
-    mfma_rows(F, pf[1], dv[1], false);
+    mfma_rows<T>(F, pf[0], dv[0], false);
+    mfma_rows<T>(F, pf[1], dv[1], false);
     __builtin_amdgcn_sched_barrier(0);
     load_tr_frags(cur, r, g, F);
-    mfma_rows(F, dsf[0], dk[0], false);
-    mfma_rows(F, dsf[1], dk[1], false);
+    mfma_rows<T>(F, dsf[0], dk[0], false);
+    mfma_rows<T>(F, dsf[1], dk[1], false);
   }
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int key = key0 + 16 * u + r;
     if (key < n) {
-      bf16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
+      r16* drow = dqkv + ((long)b * n + key) * ldd + h * DH;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        *reinterpret_cast<bf16x4*>(drow + inner + 16 * t + 4 * g) = cvt4(dk[u][t][0] * scale, dk[u][t][1] * scale, dk[u][t][2] * scale, dk[u][t][3] * scale);
-        *reinterpret_cast<bf16x4*>(drow + 2 * inner + 16 * t + 4 * g) = cvt4(dv[u][t][0], dv[u][t][1], dv[u][t][2], dv[u][t][3]);
+        *reinterpret_cast<r16x4*>(drow + inner + 16 * t + 4 * g) = cvt4<T>(dk[u][t][0] * scale, dk[u][t][1] * scale, dk[u][t][2] * scale, dk[u][t][3] * scale);
+        *reinterpret_cast<r16x4*>(drow + 2 * inner + 16 * t + 4 * g) = cvt4<T>(dv[u][t][0], dv[u][t][1], dv[u][t][2], dv[u][t][3]);
       }
     }
   }
@@ -1324,49 +1337,33 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
                "nv_attn_bwd: bad dims");
   NV_CHECK_ARG(nv_aligned16(qkv) && nv_aligned16(out) && nv_aligned16(dout) && nv_aligned16(dqkv), "nv_attn_bwd: alignment");
   hipStream_t s = (hipStream_t)stream;
+  const DropCfg drop = make_drop(drop_seed, drop_p);
   if (dim_head != DH)
-    return launch_attn_generic_bwd(qkv, ld_qkv, out, dout, ld_out, lse, B, n, heads, dim_head, scale, delta, dqkv, ld_dqkv, make_drop(drop_seed, drop_p), s);
+    return launch_attn_generic_bwd(qkv, ld_qkv, out, dout, ld_out, lse, B, n, heads, dim_head, scale, delta, dqkv, ld_dqkv, drop, s);
   const dim3 grid(((n + TQ - 1) / TQ) * B * heads);      // TQ == TK: the same 1-D grid serves the dQ and the dK / dV kernel
-  const bool dropping = make_drop(drop_seed, drop_p).thresh != 0;
+  const bool dropping = drop.thresh != 0, fp16 = nv_operand_format() == NV_OPERAND_FP16;
+  const r16* q16 = (const r16*)qkv; const r16* o16 = (const r16*)out; const r16* do16 = (const r16*)dout; r16* dq16 = (r16*)dqkv;
   const int slot = nv_prof_begin(4, 10.0 * B * heads * (double)n * n * DH, stream);   // algorithmic: 5 products
   if (attn_resident(n) && g_attn_mode != 3) {
     NV_CHECK_ARG((long)n * ld_qkv < (1L << 30) && (long)n * ld_out < (1L << 30), "nv_attn_bwd: operand too large for 32-bit buffer offsets");
     const int nt = (n + TK - 1) / TK;
     static bool attr = false;
     if (!attr) {
-      attn_res_attr(attn_bwd_dq_res_kernel<false>, 2 * RES_MAX_TILES * IMG);
-      attn_res_attr(attn_bwd_dq_res_kernel<true>, 2 * RES_MAX_TILES * IMG);
-      attn_res_attr(attn_bwd_dkv_res_kernel<false>, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
-      attn_res_attr(attn_bwd_dkv_res_kernel<true>, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
+      ATTN_ATTR(K_DQ_RES, 2 * RES_MAX_TILES * IMG);
+      ATTN_ATTR(K_DKV_RES, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
+      ATTN_ATTR(K_BWD_RES, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
       attr = true;
     }
     const dim3 rgrid(attn_res_blocks(n) * B * heads);       // 1-D: whole heads per XCD (res_block)
     if (g_attn_bwd_merged) {
-      static bool attr2 = false;
-      if (!attr2) {
-        attn_res_attr(attn_bwd_res_kernel<false>, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
-        attn_res_attr(attn_bwd_res_kernel<true>, 2 * RES_MAX_TILES * IMG + 2 * RES_MAX_TILES * TQ * 4);
-        attr2 = true;
-      }
-      const dim3 mgrid(2 * rgrid.x);
-      const int lds = 2 * nt * IMG + 2 * nt * TQ * 4;
-      if (dropping) hipLaunchKernelGGL((attn_bwd_res_kernel<true>), mgrid, dim3(RES_THREADS), lds, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out,
-                                       lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
-      else hipLaunchKernelGGL((attn_bwd_res_kernel<false>), mgrid, dim3(RES_THREADS), lds, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out,
-                              lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
+      ATTN_LAUNCH(K_BWD_RES, dim3(2 * rgrid.x), dim3(RES_THREADS), 2 * nt * IMG + 2 * nt * TQ * 4, s, q16, ld_qkv, o16, do16, ld_out, lse, n, heads, scale, delta, dq16, ld_dqkv, drop);
       nv_prof_end(slot, stream);
       NV_CHECK_LAUNCH("nv_attn_bwd(resident, one launch)");
       return NV_OK;
     }
-    { if (dropping) hipLaunchKernelGGL((attn_bwd_dq_res_kernel<true>), rgrid, dim3(RES_THREADS), 2 * nt * IMG, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
-                       (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
-    else hipLaunchKernelGGL((attn_bwd_dq_res_kernel<false>), rgrid, dim3(RES_THREADS), 2 * nt * IMG, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
-                       (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
+    ATTN_LAUNCH(K_DQ_RES, rgrid, dim3(RES_THREADS), 2 * nt * IMG, s, q16, ld_qkv, o16, do16, ld_out, lse, n, heads, scale, delta, dq16, ld_dqkv, drop);
     NV_CHECK_LAUNCH("nv_attn_bwd/dq(resident)");
-    { if (dropping) hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<true>), rgrid, dim3(RES_THREADS), 2 * nt * IMG + 2 * nt * TQ * 4, s, (const bf16*)qkv, ld_qkv,
-                       (const bf16*)dout, ld_out, lse, delta, n, heads, scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
-    else hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<false>), rgrid, dim3(RES_THREADS), 2 * nt * IMG + 2 * nt * TQ * 4, s, (const bf16*)qkv, ld_qkv,
-                       (const bf16*)dout, ld_out, lse, delta, n, heads, scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
+    ATTN_LAUNCH(K_DKV_RES, rgrid, dim3(RES_THREADS), 2 * nt * IMG + 2 * nt * TQ * 4, s, q16, ld_qkv, do16, ld_out, lse, delta, n, heads, scale, dq16, ld_dqkv, drop);
     nv_prof_end(slot, stream);
     NV_CHECK_LAUNCH("nv_attn_bwd/dkv(resident)");
     return NV_OK;
@@ -1374,27 +1371,12 @@ extern "C" int nv_attn_bwd(const void* qkv, long ld_qkv, const void* out, const 
   // wide kernels (32 rows / keys per wave) once the grid is large enough to fill the chip with them; small grids keep 16
   const bool wide = g_attn_mode != 1 && (long)n * ld_qkv < (1L << 30) && (long)n * ld_out < (1L << 30) &&
                     (g_attn_mode >= 3 || (long)B * heads * ((n + WIDE_ROWS - 1) / WIDE_ROWS) >= 512);
-  if (wide)
-    { if (dropping) hipLaunchKernelGGL((attn_bwd_dq_wide_kernel<true>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
-                       (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
-    else hipLaunchKernelGGL((attn_bwd_dq_wide_kernel<false>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out,
-                       (const bf16*)dout, ld_out, lse, n, heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
-  else
-  { if (dropping) hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out, lse, n,
-                     heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)out, (const bf16*)dout, ld_out, lse, n,
-                     heads, scale, delta, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
+  const dim3 wgrid(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads);
+  if (wide) ATTN_LAUNCH(K_DQ_WIDE, wgrid, dim3(256), 0, s, q16, ld_qkv, o16, do16, ld_out, lse, n, heads, scale, delta, dq16, ld_dqkv, drop);
+  else ATTN_LAUNCH(K_DQ, grid, dim3(256), 0, s, q16, ld_qkv, o16, do16, ld_out, lse, n, heads, scale, delta, dq16, ld_dqkv, drop);
   NV_CHECK_LAUNCH("nv_attn_bwd/dq");
-  if (wide)
-    { if (dropping) hipLaunchKernelGGL((attn_bwd_dkv_wide_kernel<true>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
-                       (const bf16*)dout, ld_out, lse, delta, n, heads, scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
-    else hipLaunchKernelGGL((attn_bwd_dkv_wide_kernel<false>), dim3(((n + WIDE_ROWS - 1) / WIDE_ROWS) * B * heads), dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
-                       (const bf16*)dout, ld_out, lse, delta, n, heads, scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
-  else
-  { if (dropping) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)dout, ld_out, lse, delta, n, heads,
-                     scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p));
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)dout, ld_out, lse, delta, n, heads,
-                     scale, (bf16*)dqkv, ld_dqkv, make_drop(drop_seed, drop_p)); }
+  if (wide) ATTN_LAUNCH(K_DKV_WIDE, wgrid, dim3(256), 0, s, q16, ld_qkv, do16, ld_out, lse, delta, n, heads, scale, dq16, ld_dqkv, drop);
+  else ATTN_LAUNCH(K_DKV, grid, dim3(256), 0, s, q16, ld_qkv, do16, ld_out, lse, delta, n, heads, scale, dq16, ld_dqkv, drop);
   nv_prof_end(slot, stream);
   NV_CHECK_LAUNCH("nv_attn_bwd/dkv");
   return NV_OK;

@@ -5,12 +5,25 @@
 #include <stdint.h>
 #include <math.h>
 
-typedef __bf16 bf16;
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// 16-bit MFMA operand formats.  Buffers, LDS images and register fragments carry RAW 16-bit words (r16 ...): loads, LDS-DMA, swizzles and
+// transposed reads are format-agnostic.  The element format T - bf16_t (default) or fp16_t (the reference's own autocast arithmetic,
+// src/Trainer.py:29,68) - enters only where a value is produced or interpreted: cvt* / dec* and the MFMA instruction (mfma16<T>), which
+// issue at the same rate for both on gfx950.  Kernels are templates over T; launchers pick the instantiation from the process-wide
+// nv_set_operand_format (api.cpp).  r16 is an integer type on purpose: a stray (float)x on raw words is wrong in BOTH formats.
+typedef __bf16 bf16_t;
+typedef _Float16 fp16_t;
+typedef short r16;
+typedef short r16x2 __attribute__((ext_vector_type(2)));
+typedef short r16x4 __attribute__((ext_vector_type(4)));
+typedef short r16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) r16x4 lds_r16x4;
+template <typename T> struct vec16 {
+  typedef T x2 __attribute__((ext_vector_type(2)));
+  typedef T x4 __attribute__((ext_vector_type(4)));
+  typedef T x8 __attribute__((ext_vector_type(8)));
+};
 
 #include "../../include/neurovit_hip.h"   // every definition is checked against the published C-ABI declarations
 
@@ -56,23 +69,63 @@ __device__ __forceinline__ int img256_off(int row, int chunk) {
   return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
 }
 
-__device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+__device__ __forceinline__ r16x4 lds_read_tr(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_r16x4*)(p));
 }
 
-__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
+__device__ __forceinline__ r16x8 cat4(r16x4 a, r16x4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__device__ __forceinline__ bf16x4 cvt4(float a, float b, float c, float d) {
-  bf16x4 r = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
-  return r;
+// float -> operand format T (round to nearest even: v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32), as raw words; and back
+template <typename T>
+__device__ __forceinline__ r16 cvt1(float a) {
+  const T v = (T)a;
+  return __builtin_bit_cast(r16, v);
+}
+template <typename T>
+__device__ __forceinline__ r16x4 cvt4(float a, float b, float c, float d) {
+  const typename vec16<T>::x4 r = {(T)a, (T)b, (T)c, (T)d};
+  return __builtin_bit_cast(r16x4, r);
+}
+template <typename T>
+__device__ __forceinline__ r16x8 cvt8(f32x4 a, f32x4 b) {
+  const typename vec16<T>::x8 r = {(T)a[0], (T)a[1], (T)a[2], (T)a[3], (T)b[0], (T)b[1], (T)b[2], (T)b[3]};
+  return __builtin_bit_cast(r16x8, r);
+}
+template <typename T>
+__device__ __forceinline__ float dec1(r16 w) { return (float)__builtin_bit_cast(T, w); }
+template <typename T>
+__device__ __forceinline__ f32x4 dec4(r16x4 w) {
+  const typename vec16<T>::x4 v = __builtin_bit_cast(typename vec16<T>::x4, w);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+// D = A . B + C on the matrix pipe: v_mfma_f32_16x16x32_{bf16,f16} (8 passes) / v_mfma_f32_32x32x16_{bf16,f16}
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(r16x8 a, r16x8 b, f32x4 c) {
+  typedef typename vec16<T>::x8 V;
+  if constexpr (__is_same(T, fp16_t)) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(V, a), __builtin_bit_cast(V, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(V, a), __builtin_bit_cast(V, b), c, 0, 0, 0);
+}
+template <typename T>
+__device__ __forceinline__ f32x16 mfma32(r16x8 a, r16x8 b, f32x16 c) {
+  typedef typename vec16<T>::x8 V;
+  if constexpr (__is_same(T, fp16_t)) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(V, a), __builtin_bit_cast(V, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(V, a), __builtin_bit_cast(V, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ bf16x8 cvt8(f32x4 a, f32x4 b) {
-  bf16x8 r = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
-  return r;
-}
+// Host side: the operand format of this process (nv_set_operand_format, api.cpp) and the dispatch of a templated launch on it.
+extern "C" int nv_operand_format(void);
+#define NV_DISPATCH_OPERAND(T, ...)                  \
+  do {                                               \
+    if (nv_operand_format() == NV_OPERAND_FP16) {    \
+      typedef fp16_t T;                              \
+      __VA_ARGS__;                                   \
+    } else {                                         \
+      typedef bf16_t T;                              \
+      __VA_ARGS__;                                   \
+    }                                                \
+  } while (0)
 
 // exact-erf GELU (nn.GELU() default, vit_3d.py:20) and its derivative.  erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7 absolute - three orders below the bf16 resolution of the values these feed), ~16 VALU ops
@@ -183,6 +236,16 @@ __device__ __forceinline__ float ce_row_term(const float* __restrict__ row, long
     for (int c = tid; c < C; c += 256) dl[c] = (expf(row[c] - mx) / se - (c == t ? 1.f : 0.f)) * gscale_over_B;
   return term;
 }
+
+// ---- dynamic loss scale: indices into the device state block of nv_loss_scale_* (optim.hip; NV_LOSS_SCALE_FLOATS floats)
+enum { LS_SCALE = 0,       // what the NEXT loss gradient is multiplied by
+       LS_UNSCALE = 1,     // 1 / (scale of the gradients now in the arena): AdamW's extra grad factor
+       LS_FOUND_INF = 2,   // a gradient of the current step was inf / NaN (nv_loss_scale_check)
+       LS_SKIP = 3,        // the current optimizer update is skipped (set by nv_loss_scale_update)
+       LS_TRACKER = 4,     // clean steps since the scale last changed
+       LS_STEPS = 5,       // optimizer updates applied so far (AdamW's t; skipped steps do not count - as with GradScaler + torch.optim)
+       LS_STEP_SIZE = 6, LS_BC2_SQRT = 7,      // lr / (1 - beta1^t), sqrt(1 - beta2^t) of the current update
+       LS_GROWTH = 8, LS_BACKOFF = 9, LS_INTERVAL = 10, LS_SKIPPED = 11 };
 
 // ---- AdamW (torch.optim.AdamW, Trainer.py:31,75), shared by the streaming kernel (optim.hip) and the weight-gradient GEMM epilogue
 // that applies the update in place (gemm_common.h EPI_ADAMW): ONE definition, so both forms produce the same bits.

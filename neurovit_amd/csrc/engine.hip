@@ -313,7 +313,7 @@ static int forward_in_impl(const nv_vit_config* cfg, int B, const float* video, 
   NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params) && nv_aligned16(params16), "nv_vit_forward: alignment");
   char* ws = (char*)workspace;
   const float* p = params;
-  const bf16* p16 = (const bf16*)params16;
+  const r16* p16 = (const r16*)params16;
   const float eps = cfg->ln_eps;
   const int M = D.M, d = D.d;
 
@@ -489,6 +489,7 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, 0, W);
+  NV_CHECK_ARG(nv_operand_format() == NV_OPERAND_BF16, "nv_vit_forward_fp8: the fp8 path is built beside bf16 operands (nv_set_operand_format(NV_OPERAND_BF16))");
   NV_CHECK_ARG(video && shape5 && strides5 && params && params16 && params8 && colscales && act_scales && workspace && logits, "nv_vit_forward_fp8: null pointer");
   NV_CHECK_ARG((in && in->time_points > 0) || (shape5[0] == B && shape5[1] == cfg->channels && shape5[2] == cfg->frames && shape5[3] == cfg->image_size && shape5[4] == img_w(cfg)),
                "nv_vit_forward_fp8: video is [%ld,%ld,%ld,%ld,%ld], the model was built for [%d,%d,%d,%d,%d] (B, channels, frames, height, width)",
@@ -498,7 +499,7 @@ extern "C" int nv_vit_forward_fp8(const nv_vit_config* cfg, int B, const float* 
   NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params) && nv_aligned16(params16) && nv_aligned16(params8), "nv_vit_forward_fp8: alignment");
   char* ws = (char*)workspace;
   const float* p = params;
-  const bf16* p16 = (const bf16*)params16;
+  const r16* p16 = (const r16*)params16;
   const char* p8 = (const char*)params8;
   const float eps = cfg->ln_eps;
   const int M = D.M, d = D.d;
@@ -583,7 +584,7 @@ extern "C" int nv_vit_forward_fp8_train(const nv_vit_config* cfg, int B, const f
   NV_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && nv_aligned16(params) && nv_aligned16(params16) && nv_aligned16(params8), "nv_vit_forward_fp8_train: alignment");
   char* ws = (char*)workspace;
   const float* p = params;
-  const bf16* p16 = (const bf16*)params16;
+  const r16* p16 = (const r16*)params16;
   const char* p8 = (const char*)params8;
   const float eps = cfg->ln_eps;
   const int M = D.M, d = D.d;
@@ -688,11 +689,11 @@ static int backward_impl(const nv_vit_config* cfg, int B, const float* video, co
   NV_CHECK_ARG(ws_bytes >= W.total, "nv_vit_backward: workspace too small (%ld < %ld) - forward must run with training=1", ws_bytes, W.total);
   NV_CHECK_ARG(nv_aligned16(grads) && nv_aligned16(grads16), "nv_vit_backward: grads / grads16 must be 16-byte aligned");
   const bool tail_fwd = cls_tail_wanted(D, 1, drop_p, rows_form);     // the form the (training) forward took, given the same arguments
-  bf16* gr16 = (bf16*)grads16;                     // optional bf16 mirror of the Linear weight gradients (data-parallel messages)
+  r16* gr16 = (r16*)grads16;                     // optional bf16 mirror of the Linear weight gradients (data-parallel messages)
   auto M16 = [&](long off) -> void* { return gr16 ? (void*)(gr16 + off) : nullptr; };
   char* ws = (char*)workspace;
   const float* p = params;
-  const bf16* p16 = (const bf16*)params16;
+  const r16* p16 = (const r16*)params16;
   float* gr = grads;
   const int M = D.M, d = D.d, acc = accumulate;
   float* g = (float*)(ws + W.g);
@@ -907,8 +908,16 @@ extern "C" int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* v
                hp ? hp->struct_size : -1, (int)sizeof(nv_train_hparams), NV_ABI_VERSION);
   NV_CHECK_ARG(labels && loss && dlogits && grads && (!hp->update || (adam_m && adam_v && hp->step >= 1)), "nv_vit_train_step: null pointer (labels / loss / dlogits / grads / optimizer state) or step < 1");
   NV_CHECK_ARG(!(in && in->time_points > 0), "nv_vit_train_step: the fused 4D input form is forward-only (the 4D model's encoder is frozen, NeuroEncoder.py:34-36)");
-  // the head's forward, the loss and the head's backward as two launches instead of five (nv_head_step: bit-identical to the three calls)
-  const bool head_fused = g_head_step && !cfg->pool_mean;
+  // every argument check ahead of the first launch (a refused call must not leave half a step in the queue)
+  NV_CHECK_ARG(hp->fuse_update >= 0 && hp->fuse_update <= 3, "nv_vit_train_step: fuse_update = %d (0 .. 3)", hp->fuse_update);
+  NV_CHECK_ARG(hp->loss_scale >= 0.f && !(hp->loss_scale_state && hp->loss_scale > 0.f && hp->loss_scale != 1.f),
+               "nv_vit_train_step: loss_scale must be >= 0 (0 = 1 = none) and is not combined with a dynamic loss_scale_state");
+  const bool fused = hp->update && !hp->accumulate && hp->fuse_update;
+  NV_CHECK_ARG(!(fused && hp->loss_scale_state), "nv_vit_train_step: a dynamic loss scale decides AFTER the backward pass whether the step is applied: fuse_update must be 0");
+  const float lscale = hp->loss_scale > 0.f ? hp->loss_scale : 1.f;      // static loss scale: folded into d(loss)/d(logits), undone by the update's grad_scale
+  // the head's forward, the loss and the head's backward as two launches instead of five (nv_head_step: bit-identical to the three calls;
+  // it needs num_classes <= dim and dim % 8 == 0 - other heads take the five-launch path, which has no such limit)
+  const bool head_fused = g_head_step && !cfg->pool_mean && cfg->num_classes <= cfg->dim && cfg->dim % 8 == 0;
   RUN(forward_in_impl(cfg, B, video, shape5, strides5, in, params, params16, workspace, ws_bytes, 1, drop_p, emb_drop_p, drop_seed, logits, stream, head_fused));
   if (head_fused) {
     Dims D; RUN(make_dims(cfg, B, D));
@@ -916,24 +925,27 @@ extern "C" int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* v
     WS W; make_ws(D, 1, W);
     char* ws = (char*)workspace;
     const int Ll = D.L - 1;
-    RUN(nv_head_step((const float*)(ws + W.layer[Ll].x2), (long)D.n * D.d, B, D.d, params + T.hg, params + T.hb, cfg->ln_eps, params + T.hw, params + T.hbias, D.C,
-                     labels, 1.f, (float*)(ws + W.xh), (float*)(ws + W.hst), logits, loss, dlogits, D.n, (float*)(ws + W.g), D.d,
-                     ws + ((Ll & 1) ? W.alt[0] : W.g16), D.d, grads + T.hg, grads + T.hb, grads + T.hw, grads + T.hbias, grads + T.layer[Ll].b2,
-                     hp->accumulate ? 1 : 0, ws + W.red, W.red_bytes, site_seed(drop_seed, 4 * Ll + 3), drop_p, stream));
+    RUN(nv_head_step_scaled((const float*)(ws + W.layer[Ll].x2), (long)D.n * D.d, B, D.d, params + T.hg, params + T.hb, cfg->ln_eps, params + T.hw, params + T.hbias, D.C,
+                            labels, lscale, hp->loss_scale_state, (float*)(ws + W.xh), (float*)(ws + W.hst), logits, loss, dlogits, D.n, (float*)(ws + W.g), D.d,
+                            ws + ((Ll & 1) ? W.alt[0] : W.g16), D.d, grads + T.hg, grads + T.hb, grads + T.hw, grads + T.hbias, grads + T.layer[Ll].b2,
+                            hp->accumulate ? 1 : 0, ws + W.red, W.red_bytes, site_seed(drop_seed, 4 * Ll + 3), drop_p, stream));
   } else {
-    RUN(nv_ce_loss(logits, labels, B, cfg->num_classes, 1.f, loss, dlogits, stream));
+    RUN(nv_ce_loss_scaled(logits, labels, B, cfg->num_classes, lscale, hp->loss_scale_state, loss, dlogits, stream));
   }
-  NV_CHECK_ARG(hp->fuse_update >= 0 && hp->fuse_update <= 3, "nv_vit_train_step: fuse_update = %d (0 .. 3)", hp->fuse_update);
-  const bool fused = hp->update && !hp->accumulate && hp->fuse_update;
   nv_adamw_arena opt;
   opt.struct_size = (int)sizeof(opt); opt.step = hp->step; opt.lr = hp->lr; opt.beta1 = hp->beta1; opt.beta2 = hp->beta2; opt.eps = hp->eps;
-  opt.weight_decay = hp->weight_decay; opt.grad_scale = hp->grad_scale; opt.keep_grads = hp->fuse_update == 2;
+  opt.weight_decay = hp->weight_decay; opt.grad_scale = hp->grad_scale / lscale; opt.keep_grads = hp->fuse_update == 2;
   opt.params = params; opt.grads = grads; opt.adam_m = adam_m; opt.adam_v = adam_v; opt.params16 = params16;
   RUN(backward_impl(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, nullptr, hp->accumulate ? 1 : 0, head_fused ? 1 : 0, cfg->depth + 1,
                     drop_p, emb_drop_p, drop_seed, stream, aux_stream, 1, in ? in->rows_form : 0, fused ? &opt : nullptr, hp->fuse_update));
   if (hp->update && !fused) {
     const long total = nv_vit_param_count(cfg);
-    RUN(nv_adamw_step(params, grads, 0, adam_m, adam_v, params16, total, hp->step, hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, hp->grad_scale, 0, stream));
+    if (hp->loss_scale_state) {      // GradScaler.step / .update (Trainer.py:75-76) on the device: any inf / NaN gradient skips the update and halves the scale
+      RUN(nv_loss_scale_check(grads, total, hp->loss_scale_state, stream));
+      RUN(nv_loss_scale_update(hp->loss_scale_state, hp->lr, hp->beta1, hp->beta2, stream));
+    }
+    RUN(nv_adamw_step_scaled(params, grads, 0, adam_m, adam_v, params16, total, hp->step, hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, hp->grad_scale / lscale, 0,
+                             hp->loss_scale_state, stream));
   } else if (fused) {
     // what was not updated during the backward pass: the arena minus the four Linear weights of every layer (arena order:
     // ... n1b | wqkv | wo | bo n2g n2b | w1 | b1 | w2 | b2 n1g' ...), one launch

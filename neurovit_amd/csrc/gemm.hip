@@ -20,7 +20,7 @@
 #include "gemm_common.h"
 #include "gemm_pp.h"
 
-template <int BM, int BN, bool A_T, bool B_T, int EPI>
+template <typename T, int BM, int BN, bool A_T, bool B_T, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmArgs g) {
 
   // LDS-DMA source pointers (advance by one K tile per issue)
   const int uwid = __builtin_amdgcn_readfirstlane(wid);
-  const bf16* pa[BM / 32];
-  const bf16* pb[BN / 32];
+  const r16* pa[BM / 32];
+  const r16* pb[BN / 32];
   if constexpr (A_T) dma_init_kmajor<BM>(g.A, g.lda, g.M, m0, uwid, lane, pa); else dma_init_rowmajor<BM>(g.A, g.lda, g.M, m0, uwid, lane, pa);
   if constexpr (B_T) dma_init_kmajor<BN>(g.B, g.ldb, g.N, n0, uwid, lane, pb); else dma_init_rowmajor<BN>(g.B, g.ldb, g.N, n0, uwid, lane, pb);
   const long stepA = A_T ? (long)BK * g.lda : BK, stepB = B_T ? (long)BK * g.ldb : BK;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmArgs g) {
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[MI], bfr[NI];
+      r16x8 af[MI], bfr[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) af[i] = read_frag<A_T, BM>(a, wm * TM + 16 * i, ks, lane);
 #pragma unroll
@@ -99,13 +99,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmArgs g) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<T>(bfr[j], af[i], acc[i][j]);
     }
     if (next_tail) swrite(na, nb);
     __syncthreads();
   }
 
-  epilogue<EPI, MI, NI>(acc, g, m0 + wm * TM, n0 + wn * TN, lane);
+  epilogue<EPI, T, MI, NI>(acc, g, m0 + wm * TM, n0 + wn * TN, lane);
 }
 
 // =====================================================================================================
@@ -168,7 +168,7 @@ __device__ __forceinline__ void ws_wait_tiles_in_flight(int tiles) {
 }
 #undef WS_VM
 
-template <int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>   // S = LDS ring stages, KS = 64-deep sub-tiles per stage
+template <typename T, int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>   // S = LDS ring stages, KS = 64-deep sub-tiles per stage
 __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, const int bid) {   // bid = logical tile of this workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_BYTES = BM * BK * 2, SUB = (BM + BN) * BK * 2, STAGE = KS * SUB;
@@ -213,7 +213,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, const int bid) {
       fs = (fs + 1 == S) ? 0 : fs + 1;
     }
     __builtin_amdgcn_s_barrier();                       // barrier E: the consumers have parked the C tile in LDS
-    epilogue_lds<EPI, BM, BN, WS_THREADS>(smem, g, m0, n0, tid);
+    epilogue_lds<EPI, T, BM, BN, WS_THREADS>(smem, g, m0, n0, tid);
     return;
   }
 
@@ -224,7 +224,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, const int bid) {
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+  r16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
   int ci = 0;                                           // ring slot of the current stage
   char* cur = smem;
   char* nxt = smem + STAGE;
@@ -236,7 +236,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, const int bid) {
 #define WS_MFMA(FA, FB)                                                       \
   _Pragma("unroll") for (int i = 0; i < MI; ++i)                             \
     _Pragma("unroll") for (int j = 0; j < NI; ++j)                           \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[i][j], 0, 0, 0);
+      acc[i][j] = mfma16<T>(FB[j], FA[i], acc[i][j]);
 #define SB __builtin_amdgcn_sched_barrier(0);   // pin the phase order: [reads of a later half step][MFMAs of this one]
 #define WS_ADVANCE ci = (ci + 1 == S) ? 0 : ci + 1; cur = nxt; nxt = smem + ((ci + 1 == S) ? 0 : ci + 1) * STAGE;
 
@@ -263,7 +263,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, const int bid) {
     // not cover an LDS read under load); only the first half step of a stage, whose reads must follow the barrier, is one
     // ahead.  Every stage body is branch free (the last stage prefetches two unused half steps from a valid slot), so hipcc
     // derives exact lgkmcnt values.
-    bf16x8 fa2[MI], fb2[NI];
+    r16x8 fa2[MI], fb2[NI];
 #define WS_STAGE(A0, B0, A1, B1, A2, B2)                                      \
     WS_READ(A2, B2, cur, 2)                                                   \
     SB WS_MFMA(A0, B0) SB                                                     \
@@ -299,20 +299,20 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, const int bid) {
   park_acc<MI, NI, BN>(acc, smem, wm * TM, wn * TN, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw barrier carries no wait: the parked tile must be written first
   __builtin_amdgcn_s_barrier();                         // barrier E
-  epilogue_lds<EPI, BM, BN, WS_THREADS>(smem, g, m0, n0, tid);
+  epilogue_lds<EPI, T, BM, BN, WS_THREADS>(smem, g, m0, n0, tid);
 }
 
-template <int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>
+template <typename T, int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>
 __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const GemmArgs g) {
-  gemm_ws_body<BM, BN, S, KS, A_T, B_T, EPI>(g, xcd_remap(blockIdx.x, gridDim.x));
+  gemm_ws_body<T, BM, BN, S, KS, A_T, B_T, EPI>(g, xcd_remap(blockIdx.x, gridDim.x));
 }
 
-template <int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>
+template <typename T, int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>
 __global__ __launch_bounds__(WS_THREADS) void gemm_ws_grouped_kernel(const GemmGroup G) {
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int p = 0;
   while (p + 1 < G.count && bid >= G.tile_end[p]) ++p;      // workgroup-uniform
-  gemm_ws_body<BM, BN, S, KS, A_T, B_T, EPI>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
+  gemm_ws_body<T, BM, BN, S, KS, A_T, B_T, EPI>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
@@ -339,11 +339,11 @@ extern "C" int nv_gemm_set_tile(int bm, int bn) {   // tuning aid (tools/gemm_be
   return 0;
 }
 
-template <int BM, int BN, bool A_T, bool B_T, int EPI>
+template <typename T, int BM, int BN, bool A_T, bool B_T, int EPI>
 static int launch_tile(const GemmArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * (BM + BN) * BK * 2;
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  auto kern = gemm_bf16_kernel<BM, BN, A_T, B_T, EPI>;
+  auto kern = gemm_bf16_kernel<T, BM, BN, A_T, B_T, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -357,12 +357,12 @@ static int launch_tile(const GemmArgs& a, hipStream_t s) {
   return NV_OK;
 }
 
-template <int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>
+template <typename T, int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>
 static int launch_ws(const GemmArgs& a, hipStream_t s) {
   constexpr int LDS = S * KS * (BM + BN) * BK * 2;
   static_assert(LDS <= 160 * 1024, "LDS ring too large");
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  auto kern = gemm_ws_kernel<BM, BN, S, KS, A_T, B_T, EPI>;
+  auto kern = gemm_ws_kernel<T, BM, BN, S, KS, A_T, B_T, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -431,8 +431,8 @@ static GemmPlan plan_gemm(bool A_T, bool B_T, int epi, int M, int N, int K, long
   return p;
 }
 
-template <bool A_T, bool B_T, int EPI>
-static int launch(const GemmArgs& a, hipStream_t s) {
+template <typename T, bool A_T, bool B_T, int EPI>
+static int launch_fmt(const GemmArgs& a, hipStream_t s) {
   const GemmPlan p = plan_gemm(A_T, B_T, EPI, a.M, a.N, a.K, a.lda, a.ldb);
   if (p.family == 3) return launch_pq(A_T ? 2 : (B_T ? 1 : 0), EPI, a, s);
   if (p.family == 2) return launch_pp(A_T ? 2 : (B_T ? 1 : 0), EPI, a, s);
@@ -440,19 +440,24 @@ static int launch(const GemmArgs& a, hipStream_t s) {
     const int ws = p.ws, ring = p.ring;
     // (the 128 x 64 tile and the deep 6 / 4-stage rings, reachable only through nv_gemm_set_tile, lost every comparison of
     // profiles/r01_gemm_shapes_tiles.log and are no longer compiled: 50 instantiations)
-    if (ws == 1) return launch_ws<128, 128, 3, 1, A_T, B_T, EPI>(a, s);
-    return ring == 3 ? launch_ws<64, 128, 3, 2, A_T, B_T, EPI>(a, s) : launch_ws<64, 128, 3, 1, A_T, B_T, EPI>(a, s);
+    if (ws == 1) return launch_ws<T, 128, 128, 3, 1, A_T, B_T, EPI>(a, s);
+    return ring == 3 ? launch_ws<T, 64, 128, 3, 2, A_T, B_T, EPI>(a, s) : launch_ws<T, 64, 128, 3, 1, A_T, B_T, EPI>(a, s);
   }
   if constexpr (EPI == EPI_DGELU_COLSUM) {
     nv_set_error("nv_gemm_bf16: the fused column-sum epilogue needs a large-tile kernel for this shape (ask nv_gemm_tile_rows first)");
     return NV_ERR_ARG;
   } else {
     switch (p.sel) {
-      case 128128: return launch_tile<128, 128, A_T, B_T, EPI>(a, s);
-      case 64128: return launch_tile<64, 128, A_T, B_T, EPI>(a, s);
-      default: return launch_tile<64, 64, A_T, B_T, EPI>(a, s);
+      case 128128: return launch_tile<T, 128, 128, A_T, B_T, EPI>(a, s);
+      case 64128: return launch_tile<T, 64, 128, A_T, B_T, EPI>(a, s);
+      default: return launch_tile<T, 64, 64, A_T, B_T, EPI>(a, s);
     }
   }
+}
+
+template <bool A_T, bool B_T, int EPI>
+static int launch(const GemmArgs& a, hipStream_t s) {
+  NV_DISPATCH_OPERAND(T, return launch_fmt<T, A_T, B_T, EPI>(a, s));
 }
 
 // Rows of the workgroup tile nv_gemm_bf16 will use for this problem when asked for the fused column-sum epilogue (6): the
@@ -476,7 +481,7 @@ extern "C" int nv_gemm_bf16(int layout, int epi, int M, int N, int K, const void
   if (layout == 2) NV_CHECK_ARG((M % 8) == 0 && lda >= M && ldb >= N, "nv_gemm_bf16[TN]: M=%d must be a multiple of 8; lda>=M, ldb>=N", M);
   NV_CHECK_ARG(ldc >= N, "nv_gemm_bf16: ldc < N");
   GemmArgs a;
-  a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C; a.bias = bias; a.aux_in = aux_in; a.aux_out = aux_out;
+  a.A = (const r16*)A; a.B = (const r16*)B; a.C = C; a.bias = bias; a.aux_in = aux_in; a.aux_out = aux_out;
   a.aux_out2 = nullptr; a.ld_aux_out2 = 0;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ld_aux_in = ld_aux_in; a.ld_aux_out = ld_aux_out;
   a.M = M; a.N = N; a.K = K; a.accumulate = accumulate; a.alpha = alpha;
@@ -544,6 +549,7 @@ extern "C" int nv_gemm_f8_resid_drop(int M, int N, int K, const void* A8, long l
 static int gemm_f8_impl(int epi, int M, int N, int K, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc, const float* colscale,
                         const float* bias, const void* aux_in, long ld_aux_in, float out_scale, void* u16, long ldu16, void* h16, long ldh16, void* stream,
                         unsigned long drop_seed, float drop_p) {
+  NV_CHECK_ARG(nv_operand_format() == NV_OPERAND_BF16, "nv_gemm_f8: the fp8 path is built beside bf16 operands (nv_set_operand_format(NV_OPERAND_BF16))");
   NV_CHECK_ARG(M > 0 && N > 0 && K > 0 && A8 && B8 && C && colscale, "nv_gemm_f8: null operand / empty problem");
   NV_CHECK_ARG((K % 128) == 0 && (N % 8) == 0 && (lda % 16) == 0 && (ldb % 16) == 0 && lda >= K && ldb >= K && ldc >= N && (ldc % 4) == 0,
                "nv_gemm_f8: K must be a multiple of 128, N of 8, lda / ldb of 16, ldc of 4");
@@ -553,7 +559,7 @@ static int gemm_f8_impl(int epi, int M, int N, int K, const void* A8, long lda, 
   NV_CHECK_ARG(!need_bias || (bias && nv_aligned16(bias)), "nv_gemm_f8: epilogue %d needs a bias", epi);
   NV_CHECK_ARG(epi != EPI_BIAS_RESID || (aux_in && nv_aligned16(aux_in) && (ld_aux_in % 4) == 0), "nv_gemm_f8: epilogue 4 needs aux_in");
   GemmArgs a;
-  a.A = (const bf16*)A8; a.B = (const bf16*)B8; a.C = C; a.bias = bias; a.aux_in = aux_in; a.aux_out = u16;
+  a.A = (const r16*)A8; a.B = (const r16*)B8; a.C = C; a.bias = bias; a.aux_in = aux_in; a.aux_out = u16;
   a.aux_out2 = h16; a.ld_aux_out2 = ldh16;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ld_aux_in = ld_aux_in; a.ld_aux_out = ldu16;
   a.M = M; a.N = N; a.K = K; a.accumulate = 0; a.alpha = out_scale;
@@ -591,7 +597,7 @@ static int grouped_tn_impl(int count, const nv_gemm_problem* pr, const nv_adamw_
     NV_CHECK_ARG((long)q.K * q.lda < (1L << 30) && (long)q.K * q.ldb < (1L << 30), "nv_gemm_bf16_grouped: problem %d too large for 32-bit offsets", i);
     GemmArgs& a = G.p[i];
     NV_CHECK_ARG(!q.C16 || (((uintptr_t)q.C16 & 7) == 0 && (q.ldc16 % 4) == 0 && q.ldc16 >= q.N), "nv_gemm_bf16_grouped: problem %d: bf16 mirror alignment / leading dimension", i);
-    a.A = (const bf16*)q.A; a.B = (const bf16*)q.B; a.C = q.C; a.bias = nullptr; a.aux_in = nullptr; a.aux_out = q.C16;
+    a.A = (const r16*)q.A; a.B = (const r16*)q.B; a.C = q.C; a.bias = nullptr; a.aux_in = nullptr; a.aux_out = q.C16;
     a.aux_out2 = nullptr; a.ld_aux_out2 = 0;
     a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ld_aux_in = 0; a.ld_aux_out = q.ldc16;
     a.M = q.M; a.N = q.N; a.K = q.K; a.accumulate = q.accumulate; a.alpha = 1.f;
@@ -601,7 +607,7 @@ static int grouped_tn_impl(int count, const nv_gemm_problem* pr, const nv_adamw_
     if (opt) {
       const long off = (const float*)q.C - opt->grads;
       NV_CHECK_ARG(!q.accumulate && !q.C16 && off >= 0 && (off % 4) == 0, "nv_gemm_bf16_grouped_adamw: problem %d: C must lie in opt->grads (16-byte aligned offset), accumulate = 0, no C16", i);
-      a.opt.p = opt->params + off; a.opt.m = opt->adam_m + off; a.opt.v = opt->adam_v + off; a.opt.p16 = (bf16*)opt->params16 + off;
+      a.opt.p = opt->params + off; a.opt.m = opt->adam_m + off; a.opt.v = opt->adam_v + off; a.opt.p16 = (r16*)opt->params16 + off;
       a.opt.a = adam; a.opt.keep_grad = opt->keep_grads ? 1 : 0;
     }
     tiles += ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN);
@@ -620,11 +626,12 @@ static int grouped_tn_impl(int count, const nv_gemm_problem* pr, const nv_adamw_
     return launch_pp_grouped_tn(G, tpp, flops, (hipStream_t)stream, opt != nullptr);
   }
   constexpr int LDS = 3 * (BM + BN) * BK * 2;
-  auto kern = gemm_ws_grouped_kernel<BM, BN, 3, 1, true, true, EPI_STORE_F32>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  const bool fp16 = nv_operand_format() == NV_OPERAND_FP16;
+  auto kern = fp16 ? gemm_ws_grouped_kernel<fp16_t, BM, BN, 3, 1, true, true, EPI_STORE_F32> : gemm_ws_grouped_kernel<bf16_t, BM, BN, 3, 1, true, true, EPI_STORE_F32>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[fp16]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
+    attr_set[fp16] = true;
   }
   hipStream_t s = (hipStream_t)stream;
   const int slot = nv_prof_begin(2, flops, s);

@@ -21,14 +21,14 @@ enum {
 };
 
 struct OptFuse {        // EPI_ADAMW: element (m, n) of the problem is p[m * ldc + n] (the arenas share element offsets with the gradient arena)
-  float* p = nullptr; float* m = nullptr; float* v = nullptr; bf16* p16 = nullptr;
+  float* p = nullptr; float* m = nullptr; float* v = nullptr; r16* p16 = nullptr;
   AdamArgs a = {};
   int keep_grad = 0;
 };
 
 struct GemmArgs {
-  const bf16* A;
-  const bf16* B;
+  const r16* A;
+  const r16* B;
   void* C;
   const float* bias;
   const void* aux_in;
@@ -82,7 +82,7 @@ __device__ __forceinline__ int imgT_off(int krow, int chunk) {
 // ---- staging: global -> registers ---------------------------------------------------------------
 // rows x K operand (K contiguous): BX rows x 8 chunks of 8 bf16.  TAIL: zero-fill k >= K.
 template <int BX, bool TAIL>
-__device__ __forceinline__ void gload_rowmajor(const bf16* X, long ld, int R, int K, int r0, int k0, int tid, uint4 (&reg)[BX / 32]) {
+__device__ __forceinline__ void gload_rowmajor(const r16* X, long ld, int R, int K, int r0, int k0, int tid, uint4 (&reg)[BX / 32]) {
 #pragma unroll
   for (int i = 0; i < BX / 32; ++i) {
     const int c = tid + NTHREADS * i;
@@ -98,7 +98,7 @@ __device__ __forceinline__ void gload_rowmajor(const bf16* X, long ld, int R, in
 }
 // K x cols operand (cols contiguous): 64 k-rows x BX/8 chunks.  TAIL: zero-fill rows k >= K.
 template <int BX, bool TAIL>
-__device__ __forceinline__ void gload_kmajor(const bf16* X, long ld, int Ccols, int K, int c0, int k0, int tid, uint4 (&reg)[BX / 32]) {
+__device__ __forceinline__ void gload_kmajor(const r16* X, long ld, int Ccols, int K, int c0, int k0, int tid, uint4 (&reg)[BX / 32]) {
   constexpr int CPR = BX / 8;   // chunks per k-row
 #pragma unroll
   for (int i = 0; i < BX / 32; ++i) {
@@ -133,14 +133,14 @@ __device__ __forceinline__ void swrite_kmajor(char* img, int tid, const uint4 (&
 
 // ---- staging: global -> LDS directly (LDS-DMA) ----------------------------------------------------
 typedef __attribute__((address_space(1))) const void gbl_void_t;
-__device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
+__device__ __forceinline__ void glds16(const r16* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 // One wave-instruction fills 1 KiB of the image = 64 consecutive 16-byte chunk POSITIONS; the chunk a lane
 // fetches is the inverse swizzle of its position.  Wave `wid` issues instructions wid, wid+4, ...
 // Per-lane source pointers are computed once (init) and advanced by one K tile per iteration.
 template <int BX>
-__device__ __forceinline__ void dma_init_rowmajor(const bf16* X, long ld, int R, int r0, int wid, int lane, const bf16* (&p)[BX / 32]) {
+__device__ __forceinline__ void dma_init_rowmajor(const r16* X, long ld, int R, int r0, int wid, int lane, const r16* (&p)[BX / 32]) {
 #pragma unroll
   for (int i = 0; i < BX / 32; ++i) {
     const int I = wid + 4 * i;
@@ -149,7 +149,7 @@ __device__ __forceinline__ void dma_init_rowmajor(const bf16* X, long ld, int R,
   }
 }
 template <int BX>
-__device__ __forceinline__ void dma_init_kmajor(const bf16* X, long ld, int Ccols, int c0, int wid, int lane, const bf16* (&p)[BX / 32]) {
+__device__ __forceinline__ void dma_init_kmajor(const r16* X, long ld, int Ccols, int c0, int wid, int lane, const r16* (&p)[BX / 32]) {
 #pragma unroll
   for (int i = 0; i < BX / 32; ++i) {
     const int I = wid + 4 * i;
@@ -165,7 +165,7 @@ __device__ __forceinline__ void dma_init_kmajor(const bf16* X, long ld, int Ccol
   }
 }
 template <int BX>
-__device__ __forceinline__ void dma_issue(const bf16* (&p)[BX / 32], long step, char* img, int wid) {
+__device__ __forceinline__ void dma_issue(const r16* (&p)[BX / 32], long step, char* img, int wid) {
 #pragma unroll
   for (int i = 0; i < BX / 32; ++i) {
     glds16(p[i], img + (wid + 4 * i) * 1024);
@@ -177,22 +177,22 @@ __device__ __forceinline__ void dma_issue(const bf16* (&p)[BX / 32], long step, 
 // Operand fragment of v_mfma_f32_16x16x32_bf16: lane (r = lane&15, g = lane>>4) holds the 8 values
 // k = 8g .. 8g+7 of row/column r.
 template <bool T, int BX>
-__device__ __forceinline__ bf16x8 read_frag(const char* img, int rc0, int ks, int lane) {
+__device__ __forceinline__ r16x8 read_frag(const char* img, int rc0, int ks, int lane) {
   const int r = lane & 15, g = lane >> 4;
   if constexpr (!T) {
-    return *reinterpret_cast<const bf16x8*>(img + img128_off(rc0 + r, 4 * ks + g));
+    return *reinterpret_cast<const r16x8*>(img + img128_off(rc0 + r, 4 * ks + g));
   } else {
     const int q = r >> 2, p = r & 3;
     const int k0 = 32 * ks + 8 * g + q;
     const int ch = (rc0 >> 3) + (p >> 1), sub = (p & 1) << 3;
-    const bf16x4 lo = lds_read_tr(img + imgT_off<BX>(k0, ch) + sub);
-    const bf16x4 hi = lds_read_tr(img + imgT_off<BX>(k0 + 4, ch) + sub);
+    const r16x4 lo = lds_read_tr(img + imgT_off<BX>(k0, ch) + sub);
+    const r16x4 hi = lds_read_tr(img + imgT_off<BX>(k0 + 4, ch) + sub);
     return cat4(lo, hi);
   }
 }
 
 // ---- epilogue core: four consecutive output columns (m, n .. n+3) ----------------------------------------------------
-template <int EPI>
+template <int EPI, typename T>
 __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, int n) {
   if (g.colscale) v *= *reinterpret_cast<const f32x4*>(g.colscale + n);
   if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_GELU_F8 || EPI == EPI_BIAS_GELU_F8T) v += *reinterpret_cast<const f32x4*>(g.bias + n);
@@ -203,14 +203,14 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, in
     }
   }
   if constexpr (EPI == EPI_STORE_BF16) {
-    *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) = cvt4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<r16x4*>((r16*)g.C + (long)m * g.ldc + n) = cvt4<T>(v[0], v[1], v[2], v[3]);
   } else if constexpr (EPI == EPI_STORE_F32) {
     float* c = (float*)g.C + (long)m * g.ldc + n;
     if (g.accumulate) v += *reinterpret_cast<const f32x4*>(c);
     *reinterpret_cast<f32x4*>(c) = v;
     // optional bf16 mirror of what was stored (data-parallel gradient messages: the weight gradient leaves its GEMM already in the
     // wire format, no cast pass over the arena afterwards)
-    if (g.aux_out) *reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n) = cvt4(v[0], v[1], v[2], v[3]);
+    if (g.aux_out) *reinterpret_cast<r16x4*>((r16*)g.aux_out + (long)m * g.ld_aux_out + n) = cvt4<T>(v[0], v[1], v[2], v[3]);
   } else if constexpr (EPI == EPI_ADAMW) {
     // the arithmetic of adamw_kernel (optim.hip) on the gradient the fp32-store epilogue would have written: same bits
     const long off = (long)m * g.ldc + n;
@@ -222,38 +222,38 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, in
     __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(g.opt.p + off));
     __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(g.opt.m + off));
     __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(g.opt.v + off));
-    *reinterpret_cast<bf16x4*>(g.opt.p16 + off) = cvt4(pv[0], pv[1], pv[2], pv[3]);
+    *reinterpret_cast<r16x4*>(g.opt.p16 + off) = cvt4<T>(pv[0], pv[1], pv[2], pv[3]);
   } else if constexpr (EPI == EPI_BIAS_F32) {
     *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
   } else if constexpr (EPI == EPI_BIAS_GELU) {
     // the pre-activation is only read again in the backward pass, milliseconds later: non-temporal store
     // (aux_out = null: inference, nobody reads it - half of this epilogue's HBM bytes saved)
-    if (g.aux_out) __builtin_nontemporal_store(cvt4(v[0], v[1], v[2], v[3]), reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n));
-    *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) =
-        cvt4(gelu_f(v[0]) * keep[0], gelu_f(v[1]) * keep[1], gelu_f(v[2]) * keep[2], gelu_f(v[3]) * keep[3]);
+    if (g.aux_out) __builtin_nontemporal_store(cvt4<T>(v[0], v[1], v[2], v[3]), reinterpret_cast<r16x4*>((r16*)g.aux_out + (long)m * g.ld_aux_out + n));
+    *reinterpret_cast<r16x4*>((r16*)g.C + (long)m * g.ldc + n) =
+        cvt4<T>(gelu_f(v[0]) * keep[0], gelu_f(v[1]) * keep[1], gelu_f(v[2]) * keep[2], gelu_f(v[3]) * keep[3]);
   } else if constexpr (EPI == EPI_BIAS_GELU_F8) {
     const f32x4 h = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])} * g.alpha;
     *reinterpret_cast<unsigned*>((char*)g.C + (long)m * g.ldc + n) = pack_fp8x4(h);
   } else if constexpr (EPI == EPI_BIAS_GELU_F8T) {
     const f32x4 h = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])} * keep;      // nn.Dropout behind the GELU (vit_3d.py:21): h16 and h8 carry the same mask
-    if (g.aux_out) __builtin_nontemporal_store(cvt4(v[0], v[1], v[2], v[3]), reinterpret_cast<bf16x4*>((bf16*)g.aux_out + (long)m * g.ld_aux_out + n));
-    *reinterpret_cast<bf16x4*>((bf16*)g.aux_out2 + (long)m * g.ld_aux_out2 + n) = cvt4(h[0], h[1], h[2], h[3]);
+    if (g.aux_out) __builtin_nontemporal_store(cvt4<T>(v[0], v[1], v[2], v[3]), reinterpret_cast<r16x4*>((r16*)g.aux_out + (long)m * g.ld_aux_out + n));
+    *reinterpret_cast<r16x4*>((r16*)g.aux_out2 + (long)m * g.ld_aux_out2 + n) = cvt4<T>(h[0], h[1], h[2], h[3]);
     *reinterpret_cast<unsigned*>((char*)g.C + (long)m * g.ldc + n) = pack_fp8x4(h * g.alpha);
   } else if constexpr (EPI == EPI_BIAS_RESID) {
     v = v * keep + *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
     *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
   } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DGELU_COLSUM) {
-    const bf16x4 u = *reinterpret_cast<const bf16x4*>((const bf16*)g.aux_in + (long)m * g.ld_aux_in + n);
-    const bf16x4 o = cvt4(v[0] * keep[0] * gelu_grad_f((float)u[0]), v[1] * keep[1] * gelu_grad_f((float)u[1]),
-                          v[2] * keep[2] * gelu_grad_f((float)u[2]), v[3] * keep[3] * gelu_grad_f((float)u[3]));
-    *reinterpret_cast<bf16x4*>((bf16*)g.C + (long)m * g.ldc + n) = o;
-    v = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};     // what the weight-gradient GEMM will read: summed as stored
+    const f32x4 u = dec4<T>(*reinterpret_cast<const r16x4*>((const r16*)g.aux_in + (long)m * g.ld_aux_in + n));
+    const r16x4 o = cvt4<T>(v[0] * keep[0] * gelu_grad_f(u[0]), v[1] * keep[1] * gelu_grad_f(u[1]),
+                            v[2] * keep[2] * gelu_grad_f(u[2]), v[3] * keep[3] * gelu_grad_f(u[3]));
+    *reinterpret_cast<r16x4*>((r16*)g.C + (long)m * g.ldc + n) = o;
+    v = dec4<T>(o);     // what the weight-gradient GEMM will read: summed as stored
   }
   return v;
 }
 
 // ---- register epilogue: lane holds C[m = mb + 16i + (lane&15)][n = nb + 16j + 4*(lane>>4) + 0..3] -----------------
-template <int EPI, int MI, int NI>
+template <int EPI, typename T, int MI, int NI>
 __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmArgs& g, int mb, int nb, int lane) {
   static_assert(EPI != EPI_DGELU_COLSUM, "fused column sums need the LDS epilogue");
   const int lr = lane & 15, lg = lane >> 4;
@@ -265,7 +265,7 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmA
     for (int j = 0; j < NI; ++j) {
       const int n = nb + 16 * j + 4 * lg;
       if (n >= g.N) continue;
-      epilogue4<EPI>(acc[i][j], g, m, n);
+      epilogue4<EPI, T>(acc[i][j], g, m, n);
     }
   }
 }
@@ -288,7 +288,7 @@ template <int BM, int BN, int NT> constexpr int colsum_scratch_bytes() { return 
 // stores of the one before (the arenas are not `restrict` to it): issued chunk by chunk every wave would sit out one full memory
 // latency per chunk.  Loads of ADAM_U chunks are issued together, as the streaming kernel does (optim.hip).
 constexpr int ADAM_U = 4;
-template <int BM, int BN, int NT>
+template <typename T, int BM, int BN, int NT>
 __device__ __forceinline__ void epilogue_lds_adamw(const char* ctile, const GemmArgs& g, int m0, int n0, int tid) {
   constexpr int CPR = BN / 4, TOT = BM * CPR;
   for (int c0 = tid; c0 < TOT; c0 += NT * ADAM_U) {
@@ -316,15 +316,15 @@ __device__ __forceinline__ void epilogue_lds_adamw(const char* ctile, const Gemm
         __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(g.opt.p + off[u]));
         __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(g.opt.m + off[u]));
         __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(g.opt.v + off[u]));
-        *reinterpret_cast<bf16x4*>(g.opt.p16 + off[u]) = cvt4(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
+        *reinterpret_cast<r16x4*>(g.opt.p16 + off[u]) = cvt4<T>(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
       }
     }
   }
 }
 
-template <int EPI, int BM, int BN, int NT>
+template <int EPI, typename T, int BM, int BN, int NT>
 __device__ __forceinline__ void epilogue_lds(char* ctile, const GemmArgs& g, int m0, int n0, int tid) {
-  if constexpr (EPI == EPI_ADAMW) { epilogue_lds_adamw<BM, BN, NT>(ctile, g, m0, n0, tid); return; }
+  if constexpr (EPI == EPI_ADAMW) { epilogue_lds_adamw<T, BM, BN, NT>(ctile, g, m0, n0, tid); return; }
   constexpr int CPR = BN / 4;                 // 16-byte chunks per row
   static_assert(NT % CPR == 0 && 64 % CPR == 0, "every thread keeps one column group");
   f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -333,7 +333,7 @@ __device__ __forceinline__ void epilogue_lds(char* ctile, const GemmArgs& g, int
     const int row = c / CPR, col = (c % CPR) * 4;
     const int m = m0 + row, n = n0 + col;
     if (m < g.M && n < g.N) {
-      const f32x4 r = epilogue4<EPI>(*reinterpret_cast<const f32x4*>(ctile + row * cpitch<BN>() + col * 4), g, m, n);
+      const f32x4 r = epilogue4<EPI, T>(*reinterpret_cast<const f32x4*>(ctile + row * cpitch<BN>() + col * 4), g, m, n);
       if constexpr (EPI == EPI_DGELU_COLSUM) csum += r;
     }
   }

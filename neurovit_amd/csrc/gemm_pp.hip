@@ -65,7 +65,7 @@ __device__ __forceinline__ void pp_offsets(long ld, int rc0, int lw, int lane, i
 }
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ i32x8 f8cat(bf16x8 lo, bf16x8 hi) {      // 2 x 16 bytes -> the 32-byte fp8 operand of one lane
+__device__ __forceinline__ i32x8 f8cat(r16x8 lo, r16x8 hi) {      // 2 x 16 bytes -> the 32-byte fp8 operand of one lane
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const i32x4 a = __builtin_bit_cast(i32x4, lo), b = __builtin_bit_cast(i32x4, hi);
   return i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -94,7 +94,7 @@ __device__ __forceinline__ i32x8 f8cat(bf16x8 lo, bf16x8 hi) {      // 2 x 16 by
 // half the operand register reads per FLOP.  A bare loop of either shape on random data (tools/mfma_shape_bench.hip,
 // profiles/r04_mfma_shape_microbench.log): 1.27 against 1.08 PFLOP/s at one wave per SIMD with the fragments re-read from LDS,
 // 1.82 against 1.43 from registers - the chip holds a higher clock on the wider shape.
-template <int BM, int BN, int WM, int WN, bool A_T, bool B_T, int EPI, int DBG = 0, bool F8 = false, bool W32 = false>
+template <typename T, int BM, int BN, int WM, int WN, bool A_T, bool B_T, int EPI, int DBG = 0, bool F8 = false, bool W32 = false>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the declaration (it rejects the TN instantiation of this body)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -167,14 +167,13 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
     }
     __builtin_amdgcn_s_barrier();                                  // B_nk: every fragment read has returned
     __builtin_amdgcn_s_barrier();                                  // accumulators parked
-    epilogue_lds<EPI, BM, BN, PP_THREADS>(smem, g, m0, n0, tid);
+    epilogue_lds<EPI, T, BM, BN, PP_THREADS>(smem, g, m0, n0, tid);
     return;
   }
 
   // -------------------------------------------------------------------- compute waves
   const int grp = wid >> 2;                   // waves w and w + 4 share a SIMD: group 1 runs half a tile behind group 0
   const int wm = wid / WN, wn = wid % WN;
-  typedef float f32x16 __attribute__((ext_vector_type(16)));
   typedef typename std::conditional<W32, f32x16, f32x4>::type acc_t;
   acc_t acc[MI][NI];
 #pragma unroll
@@ -187,10 +186,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
   const int a_off = ((wm * TM) / 128) * PP_SUB, a_rc = (wm * TM) % 128;
   const int b_off = (NSA + (wn * TN) / 128) * PP_SUB, b_rc = (wn * TN) % 128;
   constexpr int KS = W32 ? 4 : 2;                    // fragments per block and 64-deep K tile (16- or 32-deep MFMAs)
-  bf16x8 fb[NI][KS], fa[MI][KS];
+  r16x8 fb[NI][KS], fa[MI][KS];
   // 32-row fragment: lane l holds row l & 31, k = 16 ks + 8 (l >> 5) .. + 7: ONE ds_read_b128 at chunk 2 ks + (l >> 5)
-  auto frag32 = [&](const char* img, int rc0, int ks) -> bf16x8 {
-    return *reinterpret_cast<const bf16x8*>(img + img128w_off(rc0 + (lane & 31), 2 * ks + (lane >> 5)));
+  auto frag32 = [&](const char* img, int rc0, int ks) -> r16x8 {
+    return *reinterpret_cast<const r16x8*>(img + img128w_off(rc0 + (lane & 31), 2 * ks + (lane >> 5)));
   };
 
 #define PP_READ_B(img)                                                          \
@@ -216,12 +215,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                          \
       _Pragma("unroll") for (int i = (I0); i < (I0) + MH; ++i)                 \
         _Pragma("unroll") for (int j = 0; j < NI; ++j)                         \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);  \
+          acc[i][j] = mfma32<T>(fb[j][ks], fa[i][ks], acc[i][j]);  \
   } else if constexpr (!F8) {                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                           \
       _Pragma("unroll") for (int i = (I0); i < (I0) + MH; ++i)                 \
         _Pragma("unroll") for (int j = 0; j < NI; ++j)                         \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);  \
+          acc[i][j] = mfma16<T>(fb[j][ks], fa[i][ks], acc[i][j]);  \
   } else {                                                                      \
     _Pragma("unroll") for (int i = (I0); i < (I0) + MH; ++i)                   \
       _Pragma("unroll") for (int j = 0; j < NI; ++j)                           \
@@ -290,55 +289,57 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  epilogue_lds<EPI, BM, BN, PP_THREADS>(smem, g, m0, n0, tid);
+  epilogue_lds<EPI, T, BM, BN, PP_THREADS>(smem, g, m0, n0, tid);
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, bool A_T, bool B_T, int EPI>
+template <typename T, int BM, int BN, int WM, int WN, bool A_T, bool B_T, int EPI>
 __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_kernel(const GemmArgs g) {
-  gemm_pp_body<BM, BN, WM, WN, A_T, B_T, EPI>(g, xcd_remap(blockIdx.x, gridDim.x));
+  gemm_pp_body<T, BM, BN, WM, WN, A_T, B_T, EPI>(g, xcd_remap(blockIdx.x, gridDim.x));
+}
+template <typename T, int EPI>
+__global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_w32_kernel(const GemmArgs g) {      // NT, 32 x 32 x 16 MFMAs
+  gemm_pp_body<T, PP_BM, PP_BN, 4, 2, false, false, EPI, 0, false, true>(g, xcd_remap(blockIdx.x, gridDim.x));
 }
 template <int EPI>
-__global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_w32_kernel(const GemmArgs g) {      // NT, bf16, 32 x 32 x 16 MFMAs
-  gemm_pp_body<PP_BM, PP_BN, 4, 2, false, false, EPI, 0, false, true>(g, xcd_remap(blockIdx.x, gridDim.x));
-}
-template <int EPI>
-__global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_f8_kernel(const GemmArgs g) {
-  gemm_pp_body<PP_BM, PP_BN, 4, 2, false, false, EPI, 0, true>(g, xcd_remap(blockIdx.x, gridDim.x));
+__global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_f8_kernel(const GemmArgs g) {      // (16-bit outputs of the fp8 path are bf16)
+  gemm_pp_body<bf16_t, PP_BM, PP_BN, 4, 2, false, false, EPI, 0, true>(g, xcd_remap(blockIdx.x, gridDim.x));
 }
 template <int DBG>
 __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_dbg_kernel(const GemmArgs g) {
-  gemm_pp_body<PP_BM, PP_BN, 4, 2, false, false, EPI_STORE_BF16, DBG>(g, xcd_remap(blockIdx.x, gridDim.x));
+  gemm_pp_body<bf16_t, PP_BM, PP_BN, 4, 2, false, false, EPI_STORE_BF16, DBG>(g, xcd_remap(blockIdx.x, gridDim.x));
 }
 
-// grouped weight gradients (TN, fp32 store / accumulate): one instantiation, written without template parameters
+// grouped weight gradients (TN, fp32 store / accumulate)
+template <typename T>
 __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_grouped_tn_kernel(const GemmGroup G) {
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int p = 0;
   while (p + 1 < G.count && bid >= G.tile_end[p]) ++p;      // workgroup-uniform
-  gemm_pp_body<PP_BM, PP_BN, 4, 2, true, true, EPI_STORE_F32>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
+  gemm_pp_body<T, PP_BM, PP_BN, 4, 2, true, true, EPI_STORE_F32>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
 }
 
 // the same with the AdamW update of the differentiated weights in the epilogue (EPI_ADAMW)
 // A workgroup walks tiles bid, bid + grid, ...: with fewer workgroups than tiles (g_pp_adamw_wgs) the HBM-bound epilogues - 26 B per
 // weight, during which the workgroup's CU computes nothing - occupy that many CUs instead of one per tile, and the rest of the
 // chip stays with the other stream's kernels.
+template <typename T>
 __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_grouped_tn_adamw_kernel(const GemmGroup G) {
   const int total = G.tile_end[GROUP_MAX - 1];
   for (int bid = xcd_remap(blockIdx.x, gridDim.x); bid < total; bid += gridDim.x) {
     int p = 0;
     while (p + 1 < G.count && bid >= G.tile_end[p]) ++p;
-    gemm_pp_body<PP_BM, PP_BN, 4, 2, true, true, EPI_ADAMW>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
+    gemm_pp_body<T, PP_BM, PP_BN, 4, 2, true, true, EPI_ADAMW>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
     __syncthreads();      // the parked tile has been consumed before the next tile's first DMA lands on it
   }
 }
 
-template <bool A_T, bool B_T, int EPI>
+template <typename T, bool A_T, bool B_T, int EPI>
 int launch_pp_t(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = PP_BM, BN = PP_BN;
   constexpr int LDS = PP_S * (BM / 128 + BN / 128) * PP_SUB;
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  auto kern = gemm_pp_kernel<BM, BN, 4, 2, A_T, B_T, EPI>;
+  auto kern = gemm_pp_kernel<T, BM, BN, 4, 2, A_T, B_T, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -359,11 +360,11 @@ int launch_pp_t(const GemmArgs& a, hipStream_t s) {
 // 108: 1133 against 1140 for 128 on another box, 96: 1055, 72: 1078; update unfused 1094 (profiles/r04_adamw_in_wgrad_epilogue.log)
 int g_pp_adamw_wgs = 128;
 int g_pp_w32 = 0;   // NT problems on the 32 x 32 x 16 MFMA form of the kernel (nv_gemm_set_tile(11, 0 | 1))
-template <int EPI>
+template <typename T, int EPI>
 static int launch_pp_w32_t(const GemmArgs& a, hipStream_t s) {
   constexpr int LDS = PP_S * (PP_BM / 128 + PP_BN / 128) * PP_SUB;
   const int tiles = ((a.M + PP_BM - 1) / PP_BM) * ((a.N + PP_BN - 1) / PP_BN);
-  auto kern = gemm_pp_w32_kernel<EPI>;
+  auto kern = gemm_pp_w32_kernel<T, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -389,7 +390,8 @@ static int launch_pp_dbg(const GemmArgs& a, hipStream_t s) {
   return NV_OK;
 }
 
-int launch_pp(int layout, int epi, const GemmArgs& a, hipStream_t s) {
+template <typename T>
+static int launch_pp_fmt(int layout, int epi, const GemmArgs& a, hipStream_t s) {
   if (g_pp_dbg && layout == 0 && epi == EPI_STORE_BF16) {
     switch (g_pp_dbg) {
       case 1: return launch_pp_dbg<1>(a, s);
@@ -401,29 +403,32 @@ int launch_pp(int layout, int epi, const GemmArgs& a, hipStream_t s) {
   }
   if (g_pp_w32 && layout == 0) {
     switch (epi) {
-      case EPI_STORE_BF16: return launch_pp_w32_t<EPI_STORE_BF16>(a, s);
-      case EPI_STORE_F32: return launch_pp_w32_t<EPI_STORE_F32>(a, s);
-      case EPI_BIAS_F32: return launch_pp_w32_t<EPI_BIAS_F32>(a, s);
-      case EPI_BIAS_GELU: return launch_pp_w32_t<EPI_BIAS_GELU>(a, s);
-      case EPI_BIAS_RESID: return launch_pp_w32_t<EPI_BIAS_RESID>(a, s);
+      case EPI_STORE_BF16: return launch_pp_w32_t<T, EPI_STORE_BF16>(a, s);
+      case EPI_STORE_F32: return launch_pp_w32_t<T, EPI_STORE_F32>(a, s);
+      case EPI_BIAS_F32: return launch_pp_w32_t<T, EPI_BIAS_F32>(a, s);
+      case EPI_BIAS_GELU: return launch_pp_w32_t<T, EPI_BIAS_GELU>(a, s);
+      case EPI_BIAS_RESID: return launch_pp_w32_t<T, EPI_BIAS_RESID>(a, s);
       default: break;
     }
   }
   switch (layout * 16 + epi) {
-    case 0 * 16 + EPI_STORE_BF16: return launch_pp_t<false, false, EPI_STORE_BF16>(a, s);
-    case 0 * 16 + EPI_STORE_F32: return launch_pp_t<false, false, EPI_STORE_F32>(a, s);
-    case 0 * 16 + EPI_BIAS_F32: return launch_pp_t<false, false, EPI_BIAS_F32>(a, s);
-    case 0 * 16 + EPI_BIAS_GELU: return launch_pp_t<false, false, EPI_BIAS_GELU>(a, s);
-    case 0 * 16 + EPI_BIAS_RESID: return launch_pp_t<false, false, EPI_BIAS_RESID>(a, s);
-    case 1 * 16 + EPI_STORE_BF16: return launch_pp_t<false, true, EPI_STORE_BF16>(a, s);
-    case 1 * 16 + EPI_STORE_F32: return launch_pp_t<false, true, EPI_STORE_F32>(a, s);
-    case 1 * 16 + EPI_DGELU: return launch_pp_t<false, true, EPI_DGELU>(a, s);
-    case 1 * 16 + EPI_DGELU_COLSUM: return launch_pp_t<false, true, EPI_DGELU_COLSUM>(a, s);
-    case 2 * 16 + EPI_STORE_F32: return launch_pp_t<true, true, EPI_STORE_F32>(a, s);
+    case 0 * 16 + EPI_STORE_BF16: return launch_pp_t<T, false, false, EPI_STORE_BF16>(a, s);
+    case 0 * 16 + EPI_STORE_F32: return launch_pp_t<T, false, false, EPI_STORE_F32>(a, s);
+    case 0 * 16 + EPI_BIAS_F32: return launch_pp_t<T, false, false, EPI_BIAS_F32>(a, s);
+    case 0 * 16 + EPI_BIAS_GELU: return launch_pp_t<T, false, false, EPI_BIAS_GELU>(a, s);
+    case 0 * 16 + EPI_BIAS_RESID: return launch_pp_t<T, false, false, EPI_BIAS_RESID>(a, s);
+    case 1 * 16 + EPI_STORE_BF16: return launch_pp_t<T, false, true, EPI_STORE_BF16>(a, s);
+    case 1 * 16 + EPI_STORE_F32: return launch_pp_t<T, false, true, EPI_STORE_F32>(a, s);
+    case 1 * 16 + EPI_DGELU: return launch_pp_t<T, false, true, EPI_DGELU>(a, s);
+    case 1 * 16 + EPI_DGELU_COLSUM: return launch_pp_t<T, false, true, EPI_DGELU_COLSUM>(a, s);
+    case 2 * 16 + EPI_STORE_F32: return launch_pp_t<T, true, true, EPI_STORE_F32>(a, s);
     default: break;
   }
   nv_set_error("nv_gemm_bf16/pp: unsupported layout/epilogue combination (%d, %d)", layout, epi);
   return NV_ERR_ARG;
+}
+int launch_pp(int layout, int epi, const GemmArgs& a, hipStream_t s) {
+  NV_DISPATCH_OPERAND(T, return launch_pp_fmt<T>(layout, epi, a, s));
 }
 
 template <int EPI>
@@ -459,10 +464,11 @@ int launch_pp_f8(int epi, const GemmArgs& a, hipStream_t s) {
 }
 
 // grouped weight-gradient GEMMs (TN, fp32 store / accumulate) on 256 x 128 tiles
-int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_t s, bool adamw) {
+template <typename T>
+static int launch_pp_grouped_tn_fmt(const GemmGroup& G, int tiles, double flops, hipStream_t s, bool adamw) {
   constexpr int BM = PP_BM, BN = PP_BN;
   constexpr int LDS = PP_S * (BM / 128 + BN / 128) * PP_SUB;
-  auto kern = adamw ? gemm_pp_grouped_tn_adamw_kernel : gemm_pp_grouped_tn_kernel;
+  auto kern = adamw ? gemm_pp_grouped_tn_adamw_kernel<T> : gemm_pp_grouped_tn_kernel<T>;
   static bool attr_set[2] = {false, false};
   if (!attr_set[adamw]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -479,4 +485,7 @@ int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_bf16_grouped/pp");
   return NV_OK;
+}
+int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_t s, bool adamw) {
+  NV_DISPATCH_OPERAND(T, return launch_pp_grouped_tn_fmt<T>(G, tiles, flops, s, adamw));
 }

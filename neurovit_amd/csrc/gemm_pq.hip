@@ -47,7 +47,7 @@ __device__ __forceinline__ void pq_offsets(long ld, int rc0, int w, int lane, in
 }
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ i32x8 pq_f8cat(bf16x8 lo, bf16x8 hi) {
+__device__ __forceinline__ i32x8 pq_f8cat(r16x8 lo, r16x8 hi) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const i32x4 a = __builtin_bit_cast(i32x4, lo), b = __builtin_bit_cast(i32x4, hi);
   return i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -56,7 +56,7 @@ __device__ __forceinline__ i32x8 pq_f8cat(bf16x8 lo, bf16x8 hi) {
 #define PQ_SB __builtin_amdgcn_sched_barrier(0)
 #define PQ_FENCE asm volatile("" ::: "memory")
 
-template <bool A_T, bool B_T, int EPI, bool F8>
+template <bool A_T, bool B_T, int EPI, bool F8, typename T>
 __device__ __forceinline__ void gemm_pq_body(const GemmArgs& g, const int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,7 +102,7 @@ __device__ __forceinline__ void gemm_pq_body(const GemmArgs& g, const int bid) {
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int a_off = grp * PQ_SUB;                                   // this wave's 128 rows = A sub-image `grp`
   const int b_off = (2 + (wn >> 1)) * PQ_SUB, b_rc = (wn & 1) * 64;
-  bf16x8 fb[NI][2], fa[MH][2];
+  r16x8 fb[NI][2], fa[MH][2];
 
 #define PQ_READ_B(img)                                                          \
   _Pragma("unroll") for (int j = 0; j < NI; ++j) {                             \
@@ -119,7 +119,7 @@ __device__ __forceinline__ void gemm_pq_body(const GemmArgs& g, const int bid) {
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                           \
       _Pragma("unroll") for (int i = 0; i < MH; ++i)                           \
         _Pragma("unroll") for (int j = 0; j < NI; ++j)                         \
-          acc[(I0) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[(I0) + i][j], 0, 0, 0);  \
+          acc[(I0) + i][j] = mfma16<T>(fb[j][ks], fa[i][ks], acc[(I0) + i][j]);  \
   } else {                                                                      \
     _Pragma("unroll") for (int i = 0; i < MH; ++i)                             \
       _Pragma("unroll") for (int j = 0; j < NI; ++j)                           \
@@ -185,20 +185,20 @@ __device__ __forceinline__ void gemm_pq_body(const GemmArgs& g, const int bid) {
     if (grp == pass) park_acc<MI, NI, BN>(acc, smem, 0, wn * 64, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    epilogue_lds<EPI, 128, BN, PQ_THREADS>(smem, g, m0 + 128 * pass, n0, tid);
+    epilogue_lds<EPI, T, 128, BN, PQ_THREADS>(smem, g, m0 + 128 * pass, n0, tid);
   }
 #endif
 }
 
-template <bool A_T, bool B_T, int EPI, bool F8>
+template <bool A_T, bool B_T, int EPI, bool F8, typename T>
 __global__ __launch_bounds__(PQ_THREADS, 2) void gemm_pq_kernel(const GemmArgs g) {
-  gemm_pq_body<A_T, B_T, EPI, F8>(g, xcd_remap(blockIdx.x, gridDim.x));
+  gemm_pq_body<A_T, B_T, EPI, F8, T>(g, xcd_remap(blockIdx.x, gridDim.x));
 }
 
-template <bool A_T, bool B_T, int EPI, bool F8>
+template <bool A_T, bool B_T, int EPI, bool F8, typename T>
 int launch_pq_t(const GemmArgs& a, hipStream_t s) {
   const int tiles = ((a.M + PQ_BM - 1) / PQ_BM) * ((a.N + PQ_BN - 1) / PQ_BN);
-  auto kern = gemm_pq_kernel<A_T, B_T, EPI, F8>;
+  auto kern = gemm_pq_kernel<A_T, B_T, EPI, F8, T>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS);
@@ -212,33 +212,38 @@ int launch_pq_t(const GemmArgs& a, hipStream_t s) {
   return NV_OK;
 }
 
-}  // namespace
-
-int launch_pq(int layout, int epi, const GemmArgs& a, hipStream_t s) {
+template <typename T>
+int launch_pq_fmt(int layout, int epi, const GemmArgs& a, hipStream_t s) {
   switch (layout * 16 + epi) {
-    case 0 * 16 + EPI_STORE_BF16: return launch_pq_t<false, false, EPI_STORE_BF16, false>(a, s);
-    case 0 * 16 + EPI_STORE_F32: return launch_pq_t<false, false, EPI_STORE_F32, false>(a, s);
-    case 0 * 16 + EPI_BIAS_F32: return launch_pq_t<false, false, EPI_BIAS_F32, false>(a, s);
-    case 0 * 16 + EPI_BIAS_GELU: return launch_pq_t<false, false, EPI_BIAS_GELU, false>(a, s);
-    case 0 * 16 + EPI_BIAS_RESID: return launch_pq_t<false, false, EPI_BIAS_RESID, false>(a, s);
-    case 1 * 16 + EPI_STORE_BF16: return launch_pq_t<false, true, EPI_STORE_BF16, false>(a, s);
-    case 1 * 16 + EPI_STORE_F32: return launch_pq_t<false, true, EPI_STORE_F32, false>(a, s);
-    case 1 * 16 + EPI_DGELU: return launch_pq_t<false, true, EPI_DGELU, false>(a, s);
-    case 1 * 16 + EPI_DGELU_COLSUM: return launch_pq_t<false, true, EPI_DGELU_COLSUM, false>(a, s);
-    case 2 * 16 + EPI_STORE_F32: return launch_pq_t<true, true, EPI_STORE_F32, false>(a, s);
+    case 0 * 16 + EPI_STORE_BF16: return launch_pq_t<false, false, EPI_STORE_BF16, false, T>(a, s);
+    case 0 * 16 + EPI_STORE_F32: return launch_pq_t<false, false, EPI_STORE_F32, false, T>(a, s);
+    case 0 * 16 + EPI_BIAS_F32: return launch_pq_t<false, false, EPI_BIAS_F32, false, T>(a, s);
+    case 0 * 16 + EPI_BIAS_GELU: return launch_pq_t<false, false, EPI_BIAS_GELU, false, T>(a, s);
+    case 0 * 16 + EPI_BIAS_RESID: return launch_pq_t<false, false, EPI_BIAS_RESID, false, T>(a, s);
+    case 1 * 16 + EPI_STORE_BF16: return launch_pq_t<false, true, EPI_STORE_BF16, false, T>(a, s);
+    case 1 * 16 + EPI_STORE_F32: return launch_pq_t<false, true, EPI_STORE_F32, false, T>(a, s);
+    case 1 * 16 + EPI_DGELU: return launch_pq_t<false, true, EPI_DGELU, false, T>(a, s);
+    case 1 * 16 + EPI_DGELU_COLSUM: return launch_pq_t<false, true, EPI_DGELU_COLSUM, false, T>(a, s);
+    case 2 * 16 + EPI_STORE_F32: return launch_pq_t<true, true, EPI_STORE_F32, false, T>(a, s);
     default: break;
   }
   nv_set_error("nv_gemm_bf16/pq: unsupported layout/epilogue combination (%d, %d)", layout, epi);
   return NV_ERR_ARG;
 }
 
+}  // namespace
+
+int launch_pq(int layout, int epi, const GemmArgs& a, hipStream_t s) {
+  NV_DISPATCH_OPERAND(T, return launch_pq_fmt<T>(layout, epi, a, s));
+}
+
 int launch_pq_f8(int epi, const GemmArgs& a, hipStream_t s) {
   switch (epi) {
-    case EPI_STORE_BF16: return launch_pq_t<false, false, EPI_STORE_BF16, true>(a, s);
-    case EPI_STORE_F32: return launch_pq_t<false, false, EPI_STORE_F32, true>(a, s);
-    case EPI_BIAS_RESID: return launch_pq_t<false, false, EPI_BIAS_RESID, true>(a, s);
-    case EPI_BIAS_GELU_F8: return launch_pq_t<false, false, EPI_BIAS_GELU_F8, true>(a, s);
-    case EPI_BIAS_GELU_F8T: return launch_pq_t<false, false, EPI_BIAS_GELU_F8T, true>(a, s);
+    case EPI_STORE_BF16: return launch_pq_t<false, false, EPI_STORE_BF16, true, bf16_t>(a, s);
+    case EPI_STORE_F32: return launch_pq_t<false, false, EPI_STORE_F32, true, bf16_t>(a, s);
+    case EPI_BIAS_RESID: return launch_pq_t<false, false, EPI_BIAS_RESID, true, bf16_t>(a, s);
+    case EPI_BIAS_GELU_F8: return launch_pq_t<false, false, EPI_BIAS_GELU_F8, true, bf16_t>(a, s);
+    case EPI_BIAS_GELU_F8T: return launch_pq_t<false, false, EPI_BIAS_GELU_F8T, true, bf16_t>(a, s);
     default: break;
   }
   nv_set_error("nv_gemm_f8/pq: unsupported epilogue %d", epi);

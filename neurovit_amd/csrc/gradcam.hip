@@ -15,7 +15,8 @@ namespace {
 constexpr int GC_THREADS = 256;
 constexpr int GC_WAVES = GC_THREADS / 64;
 
-__global__ __launch_bounds__(GC_THREADS) void gradcam_reduce_kernel(const bf16* __restrict__ act, const float* __restrict__ grad, int B, int n,
+template <typename T>
+__global__ __launch_bounds__(GC_THREADS) void gradcam_reduce_kernel(const r16* __restrict__ act, const float* __restrict__ grad, int B, int n,
                                                                     int d, float* cam, float* __restrict__ part, unsigned* ticket,
                                                                     float* minmax) {
   __shared__ float s_min[GC_WAVES], s_max[GC_WAVES];
@@ -28,10 +29,10 @@ __global__ __launch_bounds__(GC_THREADS) void gradcam_reduce_kernel(const bf16* 
     const long base = ((long)b * n + t) * d;
     float sg = 0.f, sa = 0.f;
     for (int k = lane * 8; k < d; k += 64 * 8) {         // d % 8 == 0 (engine requirement)
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(act + base + k);
+      const r16x8 a = *reinterpret_cast<const r16x8*>(act + base + k);
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(grad + base + k), g1 = *reinterpret_cast<const f32x4*>(grad + base + k + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sa += (float)a[j];
+      for (int j = 0; j < 8; ++j) sa += dec1<T>(a[j]);
       sg += (g0[0] + g0[1]) + (g0[2] + g0[3]) + (g1[0] + g1[1]) + (g1[2] + g1[3]);
     }
     sg = wave_sum(sg); sa = wave_sum(sa);
@@ -88,8 +89,8 @@ extern "C" int nv_gradcam_reduce(const void* act, const float* grad, int B, int 
   unsigned* ticket = (unsigned*)workspace;
   float* part = (float*)((char*)workspace + 16);
   if (hipMemsetAsync(ticket, 0, 16, (hipStream_t)stream) != hipSuccess) { nv_set_error("nv_gradcam_reduce: memset failed"); return NV_ERR_HIP; }
-  hipLaunchKernelGGL(gradcam_reduce_kernel, dim3(gradcam_blocks(B, n)), dim3(GC_THREADS), 0, (hipStream_t)stream, (const bf16*)act, grad, B, n, d, cam,
-                     part, ticket, minmax);
+  NV_DISPATCH_OPERAND(T, hipLaunchKernelGGL(gradcam_reduce_kernel<T>, dim3(gradcam_blocks(B, n)), dim3(GC_THREADS), 0, (hipStream_t)stream, (const r16*)act, grad, B, n,
+                                            d, cam, part, ticket, minmax));
   NV_CHECK_LAUNCH("nv_gradcam_reduce");
   return NV_OK;
 }

@@ -14,13 +14,15 @@
 #define WAVES_PER_BLOCK 4
 
 #include <type_traits>
-// Output element type of the forward row kernels: bf16 (MFMA operand of the bf16 / fp8 paths) or float (the fp32 inference path,
-// precise.hip: the reference validates in fp32, Trainer.py:101-118).
+// Output element type of the forward row kernels: bf16_t / fp16_t (MFMA operand of the 16-bit paths, by nv_set_operand_format) or float
+// (the fp32 inference path, precise.hip: the reference validates in fp32, Trainer.py:101-118).
 template <typename OT>
 __device__ __forceinline__ void store4(OT* p, const f32x4& o) {
   if constexpr (std::is_same<OT, float>::value) *reinterpret_cast<f32x4*>(p) = o;
-  else *reinterpret_cast<bf16x4*>(p) = cvt4(o[0], o[1], o[2], o[3]);
+  else *reinterpret_cast<r16x4*>(p) = cvt4<OT>(o[0], o[1], o[2], o[3]);
 }
+// scalar store of one 16-bit operand in the format chosen at run time (the head kernels: a few hundred values per launch)
+__device__ __forceinline__ r16 cvt1_rt(float v, int fp16) { return fp16 ? cvt1<fp16_t>(v) : cvt1<bf16_t>(v); }
 
 // --------------------------------------------------------------------------------------- helpers
 // Row of d floats (d % 4 == 0, d <= 256*NV) spread over a wave: lane holds float4 #(lane + 64 v).
@@ -83,8 +85,9 @@ extern "C" int nv_ln_fwd(const float* x, long ldx, int M, int d, const float* ga
                "nv_ln_fwd: alignment");
   const dim3 grid((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (d <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<4, bf16>), grid, block, 0, s, x, ldx, M, d, gamma, beta, eps, (bf16*)y, ldy, mean, rstd);
-  else hipLaunchKernelGGL((ln_fwd_kernel<8, bf16>), grid, block, 0, s, x, ldx, M, d, gamma, beta, eps, (bf16*)y, ldy, mean, rstd);
+  NV_DISPATCH_OPERAND(T,
+    if (d <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<4, T>), grid, block, 0, s, x, ldx, M, d, gamma, beta, eps, (T*)y, ldy, mean, rstd);
+    else hipLaunchKernelGGL((ln_fwd_kernel<8, T>), grid, block, 0, s, x, ldx, M, d, gamma, beta, eps, (T*)y, ldy, mean, rstd));
   NV_CHECK_LAUNCH("nv_ln_fwd");
   return NV_OK;
 }
@@ -107,11 +110,11 @@ extern "C" int nv_ln_fwd_f32(const float* x, long ldx, int M, int d, const float
 // g_out = g_in + LN'(dy);  g16 = bf16(g_out * dropmask);  partials[blk][0] = sum dy*xhat, [1] = sum dy, [2] = sum g_out * dropmask.
 // ROWS rows per wave are in flight together (x, dy and the incoming residual gradient are all requested before the first
 // use): the kernel is one dependent memory round trip, not 2 * ROWS of them.
-template <int NV, int ROWS>
+template <int NV, int ROWS, typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, int M, int d, const float* g_in, float* g_out,
-                                                     long ldg, bf16* __restrict__ g16, long ldg16, float* __restrict__ partials,
+                                                     long ldg, r16* __restrict__ g16, long ldg16, float* __restrict__ partials,
                                                      DropCfg drop, int seg_rows, int seg_skip) {
   // seg_rows > 0: dy is segmented - after every seg_rows rows seg_skip rows are skipped (token rows of a [B, 1+N, d] tensor)
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][d]
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             if (drop.thresh) {
               o *= drop_factor4(drop, (unsigned long long)row * ldg + c);      // element index of the DENSE [M, d] tensor g is a (row-strided) view of: ldg = d x row spacing
             }
-            if (g16) *reinterpret_cast<bf16x4*>(g16 + (long)row * ldg16 + c) = cvt4(o[0], o[1], o[2], o[3]);
+            if (g16) *reinterpret_cast<r16x4*>(g16 + (long)row * ldg16 + c) = cvt4<T>(o[0], o[1], o[2], o[3]);
             a_c[v] += o;
           }
         }
@@ -332,12 +335,13 @@ static int ln_bwd_launch(const float* dy, long lddy, const float* x, long ldx, c
   const int nb = ln_bwd_blocks(M);
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)WAVES_PER_BLOCK * d * sizeof(float);
-  if (d <= 1024)
-    hipLaunchKernelGGL((ln_bwd_kernel<4, 2>), dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
-                       (bf16*)g16, ldg16, (float*)workspace, drop, seg_rows, seg_skip);
-  else
-    hipLaunchKernelGGL((ln_bwd_kernel<8, 1>), dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
-                       (bf16*)g16, ldg16, (float*)workspace, drop, seg_rows, seg_skip);
+  NV_DISPATCH_OPERAND(T,
+    if (d <= 1024)
+      hipLaunchKernelGGL((ln_bwd_kernel<4, 2, T>), dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
+                         (r16*)g16, ldg16, (float*)workspace, drop, seg_rows, seg_skip);
+    else
+      hipLaunchKernelGGL((ln_bwd_kernel<8, 1, T>), dim3(nb), dim3(256), lds, s, dy, lddy, x, ldx, mean, rstd, gamma, M, d, g_in, g_out, ldg,
+                         (r16*)g16, ldg16, (float*)workspace, drop, seg_rows, seg_skip));
   NV_CHECK_LAUNCH("nv_ln_bwd");
   // the parameter-gradient reduction is off the data path: it may run on another stream (the caller then owns `workspace`
   // until that stream has passed this point), or be left to a later nv_ln_bwd_reduce call (reduce_stream = NV_LN_NO_REDUCE)
@@ -497,7 +501,7 @@ static int patch_ln_fwd_launch(const float* video, const long* strides5, int B, 
 extern "C" int nv_patch_ln_fwd(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
                                const float* gamma, const float* beta, float eps, void* out, long ldo, float* mean, float* rstd,
                                const float* vol_sigma, void* stream) {
-  return patch_ln_fwd_launch<bf16>(video, strides5, B, C, F, H, W, p1, p2, pf, gamma, beta, eps, (bf16*)out, ldo, mean, rstd, vol_sigma, stream);
+  NV_DISPATCH_OPERAND(T, return patch_ln_fwd_launch<T>(video, strides5, B, C, F, H, W, p1, p2, pf, gamma, beta, eps, (T*)out, ldo, mean, rstd, vol_sigma, stream));
 }
 // fp32 tokens [B*N, ldo] (ldo >= patch_dim; no padding columns are needed: the fp32 GEMM takes any K)
 extern "C" int nv_patch_ln_fwd_f32(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
@@ -600,7 +604,7 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_t_kernel(const float* __rest
       const int kf = k0 + 4 * pc;
       if (kf < g.P) {                                    // P % 4 == 0 and KR % 4 == 0: whole pieces
         const long tok = ((long)bo * g.T + t) * g.N + n;
-        typedef typename std::conditional<std::is_same<OT, float>::value, f32x4, bf16x4>::type V4;
+        typedef typename std::conditional<std::is_same<OT, float>::value, f32x4, r16x4>::type V4;
         *reinterpret_cast<V4*>(out + tok * ldo + kf) = *reinterpret_cast<const V4*>(tile + t * KR + 4 * pc);
       }
     }
@@ -634,7 +638,7 @@ static int patch_ln_fwd_4d_launch(const float* x, int Bo, int H, int W, int D, i
 extern "C" int nv_patch_ln_fwd_4d(const float* x, int Bo, int H, int W, int D, int T, int p1, int p2, int pf, const float* gamma,
                                   const float* beta, float eps, void* out, long ldo, float* mean, float* rstd, const float* vol_sigma,
                                   void* stream) {
-  return patch_ln_fwd_4d_launch<bf16>(x, Bo, H, W, D, T, p1, p2, pf, gamma, beta, eps, (bf16*)out, ldo, mean, rstd, vol_sigma, stream);
+  NV_DISPATCH_OPERAND(OT, return patch_ln_fwd_4d_launch<OT>(x, Bo, H, W, D, T, p1, p2, pf, gamma, beta, eps, (OT*)out, ldo, mean, rstd, vol_sigma, stream));
 }
 extern "C" int nv_patch_ln_fwd_4d_f32(const float* x, int Bo, int H, int W, int D, int T, int p1, int p2, int pf, const float* gamma,
                                       const float* beta, float eps, float* out, long ldo, float* mean, float* rstd, const float* vol_sigma,
@@ -897,7 +901,7 @@ extern "C" int nv_head_fwd(const float* x, long row_stride, int B, int d, const 
 __device__ __forceinline__ void head_bwd_x_row(int b, float* sh, const float* __restrict__ dlogits, int C, const float* __restrict__ Wt,
                                                const float* __restrict__ x, long row_stride, const float* __restrict__ stats,
                                                const float* __restrict__ gamma, int d, int n, float* __restrict__ g, long ldg,
-                                               bf16* __restrict__ g16, long ldg16, float* __restrict__ partials, const DropCfg& drop, int pool_mean) {
+                                               r16* __restrict__ g16, long ldg16, float* __restrict__ partials, const DropCfg& drop, int pool_mean, int fp16) {
   float* dys = sh;             // dyh[d] + 8 scratch
   float* scratch = sh + d;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -930,7 +934,7 @@ __device__ __forceinline__ void head_bwd_x_row(int b, float* sh, const float* __
         const long r = (long)b * n + t;
         g[r * ldg + c] = dx;
         const float dxm = drop.thresh ? dx * drop_factor(drop, (unsigned long long)r * d + c) : dx;
-        if (g16) g16[r * ldg16 + c] = (bf16)dxm;
+        if (g16) g16[r * ldg16 + c] = cvt1_rt(dxm, fp16);
         cs += dxm;
       }
       partials[((long)b * 3 + 2) * d + c] = cs;
@@ -938,7 +942,7 @@ __device__ __forceinline__ void head_bwd_x_row(int b, float* sh, const float* __
     }
     g[(long)b * n * ldg + c] = dx;
     const float dxm = drop.thresh ? dx * drop_factor(drop, (unsigned long long)b * n * d + c) : dx;   // last block's FF output dropout
-    if (g16) g16[(long)b * n * ldg16 + c] = (bf16)dxm;
+    if (g16) g16[(long)b * n * ldg16 + c] = cvt1_rt(dxm, fp16);
     partials[((long)b * 3 + 2) * d + c] = dxm;
   }
 }
@@ -946,8 +950,8 @@ __device__ __forceinline__ void head_bwd_x_row(int b, float* sh, const float* __
 __global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict__ dlogits, int C, const float* __restrict__ Wt,
                                                          const float* __restrict__ x, long row_stride, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, int d, int n, float* __restrict__ g, long ldg,
-                                                         bf16* __restrict__ g16, long ldg16, float* __restrict__ partials, DropCfg drop,
-                                                         int pool_mean, int nvol) {
+                                                         r16* __restrict__ g16, long ldg16, float* __restrict__ partials, DropCfg drop,
+                                                         int pool_mean, int nvol, int fp16) {
   extern __shared__ __attribute__((aligned(16))) float sh[];   // dyh[d] + 8 scratch
   if ((int)blockIdx.x >= nvol) {
     // pool = 'cls': the residual gradient is zero except for the cls rows the first nvol workgroups write - the rest of this grid
@@ -957,7 +961,7 @@ __global__ __launch_bounds__(256) void head_bwd_x_kernel(const float* __restrict
     if (g16) zero_rows_except(reinterpret_cast<char*>(g16), (long)nvol * n, (long)d * 2, n, part, nparts);
     return;
   }
-  head_bwd_x_row(blockIdx.x, sh, dlogits, C, Wt, x, row_stride, stats, gamma, d, n, g, ldg, g16, ldg16, partials, drop, pool_mean);
+  head_bwd_x_row(blockIdx.x, sh, dlogits, C, Wt, x, row_stride, stats, gamma, d, n, g, ldg, g16, ldg16, partials, drop, pool_mean, fp16);
 }
 
 // dW[c, k] = sum_b dlogits[b, c] * xh[b, k];  dbias[c] = sum_b dlogits[b, c]
@@ -1011,7 +1015,7 @@ extern "C" int nv_head_bwd(const float* dlogits, int B, int C, const float* W, c
   int fill_blocks = (int)((fill_bytes + (1 << 16) - 1) >> 16);            // ~64 KiB per workgroup
   if (fill_blocks > 1024) fill_blocks = 1024;
   hipLaunchKernelGGL(head_bwd_x_kernel, dim3(B + fill_blocks), dim3(256), (d + 8) * sizeof(float), s, dlogits, C, W, x, row_stride, stats, gamma, d, n,
-                     g, ldg, (bf16*)g16, ldg16, (float*)workspace, make_drop(drop_seed, drop_p), pool_mean, B);
+                     g, ldg, (r16*)g16, ldg16, (float*)workspace, make_drop(drop_seed, drop_p), pool_mean, B, nv_operand_format() == NV_OPERAND_FP16);
   NV_CHECK_LAUNCH("nv_head_bwd/x");
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 31) / 32), dim3(256), 0, s, (const float*)workspace, B, d, 3, dgamma, dbeta,
                      dcolsum, accumulate);
@@ -1031,8 +1035,10 @@ extern "C" int nv_head_bwd(const float* dlogits, int B, int C, const float* W, c
 struct HeadStep {
   const float* x; long row_stride; int B, d, C, n; const float* gamma; const float* beta; float eps; const float* W; const float* bias;
   const long* labels; float grad_scale; float* xh; float* stats; float* logits; float* loss; float* dlogits;
-  float* g; long ldg; bf16* g16; long ldg16; float* dgamma; float* dbeta; float* dW; float* dbias; float* dcolsum; int accumulate;
+  float* g; long ldg; r16* g16; long ldg16; float* dgamma; float* dbeta; float* dW; float* dbias; float* dcolsum; int accumulate;
   float* partials; float* terms; DropCfg drop;
+  int fp16;                     // format of g16 (nv_operand_format)
+  const float* scale_state;     // dynamic loss scale (nv_loss_scale_*): dlogits are multiplied by scale_state[0]; null = grad_scale alone
 };
 // sum over the R rows of column i of part[R][stride], in reduce_partials_kernel's order (8 row groups, four interleaved accumulators each)
 __device__ __forceinline__ float partial_column_sum(const float* part, int R, long stride, int i) {
@@ -1064,10 +1070,10 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const HeadStep a) {
   const int b = blockIdx.x;
   head_fwd_row(b, sh, a.x, a.row_stride, a.d, a.gamma, a.beta, a.eps, a.W, a.bias, a.C, a.xh, a.stats, a.logits);
   __syncthreads();                                   // logits[b], stats[b] (global, written by this workgroup) are visible to all of it
-  const float term = ce_row_term(a.logits + (long)b * a.C, a.labels[b], a.C, a.grad_scale / (float)a.B, sh + a.d + 8, a.dlogits + (long)b * a.C);
+  const float term = ce_row_term(a.logits + (long)b * a.C, a.labels[b], a.C, (a.scale_state ? a.grad_scale * a.scale_state[0] : a.grad_scale) / (float)a.B, sh + a.d + 8, a.dlogits + (long)b * a.C);
   if (threadIdx.x == 0) a.terms[b] = term;
   __syncthreads();
-  head_bwd_x_row(b, sh, a.dlogits, a.C, a.W, a.x, a.row_stride, a.stats, a.gamma, a.d, a.n, a.g, a.ldg, a.g16, a.ldg16, a.partials, a.drop, 0);
+  head_bwd_x_row(b, sh, a.dlogits, a.C, a.W, a.x, a.row_stride, a.stats, a.gamma, a.d, a.n, a.g, a.ldg, a.g16, a.ldg16, a.partials, a.drop, 0, a.fp16);
 }
 // launch 2: everything that sums over the volumes - the loss, (dgamma, dbeta, column sum of the cls-row gradient), dW, dbias
 __global__ __launch_bounds__(256) void head_sums_kernel(const HeadStep a) {
@@ -1105,6 +1111,16 @@ extern "C" int nv_head_step(const float* x, long row_stride, int B, int d, const
                             const float* bias, int C, const long* labels, float grad_scale, float* xh, float* stats, float* logits, float* loss,
                             float* dlogits, int n, float* g, long ldg, void* g16, long ldg16, float* dgamma, float* dbeta, float* dW, float* dbias,
                             float* dcolsum, int accumulate, void* workspace, long ws_bytes, unsigned long drop_seed, float drop_p, void* stream) {
+  return nv_head_step_scaled(x, row_stride, B, d, gamma, beta, eps, W, bias, C, labels, grad_scale, nullptr, xh, stats, logits, loss, dlogits, n, g, ldg, g16, ldg16,
+                             dgamma, dbeta, dW, dbias, dcolsum, accumulate, workspace, ws_bytes, drop_seed, drop_p, stream);
+}
+
+// scale_state (may be NULL): the device block of nv_loss_scale_init - dlogits (and with them every gradient) carry its current scale
+extern "C" int nv_head_step_scaled(const float* x, long row_stride, int B, int d, const float* gamma, const float* beta, float eps, const float* W,
+                                   const float* bias, int C, const long* labels, float grad_scale, const float* scale_state, float* xh, float* stats,
+                                   float* logits, float* loss, float* dlogits, int n, float* g, long ldg, void* g16, long ldg16, float* dgamma,
+                                   float* dbeta, float* dW, float* dbias, float* dcolsum, int accumulate, void* workspace, long ws_bytes,
+                                   unsigned long drop_seed, float drop_p, void* stream) {
   NV_CHECK_ARG(B > 0 && d > 0 && C > 0 && C <= d && n > 0, "nv_head_step: B = %d, d = %d, C = %d, n = %d", B, d, C, n);
   NV_CHECK_ARG(x && gamma && beta && W && bias && labels && xh && stats && logits && loss && dlogits && g && dgamma && dbeta && dW && dbias && workspace,
                "nv_head_step: null pointer");
@@ -1113,8 +1129,9 @@ extern "C" int nv_head_step(const float* x, long row_stride, int B, int d, const
   HeadStep a;
   a.x = x; a.row_stride = row_stride; a.B = B; a.d = d; a.C = C; a.n = n; a.gamma = gamma; a.beta = beta; a.eps = eps; a.W = W; a.bias = bias;
   a.labels = labels; a.grad_scale = grad_scale; a.xh = xh; a.stats = stats; a.logits = logits; a.loss = loss; a.dlogits = dlogits;
-  a.g = g; a.ldg = ldg; a.g16 = (bf16*)g16; a.ldg16 = ldg16; a.dgamma = dgamma; a.dbeta = dbeta; a.dW = dW; a.dbias = dbias; a.dcolsum = dcolsum;
+  a.g = g; a.ldg = ldg; a.g16 = (r16*)g16; a.ldg16 = ldg16; a.dgamma = dgamma; a.dbeta = dbeta; a.dW = dW; a.dbias = dbias; a.dcolsum = dcolsum;
   a.accumulate = accumulate; a.partials = (float*)workspace; a.terms = (float*)workspace + (long)B * 3 * d; a.drop = make_drop(drop_seed, drop_p);
+  a.fp16 = nv_operand_format() == NV_OPERAND_FP16; a.scale_state = scale_state;
   const long fill_bytes = (long)B * n * d * (g16 ? 6 : 4);
   int fill_blocks = (int)((fill_bytes + (1 << 16) - 1) >> 16);            // ~64 KiB per workgroup
   if (fill_blocks > 1024) fill_blocks = 1024;
@@ -1128,16 +1145,17 @@ extern "C" int nv_head_step(const float* x, long row_stride, int B, int d, const
 
 // --------------------------------------------------------------------------------------- column sum of a bf16 matrix (bias grads)
 // partial[chunk][c] = sum over the chunk's rows of X[r, c]; 8 columns per lane (16-byte loads).
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ X, long ld, int M, int N, int rows_per_chunk,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const r16* __restrict__ X, long ld, int M, int N, int rows_per_chunk,
                                                           float* __restrict__ partials) {
   const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
   if (col >= N) return;
   const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int r = r0; r < r1; ++r) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (long)r * ld + col);
+    const r16x8 v = *reinterpret_cast<const r16x8*>(X + (long)r * ld + col);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
+    for (int j = 0; j < 8; ++j) a[j] += dec1<T>(v[j]);
   }
   float* p = partials + (long)blockIdx.y * N + col;
 #pragma unroll
@@ -1153,7 +1171,7 @@ extern "C" int nv_colsum_bf16(const void* X, long ld, int M, int N, float* out, 
   NV_CHECK_ARG(ws_bytes >= nv_colsum_workspace_bytes(M, N), "nv_colsum_bf16: workspace too small");
   const int chunks = colsum_chunks(M), rpc = (M + chunks - 1) / chunks;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N / 8 + 255) / 256, chunks), dim3(256), 0, s, (const bf16*)X, ld, M, N, rpc, (float*)workspace);
+  NV_DISPATCH_OPERAND(T, hipLaunchKernelGGL(colsum_bf16_kernel<T>, dim3((N / 8 + 255) / 256, chunks), dim3(256), 0, s, (const r16*)X, ld, M, N, rpc, (float*)workspace));
   NV_CHECK_LAUNCH("nv_colsum_bf16");
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 31) / 32), dim3(256), 0, s, (const float*)workspace, chunks, N, 1, out,
                      (float*)nullptr, (float*)nullptr, accumulate);

@@ -16,9 +16,18 @@
 #define NV_ADAMW_UNROLL 2          // float4 groups per thread per pass, all loads issued before the first use: 88.6 M parameters back to back
                                    // 471 us (1) -> 402-407 (2) -> 417-420 (4) on one box = 5.64 -> 6.6 TB/s
 #endif
-template <bool G16>
+// dyn (may be null): the device block of a dynamic loss scale (nv_loss_scale_*, below) - the launch does nothing when the step is
+// skipped, and takes the bias-correction constants and the un-scaling factor from it (adam_dyn)
+__device__ __forceinline__ bool adam_dyn(AdamArgs& a, const float* __restrict__ dyn) {
+  if (!dyn) return true;
+  if (dyn[LS_SKIP] != 0.f) return false;
+  a.step_size = dyn[LS_STEP_SIZE]; a.bc2_sqrt = dyn[LS_BC2_SQRT]; a.grad_scale *= dyn[LS_UNSCALE];
+  return true;
+}
+template <bool G16, typename T>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const void* __restrict__ grad, float* __restrict__ m,
-                                                    float* __restrict__ v, bf16* __restrict__ p16, long n4, AdamArgs a) {
+                                                    float* __restrict__ v, r16* __restrict__ p16, long n4, AdamArgs a, const float* __restrict__ dyn) {
+  if (!adam_dyn(a, dyn)) return;
   // grid-stride: a full-size grid runs one iteration per thread; a capped grid (max_blocks) streams the range with a
   // fraction of the chip's wave slots so that it can run beside compute-bound kernels of another stream
   constexpr int U = NV_ADAMW_UNROLL;
@@ -30,8 +39,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       if (i < n4) {
         pv[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p) + i);
         if constexpr (G16) {
-          const bf16x4 g4 = reinterpret_cast<const bf16x4*>(grad)[i];
-          gv[u] = f32x4{(float)g4[0], (float)g4[1], (float)g4[2], (float)g4[3]} * a.grad_scale;
+          const r16x4 g4 = reinterpret_cast<const r16x4*>(grad)[i];
+          gv[u] = dec4<T>(g4) * a.grad_scale;
         } else {
           gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grad) + i) * a.grad_scale;
         }
@@ -47,7 +56,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(p) + i);
         __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(m) + i);
         __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v) + i);
-        if (p16) reinterpret_cast<bf16x4*>(p16)[i] = cvt4(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
+        if (p16) reinterpret_cast<r16x4*>(p16)[i] = cvt4<T>(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
       }
     }
   }
@@ -56,6 +65,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 // count must be a multiple of 4 (arena segments are padded); step >= 1.
 extern "C" int nv_adamw_step(float* p, const void* grad, int grad_bf16, float* m, float* v, void* p16, long count, int step, double lr,
                              double beta1, double beta2, double eps, double weight_decay, float grad_scale, int max_blocks, void* stream) {
+  return nv_adamw_step_scaled(p, grad, grad_bf16, m, v, p16, count, step, lr, beta1, beta2, eps, weight_decay, grad_scale, max_blocks, nullptr, stream);
+}
+
+extern "C" int nv_adamw_step_scaled(float* p, const void* grad, int grad_bf16, float* m, float* v, void* p16, long count, int step, double lr,
+                                    double beta1, double beta2, double eps, double weight_decay, float grad_scale, int max_blocks,
+                                    const float* scale_state, void* stream) {
   NV_CHECK_ARG(count > 0 && (count % 4) == 0 && step >= 1, "nv_adamw_step: count=%ld must be a positive multiple of 4", count);
   NV_CHECK_ARG(nv_aligned16(p) && (grad_bf16 ? ((uintptr_t)grad & 7) == 0 : nv_aligned16(grad)) && nv_aligned16(m) && nv_aligned16(v) &&
                    (!p16 || ((uintptr_t)p16 & 7) == 0),
@@ -64,8 +79,9 @@ extern "C" int nv_adamw_step(float* p, const void* grad, int grad_bf16, float* m
   const long n4 = count / 4;
   long blocks = (n4 + 256L * NV_ADAMW_UNROLL - 1) / (256L * NV_ADAMW_UNROLL);
   if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
-  if (grad_bf16) hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (bf16*)p16, n4, a);
-  else hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (bf16*)p16, n4, a);
+  NV_DISPATCH_OPERAND(T,
+    if (grad_bf16) hipLaunchKernelGGL((adamw_kernel<true, T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (r16*)p16, n4, a, scale_state);
+    else hipLaunchKernelGGL((adamw_kernel<false, T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (r16*)p16, n4, a, scale_state));
   NV_CHECK_LAUNCH("nv_adamw_step");
   return NV_OK;
 }
@@ -75,8 +91,9 @@ extern "C" int nv_adamw_step(float* p, const void* grad, int grad_bf16, float* m
 // elements and the patch-embedding weight.  A workgroup owns one 2048-element chunk of one range (chunk_end = running chunk counts).
 constexpr int ADAM_MAX_RANGES = 64, ADAM_CHUNK = 2048;
 struct AdamRanges { long begin[ADAM_MAX_RANGES]; long len[ADAM_MAX_RANGES]; int chunk_end[ADAM_MAX_RANGES]; int count; };
+template <typename T>
 __global__ __launch_bounds__(256) void adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
-                                                           float* __restrict__ v, bf16* __restrict__ p16, const AdamRanges R, AdamArgs a) {
+                                                           float* __restrict__ v, r16* __restrict__ p16, const AdamRanges R, AdamArgs a) {
   const int chunks = R.chunk_end[ADAM_MAX_RANGES - 1];
   int r = 0;
   for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {      // (a capped grid walks the chunks: few CUs for an HBM-bound pass)
@@ -103,7 +120,7 @@ __global__ __launch_bounds__(256) void adamw_ranges_kernel(float* __restrict__ p
         __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(p + base) + i);
         __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(m + base) + i);
         __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v + base) + i);
-        reinterpret_cast<bf16x4*>(p16 + base)[i] = cvt4(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
+        reinterpret_cast<r16x4*>(p16 + base)[i] = cvt4<T>(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
       }
     }
   }
@@ -135,14 +152,15 @@ extern "C" int nv_adamw_ranges(const nv_adamw_arena* opt, const long* begins, co
     R.count = n;
     for (int i = n; i < ADAM_MAX_RANGES; ++i) { R.begin[i] = 0; R.len[i] = 0; R.chunk_end[i] = chunks; }
     const int blocks = (max_blocks > 0 && max_blocks < chunks) ? max_blocks : chunks;
-    hipLaunchKernelGGL(adamw_ranges_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, opt->params, opt->grads, opt->adam_m, opt->adam_v,
-                       (bf16*)opt->params16, R, a);
+    NV_DISPATCH_OPERAND(T, hipLaunchKernelGGL(adamw_ranges_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, opt->params, opt->grads, opt->adam_m,
+                                              opt->adam_v, (r16*)opt->params16, R, a));
     NV_CHECK_LAUNCH("nv_adamw_ranges");
   }
   return NV_OK;
 }
 
-__global__ __launch_bounds__(256) void cast_bf16_2d_kernel(const float* __restrict__ src, long lds_, int rows, int cols, bf16* __restrict__ dst,
+template <typename T>
+__global__ __launch_bounds__(256) void cast_bf16_2d_kernel(const float* __restrict__ src, long lds_, int rows, int cols, r16* __restrict__ dst,
                                                            long ldd) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per 4 output columns
   const long per_row = ldd / 4;
@@ -153,7 +171,7 @@ __global__ __launch_bounds__(256) void cast_bf16_2d_kernel(const float* __restri
   float v[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) v[j] = (c + j < cols) ? s[j] : 0.f;
-  *reinterpret_cast<bf16x4*>(dst + r * ldd + c) = cvt4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<r16x4*>(dst + r * ldd + c) = cvt4<T>(v[0], v[1], v[2], v[3]);
 }
 
 // dst[r, c] = bf16(src[r, c]) for c < cols, 0 for cols <= c < ld_dst.  ld_dst % 4 == 0.
@@ -161,8 +179,8 @@ extern "C" int nv_cast_bf16_2d(const float* src, long ld_src, int rows, int cols
   NV_CHECK_ARG(rows > 0 && cols > 0 && ld_dst >= cols && (ld_dst % 4) == 0 && ld_src >= cols && ((uintptr_t)dst & 7) == 0,
                "nv_cast_bf16_2d: bad dims");
   const long tot = (long)rows * (ld_dst / 4);
-  hipLaunchKernelGGL(cast_bf16_2d_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, cols,
-                     (bf16*)dst, ld_dst);
+  NV_DISPATCH_OPERAND(T, hipLaunchKernelGGL(cast_bf16_2d_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, cols,
+                                            (r16*)dst, ld_dst));
   NV_CHECK_LAUNCH("nv_cast_bf16_2d");
   return NV_OK;
 }
@@ -173,16 +191,17 @@ extern "C" int nv_cast_bf16_2d(const float* src, long ld_src, int rows, int cols
 // elements); ranges start 8-element aligned in the arena, so the body moves 16 bytes in / 8 bytes out per lane and the tail is scalar.
 constexpr int CAST_MAX_RANGES = 48;
 struct CastRanges { long begin[CAST_MAX_RANGES]; long len[CAST_MAX_RANGES]; int count; };
-__global__ __launch_bounds__(256) void cast_ranges_kernel(const float* __restrict__ src, bf16* __restrict__ dst, const CastRanges R) {
+template <typename T>
+__global__ __launch_bounds__(256) void cast_ranges_kernel(const float* __restrict__ src, r16* __restrict__ dst, const CastRanges R) {
   for (int r = blockIdx.y; r < R.count; r += gridDim.y) {
     const long b = R.begin[r], n = R.len[r];
     const bool vec = ((b & 3) == 0);
     const long n4 = vec ? (n >> 2) : 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(src + b + 4 * i);
-      *reinterpret_cast<bf16x4*>(dst + b + 4 * i) = cvt4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<r16x4*>(dst + b + 4 * i) = cvt4<T>(v[0], v[1], v[2], v[3]);
     }
-    for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[b + i] = (bf16)src[b + i];
+    for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[b + i] = cvt1<T>(src[b + i]);
   }
 }
 
@@ -201,7 +220,7 @@ extern "C" int nv_cast_ranges_bf16(const float* src, void* dst, const long* begi
     long gx = (longest / 4 + 255) / 256;
     if (gx < 1) gx = 1;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(cast_ranges_kernel, dim3((unsigned)gx, (unsigned)R.count), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, R);
+    NV_DISPATCH_OPERAND(T, hipLaunchKernelGGL(cast_ranges_kernel<T>, dim3((unsigned)gx, (unsigned)R.count), dim3(256), 0, (hipStream_t)stream, src, (r16*)dst, R));
     NV_CHECK_LAUNCH("nv_cast_ranges_bf16");
   }
   return NV_OK;
@@ -210,7 +229,8 @@ extern "C" int nv_cast_ranges_bf16(const float* src, void* dst, const long* begi
 // out16[m, n] = bf16(x[m, n] * mask(m, n)), out32 likewise (either may be null): the nn.Dropout mask of one site (same
 // counter-based mask the GEMM epilogues apply, element index m*N + n) - used by the standalone Attention / FeedForward
 // modules, whose last Dropout (vit_3d.py:23,45) has no residual epilogue to ride in.
-__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, long ldx, int M, int N, DropCfg dc, bf16* __restrict__ out16,
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, long ldx, int M, int N, DropCfg dc, r16* __restrict__ out16,
                                                             long ld16, float* __restrict__ out32, long ld32) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per 4 columns
   const long per_row = N / 4;
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
   const int n = (int)(idx - m * per_row) * 4;
   f32x4 v = *reinterpret_cast<const f32x4*>(x + m * ldx + n);
   if (dc.thresh) v = v * drop_factor4(dc, (unsigned long long)m * N + n);
-  if (out16) *reinterpret_cast<bf16x4*>(out16 + m * ld16 + n) = cvt4(v[0], v[1], v[2], v[3]);
+  if (out16) *reinterpret_cast<r16x4*>(out16 + m * ld16 + n) = cvt4<T>(v[0], v[1], v[2], v[3]);
   if (out32) *reinterpret_cast<f32x4*>(out32 + m * ld32 + n) = v;
 }
 
@@ -228,16 +248,18 @@ extern "C" int nv_dropout_apply(const float* x, long ldx, int M, int N, unsigned
   NV_CHECK_ARG(x && M > 0 && N > 0 && (N % 4) == 0 && (ldx % 4) == 0 && nv_aligned16(x), "nv_dropout_apply: N and ldx must be multiples of 4");
   NV_CHECK_ARG((!out16 || ((ld16 % 4) == 0 && ((uintptr_t)out16 & 7) == 0)) && (!out32 || ((ld32 % 4) == 0 && nv_aligned16(out32))), "nv_dropout_apply: output alignment");
   const long tot = (long)M * (N / 4);
-  hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, make_drop(drop_seed, drop_p),
-                     (bf16*)out16, ld16, out32, ld32);
+  NV_DISPATCH_OPERAND(T, hipLaunchKernelGGL(dropout_apply_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, M, N,
+                                            make_drop(drop_seed, drop_p), (r16*)out16, ld16, out32, ld32));
   NV_CHECK_LAUNCH("nv_dropout_apply");
   return NV_OK;
 }
 
 // loss = mean_b( logsumexp(logits[b]) - logits[b, target[b]] );  dlogits = (softmax - onehot) * grad_scale / B
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const long* __restrict__ target, int B, int C,
-                                                      float grad_scale, float* __restrict__ loss, float* __restrict__ dlogits) {
+                                                      float grad_scale, const float* __restrict__ scale_state, float* __restrict__ loss,
+                                                      float* __restrict__ dlogits) {
   __shared__ float red[4];
+  if (scale_state) grad_scale *= scale_state[LS_SCALE];      // dynamic loss scale: the gradients carry it, the reported loss does not
   float total = 0.f;
   for (int b = 0; b < B; ++b)
     total += ce_row_term(logits + (long)b * C, target[b], C, grad_scale / (float)B, red, dlogits ? dlogits + (long)b * C : nullptr);
@@ -245,8 +267,13 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
 }
 
 extern "C" int nv_ce_loss(const float* logits, const long* target, int B, int C, float grad_scale, float* loss, float* dlogits, void* stream) {
+  return nv_ce_loss_scaled(logits, target, B, C, grad_scale, nullptr, loss, dlogits, stream);
+}
+
+extern "C" int nv_ce_loss_scaled(const float* logits, const long* target, int B, int C, float grad_scale, const float* scale_state, float* loss,
+                                 float* dlogits, void* stream) {
   NV_CHECK_ARG(B > 0 && C > 0 && logits && target && loss, "nv_ce_loss: bad args");
-  hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, B, C, grad_scale, loss, dlogits);
+  hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, B, C, grad_scale, scale_state, loss, dlogits);
   NV_CHECK_LAUNCH("nv_ce_loss");
   return NV_OK;
 }
@@ -269,5 +296,88 @@ extern "C" int nv_copy_2d_f32(const float* src, long ld_src, int rows, int cols,
   hipLaunchKernelGGL(copy_2d_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, cols, dst,
                      ld_dst, accumulate);
   NV_CHECK_LAUNCH("nv_copy_2d_f32");
+  return NV_OK;
+}
+
+// ---- dynamic loss scale: torch.amp.GradScaler (src/Trainer.py:29,74-76: scaler.scale(loss).backward(); scaler.step(optimizer);
+// scaler.update()) for training on fp16 operands, kept ENTIRELY on the device - the reference's scaler.step() reads found_inf back
+// to the host every step.  State block: NV_LOSS_SCALE_FLOATS floats (indices LS_*, common.h).  Per optimizer step:
+//   forward / loss:       dlogits *= state[LS_SCALE]                               (nv_ce_loss_scaled / nv_head_step_scaled)
+//   nv_loss_scale_check:  state[LS_FOUND_INF] = 1 if any gradient is inf / NaN      (every gradient, as GradScaler.unscale_ does)
+//   nv_loss_scale_update: found_inf -> skip this update, scale *= backoff, growth tracker = 0; otherwise applied steps t += 1,
+//                         AdamW's bias-correction constants for step t (double arithmetic, as torch forms them on the host),
+//                         tracker += 1 and scale *= growth every `growth_interval` clean steps; LS_UNSCALE = 1 / (the scale the
+//                         gradients in the arena carry); found_inf cleared
+//   nv_adamw_step_scaled: returns at once when LS_SKIP is set; reads LS_UNSCALE, LS_STEP_SIZE, LS_BC2_SQRT
+__global__ void loss_scale_init_kernel(float* st, float init_scale, float growth, float backoff, int interval, int start_step) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < NV_LOSS_SCALE_FLOATS; ++i) st[i] = 0.f;
+  st[LS_SCALE] = init_scale; st[LS_UNSCALE] = 1.f / init_scale; st[LS_GROWTH] = growth; st[LS_BACKOFF] = backoff;
+  st[LS_INTERVAL] = (float)interval; st[LS_STEPS] = (float)start_step;
+}
+extern "C" int nv_loss_scale_init(float* state, float init_scale, float growth_factor, float backoff_factor, int growth_interval, int start_step, void* stream) {
+  NV_CHECK_ARG(state && init_scale > 0.f && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval >= 1 && start_step >= 0,
+               "nv_loss_scale_init: scale > 0, growth >= 1, 0 < backoff <= 1, interval >= 1, start_step >= 0");
+  hipLaunchKernelGGL(loss_scale_init_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, init_scale, growth_factor, backoff_factor, growth_interval, start_step);
+  NV_CHECK_LAUNCH("nv_loss_scale_init");
+  return NV_OK;
+}
+
+// any |x| that is not < inf (inf or NaN): exponent bits all ones.  HBM-bound read of the arena (354 MB for ViT3D-base: ~60 us).
+template <typename VT>
+__global__ __launch_bounds__(256) void grad_check_kernel(const VT* __restrict__ g, long nv, float* __restrict__ st) {
+  unsigned bad = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    const VT v = __builtin_nontemporal_load(g + i);
+    if constexpr (sizeof(VT) == 16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bad |= ((__builtin_bit_cast(unsigned, v[j]) & 0x7f800000u) == 0x7f800000u);
+    } else {
+      bad |= ((__builtin_bit_cast(unsigned, v) & 0x7f800000u) == 0x7f800000u);
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(bad != 0) != 0 && (threadIdx.x & 63) == 0) st[LS_FOUND_INF] = 1.f;      // racing stores of the same value
+}
+extern "C" int nv_loss_scale_check(const float* grads, long count, float* state, void* stream) {
+  NV_CHECK_ARG(grads && state && count > 0, "nv_loss_scale_check: null pointer / empty range");
+  if (nv_aligned16(grads) && (count % 4) == 0) {
+    const long nv = count / 4;
+    long blocks = (nv + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(grad_check_kernel<f32x4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(grads), nv, state);
+  } else {
+    long blocks = (count + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(grad_check_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grads, count, state);
+  }
+  NV_CHECK_LAUNCH("nv_loss_scale_check");
+  return NV_OK;
+}
+
+__global__ void loss_scale_update_kernel(float* st, double lr, double beta1, double beta2) {
+  if (threadIdx.x != 0) return;
+  const float scale = st[LS_SCALE];
+  st[LS_UNSCALE] = 1.f / scale;                 // of the gradients that are in the arena now
+  if (st[LS_FOUND_INF] != 0.f) {
+    st[LS_SKIP] = 1.f;
+    st[LS_SCALE] = scale * st[LS_BACKOFF];
+    st[LS_TRACKER] = 0.f;
+    st[LS_SKIPPED] += 1.f;
+  } else {
+    st[LS_SKIP] = 0.f;
+    const double t = (double)st[LS_STEPS] + 1.0;
+    st[LS_STEPS] = (float)t;
+    st[LS_STEP_SIZE] = (float)(lr / (1.0 - pow(beta1, t)));
+    st[LS_BC2_SQRT] = (float)sqrt(1.0 - pow(beta2, t));
+    const float tr = st[LS_TRACKER] + 1.f;
+    if (tr >= st[LS_INTERVAL]) { st[LS_SCALE] = scale * st[LS_GROWTH]; st[LS_TRACKER] = 0.f; }
+    else st[LS_TRACKER] = tr;
+  }
+  st[LS_FOUND_INF] = 0.f;
+}
+extern "C" int nv_loss_scale_update(float* state, double lr, double beta1, double beta2, void* stream) {
+  NV_CHECK_ARG(state, "nv_loss_scale_update: null state");
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, beta1, beta2);
+  NV_CHECK_LAUNCH("nv_loss_scale_update");
   return NV_OK;
 }

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64 * QW) void quant_rows_f8_kernel(const float* __r
 // bit (same summation order, same formula) - for a TRAINING forward on fp8 operands, whose bf16 backward pass reads them
 __global__ __launch_bounds__(64 * QW) void ln_fwd_f8_kernel(const float* __restrict__ x, long ldx, int M, int d, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, float out_scale, unsigned char* __restrict__ y, long ldy,
-                                                            bf16* __restrict__ y16, long ldy16, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                            r16* __restrict__ y16, long ldy16, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * QW + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* xr = x + (long)row * ldx;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64 * QW) void ln_fwd_f8_kernel(const float* __restr
     if (c < d) {
       const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
       const f32x4 o = (xv[v] - mean) * rstd * gm + bt;
-      if (y16) *reinterpret_cast<bf16x4*>(y16 + (long)row * ldy16 + c) = cvt4(o[0], o[1], o[2], o[3]);
+      if (y16) *reinterpret_cast<r16x4*>(y16 + (long)row * ldy16 + c) = cvt4<bf16_t>(o[0], o[1], o[2], o[3]);      // (the fp8 path sits beside bf16 operands: nv_set_operand_format)
       *reinterpret_cast<unsigned*>(y + (long)row * ldy + c) = pack_fp8x4(o * out_scale);
     }
   }
@@ -88,7 +88,7 @@ extern "C" int nv_ln_fwd_f8(const float* x, long ldx, int M, int d, const float*
   NV_CHECK_ARG(x && gamma && beta && y8 && M > 0 && d > 0 && (d % 4) == 0 && d <= 2048 && (ldx % 4) == 0 && (ldy % 4) == 0, "nv_ln_fwd_f8: d must be a multiple of 4 and <= 2048");
   NV_CHECK_ARG(nv_aligned16(x) && nv_aligned16(gamma) && nv_aligned16(beta) && ((uintptr_t)y8 & 3) == 0, "nv_ln_fwd_f8: alignment");
   hipLaunchKernelGGL(ln_fwd_f8_kernel, dim3((M + QW - 1) / QW), dim3(64 * QW), 0, (hipStream_t)stream, x, ldx, M, d, gamma, beta, eps, out_scale,
-                     (unsigned char*)y8, ldy, (bf16*)nullptr, 0L, (float*)nullptr, (float*)nullptr);
+                     (unsigned char*)y8, ldy, (r16*)nullptr, 0L, (float*)nullptr, (float*)nullptr);
   NV_CHECK_LAUNCH("nv_ln_fwd_f8");
   return NV_OK;
 }
@@ -97,11 +97,12 @@ extern "C" int nv_ln_fwd_f8(const float* x, long ldx, int M, int d, const float*
 // statistics of nv_ln_fwd for the bf16 backward pass, in one pass over x
 extern "C" int nv_ln_fwd_f8_train(const float* x, long ldx, int M, int d, const float* gamma, const float* beta, float eps, float out_scale, void* y8, long ldy8,
                                   void* y16, long ldy16, float* mean, float* rstd, void* stream) {
+  NV_CHECK_ARG(nv_operand_format() == NV_OPERAND_BF16, "nv_ln_fwd_f8_train: the fp8 path is built beside bf16 operands (nv_set_operand_format(NV_OPERAND_BF16))");
   NV_CHECK_ARG(x && gamma && beta && y8 && y16 && mean && rstd && M > 0 && d > 0 && (d % 4) == 0 && d <= 2048 && (ldx % 4) == 0 && (ldy8 % 4) == 0 && (ldy16 % 4) == 0,
                "nv_ln_fwd_f8_train: d must be a multiple of 4 and <= 2048");
   NV_CHECK_ARG(nv_aligned16(x) && nv_aligned16(gamma) && nv_aligned16(beta) && ((uintptr_t)y8 & 3) == 0 && ((uintptr_t)y16 & 7) == 0, "nv_ln_fwd_f8_train: alignment");
   hipLaunchKernelGGL(ln_fwd_f8_kernel, dim3((M + QW - 1) / QW), dim3(64 * QW), 0, (hipStream_t)stream, x, ldx, M, d, gamma, beta, eps, out_scale,
-                     (unsigned char*)y8, ldy8, (bf16*)y16, ldy16, mean, rstd);
+                     (unsigned char*)y8, ldy8, (r16*)y16, ldy16, mean, rstd);
   NV_CHECK_LAUNCH("nv_ln_fwd_f8_train");
   return NV_OK;
 }

@@ -20,29 +20,29 @@ constexpr int SK_R = 4;       // rows per launch slice (blockIdx.y walks slices)
 enum { SK_NT_RESID = 0, SK_NT_GELU = 1 };
 enum { SK_NN_DGELU = 0, SK_NN_F32 = 1, SK_NN_BF16 = 2 };
 
-template <int EPI>
-__global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16* __restrict__ A, long lda, int R, const bf16* __restrict__ W, long ldw, int N, int K,
+template <int EPI, typename T>
+__global__ __launch_bounds__(256) void skinny_nt_kernel(const r16* __restrict__ A, long lda, int R, const r16* __restrict__ W, long ldw, int N, int K,
                                                         const float* __restrict__ bias, const float* __restrict__ resid, long ldr,
-                                                        void* __restrict__ out, long ldo, bf16* __restrict__ u_out, long ldu, DropCfg drop) {
+                                                        void* __restrict__ out, long ldo, r16* __restrict__ u_out, long ldu, DropCfg drop) {
   const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int r0 = blockIdx.y * SK_R, rows = (R - r0 < SK_R) ? R - r0 : SK_R;
   if (n >= N) return;
   float acc[SK_R];
 #pragma unroll
   for (int r = 0; r < SK_R; ++r) acc[r] = 0.f;
-  const bf16* w = W + (long)n * ldw;
+  const r16* w = W + (long)n * ldw;
   // four 512-element steps per pass, every load of a pass issued before its arithmetic: the loop is a chain of memory round trips
   // (K = 3072 is six steps per lane - two passes)
   for (int k = lane * 8; k < K; k += 4 * 512) {
-    bf16x8 wq[4], aq[4][SK_R];
+    r16x8 wq[4], aq[4][SK_R];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int kq = k + 512 * q;
       if (kq < K) {
-        wq[q] = *reinterpret_cast<const bf16x8*>(w + kq);
+        wq[q] = *reinterpret_cast<const r16x8*>(w + kq);
 #pragma unroll
         for (int r = 0; r < SK_R; ++r)
-          if (r < rows) aq[q][r] = *reinterpret_cast<const bf16x8*>(A + (long)(r0 + r) * lda + kq);
+          if (r < rows) aq[q][r] = *reinterpret_cast<const r16x8*>(A + (long)(r0 + r) * lda + kq);
       }
     }
 #pragma unroll
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16* __restrict__
         for (int r = 0; r < SK_R; ++r) {
           if (r < rows) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[r] = __builtin_fmaf((float)aq[q][r][e], (float)wq[q][e], acc[r]);
+            for (int e = 0; e < 8; ++e) acc[r] = __builtin_fmaf(dec1<T>(aq[q][r][e]), dec1<T>(wq[q][e]), acc[r]);
           }
         }
       }
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16* __restrict__
     if constexpr (EPI == SK_NT_RESID) {
       ((float*)out)[row * ldo + n] = v * keep + resid[row * ldr + n];
     } else {
-      if (u_out) u_out[row * ldu + n] = (bf16)v;
-      ((bf16*)out)[row * ldo + n] = (bf16)(gelu_f(v) * keep);
+      if (u_out) u_out[row * ldu + n] = cvt1<T>(v);
+      ((r16*)out)[row * ldo + n] = cvt1<T>(gelu_f(v) * keep);
     }
   }
 }
@@ -84,9 +84,9 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16* __restrict__
 constexpr int NN_COLS = 16;    // output columns per workgroup (two 16-byte lanes per k-row)
 constexpr int NN_KK = 64 / (NN_COLS / 8);   // k-rows per wave-instruction: 32
 
-template <int EPI>
-__global__ __launch_bounds__(1024) void skinny_nn_kernel(const bf16* __restrict__ A, long lda, int R, const bf16* __restrict__ W, long ldw, int N, int K,
-                                                         const bf16* __restrict__ u, long ldu, void* __restrict__ out, long ldo,
+template <int EPI, typename T>
+__global__ __launch_bounds__(1024) void skinny_nn_kernel(const r16* __restrict__ A, long lda, int R, const r16* __restrict__ W, long ldw, int N, int K,
+                                                         const r16* __restrict__ u, long ldu, void* __restrict__ out, long ldo,
                                                          float* __restrict__ dcol, int accumulate, long fill_rows, int keep_every, DropCfg drop) {
   // LDS: every lane's partial sums [16 waves][32 k-row lanes][SK_R][16 columns] (128 KiB), then per-wave sums [16][SK_R][16]
   extern __shared__ __attribute__((aligned(16))) float sk_lds[];
@@ -110,16 +110,16 @@ __global__ __launch_bounds__(1024) void skinny_nn_kernel(const bf16* __restrict_
     constexpr int STEP = 16 * NN_KK;                             // k-rows per workgroup step: 512
     // four steps per pass, loads first: a thread walks K / 512 rows (six at K = 3072) and each is a memory round trip
     for (int k = wv * NN_KK + kk; k < K; k += 4 * STEP) {
-      bf16x8 wq[4];
+      r16x8 wq[4];
       float aq[4][SK_R];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int kq = k + STEP * q;
         if (kq < K) {
-          wq[q] = *reinterpret_cast<const bf16x8*>(W + (long)kq * ldw + nc);
+          wq[q] = *reinterpret_cast<const r16x8*>(W + (long)kq * ldw + nc);
 #pragma unroll
           for (int r = 0; r < SK_R; ++r)
-            if (r < rows) aq[q][r] = (float)A[(long)(r0 + r) * lda + kq];
+            if (r < rows) aq[q][r] = dec1<T>(A[(long)(r0 + r) * lda + kq]);
         }
       }
 #pragma unroll
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(1024) void skinny_nn_kernel(const bf16* __restrict_
           for (int r = 0; r < SK_R; ++r) {
             if (r < rows) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) acc[r][e] = __builtin_fmaf(aq[q][r], (float)wq[q][e], acc[r][e]);
+              for (int e = 0; e < 8; ++e) acc[r][e] = __builtin_fmaf(aq[q][r], dec1<T>(wq[q][e]), acc[r][e]);
             }
           }
         }
@@ -163,13 +163,13 @@ __global__ __launch_bounds__(1024) void skinny_nn_kernel(const bf16* __restrict_
     const int n = n0 + c;
     if constexpr (EPI == SK_NN_DGELU) {
       const float keep = drop.thresh ? drop_factor(drop, (unsigned long long)(row * ldo + n)) : 1.f;      // the mask of the GELU output this gradient flows back through
-      const bf16 o = (bf16)(v * keep * gelu_grad_f((float)u[row * ldu + n]));
-      ((bf16*)out)[row * ldo + n] = o;
-      stored = (float)o;                                         // what the weight-gradient product will read: summed as stored
+      const r16 o = cvt1<T>(v * keep * gelu_grad_f(dec1<T>(u[row * ldu + n])));
+      ((r16*)out)[row * ldo + n] = o;
+      stored = dec1<T>(o);                                         // what the weight-gradient product will read: summed as stored
     } else if constexpr (EPI == SK_NN_F32) {
       ((float*)out)[row * ldo + n] = v;
     } else {
-      ((bf16*)out)[row * ldo + n] = (bf16)v;
+      ((r16*)out)[row * ldo + n] = cvt1<T>(v);
     }
   }
   if constexpr (EPI == SK_NN_DGELU) {
@@ -187,6 +187,20 @@ __global__ __launch_bounds__(1024) void skinny_nn_kernel(const bf16* __restrict_
   }
 }
 
+constexpr int NN_LDS = (16 * NN_KK * SK_R * NN_COLS + 16 * SK_R * NN_COLS) * (int)sizeof(float);
+template <typename T>
+void nn_attrs_fmt() {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_nn_kernel<SK_NN_DGELU, T>), hipFuncAttributeMaxDynamicSharedMemorySize, NN_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_nn_kernel<SK_NN_F32, T>), hipFuncAttributeMaxDynamicSharedMemorySize, NN_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_nn_kernel<SK_NN_BF16, T>), hipFuncAttributeMaxDynamicSharedMemorySize, NN_LDS);
+}
+void nn_attrs() {
+  static bool attr = false;
+  if (attr) return;
+  nn_attrs_fmt<bf16_t>(); nn_attrs_fmt<fp16_t>();
+  attr = true;
+}
+
 }  // namespace
 
 // out[r, n] = resid[r, n] + (bias[n] + sum_k A[r, k] W[n, k])   (epi 0, out f32)   |   u = bias + sum; out = gelu(u) (epi 1, out / u bf16)
@@ -199,10 +213,11 @@ extern "C" int nv_skinny_nt(int epi, int R, int N, int K, const void* A, long ld
   NV_CHECK_ARG(epi == SK_NT_GELU || (epi == SK_NT_RESID && resid), "nv_skinny_nt: epilogue 0 needs resid; epilogues are 0 (bias + residual, f32) and 1 (bias + GELU, bf16)");
   const dim3 grid((N + 3) / 4, (R + SK_R - 1) / SK_R), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (epi == SK_NT_RESID)
-    hipLaunchKernelGGL(skinny_nt_kernel<SK_NT_RESID>, grid, block, 0, s, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, bias, resid, ldr, out, ldo, (bf16*)nullptr, 0L, drop);
-  else
-    hipLaunchKernelGGL(skinny_nt_kernel<SK_NT_GELU>, grid, block, 0, s, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, bias, resid, ldr, out, ldo, (bf16*)u_out, ldu, drop);
+  NV_DISPATCH_OPERAND(T,
+    if (epi == SK_NT_RESID)
+      hipLaunchKernelGGL((skinny_nt_kernel<SK_NT_RESID, T>), grid, block, 0, s, (const r16*)A, lda, R, (const r16*)W, ldw, N, K, bias, resid, ldr, out, ldo, (r16*)nullptr, 0L, drop);
+    else
+      hipLaunchKernelGGL((skinny_nt_kernel<SK_NT_GELU, T>), grid, block, 0, s, (const r16*)A, lda, R, (const r16*)W, ldw, N, K, bias, resid, ldr, out, ldo, (r16*)u_out, ldu, drop));
   NV_CHECK_LAUNCH("nv_skinny_nt");
   return NV_OK;
 }
@@ -217,16 +232,9 @@ extern "C" int nv_skinny_nn(int epi, int R, int N, int K, const void* A, long ld
   NV_CHECK_ARG(epi >= 0 && epi <= 2 && (epi != SK_NN_DGELU || u) && (!dcol || (epi == SK_NN_DGELU && R <= SK_R)), "nv_skinny_nn: epilogue 0 needs u; column sums only with epilogue 0 and R <= 4");
   const dim3 grid((N + NN_COLS - 1) / NN_COLS, (R + SK_R - 1) / SK_R), block(1024);
   hipStream_t s = (hipStream_t)stream;
-  constexpr int NN_LDS = (16 * NN_KK * SK_R * NN_COLS + 16 * SK_R * NN_COLS) * (int)sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_nn_kernel<SK_NN_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, NN_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_nn_kernel<SK_NN_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, NN_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_nn_kernel<SK_NN_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, NN_LDS);
-    attr = true;
-  }
-#define SK_NN(E) hipLaunchKernelGGL(skinny_nn_kernel<E>, grid, block, NN_LDS, s, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, (const bf16*)u, ldu, out, ldo, dcol, accumulate, 0L, 0, drop)
-  if (epi == SK_NN_DGELU) SK_NN(SK_NN_DGELU); else if (epi == SK_NN_F32) SK_NN(SK_NN_F32); else SK_NN(SK_NN_BF16);
+  nn_attrs();
+#define SK_NN(E) hipLaunchKernelGGL((skinny_nn_kernel<E, T>), grid, block, NN_LDS, s, (const r16*)A, lda, R, (const r16*)W, ldw, N, K, (const r16*)u, ldu, out, ldo, dcol, accumulate, 0L, 0, drop)
+  NV_DISPATCH_OPERAND(T, if (epi == SK_NN_DGELU) SK_NN(SK_NN_DGELU); else if (epi == SK_NN_F32) SK_NN(SK_NN_F32); else SK_NN(SK_NN_BF16));
 #undef SK_NN
   NV_CHECK_LAUNCH("nv_skinny_nn");
   return NV_OK;
@@ -237,17 +245,12 @@ extern "C" int nv_skinny_nn(int epi, int R, int N, int K, const void* A, long ld
 extern "C" int nv_skinny_nn_sparse(int R, int N, int K, const void* A, long lda, const void* W, long ldw, void* out, long total_rows, int keep_every,
                                    void* stream) {
   NV_CHECK_ARG(R > 0 && N > 0 && K > 0 && (N % 8) == 0 && (ldw % 8) == 0 && A && W && out && nv_aligned16(W) && nv_aligned16(out) && keep_every >= 1 &&
-                   (long)(R - 1) * keep_every < total_rows,
-               "nv_skinny_nn_sparse: N, ldw multiples of 8; W, out 16-byte aligned; (R - 1) * keep_every < total_rows");
+                   (long)(R - 1) * keep_every < total_rows && (long)R * keep_every >= total_rows,
+               "nv_skinny_nn_sparse: N, ldw multiples of 8; W, out 16-byte aligned; R = ceil(total_rows / keep_every) (every kept row is computed: the fill skips them all)");
   const dim3 grid((N + NN_COLS - 1) / NN_COLS, (R + SK_R - 1) / SK_R, 2), block(1024);
-  constexpr int NN_LDS = (16 * NN_KK * SK_R * NN_COLS + 16 * SK_R * NN_COLS) * (int)sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_nn_kernel<SK_NN_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, NN_LDS);
-    attr = true;
-  }
-  hipLaunchKernelGGL(skinny_nn_kernel<SK_NN_BF16>, grid, block, NN_LDS, (hipStream_t)stream, (const bf16*)A, lda, R, (const bf16*)W, ldw, N, K, (const bf16*)nullptr, 0L,
-                     out, (long)N * keep_every, (float*)nullptr, 0, total_rows, keep_every, make_drop(0, 0.f));
+  nn_attrs();
+  NV_DISPATCH_OPERAND(T, hipLaunchKernelGGL((skinny_nn_kernel<SK_NN_BF16, T>), grid, block, NN_LDS, (hipStream_t)stream, (const r16*)A, lda, R, (const r16*)W, ldw, N, K,
+                                            (const r16*)nullptr, 0L, out, (long)N * keep_every, (float*)nullptr, 0, total_rows, keep_every, make_drop(0, 0.f)));
   NV_CHECK_LAUNCH("nv_skinny_nn_sparse");
   return NV_OK;
 }

@@ -14,10 +14,10 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from . import ops
+from . import _cabi, ops
 from ._cabi import TrainHparams, VitConfig, VitInput, check, lib
 
-_BYTES = {torch.float32: 4, torch.bfloat16: 2}
+_BYTES = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2}
 
 
 def make_config(*, image_size, image_patch_size, frames, frame_patch_size, num_classes, dim, depth, heads, mlp_dim,
@@ -76,6 +76,7 @@ class VitRuntime:
         # last block under pool='cls': 0 = the library's process default (cls rows), 1 = every row (A/B runs, debugging)
         self.rows_form = 1 if os.environ.get("NEUROVIT_CLS_TAIL") == "0" else 0
         self._rows_form = 0
+        self.operands = "bf16"       # 16-bit operand format of this runtime's calls (ViT.set_operands); set in the library before each of them
 
     def workspace(self, B: int, training, device) -> torch.Tensor:
         """training: False / True, or 2 for the fp32 inference layout."""
@@ -124,6 +125,7 @@ class VitRuntime:
         rows_form: 1 = the last block on every row (as the reference computes it), 2 = on the cls rows when eligible,
         None = this runtime's default (`self.rows_form`: the process default unless NEUROVIT_CLS_TAIL=0)."""
         rows_form = self.rows_form if rows_form is None else int(rows_form)
+        _cabi.set_operand_format(self.operands)
         B, inp = self._input_form(video, vol_sigma, time_points, rows_form)
         ws = self.workspace(B, training, video.device)
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
@@ -198,6 +200,7 @@ class VitRuntime:
         """TRAINING forward with qkv / FC1 / FC2 of every block on e4m3 operands (nv_vit_forward_fp8_train): fills the training
         workspace exactly as forward(training=True) does, so backward() follows as usual (on bf16 operands); dropout as in forward()."""
         rows_form = self.rows_form if rows_form is None else int(rows_form)
+        _cabi.set_operand_format(self.operands)
         B, inp = self._input_form(video, vol_sigma, 0, rows_form)
         ws = self.workspace(B, True, video.device)
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
@@ -215,6 +218,7 @@ class VitRuntime:
         return logits
 
     def forward_fp8(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, f8, vol_sigma=None, time_points: int = 0) -> torch.Tensor:
+        _cabi.set_operand_format(self.operands)
         B, inp = self._input_form(video, vol_sigma, time_points, self.rows_form)
         ws = self.workspace(B, False, video.device)
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
@@ -239,6 +243,7 @@ class VitRuntime:
         if getattr(self, "_keep", (None, None))[1] is not None and self._keep[1].time_points:
             raise NotImplementedError("neurovit_amd: the fused 4D input form is forward-only (the 4D model's encoder is frozen, NeuroEncoder.py:34-36)")
         first, last = (0, self.cfg.depth + 1) if stages is None else stages
+        _cabi.set_operand_format(self.operands)
         if first == 0:
             self._dlogits = dlogits.contiguous().float()
         # grads16: bf16 arena (element offsets of `grads`) that also receives the Linear weight gradients, rounded, straight from
@@ -253,13 +258,17 @@ class VitRuntime:
     def train_step(self, video: torch.Tensor, labels: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, grads: torch.Tensor,
                    adam_m: torch.Tensor, adam_v: torch.Tensor, *, step: int, lr: float, betas, eps: float, weight_decay: float,
                    grad_scale: float = 1.0, accumulate: bool = False, update: bool = True, fuse_update: int = 0,
-                   dropout: Tuple[float, float, int] = (0.0, 0.0, 0), vol_sigma=None, rows_form: Optional[int] = None):
+                   dropout: Tuple[float, float, int] = (0.0, 0.0, 0), vol_sigma=None, rows_form: Optional[int] = None,
+                   loss_scale: float = 0.0, loss_scale_state: Optional[torch.Tensor] = None):
         """The reference's whole train step (Trainer.py:65-79) as ONE native call (nv_vit_train_step): forward, CrossEntropyLoss,
         backward of every stage, AdamW over the arena + bf16 shadow refresh.  Returns (loss [1], logits [B, C]) on the device.
         Same launches, streams and arithmetic as forward() + ops.ce_loss + backward() + ops.adamw_step.
         fuse_update (only with update and not accumulate): 1 = the transformer layers' Linear weights are updated by their
-        weight-gradient GEMMs (their gradients are then not left in `grads`), 2 = the same but they are; same bits either way."""
+        weight-gradient GEMMs (their gradients are then not left in `grads`), 2 = the same but they are; same bits either way.
+        loss_scale: static factor on d(loss)/d(logits), divided out again by the update; loss_scale_state: the device block of a
+        dynamic loss scale (optim.LossScaler) - GradScaler semantics on the device, needs fuse_update = 0."""
         rows_form = self.rows_form if rows_form is None else int(rows_form)
+        _cabi.set_operand_format(self.operands)
         B, inp = self._input_form(video, vol_sigma, 0, rows_form)
         ws = self.workspace(B, True, video.device)
         dev = video.device
@@ -268,7 +277,8 @@ class VitRuntime:
         self._dlogits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=dev)
         assert labels.is_cuda and labels.dtype == torch.int64 and labels.numel() == B and labels.is_contiguous()
         hp = TrainHparams(ctypes.sizeof(TrainHparams), int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
-                          float(grad_scale), int(bool(accumulate)), int(bool(update)), int(fuse_update))
+                          float(grad_scale), int(bool(accumulate)), int(bool(update)), int(fuse_update), float(loss_scale),
+                          None if loss_scale_state is None else loss_scale_state.data_ptr())
         check(lib.nv_vit_train_step(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
                                     None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p),
                                     params.data_ptr(), params16.data_ptr(), grads.data_ptr(), adam_m.data_ptr(), adam_v.data_ptr(),

@@ -10,7 +10,14 @@ from typing import Optional, Tuple
 
 import torch
 
+from . import _cabi
 from ._cabi import check, lib
+
+
+def op16() -> torch.dtype:
+    """torch dtype of the 16-bit operand buffers under the current operand format (_cabi.set_operand_format): bfloat16 or float16"""
+    return torch.float16 if _cabi.operand_format() == "fp16" else torch.bfloat16
+
 
 NT, NN, TN = 0, 1, 2
 EPI_STORE_BF16, EPI_STORE_F32, EPI_BIAS_F32, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_DGELU, EPI_DGELU_COLSUM = 0, 1, 2, 3, 4, 5, 6
@@ -38,7 +45,7 @@ def shape5(video: torch.Tensor):
 def cast_ranges_bf16(src: torch.Tensor, dst: torch.Tensor, ranges) -> None:
     """dst[b:e] = bf16(src[b:e]) for the element ranges [(b, e), ...] of two flat arenas (fp32 -> bf16), one launch per 48 ranges."""
     _need_cuda(src, dst)
-    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.dim() == 1 and dst.numel() >= src.numel()
+    assert src.dtype == torch.float32 and dst.dtype == op16() and src.dim() == 1 and dst.numel() >= src.numel()
     ranges = [(int(b), int(e)) for b, e in ranges if e > b]
     if not ranges:
         return
@@ -80,14 +87,14 @@ def gemm(layout: int, epi: int, A: torch.Tensor, B: torch.Tensor, *, out: Option
          aux_in=None, aux_out=None, accumulate: bool = False, alpha: float = 1.0, drop_seed: int = 0, drop_p: float = 0.0) -> torch.Tensor:
     """C = op(A) op(B) with a fused epilogue; A, B bf16 2-D row-major (last stride 1)."""
     _need_cuda(A, B)
-    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.stride(1) == 1 and B.stride(1) == 1
+    assert A.dtype == op16() and B.dtype == op16() and A.stride(1) == 1 and B.stride(1) == 1
     if layout == NT:
         M, K = A.shape; N = B.shape[0]; assert B.shape[1] == K
     elif layout == NN:
         M, K = A.shape; N = B.shape[1]; assert B.shape[0] == K
     else:
         K, M = A.shape; N = B.shape[1]; assert B.shape[0] == K
-    odt = torch.bfloat16 if epi in (EPI_STORE_BF16, EPI_BIAS_GELU, EPI_DGELU, EPI_DGELU_COLSUM) else torch.float32
+    odt = op16() if epi in (EPI_STORE_BF16, EPI_BIAS_GELU, EPI_DGELU, EPI_DGELU_COLSUM) else torch.float32
     if out is None:
         out = torch.empty((M, N), dtype=odt, device=A.device)
     assert out.dtype == odt and out.shape == (M, N) and out.stride(1) == 1
@@ -163,7 +170,7 @@ def gemm_tn_grouped(problems) -> None:
         K, M = A.shape
         N = B.shape[1]
         assert B.shape[0] == K and C.shape == (M, N) and C.dtype == torch.float32
-        assert C16 is None or (C16.shape == (M, N) and C16.dtype == torch.bfloat16)
+        assert C16 is None or (C16.shape == (M, N) and C16.dtype == op16())
         arr[i] = GemmProblem(M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0), int(acc),
                              _p(C16), 0 if C16 is None else C16.stride(0))
     check(lib.nv_gemm_bf16_grouped(TN, EPI_STORE_F32, len(problems), ctypes.cast(arr, ctypes.c_void_p), _stream()), "nv_gemm_bf16_grouped")
@@ -174,7 +181,7 @@ def adamw_arena(params, grads, adam_m, adam_v, params16, step, lr, betas=(0.9, 0
     from ._cabi import AdamwArena
     n = params.numel()
     assert all(t.is_cuda and t.is_contiguous() and t.numel() == n for t in (params, grads, adam_m, adam_v, params16))
-    assert params16.dtype == torch.bfloat16 and all(t.dtype == torch.float32 for t in (params, grads, adam_m, adam_v))
+    assert params16.dtype == op16() and all(t.dtype == torch.float32 for t in (params, grads, adam_m, adam_v))
     return AdamwArena(ctypes.sizeof(AdamwArena), int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(grad_scale),
                       int(bool(keep_grads)), params.data_ptr(), grads.data_ptr(), adam_m.data_ptr(), adam_v.data_ptr(), params16.data_ptr())
 
@@ -204,7 +211,7 @@ def adamw_ranges(opt, ranges) -> None:
 def ln_fwd(x: torch.Tensor, gamma, beta, eps: float = 1e-5):
     _need_cuda(x)
     M, d = x.shape
-    y = torch.empty((M, d), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((M, d), dtype=op16(), device=x.device)
     st = torch.empty((2, M), dtype=torch.float32, device=x.device)
     check(lib.nv_ln_fwd(_p(x), x.stride(0), M, d, _p(gamma), _p(beta), eps, _p(y), d, _p(st[0]), _p(st[1]), _stream()), "nv_ln_fwd")
     return y, st
@@ -214,7 +221,7 @@ def ln_bwd(dy, x, st, gamma, g_in=None, want_g16=True, accumulate=False, dgamma=
     _need_cuda(dy, x)
     M, d = x.shape
     g_out = torch.empty((M, d), dtype=torch.float32, device=x.device) if g_in is None else g_in
-    g16 = torch.empty((M, d), dtype=torch.bfloat16, device=x.device) if want_g16 else None
+    g16 = torch.empty((M, d), dtype=op16(), device=x.device) if want_g16 else None
     dgamma = torch.empty(d, device=x.device) if dgamma is None else dgamma
     dbeta = torch.empty(d, device=x.device) if dbeta is None else dbeta
     dcolsum = torch.empty(d, device=x.device) if dcolsum is None else dcolsum
@@ -232,7 +239,7 @@ def patch_ln_fwd(video: torch.Tensor, p1: int, p2: int, pf: int, gamma, beta, ep
     P = C * p1 * p2 * pf
     N = (F // pf) * (H // p1) * (W // p2)
     ldo = (P + 7) // 8 * 8 if ldo is None else ldo
-    out = torch.empty((B * N, ldo), dtype=torch.bfloat16, device=video.device)
+    out = torch.empty((B * N, ldo), dtype=op16(), device=video.device)
     st = torch.empty((2, B * N), dtype=torch.float32, device=video.device)
     check(lib.nv_patch_ln_fwd(_p(video), strides5(video), B, C, F, H, W, p1, p2, pf, _p(gamma), _p(beta), eps, _p(out), ldo, _p(st[0]),
                               _p(st[1]), _p(vol_sigma), _stream()), "nv_patch_ln_fwd")
@@ -263,7 +270,7 @@ def embed_finish_fwd(t, B, N, gamma, beta, pos, cls, eps=1e-5, drop_seed=0, drop
 def embed_finish_bwd(g, t, st, gamma, B, N, drop_seed=0, drop_p=0.0):
     d = t.shape[1]
     dev = t.device
-    dt = torch.empty((B * N, d), device=dev); dt16 = torch.empty((B * N, d), dtype=torch.bfloat16, device=dev)
+    dt = torch.empty((B * N, d), device=dev); dt16 = torch.empty((B * N, d), dtype=op16(), device=dev)
     dgamma, dbeta, dbias = (torch.empty(d, device=dev) for _ in range(3))
     dpos = torch.empty((N + 1, d), device=dev); dcls = torch.empty(d, device=dev)
     nb = lib.nv_embed_finish_bwd_workspace_bytes(B, N, d)
@@ -278,7 +285,7 @@ def attn_fwd(qkv: torch.Tensor, B: int, n: int, heads: int, dim_head: int = 64, 
     """qkv bf16 [B*n, 3*inner] -> (out bf16 [B*n, inner], lse f32 [B, heads, n])."""
     _need_cuda(qkv)
     inner = heads * dim_head
-    out = torch.empty((B * n, inner), dtype=torch.bfloat16, device=qkv.device)
+    out = torch.empty((B * n, inner), dtype=op16(), device=qkv.device)
     lse = torch.empty((B, heads, n), dtype=torch.float32, device=qkv.device)
     check(lib.nv_attn_fwd(_p(qkv), qkv.stride(0), B, n, heads, dim_head, dim_head ** -0.5, _p(out), inner, _p(lse), drop_seed, drop_p, _stream()), "nv_attn_fwd")
     return out, lse
@@ -295,7 +302,7 @@ def attn_fwd_o8(qkv: torch.Tensor, B: int, n: int, heads: int, out_scale: float,
 
 def attn_bwd(qkv, out, dout, lse, B, n, heads, dim_head=64, drop_seed=0, drop_p=0.0):
     inner = heads * dim_head
-    dqkv = torch.empty((B * n, 3 * inner), dtype=torch.bfloat16, device=qkv.device)
+    dqkv = torch.empty((B * n, 3 * inner), dtype=op16(), device=qkv.device)
     delta = torch.empty((B, heads, n), dtype=torch.float32, device=qkv.device)
     check(lib.nv_attn_bwd(_p(qkv), qkv.stride(0), _p(out), _p(dout), inner, _p(lse), B, n, heads, dim_head, dim_head ** -0.5, _p(delta),
                           _p(dqkv), 3 * inner, drop_seed, drop_p, _stream()), "nv_attn_bwd")
@@ -316,7 +323,7 @@ def head_bwd(dlogits, W, x, st, xh, gamma, drop_seed=0, drop_p=0.0):
     B, n, d = x.shape
     C = W.shape[0]
     dev = x.device
-    g = torch.empty((B, n, d), device=dev); g16 = torch.empty((B, n, d), dtype=torch.bfloat16, device=dev)
+    g = torch.empty((B, n, d), device=dev); g16 = torch.empty((B, n, d), dtype=op16(), device=dev)
     dgamma, dbeta, dcol = (torch.empty(d, device=dev) for _ in range(3))
     dW = torch.empty((C, d), device=dev); db = torch.empty(C, device=dev)
     nb = lib.nv_head_bwd_workspace_bytes(B, d)
@@ -334,7 +341,7 @@ def head_step(x, gamma, beta, W, bias, labels, eps=1e-5, drop_seed=0, drop_p=0.0
     dev = x.device
     xh = torch.empty((B, d), device=dev); st = torch.empty((B, 2), device=dev)
     logits = torch.empty((B, C), device=dev); dl = torch.empty((B, C), device=dev); loss = torch.empty(1, device=dev)
-    g = torch.full((B, n, d), float("nan"), device=dev); g16 = torch.full((B, n, d), float("nan"), dtype=torch.bfloat16, device=dev)
+    g = torch.full((B, n, d), float("nan"), device=dev); g16 = torch.full((B, n, d), float("nan"), dtype=op16(), device=dev)
     dgamma, dbeta, dcol = (torch.empty(d, device=dev) for _ in range(3))
     dW = torch.empty((C, d), device=dev); db = torch.empty(C, device=dev)
     nb = lib.nv_head_step_workspace_bytes(B, d)
@@ -353,19 +360,38 @@ def colsum_bf16(X: torch.Tensor, accumulate=False, out=None):
     return out
 
 
-def ce_loss(logits: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0, want_grad=True):
+def ce_loss(logits: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0, want_grad=True, scale_state=None):
     B, C = logits.shape
     loss = torch.empty(1, device=logits.device)
     dl = torch.empty_like(logits) if want_grad else None
-    check(lib.nv_ce_loss(_p(logits), _p(target), B, C, grad_scale, _p(loss), _p(dl), _stream()), "nv_ce_loss")
+    check(lib.nv_ce_loss_scaled(_p(logits), _p(target), B, C, grad_scale, _p(scale_state), _p(loss), _p(dl), _stream()), "nv_ce_loss")
     return loss, dl
 
 
-def adamw_step(p, grad, m, v, p16, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0, max_blocks=0):
-    """grad may be fp32 or bf16 (same numel as p)."""
-    assert grad.dtype in (torch.float32, torch.bfloat16) and grad.numel() == p.numel()
-    check(lib.nv_adamw_step(_p(p), _p(grad), int(grad.dtype == torch.bfloat16), _p(m), _p(v), _p(p16), p.numel(), step, lr, betas[0], betas[1],
-                            eps, weight_decay, grad_scale, int(max_blocks), _stream()), "nv_adamw_step")
+def adamw_step(p, grad, m, v, p16, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0, max_blocks=0, scale_state=None):
+    """grad may be fp32 or the 16-bit operand format (same numel as p).  scale_state: device block of a dynamic loss scale
+    (optim.LossScaler.state) - the launch then does nothing when that step is skipped, un-scales the gradients and takes the step
+    count / bias corrections from the block (`step` is ignored)."""
+    assert grad.dtype in (torch.float32, op16()) and grad.numel() == p.numel()
+    check(lib.nv_adamw_step_scaled(_p(p), _p(grad), int(grad.dtype == op16()), _p(m), _p(v), _p(p16), p.numel(), max(int(step), 1), lr, betas[0], betas[1],
+                                   eps, weight_decay, grad_scale, int(max_blocks), _p(scale_state), _stream()), "nv_adamw_step")
+
+
+def loss_scale_init(state: torch.Tensor, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, start_step=0) -> None:
+    assert state.is_cuda and state.dtype == torch.float32 and state.numel() >= 16 and state.is_contiguous()
+    check(lib.nv_loss_scale_init(_p(state), float(init_scale), float(growth_factor), float(backoff_factor), int(growth_interval), int(start_step), _stream()),
+          "nv_loss_scale_init")
+
+
+def loss_scale_check(grads: torch.Tensor, state: torch.Tensor) -> None:
+    """state[found_inf] |= any inf / NaN in the fp32 tensor `grads` (contiguous)."""
+    assert grads.is_cuda and grads.dtype == torch.float32 and grads.is_contiguous()
+    if grads.numel():
+        check(lib.nv_loss_scale_check(_p(grads), grads.numel(), _p(state), _stream()), "nv_loss_scale_check")
+
+
+def loss_scale_update(state: torch.Tensor, lr: float, betas) -> None:
+    check(lib.nv_loss_scale_update(_p(state), float(lr), float(betas[0]), float(betas[1]), _stream()), "nv_loss_scale_update")
 
 
 def cast_bf16(src: torch.Tensor, ld_dst: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -375,7 +401,7 @@ def cast_bf16(src: torch.Tensor, ld_dst: Optional[int] = None, out: Optional[tor
     if out is not None:
         ld_dst = out.stride(0) if rows > 1 else out.shape[1]
     ld_dst = (cols + 3) // 4 * 4 if ld_dst is None else ld_dst
-    dst = torch.empty((rows, ld_dst), dtype=torch.bfloat16, device=src.device) if out is None else out
+    dst = torch.empty((rows, ld_dst), dtype=op16(), device=src.device) if out is None else out
     check(lib.nv_cast_bf16_2d(_p(src), src.stride(0), rows, cols, _p(dst), ld_dst, _stream()), "nv_cast_bf16_2d")
     return dst
 
@@ -383,7 +409,7 @@ def cast_bf16(src: torch.Tensor, ld_dst: Optional[int] = None, out: Optional[tor
 def gradcam_reduce(act: torch.Tensor, grad: torch.Tensor):
     """act bf16 [B, n, d], grad f32 [B, n, d] (device) -> (cam f32 [B, n-1] min-max normalised, minmax f32 [2]); one launch."""
     _need_cuda(act, grad)
-    assert act.dtype == torch.bfloat16 and grad.dtype == torch.float32 and act.shape == grad.shape and act.is_contiguous() and grad.is_contiguous()
+    assert act.dtype == op16() and grad.dtype == torch.float32 and act.shape == grad.shape and act.is_contiguous() and grad.is_contiguous()
     B, n, d = act.shape
     cam = torch.empty((B, n - 1), dtype=torch.float32, device=act.device)
     mm = torch.empty(2, dtype=torch.float32, device=act.device)
@@ -397,7 +423,7 @@ def dropout_apply(x: torch.Tensor, drop_seed: int = 0, drop_p: float = 0.0, want
     """x f32 [M, N] times the dropout mask of one site -> (bf16 copy or None, f32 copy or None)."""
     _need_cuda(x)
     M, N = x.shape
-    o16 = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if want16 else None
+    o16 = torch.empty((M, N), dtype=op16(), device=x.device) if want16 else None
     o32 = torch.empty((M, N), dtype=torch.float32, device=x.device) if want32 else None
     check(lib.nv_dropout_apply(_p(x), x.stride(0), M, N, drop_seed, drop_p, _p(o16), N, _p(o32), N, _stream()), "nv_dropout_apply")
     return o16, o32
@@ -461,7 +487,7 @@ def gemm_f8(epi: int, A8: torch.Tensor, B8: torch.Tensor, colscale: torch.Tensor
     assert A8.dtype == torch.uint8 and B8.dtype == torch.uint8
     M, K = A8.shape
     N = B8.shape[0]
-    odt = {EPI_STORE_BF16: torch.bfloat16, EPI_STORE_F32: torch.float32, EPI_BIAS_RESID: torch.float32, EPI_BIAS_GELU_F8: torch.uint8}[epi]
+    odt = {EPI_STORE_BF16: op16(), EPI_STORE_F32: torch.float32, EPI_BIAS_RESID: torch.float32, EPI_BIAS_GELU_F8: torch.uint8}[epi]
     if out is None:
         out = torch.empty((M, N), dtype=odt, device=A8.device)
     check(lib.nv_gemm_f8(epi, M, N, K, _p(A8), A8.stride(0), _p(B8), B8.stride(0), _p(out), out.stride(0), _p(colscale), _p(bias), _p(aux_in),
@@ -476,7 +502,7 @@ def patch_ln_fwd_4d(x: torch.Tensor, p1: int, p2: int, pf: int, gamma, beta, eps
     Bo, H, W, D, T = x.shape
     P = p1 * p2 * pf
     N = (D // pf) * (H // p1) * (W // p2)
-    out = torch.empty((Bo * T * N, P), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((Bo * T * N, P), dtype=op16(), device=x.device)
     st = torch.empty((2, Bo * T * N), dtype=torch.float32, device=x.device)
     check(lib.nv_patch_ln_fwd_4d(_p(x), Bo, H, W, D, T, p1, p2, pf, _p(gamma), _p(beta), eps, _p(out), P, _p(st[0]), _p(st[1]), _p(vol_sigma),
                                  _stream()), "nv_patch_ln_fwd_4d")

@@ -12,8 +12,46 @@ from typing import Dict, List
 
 import torch
 
-from . import ops
+from . import _cabi, ops
 from .vit_3d import ViT
+
+
+class LossScaler:
+    """torch.amp.GradScaler (src/Trainer.py:29,74-76: scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()) for
+    training on fp16 operands, kept on the DEVICE: the scale, the inf / NaN flag, the growth tracker and the count of applied
+    optimizer updates live in one 16-float block (csrc/optim.hip, nv_loss_scale_*), and the fused AdamW reads that block - so a
+    step costs no host synchronisation, where the reference's scaler.step() reads found_inf back every step.  Same policy and
+    defaults as GradScaler: the loss gradient is multiplied by `scale`; any non-finite gradient skips the update and multiplies the
+    scale by backoff_factor; growth_interval clean steps in a row multiply it by growth_factor."""
+
+    def __init__(self, device, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000,
+                 start_step: int = 0):
+        self.state = torch.zeros(16, dtype=torch.float32, device=device)
+        ops.loss_scale_init(self.state, init_scale, growth_factor, backoff_factor, growth_interval, start_step)
+
+    def scale(self, loss: torch.Tensor) -> torch.Tensor:
+        """loss * current scale, as a device-side product (GradScaler.scale): backward() of the result carries the scale."""
+        return loss * self.state[0]
+
+    def check(self, grads: torch.Tensor) -> None:
+        ops.loss_scale_check(grads, self.state)
+
+    def update(self, lr: float, betas) -> None:
+        """Decide skip-or-step for the gradients checked since the last update, adjust the scale, prepare AdamW's constants."""
+        ops.loss_scale_update(self.state, lr, betas)
+
+    # host-side views (each synchronises: logging / tests only)
+    def get_scale(self) -> float:
+        return float(self.state[0])
+
+    def steps_applied(self) -> int:
+        return int(self.state[5])
+
+    def steps_skipped(self) -> int:
+        return int(self.state[11])
+
+    def last_step_skipped(self) -> bool:
+        return bool(self.state[3] != 0)
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -59,18 +97,38 @@ class FusedAdamW(torch.optim.Optimizer):
         self._bound = True
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0, reduced_bf16=None):
+    def step(self, closure=None, grad_scale: float = 1.0, reduced_bf16=None, scaler: "LossScaler" = None):
         """reduced_bf16: {id(vit): flat bf16 gradient buffer} - when the data-parallel all-reduce ran on bf16 messages the
-        optimizer reads the reduced gradients straight from that buffer (no cast back into the fp32 gradient arena)."""
+        optimizer reads the reduced gradients straight from that buffer (no cast back into the fp32 gradient arena).
+        scaler: a LossScaler whose scale the gradients carry (GradScaler.step + GradScaler.update, Trainer.py:75-76): every arena's
+        gradients are checked for inf / NaN, then the update is applied - un-scaled - or skipped, all on the device."""
         if not self._bound:
             self._bind()
         self._steps += 1
         g0 = self.param_groups[0]
-        for holder in self._arenas:
-            if self._no_gradients(holder):
-                continue
-            self._step_arena(holder, grad_scale, None if reduced_bf16 is None else reduced_bf16.get(id(holder)))
+        live = [h for h in self._arenas if not self._no_gradients(h)]
+        if scaler is not None:
+            for holder in live:
+                if hasattr(holder, "gather_foreign_grads"):
+                    holder.gather_foreign_grads()
+                red = None if reduced_bf16 is None else reduced_bf16.get(id(holder))
+                scaler.check(holder.flat_gradients() if red is None else red.float())
+            if self._rest is not None:
+                for g in self._rest.param_groups:
+                    for p in g["params"]:
+                        if p.grad is not None:
+                            scaler.check(p.grad.contiguous().float())
+            scaler.update(g0["lr"], g0["betas"])
+        for holder in live:
+            self._step_arena(holder, grad_scale, None if reduced_bf16 is None else reduced_bf16.get(id(holder)), scaler)
         if self._rest is not None:
+            if scaler is not None:
+                if scaler.last_step_skipped():          # (stock parameters beside a scaled arena: the one place that reads the flag back)
+                    return None
+                for g in self._rest.param_groups:
+                    for p in g["params"]:
+                        if p.grad is not None:
+                            p.grad.mul_(scaler.state[1])
             for g in self._rest.param_groups:
                 g["lr"] = g0["lr"]
             self._rest.step()
@@ -86,6 +144,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self._state_mv[key] = (torch.zeros_like(arena), torch.zeros_like(arena))
         m, v = self._state_mv[key]
         g0 = self.param_groups[0]
+        _cabi.set_operand_format(getattr(vit, "operands", "bf16"))
         ops.adamw_step(arena[begin:end], grads[begin:end], m[begin:end], v[begin:end], shadow[begin:end], self._steps, g0["lr"],
                        g0["betas"], g0["eps"], g0["weight_decay"], grad_scale, max_blocks)
         vit._param_generation += 1             # the arena changed under derived copies (fp8 weights re-quantise on their next use)
@@ -116,14 +175,16 @@ class FusedAdamW(torch.optim.Optimizer):
         as a whole.  (A PARTIALLY populated arena is stepped with zeros for the missing gradients: see TemporalHead.gather_foreign_grads.)"""
         return all(p.grad is None for p in holder._plist)
 
-    def _step_arena(self, holder, grad_scale, reduced=None):
+    def _step_arena(self, holder, grad_scale, reduced=None, scaler=None):
         arena, shadow = holder.flat_parameters()
         grads = holder.flat_gradients()
         if hasattr(holder, "gather_foreign_grads"):
             holder.gather_foreign_grads()
         m, v = self.arena_state(holder)
         g0 = self.param_groups[0]
-        ops.adamw_step(arena, grads if reduced is None else reduced, m, v, shadow, self._steps, g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"], grad_scale)
+        _cabi.set_operand_format(getattr(holder, "operands", "bf16"))      # the format of the shadow this launch rewrites
+        ops.adamw_step(arena, grads if reduced is None else reduced, m, v, shadow, self._steps, g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"], grad_scale,
+                       scale_state=None if scaler is None else scaler.state)
         holder.mark_shadow_fresh()
 
     @torch.no_grad()

@@ -142,7 +142,7 @@ class GradSync:
                        2 S / W instead of 2 (W-1)/W S: 0.29 ms instead of 2.0 ms for the 177 MB above.
         Every algo leaves the same values on every rank (replicas stay bit-identical); "rs_ag" and "one_hop" sum in an order of
         their own, so against "allreduce" they agree to fp32 / bf16 rounding, and bit for bit at world 2."""
-        assert comm_dtype in (torch.float32, torch.bfloat16)
+        assert comm_dtype in (torch.float32, torch.bfloat16, torch.float16)      # 16-bit messages: the model's operand format (the weight-gradient GEMMs write their share of the message buffer in it)
         import os
         self.algo = algo or os.environ.get("NEUROVIT_DP_ALGO", "allreduce")
         if self.algo not in self.ALGOS:
@@ -171,10 +171,10 @@ class GradSync:
 
     def message_buffer(self, flat_grads: torch.Tensor) -> Optional[torch.Tensor]:
         """bf16 messages: the arena-shaped bf16 buffer the buckets are sent from (allocated on first use)."""
-        if self.comm_dtype != torch.bfloat16:
+        if self.comm_dtype == torch.float32:
             return None
         if self._comm_buf is None or self._comm_buf.numel() != flat_grads.numel() or self._comm_buf.device != flat_grads.device:
-            self._comm_buf = torch.empty(flat_grads.numel(), dtype=torch.bfloat16, device=flat_grads.device)
+            self._comm_buf = torch.empty(flat_grads.numel(), dtype=self.comm_dtype, device=flat_grads.device)
         return self._comm_buf
 
     def _staging(self, like: torch.Tensor, padded: int, names):
@@ -275,7 +275,7 @@ class GradSync:
 
     def reduced_buffer(self) -> Optional[torch.Tensor]:
         """The flat bf16 buffer holding the reduced gradients of every bucket of this step (bf16 messages only)."""
-        return self._comm_buf if self.comm_dtype == torch.bfloat16 else None
+        return self._comm_buf if self.comm_dtype != torch.float32 else None
 
     def finish(self):
         """Make the current stream wait for every outstanding bucket."""

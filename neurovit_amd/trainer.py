@@ -4,8 +4,9 @@
     optimizer.zero_grad(set_to_none=True); loss.backward(); optimizer.step()
 
 `TrainStep` runs exactly that sequence with the gfx950 kernels: engine forward, fused CE, staged engine backward
-(gradient buckets all-reduced over RCCL while later stages still run), fused AdamW (+ bf16 shadow refresh).
-bf16 MFMA operands with fp32 master weights need no GradScaler (Trainer.py:29,74-76 exist for fp16 autocast).
+(gradient buckets all-reduced over RCCL while later stages still run), fused AdamW (+ 16-bit shadow refresh).
+bf16 MFMA operands with fp32 master weights need no GradScaler; a model on fp16 operands (ViT.set_operands("fp16"), the
+reference's own autocast arithmetic) gets the reference's GradScaler (Trainer.py:29,74-76) as optim.LossScaler, kept on the device.
 No host synchronisation happens inside a step; `loss` is returned as a device tensor.
 """
 from __future__ import annotations
@@ -18,7 +19,7 @@ import torch.distributed as dist
 
 from .NeuroEncoder import NeuroEncoder
 from .nn import CrossEntropyLoss
-from .optim import FusedAdamW
+from .optim import FusedAdamW, LossScaler
 from .parallel import GradSync, broadcast_parameters
 
 
@@ -27,8 +28,12 @@ class TrainStep:
 
     def __init__(self, model: NeuroEncoder, lr: Optional[float] = None, weight_decay: Optional[float] = None, process_group=None,
                  n_buckets: int = 4, accumulation_steps: int = 1, overlap_optimizer: bool = False,
-                 grad_comm_dtype: torch.dtype = torch.float32, grad_comm_algo: Optional[str] = None, fuse_update: Optional[int] = None):
+                 grad_comm_dtype: torch.dtype = torch.float32, grad_comm_algo: Optional[str] = None, fuse_update: Optional[int] = None,
+                 loss_scale=None):
         cfg = model.config
+        # loss_scale: None = by operand format - "dynamic" for fp16 operands (torch.amp.GradScaler semantics, on the device:
+        # optim.LossScaler), none for bf16; "dynamic"; or a number = a static scale (no overflow check, no skipped steps - keeps
+        # the optimizer update inside the backward pass, fuse_update).  A power of two changes no bit of a finite result.
         # native step only - where AdamW runs for the layers' Linear weights (96 % of the parameters); same bits in every mode:
         #   0  with the rest of the arena, one launch behind the backward pass
         #   3  per layer on the auxiliary stream, behind that layer's weight-gradient GEMMs, beside the main stream's chain
@@ -62,12 +67,14 @@ class TrainStep:
         self.last_outputs = None
         self._overlap_opt = bool(overlap_optimizer)
         self._opt_blocks = int(os.environ.get("NEUROVIT_OPT_BLOCKS", "0"))
+        if grad_comm_dtype != torch.float32:           # 16-bit messages travel in the model's operand format (what the GEMM epilogues write)
+            grad_comm_dtype = vit._dtype16()
         if self._arena_trainable and (world > 1 or overlap_optimizer):
             self.sync = GradSync(process_group, n_buckets, after_bucket=self._bucket_update if overlap_optimizer else None,
                                  comm_dtype=grad_comm_dtype, algo=grad_comm_algo)
             # bf16 messages: the fused AdamW reads the reduced bf16 gradients directly; param.grad then keeps the LOCAL
             # (pre-reduction) gradients, which nothing downstream of this fused step reads
-            self.sync.write_back = bool(overlap_optimizer) or grad_comm_dtype != torch.bfloat16
+            self.sync.write_back = bool(overlap_optimizer) or grad_comm_dtype == torch.float32
         if world > 1:
             arena, _ = vit.flat_parameters()
             broadcast_parameters(arena, process_group)
@@ -95,6 +102,20 @@ class TrainStep:
         self._native = None                                            # decided at the first step (see _native_ok)
         self._graphs_on = os.environ.get("NEUROVIT_GRAPH_STEP", "0") == "1"   # replay the native step from captured graphs (see _graph_step)
         self._graphs, self._graph_seen, self._graph_warm = {}, {}, 0
+        if loss_scale is None:
+            loss_scale = "dynamic" if (vit.operands == "fp16" and self._arena_trainable) else 0.0
+        self.scaler = None
+        self.static_scale = 0.0
+        if loss_scale == "dynamic":
+            assert not overlap_optimizer, "a dynamic loss scale decides after the backward pass whether the step is applied: no per-bucket optimizer updates"
+            self.scaler = LossScaler(dev0)
+            if self.sync is not None:
+                self.sync.write_back = True            # the overflow check reads the reduced gradients from the fp32 arena
+        else:
+            self.static_scale = float(loss_scale)
+            assert self.static_scale >= 0.0, "loss_scale: None, 'dynamic' or a non-negative number"
+        self.last_path = None                          # "native" | "general": which path the most recent step took (last_fuse_update: where AdamW ran)
+        self._all_modules = list(model.modules())
         self._head = getattr(model, "_temporal_head", None)            # 4D: its 16 parameters are one arena (temporal.TemporalHead)
         self._head_ids = set()
         if self._head is not None:
@@ -102,7 +123,10 @@ class TrainStep:
             self._head_ids = {id(p) for p in self._head._plist}
 
     def _bucket_update(self, begin: int, end: int):
-        self.optimizer.step_range(self._vit, begin, end, grad_scale=1.0 / self.world, max_blocks=self._opt_blocks)
+        gs = 1.0 / self.world
+        if self.static_scale > 0:
+            gs /= self.static_scale
+        self.optimizer.step_range(self._vit, begin, end, grad_scale=gs, max_blocks=self._opt_blocks)
 
     def __call__(self, fmri: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         cs = self._compute_stream
@@ -127,11 +151,15 @@ class TrainStep:
         if self._native is None:
             model, vit = self.model, self._vit
             self._native = bool(
-                os.environ.get("NEUROVIT_NATIVE_STEP", "1") != "0" and model.config.get('TRAINING_DIM') == 3 and self._arena_trainable
-                and self.sync is None and self.world == 1 and not self._outside and self._compute_stream is None
-                and not any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None)
-                            for m in model.modules()))
+                os.environ.get("NEUROVIT_NATIVE_STEP", "1") != "0" and model.config.get('TRAINING_DIM') == 3
+                and self.sync is None and self.world == 1 and not self._outside and self._compute_stream is None)
         if not self._native or not (torch.is_tensor(fmri) and fmri.is_cuda and fmri.dtype == torch.float32 and fmri.dim() == 4):
+            return False
+        # checked on EVERY step (hooks registered, parameters frozen after the first step must not be bypassed: the native call
+        # runs no module forward and updates the whole arena)
+        if not all(p.requires_grad for p in self._vit._plist or self._vit.parameters()):
+            return False
+        if any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None) for m in self._all_modules):
             return False
         if not (torch.is_tensor(labels) and labels.is_cuda and labels.dtype == torch.int64 and labels.dim() == 1 and labels.shape[0] == fmri.shape[0]):
             return False
@@ -159,9 +187,16 @@ class TrainStep:
         for the graph.  The returned loss / logits tensors are the graph's own outputs: the next replay of the same graph overwrites
         them (clone what must outlive the next step - as with any captured graph)."""
         vit, opt = self._vit, self.optimizer
-        if not self._graphs_on or self.accumulation_steps != 1 or vit._dropout_p != (0.0, 0.0):
+        if not self._graphs_on or self.accumulation_steps != 1 or vit._dropout_p != (0.0, 0.0) or self.scaler is not None:
             return None
-        key = (fmri.data_ptr(), labels.data_ptr(), tuple(fmri.shape), tuple(fmri.stride()), vit._arena.data_ptr())
+        if vit._grads is None:
+            vit._grads = torch.zeros_like(vit._arena)
+        m_, v_ = opt.arena_state(vit)
+        # everything a captured launch holds by address: a rebuilt gradient arena, re-created optimizer state or another form of the
+        # last block at the same input address must not replay a graph that writes stale or freed buffers
+        key = (fmri.data_ptr(), labels.data_ptr(), tuple(fmri.shape), tuple(fmri.stride()), vit._arena.data_ptr(), vit._shadow.data_ptr(),
+               vit._grads.data_ptr(), m_.data_ptr(), v_.data_ptr(), vit._rt.workspace(fmri.shape[0], True, fmri.device).data_ptr(), vit._rt.rows_form,
+               vit.operands, self.static_scale)
         ent = self._graphs.get(key)
         if ent is None:
             self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
@@ -181,7 +216,8 @@ class TrainStep:
             try:
                 with torch.cuda.graph(graph):
                     loss, logits = vit._rt.train_step(video, labels, vit._arena, vit._shadow, vit._grads, m, v, step=1, lr=g0["lr"], betas=g0["betas"],
-                                                      eps=g0["eps"], weight_decay=g0["weight_decay"], accumulate=False, update=False)
+                                                      eps=g0["eps"], weight_decay=g0["weight_decay"], accumulate=False, update=False,
+                                                      loss_scale=self.static_scale)
             except Exception as e:                                       # capture refused (an unsupported call inside it): eager from now on
                 self._graphs_on = False
                 import warnings
@@ -198,7 +234,7 @@ class TrainStep:
         rt.backward_done = True
         rt._dropout = (0.0, 0.0, 0)
         opt._steps += 1
-        opt._step_arena(vit, 1.0)                                        # AdamW over the arena + bf16 shadow (mark_shadow_fresh inside)
+        opt._step_arena(vit, 1.0 / self.static_scale if self.static_scale > 0 else 1.0)      # AdamW over the arena + 16-bit shadow (mark_shadow_fresh inside)
         vit._last_logits = logits
         self.last_outputs = logits
         if vit._plist[0].grad is None:
@@ -222,20 +258,22 @@ class TrainStep:
         if not opt._bound:
             opt._bind()
         m, v = opt.arena_state(vit)
-        if last_micro:
-            opt._steps += 1
         g0 = opt.param_groups[0]
         # the update inside the weight-gradient GEMMs: only a step that overwrites its gradients AND updates (no accumulation window)
         fuse = self.fuse_update
         if fuse is None:
             fuse = 3 if fmri.shape[0] * vit.pos_embedding.shape[1] <= self.FUSE_MAX_ROWS else 0
-        if self.accumulation_steps != 1 or vit._phantom:
-            fuse = 0
+        if self.accumulation_steps != 1 or vit._phantom or self.scaler is not None:
+            fuse = 0                        # (a dynamic loss scale decides after the backward pass whether the update is applied)
         self.last_fuse_update = fuse
+        self.last_path = "native"
         accumulate = self._micro > 0        # the first micro-step of a window overwrites (zero_grad(set_to_none=True), Trainer.py:72), the others add
-        loss, logits = vit._rt.train_step(video, labels.contiguous(), arena, shadow, grads, m, v, step=max(opt._steps, 1), lr=g0["lr"], betas=g0["betas"],
+        loss, logits = vit._rt.train_step(video, labels.contiguous(), arena, shadow, grads, m, v, step=opt._steps + 1, lr=g0["lr"], betas=g0["betas"],
                                           eps=g0["eps"], weight_decay=g0["weight_decay"], grad_scale=1.0, accumulate=accumulate, update=last_micro,
-                                          fuse_update=fuse, dropout=vit.draw_dropout())
+                                          fuse_update=fuse, dropout=vit.draw_dropout(), loss_scale=self.static_scale,
+                                          loss_scale_state=None if self.scaler is None else self.scaler.state)
+        if last_micro:
+            opt._steps += 1                 # (after the call: a refused step leaves the counter where it was)
         vit._last_logits = logits
         self.last_outputs = logits
         if vit._plist[0].grad is None:                                   # .grad = views of the gradient arena (once; they stay valid)
@@ -266,12 +304,18 @@ class TrainStep:
         vit._grad_sync = self.sync if pipelined else None
         if pipelined and self._overlap_opt:
             self.optimizer.begin_step()
+        self.last_path = "general"
         outputs = model(fmri)
         self.last_outputs = outputs.detach()           # the Trainer shell counts accuracy from these (3D and 4D alike)
         loss = self.criterion(outputs, labels)
         if self._micro == 0:
             self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        if self.scaler is not None:
+            self.scaler.scale(loss).backward()         # Trainer.py:74: scaler.scale(loss).backward()
+        elif self.static_scale > 0:
+            (loss * self.static_scale).backward()
+        else:
+            loss.backward()
         self._micro += 1
         if last_micro:
             scale = 1.0 / self.world
@@ -297,12 +341,14 @@ class TrainStep:
                             p.grad.mul_(scale)
                 if not arena_synced:
                     scale = 1.0                        # already averaged above
+            if self.static_scale > 0:
+                scale = scale / self.static_scale
             if pipelined and self._overlap_opt:
                 vit.mark_shadow_fresh()                # every range was updated (and its bf16 shadow refreshed) by the buckets
                 self.optimizer.step_rest(grad_scale=scale)
             else:
                 red = self.sync.reduced_buffer() if (pipelined and not self.sync.write_back) else None
-                self.optimizer.step(grad_scale=scale, reduced_bf16=None if red is None else {id(vit): red})
+                self.optimizer.step(grad_scale=scale, reduced_bf16=None if red is None else {id(vit): red}, scaler=self.scaler)
             self._micro = 0
         return loss.detach()
 

@@ -19,7 +19,7 @@ from typing import List, Optional
 import torch
 from torch import nn
 
-from . import engine, ops
+from . import _cabi, engine, ops
 
 
 def pair(t):
@@ -27,7 +27,8 @@ def pair(t):
 
 
 def _w16(w: torch.Tensor) -> torch.Tensor:
-    """bf16 MFMA operand copy of an fp32 [out, in] weight (standalone modules; inside a ViT the arena's shadow serves)."""
+    """16-bit MFMA operand copy (the process's current operand format, _cabi.set_operand_format) of an fp32 [out, in] weight
+    (standalone modules; inside a ViT the arena's shadow serves)."""
     return ops.cast_bf16(w.detach().reshape(w.shape[0], -1).float())
 
 
@@ -51,7 +52,7 @@ class _FeedForwardFn(torch.autograd.Function):
         x2, d = _as_rows(x)
         xn, st = ops.ln_fwd(x2, gamma.detach(), beta.detach())
         w1_16, w2_16 = _w16(w1), _w16(w2)
-        u = torch.empty((x2.shape[0], w1.shape[0]), dtype=torch.bfloat16, device=x.device)
+        u = torch.empty((x2.shape[0], w1.shape[0]), dtype=ops.op16(), device=x.device)
         h = ops.gemm(ops.NT, ops.EPI_BIAS_GELU, xn, w1_16, bias=b1.detach(), aux_out=u, drop_seed=seeds[0], drop_p=p if seeds[0] else 0.0)
         y = ops.gemm(ops.NT, ops.EPI_BIAS_F32, h, w2_16, bias=b2.detach())
         if seeds[1]:
@@ -299,6 +300,27 @@ class ViT(nn.Module):
         # of its CPU forward, about 3x the time).  Set directly, through `precision(...)`, or by the config key
         # TRAINING_VIT_EVAL_PRECISION of ViT3DEncoder.
         self.eval_precision = "bf16"
+        # 16-bit MFMA operand format: "bf16" (default, BASELINE.json's dtype) or "fp16" - the reference's own training arithmetic
+        # (torch.autocast(float16), Trainer.py:68): 11 instead of 8 significand bits at the same MFMA rate, which puts the logits
+        # within 1e-3 of the reference's fp32 CPU forward; TrainStep then scales the loss (GradScaler, Trainer.py:29,74-76).  set_operands().
+        self.operands = "bf16"
+
+    def set_operands(self, fmt: str):
+        """Switch the operand format of the shadow arena, the activations and the MFMA kernels: "bf16" or "fp16"."""
+        if fmt not in _cabi.OPERAND_FORMATS:
+            raise ValueError(f"neurovit_amd.ViT: operands must be 'bf16' or 'fp16', got {fmt!r}")
+        if fmt != self.operands:
+            if fmt == "fp16" and self._fp8 is not None:
+                raise RuntimeError("neurovit_amd.ViT: the fp8 path is built beside bf16 operands - disable_fp8() first")
+            self.operands = fmt
+            self._rt.operands = fmt
+            if self._shadow is not None:
+                self._shadow = torch.empty(self._shadow.numel(), dtype=self._dtype16(), device=self._shadow.device)
+            self._shadow_key = None
+        return self
+
+    def _dtype16(self) -> torch.dtype:
+        return torch.float16 if self.operands == "fp16" else torch.bfloat16
 
     # ------------------------------------------------------------------ arena management
     def _build_arena(self):
@@ -333,7 +355,7 @@ class ViT(nn.Module):
                 arena[o:o + n].copy_(p.detach().reshape(-1).float())
                 p.data = arena[o:o + n].view(p.shape)
         self._arena, self._plist = arena, plist
-        self._shadow = torch.empty(total, dtype=torch.bfloat16, device=dev)
+        self._shadow = torch.empty(total, dtype=self._dtype16(), device=dev)
         self._shadow_key = None
         if not grads_alive:
             self._grads = None
@@ -379,6 +401,7 @@ class ViT(nn.Module):
     def _refresh_shadow(self):
         key = tuple(p._version for p in self._plist)
         if key != self._shadow_key:
+            _cabi.set_operand_format(self.operands)
             ops.cast_bf16(self._arena.view(1, -1), out=self._shadow.view(1, -1))
             self._shadow_key = key
 
@@ -391,6 +414,8 @@ class ViT(nn.Module):
         backward pass stays on bf16 operands and reads the bf16 activations the same forward kernels write): the weights are
         re-quantised after every optimizer step (in place), the activation scales stay those of the calibration batch - call
         enable_fp8 again to recalibrate.  Dropout works as in the bf16 forward (same masks).  Default: training forwards keep using bf16."""
+        if self.operands != "bf16":
+            raise RuntimeError("neurovit_amd.ViT: the fp8 path is built beside bf16 operands - set_operands('bf16') first")
         self.flat_parameters()
         self._refresh_shadow()
         scales = self._rt.calibrate_fp8(calibration_video.float(), self._arena, self._shadow, headroom, out_proj)
@@ -410,10 +435,11 @@ class ViT(nn.Module):
         return self._fp8
 
     def precision(self, mode: str):
-        """Context manager: eval-mode no-grad forwards inside it run in `mode` ("bf16" | "fp32")."""
+        """Context manager: eval-mode no-grad forwards inside it run in `mode`: "fp32" (every operand fp32), or "bf16" / "fp16" - both
+        name the 16-bit operand path, which runs in this module's operand format (`operands`)."""
         import contextlib
-        if mode not in ("bf16", "fp32"):
-            raise ValueError(f"neurovit_amd.ViT: precision must be 'bf16' or 'fp32', got {mode!r}")
+        if mode not in ("bf16", "fp16", "fp32"):
+            raise ValueError(f"neurovit_amd.ViT: precision must be 'bf16', 'fp16' or 'fp32', got {mode!r}")
 
         @contextlib.contextmanager
         def scope():
@@ -441,8 +467,8 @@ class ViT(nn.Module):
     def _run_forward(self, video, need_grad, extra=(None, 0)):
         vol_sigma, time_points = extra
         drop = self.draw_dropout()
-        if self.eval_precision not in ("bf16", "fp32"):
-            raise ValueError(f"neurovit_amd.ViT: eval_precision must be 'bf16' or 'fp32', got {self.eval_precision!r}")
+        if self.eval_precision not in ("bf16", "fp16", "fp32"):
+            raise ValueError(f"neurovit_amd.ViT: eval_precision must be 'bf16', 'fp16' or 'fp32', got {self.eval_precision!r}")
         if self.eval_precision == "fp32" and not need_grad and not self.training:
             self._last_logits = self._rt.forward_f32(video, self._arena, vol_sigma=vol_sigma, time_points=time_points)
             return self._last_logits
@@ -547,10 +573,10 @@ class ViT(nn.Module):
 
     # activations / gradients of the last block's attention LayerNorm output (Grad-CAM contract, NeuroEncoder.py:70-82)
     def last_attn_norm_output_raw(self) -> torch.Tensor:
-        """[B, n, d] view into the workspace of the most recent forward (no copy): bf16, or fp32 after an fp32 inference forward."""
+        """[B, n, d] view into the workspace of the most recent forward (no copy): the operand format, or fp32 after an fp32 inference forward."""
         B = self._rt._last[0]
         n, d = self.pos_embedding.shape[1], self.pos_embedding.shape[2]
-        return self._rt.tap("xn1", self._cfg.depth - 1, (B, n, d), torch.float32 if self._rt._last[1] == 2 else torch.bfloat16)
+        return self._rt.tap("xn1", self._cfg.depth - 1, (B, n, d), torch.float32 if self._rt._last[1] == 2 else self._dtype16())
 
     def last_attn_norm_grad_raw(self) -> torch.Tensor:
         """fp32 [B, n, d] view into the workspace; valid once a backward of the most recent training forward has run."""

@@ -123,11 +123,34 @@ def _q8_rows(w: torch.Tensor) -> torch.Tensor:
     return _q8(w, sw)
 
 
+# 16-bit operand format the emulation rounds to: bfloat16 (the HIP path's default) or float16 (NV_OPERAND_FP16 - the reference's own
+# autocast(float16) arithmetic, src/Trainer.py:68).  Every cast point goes through _r, so ONE switch restates either product path.
+_ROUND_DTYPE = torch.bfloat16
+
+
+class operand_format:
+    """Context manager: `with operand_format("fp16"): ...` - emulate_bf16=True forwards AND their .backward() inside it round to
+    float16 instead of bfloat16 (overflow gives inf, as the hardware conversion does)."""
+
+    def __init__(self, fmt: str):
+        self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[fmt]
+
+    def __enter__(self):
+        global _ROUND_DTYPE
+        self.before, _ROUND_DTYPE = _ROUND_DTYPE, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global _ROUND_DTYPE
+        _ROUND_DTYPE = self.before
+        return False
+
+
 def _r(x: torch.Tensor, point: Optional[str] = None) -> torch.Tensor:
-    """Round-to-nearest-even to bf16, keep fp32 storage.  Autograd: identity."""
+    """Round-to-nearest-even to the 16-bit operand format (bf16 unless inside operand_format("fp16")), keep fp32 storage.  Autograd: identity."""
     if point is not None and point in CAST_OFF:
         return x
-    return x.to(torch.bfloat16).to(torch.float32)
+    return x.to(_ROUND_DTYPE).to(torch.float32)
 
 
 class _RoundGrad(torch.autograd.Function):
