@@ -324,32 +324,26 @@ extern "C" int nv_loss_scale_init(float* state, float init_scale, float growth_f
 }
 
 // any |x| that is not < inf (inf or NaN): exponent bits all ones.  HBM-bound read of the arena (354 MB for ViT3D-base: ~60 us).
-template <typename VT>
-__global__ __launch_bounds__(256) void grad_check_kernel(const VT* __restrict__ g, long nv, float* __restrict__ st) {
+// The words are read as integers (no float value is ever formed: nothing for value-based reasoning to fold).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned nonfinite_bits(unsigned w) { return ((w & 0x7f800000u) == 0x7f800000u) ? 1u : 0u; }
+__global__ __launch_bounds__(256) void grad_check_kernel(const unsigned* __restrict__ g, long count, float* __restrict__ st) {
   unsigned bad = 0;
+  const long nv = (((unsigned long)g & 15) == 0) ? count / 4 : 0;      // 16-byte pieces, then the scalar tail
+  const u32x4* gv = reinterpret_cast<const u32x4*>(g);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
-    const VT v = __builtin_nontemporal_load(g + i);
-    if constexpr (sizeof(VT) == 16) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bad |= ((__builtin_bit_cast(unsigned, v[j]) & 0x7f800000u) == 0x7f800000u);
-    } else {
-      bad |= ((__builtin_bit_cast(unsigned, v) & 0x7f800000u) == 0x7f800000u);
-    }
+    const u32x4 v = __builtin_nontemporal_load(gv + i);
+    bad |= nonfinite_bits(v[0]) | nonfinite_bits(v[1]) | nonfinite_bits(v[2]) | nonfinite_bits(v[3]);
   }
+  for (long i = 4 * nv + (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) bad |= nonfinite_bits(g[i]);
   if (__builtin_amdgcn_ballot_w64(bad != 0) != 0 && (threadIdx.x & 63) == 0) st[LS_FOUND_INF] = 1.f;      // racing stores of the same value
 }
 extern "C" int nv_loss_scale_check(const float* grads, long count, float* state, void* stream) {
   NV_CHECK_ARG(grads && state && count > 0, "nv_loss_scale_check: null pointer / empty range");
-  if (nv_aligned16(grads) && (count % 4) == 0) {
-    const long nv = count / 4;
-    long blocks = (nv + 256 * 8 - 1) / (256 * 8);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(grad_check_kernel<f32x4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(grads), nv, state);
-  } else {
-    long blocks = (count + 256 * 8 - 1) / (256 * 8);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(grad_check_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grads, count, state);
-  }
+  long blocks = (count / 4 + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(grad_check_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned*>(grads), count, state);
   NV_CHECK_LAUNCH("nv_loss_scale_check");
   return NV_OK;
 }

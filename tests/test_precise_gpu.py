@@ -247,7 +247,7 @@ def test_eval_precision_switch_on_the_module(eng):
     with torch.no_grad():
         assert torch.equal(model2(x.cuda()), f32)
     with pytest.raises(ValueError):
-        model.precision("fp16")
+        model.precision("fp64")
 
 
 def test_trainer_validate_runs_in_fp32_by_default(eng, tmp_path, monkeypatch):
