@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--no-probe", action="store_true", help="N > 1: skip the start-up stream-placement probes (streams_beside_collectives): the step "
                                                             "runs on the current stream, the engine picks its auxiliary stream itself")
     ap.add_argument("--dropout", type=float, default=0.0, help="TRAINING_DROPOUT of the timed model (headline: 0, SURVEY 8d)")
+    ap.add_argument("--operands", default="bf16", choices=["bf16", "fp16"],
+                    help="16-bit MFMA operand format of the timed model (TRAINING_VIT_OPERANDS): bf16 = BASELINE.json's dtype (headline); fp16 = the "
+                         "reference's autocast arithmetic (logits within 1e-3 of its fp32 CPU forward), trained with the device-side dynamic loss scale")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (forward-only, fwd+bwd, dropout)")
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -326,7 +329,7 @@ def forward_only_bench(a, model, x, size, S, p, B, world, rank, device, dist):
     out_line = {"metric": f"fMRI volumes/sec (forward only) ViT3D {S}^3 p{p} d{size['TRAINING_VIT_DIM']} L{size['TRAINING_VIT_DEPTH']}",
                 "value": round(value, 2), "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "fp8 (e4m3 qkv/FC1/FC2 operands, bf16 elsewhere, fp32 accumulate)" if a.fp8 else ("f32 (fp32 MFMA, every operand fp32)" if a.precise else "bf16"),
+                "dtype": "fp8 (e4m3 qkv/FC1/FC2 operands, bf16 elsewhere, fp32 accumulate)" if a.fp8 else ("f32 (fp32 MFMA, every operand fp32)" if a.precise else a.operands),
                 "data": "synthetic",
                 "config": {"workload": f"ViT3D-{a.preset} {S}^3 patch {p}, inference forward, batch {B}/GPU", "global_batch": B * world, "parallelism": f"dp{world}"},
                 "mfma_frac_bf16_peak": round(value / world * f_fwd / (PEAK_BF16_TFLOPS * 1e12), 4),
@@ -392,7 +395,7 @@ def main():
     size = nvcfg.preset(a.preset)
     S, p = size["TRAINING_VIT_INPUT_SIZE"], size["TRAINING_VIT_PATCH_SIZE"]
     config = dict(DEVICE=str(device), TRAINING_DIM=3, TRAINING_DROPOUT=a.dropout, GRADCAM_CUBE_SIZE=8, DATASET_NAME="adni",
-                  TRAINING_LEARNING_RATE=1e-4, TRAINING_WEIGHT_DECAY=1e-2, **size)
+                  TRAINING_LEARNING_RATE=1e-4, TRAINING_WEIGHT_DECAY=1e-2, TRAINING_VIT_OPERANDS=a.operands, **size)
     torch.manual_seed(42)                                   # main.py:86-88
     model = NeuroEncoder(config)
     model.train()
@@ -430,6 +433,8 @@ def main():
     step(x, y)
     host_step_ms = (time.perf_counter() - t1) * 1e3
     torch.cuda.synchronize()
+    log(f"step path: {step.last_path} (nv_vit_train_step = native; general = autograd-driven stages), AdamW placement fuse_update = {step.last_fuse_update}, "
+        f"loss scale: {'dynamic (device-side GradScaler)' if step.scaler is not None else (step.static_scale or 'none')}")
     log(f"host enqueue {host_step_ms:.3f} ms for one step from an idle queue ({enqueued / a.steps * 1e3:.3f} ms/step inside the timed loop) "
         f"of {elapsed / a.steps * 1e3:.3f} ms/step")
     if world > 1:
@@ -477,6 +482,27 @@ def main():
         also["train_step_dropout_0.1_volumes_s"] = round(timed(lambda: dstep(x, y), a.steps), 1)
         del dstep, dmodel
         torch.cuda.empty_cache()
+        if a.operands == "bf16" and not a.fp8:
+            # the same model on fp16 MFMA operands (the reference's autocast arithmetic, Trainer.py:68; the path that holds north_star's 1e-3
+            # against the reference's fp32 CPU forward: tests/test_fp16_gpu.py): forward, and the train step with the dynamic loss scale
+            # (GradScaler semantics on the device: every gradient checked, update gated - so AdamW runs behind the backward pass) and with a static one
+            torch.manual_seed(42)
+            hmodel = NeuroEncoder(dict(config, TRAINING_VIT_OPERANDS="fp16"))
+            hmodel.train()
+            hstep = TrainStep(hmodel, process_group=None, n_buckets=a.buckets)
+            fp16 = {"train_step_dynamic_loss_scale_volumes_s": round(timed(lambda: hstep(x, y), a.steps), 1),
+                    "loss_scale_after": hstep.scaler.get_scale(), "updates_applied": hstep.scaler.steps_applied(), "updates_skipped": hstep.scaler.steps_skipped()}
+            hstep2 = TrainStep(hmodel, process_group=None, n_buckets=a.buckets, loss_scale=4096.0)
+            fp16["train_step_static_loss_scale_volumes_s"] = round(timed(lambda: hstep2(x, y), a.steps), 1)
+            hmodel.eval()
+
+            def hfwd():
+                with torch.no_grad():
+                    hmodel(x)
+            fp16["forward_only_eval_volumes_s"] = round(timed(hfwd, a.steps), 1)
+            also["fp16_operands"] = fp16
+            del hstep, hstep2, hmodel
+            torch.cuda.empty_cache()
         # BASELINE.json configs[3] shape: one 4D sample = T = 20 volumes through the (frozen) encoder, forward only
         x20 = make_batch(20, S, device, 77)[0]
         model.eval()
@@ -631,7 +657,7 @@ def main():
     out = {"metric": metric, "value": round(value, 2), "unit": "volumes/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
-           "dtype": "fp8 forward (e4m3 qkv/FC1/FC2 operands, fp32 accumulate), bf16 backward" if a.fp8 else "bf16", "data": "synthetic",
+           "dtype": "fp8 forward (e4m3 qkv/FC1/FC2 operands, fp32 accumulate), bf16 backward" if a.fp8 else a.operands, "data": "synthetic",
            "config": {"workload": f"ViT3D-{a.preset} {S}^3 patch {p}, train step (fwd+bwd+AdamW), batch {B}/GPU, dropout {a.dropout:g}",
                       "global_batch": B * world, "parallelism": f"dp{world}", "grad_buckets": a.buckets,
                       "grad_allreduce": ("none (1 GPU)" if world == 1 else f"{a.grad_comm} messages, sum, overlapped with backward"),
