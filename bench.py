@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--grad-algo", default=None, choices=["allreduce", "rs_ag", "one_hop"],
                     help="how a gradient bucket is summed over the ranks (N > 1): one all-reduce (default), reduce-scatter + all-gather, or the "
                          "one-hop all-to-all form for a fully connected xGMI node (neurovit_amd/parallel.py::GradSync)")
+    ap.add_argument("--dp-path", default="native", choices=["native", "general"],
+                    help="N > 1: native = the whole step stays one nv_vit_train_step call with the RCCL all-reduce of every gradient bucket issued from native "
+                         "code (falls back to general, with a warning, if the communicator cannot be built); general = Python-driven staged backward + torch.distributed")
     ap.add_argument("--no-probe", action="store_true", help="N > 1: skip the start-up stream-placement probes (streams_beside_collectives): the step "
                                                             "runs on the current stream, the engine picks its auxiliary stream itself")
     ap.add_argument("--dropout", type=float, default=0.0, help="TRAINING_DROPOUT of the timed model (headline: 0, SURVEY 8d)")
@@ -400,7 +403,8 @@ def main():
     model = NeuroEncoder(config)
     model.train()
     step = TrainStep(model, process_group=None, n_buckets=a.buckets, overlap_optimizer=a.overlap_optimizer,
-                     grad_comm_dtype=torch.bfloat16 if a.grad_comm == "bf16" else torch.float32, grad_comm_algo=a.grad_algo)
+                     grad_comm_dtype=torch.bfloat16 if a.grad_comm == "bf16" else torch.float32, grad_comm_algo=a.grad_algo,
+                     native_dp=(a.dp_path == "native") if world > 1 else None)
     B = a.batch
     x, y = make_batch(B, S, device, 42 + (0 if a.same_data else rank))
 
@@ -433,7 +437,8 @@ def main():
     step(x, y)
     host_step_ms = (time.perf_counter() - t1) * 1e3
     torch.cuda.synchronize()
-    log(f"step path: {step.last_path} (nv_vit_train_step = native; general = autograd-driven stages), AdamW placement fuse_update = {step.last_fuse_update}, "
+    log(f"rank {rank}: step path: {step.last_path} (native = nv_vit_train_step; native-dp = the same call with RCCL all-reduce per bucket from native code"
+        f"{' ' + str(getattr(step, 'last_dp', '')) if step.last_path == 'native-dp' else ''}; general = autograd-driven stages), AdamW placement fuse_update = {step.last_fuse_update}, "
         f"loss scale: {'dynamic (device-side GradScaler)' if step.scaler is not None else (step.static_scale or 'none')}")
     log(f"host enqueue {host_step_ms:.3f} ms for one step from an idle queue ({enqueued / a.steps * 1e3:.3f} ms/step inside the timed loop) "
         f"of {elapsed / a.steps * 1e3:.3f} ms/step")
@@ -661,6 +666,7 @@ def main():
            "config": {"workload": f"ViT3D-{a.preset} {S}^3 patch {p}, train step (fwd+bwd+AdamW), batch {B}/GPU, dropout {a.dropout:g}",
                       "global_batch": B * world, "parallelism": f"dp{world}", "grad_buckets": a.buckets,
                       "grad_allreduce": ("none (1 GPU)" if world == 1 else f"{a.grad_comm} messages, sum, overlapped with backward"),
+                      "step_path": step.last_path, "dp": getattr(step, "last_dp", None),
                       "adamw": ({1: "layers' Linear weights updated in their weight-gradient GEMM epilogues, the rest in one launch",
                                  2: "layers' Linear weights updated in their weight-gradient GEMM epilogues (gradients kept), the rest in one launch",
                                  3: "layers' Linear weights updated per layer on the auxiliary stream behind their weight-gradient GEMMs, the rest in one launch"}.get(

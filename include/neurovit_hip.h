@@ -461,6 +461,32 @@ int nv_vit_set_head_step(int on);   /* A/B aid: 0 = nv_vit_train_step runs the h
  * accumulate = 1: gradients are added to `grads` (micro-steps 2.. of an accumulation window); update = 0: no optimizer update
  * (every micro-step but the last).  The arguments a separate backward would need (rows_form of `in`, dropout) are the forward's
  * by construction. */
+/* ---- data-parallel train step from native code (no counterpart in the reference, which is single-device: main.py:41-46).
+ * RCCL is bound at run time (dlopen; nv_comm_load(path) names the copy to use - the one torch's "nccl" backend has loaded - or NULL for
+ * the default search).  Communicator: rank 0 calls nv_comm_unique_id (128 bytes), every rank receives those bytes over a channel of its
+ * own (one torch.distributed broadcast) and calls nv_comm_init.  nv_comm_all_reduce: in-place SUM on `stream`; dtype 0 = f32, 1 = the
+ * 16-bit operand format.
+ * nv_dp_plan (nv_train_hparams.dp): the backward pass of nv_vit_train_step runs as n_buckets groups of stages; as soon as a group has
+ * been enqueued, comm_stream waits for it and all-reduces the group's (contiguous) gradient range while the main stream continues -
+ * fp32 in `grads` itself, or, with grads16 != NULL, as 16-bit messages in that arena (the Linear weight gradients are written there by
+ * their GEMMs, the small ranges are converted on comm_stream).  update_per_bucket = 1 queues AdamW of that range (grad * grad_scale /
+ * world) behind its all-reduce on comm_stream; 0 = one update over the arena when every bucket is in.  With grads16 the update reads
+ * the reduced messages and `grads` keeps the LOCAL gradients.  Micro-steps with update = 0 run no collective. */
+typedef struct nv_dp_plan {
+  int struct_size;
+  int world;               /* ranks: the update scales the summed gradients by 1 / world */
+  void* comm;              /* nv_comm_init */
+  void* comm_stream;       /* hipStream_t of the collectives; must not share a hardware queue with `stream` / `aux_stream` for overlap */
+  int n_buckets;           /* 1 .. depth + 2 */
+  int update_per_bucket;
+  void* grads16;           /* NULL = fp32 messages */
+} nv_dp_plan;
+int nv_comm_load(const char* path);
+int nv_comm_unique_id(void* id128);
+int nv_comm_init(const void* id128, int world, int rank, void** comm);
+int nv_comm_destroy(void* comm);
+int nv_comm_all_reduce(void* comm, void* buf, long count, int dtype, void* stream);
+
 typedef struct nv_train_hparams {
   int struct_size;
   int step;                 /* AdamW step count (>= 1) of this update: bias corrections (ignored when update = 0) */
@@ -477,6 +503,7 @@ typedef struct nv_train_hparams {
   float loss_scale;         /* (revision 6) static loss scale: d(loss)/d(logits) is multiplied by it and the update divides it out again
                              * (0 or 1 = none) - what keeps the 16-bit gradient tensors of NV_OPERAND_FP16 away from the subnormals; a power
                              * of two changes no bit of a finite result.  No overflow check: use loss_scale_state for GradScaler semantics */
+  const struct nv_dp_plan* dp;   /* (revision 6) data-parallel step: NULL, or the plan below */
   float* loss_scale_state;  /* (revision 6) device block of nv_loss_scale_init or NULL: dynamic loss scale (torch.amp.GradScaler, Trainer.py:29,
                              * 74-76) - the step is scaled by its current value, every gradient is checked for inf / NaN after the backward
                              * pass, and the update is applied or skipped on the device (requires fuse_update = 0; with accumulate / update

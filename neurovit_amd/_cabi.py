@@ -37,7 +37,13 @@ class TrainHparams(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int), ("step", ctypes.c_int), ("lr", ctypes.c_double), ("beta1", ctypes.c_double),
                 ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double), ("grad_scale", ctypes.c_float),
                 ("accumulate", ctypes.c_int), ("update", ctypes.c_int), ("fuse_update", ctypes.c_int),
-                ("loss_scale", ctypes.c_float), ("loss_scale_state", ctypes.c_void_p)]
+                ("loss_scale", ctypes.c_float), ("dp", ctypes.c_void_p), ("loss_scale_state", ctypes.c_void_p)]
+
+
+class DpPlan(ctypes.Structure):
+    """struct nv_dp_plan (neurovit_hip.h): the data-parallel form of nv_vit_train_step's backward pass + update."""
+    _fields_ = [("struct_size", ctypes.c_int), ("world", ctypes.c_int), ("comm", ctypes.c_void_p), ("comm_stream", ctypes.c_void_p),
+                ("n_buckets", ctypes.c_int), ("update_per_bucket", ctypes.c_int), ("grads16", ctypes.c_void_p)]
 
 
 class AdamwArena(ctypes.Structure):

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/neurovit_hip.h"
@@ -897,6 +898,78 @@ extern "C" int nv_vit_stage_param_range(const nv_vit_config* cfg, int stage, lon
   return NV_OK;
 }
 
+// ---- data-parallel backward + update of nv_vit_train_step (nv_dp_plan): the backward pass in groups of stages; behind each group the
+// communication stream all-reduces the group's gradient range (RCCL, comm.cpp) - and, with update_per_bucket, applies AdamW to it -
+// while the main stream is already in the next group.  The same launches as the single-process step otherwise.
+static int dp_backward_update(const nv_vit_config* cfg, int B, const float* video, const long* strides5, const nv_vit_input* in, float* params, void* params16,
+                              float* grads, float* adam_m, float* adam_v, void* workspace, long ws_bytes, const float* dlogits, const nv_train_hparams* hp,
+                              const nv_dp_plan* dp, bool head_fused, float lscale, float drop_p, float emb_drop_p, unsigned long drop_seed, void* stream,
+                              void* aux_stream) {
+  Dims D; RUN(make_dims(cfg, B, D));
+  ParamTab T; make_params(D, T);
+  const int n_stages = D.L + 2, last_stage = D.L + 1;
+  const int nb = dp->n_buckets < n_stages ? dp->n_buckets : n_stages;
+  const bool forked = aux_stream && aux_stream != stream;
+  void* C = dp->comm_stream;
+  r16* msg = (r16*)dp->grads16;
+  const float gs = hp->grad_scale / lscale / (float)dp->world;
+  // gradient ranges the GEMMs write into the 16-bit message arena themselves (nv_vit_backward_stages16): everything else of a bucket is converted here
+  std::vector<std::pair<long, long>> mirrored;
+  if (msg) {
+    if (D.P % 8 == 0) mirrored.push_back({T.pe_w, T.pe_w + (long)D.d * D.P});
+    for (int l = 0; l < D.L; ++l) {
+      const LayerP& q = T.layer[l];
+      mirrored.push_back({q.wqkv, q.wqkv + 3L * D.inner * D.d}); mirrored.push_back({q.wo, q.wo + (long)D.d * D.inner});
+      mirrored.push_back({q.w1, q.w1 + (long)D.m * D.d}); mirrored.push_back({q.w2, q.w2 + (long)D.d * D.m});
+    }
+  }
+  int s0 = 0;
+  for (int b = 0; b < nb; ++b) {
+    const int cnt = n_stages / nb + (b < n_stages % nb ? 1 : 0), s1 = s0 + cnt - 1;       // stages [s0, s1]: parallel.py::bucket_stages
+    const int first = (head_fused && s0 == 0) ? 1 : s0;                                  // (the fused head step has run stage 0 already)
+    const bool joined = (s1 == last_stage);
+    if (first <= s1)
+      RUN(nv_vit_backward_stages16(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, msg, hp->accumulate ? 1 : 0, first, s1, drop_p,
+                                   emb_drop_p, drop_seed, stream, aux_stream, joined ? 1 : 0, in ? in->rows_form : 0));
+    long begin = -1, end = -1;
+    for (int s = s0; s <= s1; ++s) {
+      long lo, hi;
+      RUN(nv_vit_stage_param_range(cfg, s, &lo, &hi));
+      begin = (begin < 0 || lo < begin) ? lo : begin; end = hi > end ? hi : end;
+    }
+    RUN(stream_sync((hipStream_t)stream, (hipStream_t)C));                                  // the bucket's gradients: complete on the main stream ...
+    if (forked && !joined) RUN(stream_sync((hipStream_t)aux_stream, (hipStream_t)C));      // ... and on the auxiliary one (not joined into the main stream yet)
+    if (msg) {
+      std::vector<long> rb, rl;
+      long cur = begin;
+      for (const auto& mr : mirrored) {
+        if (mr.second <= begin || mr.first >= end) continue;
+        if (mr.first > cur) { rb.push_back(cur); rl.push_back(mr.first - cur); }
+        cur = mr.second > cur ? mr.second : cur;
+      }
+      if (cur < end) { rb.push_back(cur); rl.push_back(end - cur); }
+      RUN(nv_cast_ranges_bf16(grads, msg, rb.data(), rl.data(), (int)rb.size(), C));
+      RUN(nv_comm_all_reduce(dp->comm, msg + begin, end - begin, 1, C));
+    } else {
+      RUN(nv_comm_all_reduce(dp->comm, grads + begin, end - begin, 0, C));
+    }
+    if (dp->update_per_bucket)
+      RUN(nv_adamw_step_scaled(params + begin, msg ? (const void*)(msg + begin) : (const void*)(grads + begin), msg ? 1 : 0, adam_m + begin, adam_v + begin,
+                               (r16*)params16 + begin, end - begin, hp->step, hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, gs, 0, nullptr, C));
+    s0 = s1 + 1;
+  }
+  RUN(stream_sync((hipStream_t)C, (hipStream_t)stream));                                    // every bucket reduced (and updated) before what follows on the main stream
+  if (!dp->update_per_bucket) {
+    if (hp->loss_scale_state) {
+      RUN(nv_loss_scale_check(grads, T.total, hp->loss_scale_state, stream));
+      RUN(nv_loss_scale_update(hp->loss_scale_state, hp->lr, hp->beta1, hp->beta2, stream));
+    }
+    RUN(nv_adamw_step_scaled(params, msg ? (const void*)msg : (const void*)grads, msg ? 1 : 0, adam_m, adam_v, params16, T.total, hp->step, hp->lr, hp->beta1, hp->beta2,
+                             hp->eps, hp->weight_decay, gs, 0, hp->loss_scale_state, stream));
+  }
+  return NV_OK;
+}
+
 // ---- the whole train step in one call (Trainer.py:65-79): forward -> CrossEntropyLoss -> backward -> AdamW.  Host-side sequencing
 // only: the same launches, in the same order, on the same streams as the four separate calls - enqueued without a Python
 // interpreter (or an autograd graph walk) between them.
@@ -914,6 +987,15 @@ extern "C" int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* v
                "nv_vit_train_step: loss_scale must be >= 0 (0 = 1 = none) and is not combined with a dynamic loss_scale_state");
   const bool fused = hp->update && !hp->accumulate && hp->fuse_update;
   NV_CHECK_ARG(!(fused && hp->loss_scale_state), "nv_vit_train_step: a dynamic loss scale decides AFTER the backward pass whether the step is applied: fuse_update must be 0");
+  const nv_dp_plan* dp = hp->dp;
+  if (dp) {
+    NV_CHECK_ARG(dp->struct_size == (int)sizeof(nv_dp_plan) && dp->comm && dp->comm_stream && dp->world >= 1 && dp->n_buckets >= 1,
+                 "nv_vit_train_step: nv_dp_plan.struct_size = %d (expected %d), or null communicator / stream, world < 1, n_buckets < 1", dp->struct_size, (int)sizeof(nv_dp_plan));
+    NV_CHECK_ARG(!fused, "nv_vit_train_step: with a data-parallel plan the optimizer update follows the all-reduce (nv_dp_plan.update_per_bucket): fuse_update must be 0");
+    NV_CHECK_ARG(!hp->loss_scale_state || (!dp->grads16 && !dp->update_per_bucket),
+                 "nv_vit_train_step: a dynamic loss scale checks the REDUCED fp32 gradients before any update: fp32 messages, update_per_bucket = 0");
+    NV_CHECK_ARG(dp->comm_stream != stream && dp->comm_stream != aux_stream, "nv_vit_train_step: nv_dp_plan.comm_stream must be a stream of its own");
+  }
   const float lscale = hp->loss_scale > 0.f ? hp->loss_scale : 1.f;      // static loss scale: folded into d(loss)/d(logits), undone by the update's grad_scale
   // the head's forward, the loss and the head's backward as two launches instead of five (nv_head_step: bit-identical to the three calls;
   // it needs num_classes <= dim and dim % 8 == 0 - other heads take the five-launch path, which has no such limit)
@@ -936,6 +1018,9 @@ extern "C" int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* v
   opt.struct_size = (int)sizeof(opt); opt.step = hp->step; opt.lr = hp->lr; opt.beta1 = hp->beta1; opt.beta2 = hp->beta2; opt.eps = hp->eps;
   opt.weight_decay = hp->weight_decay; opt.grad_scale = hp->grad_scale / lscale; opt.keep_grads = hp->fuse_update == 2;
   opt.params = params; opt.grads = grads; opt.adam_m = adam_m; opt.adam_v = adam_v; opt.params16 = params16;
+  if (dp && hp->update)
+    return dp_backward_update(cfg, B, video, strides5, in, params, params16, grads, adam_m, adam_v, workspace, ws_bytes, dlogits, hp, dp, head_fused, lscale,
+                              drop_p, emb_drop_p, drop_seed, stream, aux_stream);
   RUN(backward_impl(cfg, B, video, strides5, params, params16, workspace, ws_bytes, dlogits, grads, nullptr, hp->accumulate ? 1 : 0, head_fused ? 1 : 0, cfg->depth + 1,
                     drop_p, emb_drop_p, drop_seed, stream, aux_stream, 1, in ? in->rows_form : 0, fused ? &opt : nullptr, hp->fuse_update));
   if (hp->update && !fused) {

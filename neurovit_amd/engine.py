@@ -259,7 +259,7 @@ class VitRuntime:
                    adam_m: torch.Tensor, adam_v: torch.Tensor, *, step: int, lr: float, betas, eps: float, weight_decay: float,
                    grad_scale: float = 1.0, accumulate: bool = False, update: bool = True, fuse_update: int = 0,
                    dropout: Tuple[float, float, int] = (0.0, 0.0, 0), vol_sigma=None, rows_form: Optional[int] = None,
-                   loss_scale: float = 0.0, loss_scale_state: Optional[torch.Tensor] = None):
+                   loss_scale: float = 0.0, loss_scale_state: Optional[torch.Tensor] = None, dp=None):
         """The reference's whole train step (Trainer.py:65-79) as ONE native call (nv_vit_train_step): forward, CrossEntropyLoss,
         backward of every stage, AdamW over the arena + bf16 shadow refresh.  Returns (loss [1], logits [B, C]) on the device.
         Same launches, streams and arithmetic as forward() + ops.ce_loss + backward() + ops.adamw_step.
@@ -278,6 +278,7 @@ class VitRuntime:
         assert labels.is_cuda and labels.dtype == torch.int64 and labels.numel() == B and labels.is_contiguous()
         hp = TrainHparams(ctypes.sizeof(TrainHparams), int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
                           float(grad_scale), int(bool(accumulate)), int(bool(update)), int(fuse_update), float(loss_scale),
+                          None if dp is None else ctypes.cast(ctypes.pointer(dp), ctypes.c_void_p),      # _cabi.DpPlan (kept alive by the caller)
                           None if loss_scale_state is None else loss_scale_state.data_ptr())
         check(lib.nv_vit_train_step(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
                                     None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p),

@@ -114,6 +114,59 @@ def streams_beside_collectives(device, process_group=None, candidates: int = 8):
     return compute, aux
 
 
+class NativeComm:
+    """An RCCL communicator of the C-ABI library's own (csrc/comm.cpp: RCCL bound at run time), for the data-parallel form of the
+    NATIVE train step (nv_vit_train_step + nv_dp_plan): the gradient all-reduce of every bucket is issued from native code on
+    `stream`, between the backward stages, with no interpreter and no torch.distributed call inside a step.
+    Built from a unique id that rank 0 creates and one broadcast on the existing torch.distributed group delivers; with no group
+    (or a group of one) it is a one-rank communicator - the form the single-GPU rehearsal and tests use.  The library is pointed
+    at the RCCL torch already loaded (torch/lib/librccl.so) so that one copy serves both."""
+
+    def __init__(self, device, process_group=None):
+        import ctypes
+        import os
+        from ._cabi import check, lib
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("neurovit_amd.NativeComm: RCCL communicators exist on the GPU only")
+        grouped = dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if grouped else 1
+        self.rank = dist.get_rank(process_group) if grouped else 0
+        path = os.environ.get("NEUROVIT_RCCL_LIB") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        check(lib.nv_comm_load(path.encode() if os.path.exists(path) else None), "nv_comm_load")
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (ctypes.c_char * 128)()
+            check(lib.nv_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "nv_comm_unique_id")
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if self.world > 1:
+            backend = dist.get_backend(process_group)
+            carrier = uid.to(self.device) if backend == "nccl" else uid
+            dist.broadcast(carrier, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+            uid = carrier.cpu()
+        raw = (ctypes.c_char * 128).from_buffer_copy(bytes(uid.tolist()))
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.nv_comm_init(ctypes.cast(raw, ctypes.c_void_p), self.world, self.rank, ctypes.byref(handle)), "nv_comm_init")
+        self.handle = handle
+        self.stream = None          # the stream the step's collectives run on (TrainStep picks one with a hardware queue of its own)
+
+    def all_reduce(self, t: torch.Tensor, stream: Optional["torch.cuda.Stream"] = None) -> torch.Tensor:
+        """In-place SUM over the ranks (fp32, or the current 16-bit operand format) on `stream` (default: the current one)."""
+        from . import ops
+        from ._cabi import check, lib
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, ops.op16())
+        st = (stream or torch.cuda.current_stream(t.device)).cuda_stream
+        check(lib.nv_comm_all_reduce(self.handle, t.data_ptr(), t.numel(), int(t.dtype != torch.float32), st), "nv_comm_all_reduce")
+        return t
+
+    def close(self):
+        from ._cabi import lib
+        if getattr(self, "handle", None):
+            lib.nv_comm_destroy(self.handle)
+            self.handle = None
+
+
 class GradSync:
     """All-reduce (SUM) of gradient-arena ranges as they become final, optionally followed by a per-range callback
     (the fused AdamW of that range) on the same side stream, so both overlap the rest of the backward pass.

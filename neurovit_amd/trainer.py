@@ -20,7 +20,7 @@ import torch.distributed as dist
 from .NeuroEncoder import NeuroEncoder
 from .nn import CrossEntropyLoss
 from .optim import FusedAdamW, LossScaler
-from .parallel import GradSync, broadcast_parameters
+from .parallel import GradSync, NativeComm, broadcast_parameters
 
 
 class TrainStep:
@@ -29,8 +29,11 @@ class TrainStep:
     def __init__(self, model: NeuroEncoder, lr: Optional[float] = None, weight_decay: Optional[float] = None, process_group=None,
                  n_buckets: int = 4, accumulation_steps: int = 1, overlap_optimizer: bool = False,
                  grad_comm_dtype: torch.dtype = torch.float32, grad_comm_algo: Optional[str] = None, fuse_update: Optional[int] = None,
-                 loss_scale=None):
+                 loss_scale=None, native_dp: Optional[bool] = None):
         cfg = model.config
+        # native_dp: world > 1 - the step stays ONE native call (nv_vit_train_step with an nv_dp_plan: RCCL all-reduce per bucket issued
+        # from native code on a communicator of the library's own, AdamW behind it) instead of the Python-driven staged backward;
+        # None = on unless NEUROVIT_NATIVE_DP=0 (falls back, loudly, when the communicator cannot be built: gloo groups, CPU tensors)
         # loss_scale: None = by operand format - "dynamic" for fp16 operands (torch.amp.GradScaler semantics, on the device:
         # optim.LossScaler), none for bf16; "dynamic"; or a number = a static scale (no overflow check, no skipped steps - keeps
         # the optimizer update inside the backward pass, fuse_update).  A power of two changes no bit of a finite result.
@@ -84,11 +87,23 @@ class TrainStep:
             vit._shadow_key = None
         self._pg = process_group
         vit._grad_sync = None
+        self._ncomm = None                             # NativeComm of the native data-parallel step
+        self._dp_world = world                         # (tests force the collective path on one rank by raising it)
+        self._dp_buckets, self._dp_msg16 = n_buckets, grad_comm_dtype != torch.float32
+        want_native_dp = (os.environ.get("NEUROVIT_NATIVE_DP", "1") != "0") if native_dp is None else bool(native_dp)
+        dev_ = next(model.parameters()).device
+        if want_native_dp and (world > 1 or native_dp) and self._arena_trainable and not overlap_optimizer and dev_.type == "cuda" \
+                and (not dist.is_initialized() or dist.get_backend(process_group) == "nccl"):
+            try:
+                self._ncomm = NativeComm(dev_, process_group)
+            except RuntimeError as e:
+                import warnings
+                warnings.warn(f"neurovit_amd: native data-parallel step unavailable ({e}); using the Python-driven bucket pipeline")
         # DP: if collectives would queue behind the current stream's kernels (shared hardware queue), run the step on a stream where
         # they do not, and give the engine an auxiliary stream with the same property (parallel.streams_beside_collectives)
         self._compute_stream = None
         dev0 = next(model.parameters()).device
-        if world > 1 and dev0.type == "cuda":
+        if world > 1 and dev0.type == "cuda" and self._ncomm is None:      # (the native data-parallel step issues its collectives on a stream it names itself)
             from .parallel import streams_beside_collectives
             self._compute_stream, aux = streams_beside_collectives(dev0, process_group)
             if aux is not None and vit._rt.use_aux_stream:
@@ -152,7 +167,7 @@ class TrainStep:
             model, vit = self.model, self._vit
             self._native = bool(
                 os.environ.get("NEUROVIT_NATIVE_STEP", "1") != "0" and model.config.get('TRAINING_DIM') == 3
-                and self.sync is None and self.world == 1 and not self._outside and self._compute_stream is None)
+                and ((self.sync is None and self.world == 1) or self._ncomm is not None) and not self._outside and self._compute_stream is None)
         if not self._native or not (torch.is_tensor(fmri) and fmri.is_cuda and fmri.dtype == torch.float32 and fmri.dim() == 4):
             return False
         # checked on EVERY step (hooks registered, parameters frozen after the first step must not be bypassed: the native call
@@ -265,13 +280,17 @@ class TrainStep:
             fuse = 3 if fmri.shape[0] * vit.pos_embedding.shape[1] <= self.FUSE_MAX_ROWS else 0
         if self.accumulation_steps != 1 or vit._phantom or self.scaler is not None:
             fuse = 0                        # (a dynamic loss scale decides after the backward pass whether the update is applied)
+        dp = None
+        if self._ncomm is not None:
+            fuse = 0                        # the update follows the all-reduce: per bucket on the communication stream, or once at the end
+            dp = self._dp_plan(fmri, grads)
         self.last_fuse_update = fuse
-        self.last_path = "native"
+        self.last_path = "native" if dp is None else "native-dp"
         accumulate = self._micro > 0        # the first micro-step of a window overwrites (zero_grad(set_to_none=True), Trainer.py:72), the others add
         loss, logits = vit._rt.train_step(video, labels.contiguous(), arena, shadow, grads, m, v, step=opt._steps + 1, lr=g0["lr"], betas=g0["betas"],
                                           eps=g0["eps"], weight_decay=g0["weight_decay"], grad_scale=1.0, accumulate=accumulate, update=last_micro,
                                           fuse_update=fuse, dropout=vit.draw_dropout(), loss_scale=self.static_scale,
-                                          loss_scale_state=None if self.scaler is None else self.scaler.state)
+                                          loss_scale_state=None if self.scaler is None else self.scaler.state, dp=dp)
         if last_micro:
             opt._steps += 1                 # (after the call: a refused step leaves the counter where it was)
         vit._last_logits = logits
@@ -293,6 +312,31 @@ class TrainStep:
             vit.mark_shadow_fresh()
             self._micro = 0
         return loss.reshape(())
+
+    def _dp_plan(self, fmri, grads):
+        """nv_dp_plan of this step: communicator, a communication stream with a hardware queue of its own, bucket count, message format,
+        and where AdamW runs - per bucket behind its all-reduce while the chip has room beside the backward pass (the same batch rule
+        as fuse_update), else once when every bucket is in; a dynamic loss scale needs the single update (and fp32 messages)."""
+        import ctypes
+        from ._cabi import DpPlan
+        nc, vit = self._ncomm, self._vit
+        if nc.stream is None:
+            from .parallel import independent_stream
+            cur = torch.cuda.current_stream(fmri.device)
+            aux = vit._rt._aux_stream(fmri.device) and vit._rt.aux_stream_object(fmri.device)
+            nc.stream = independent_stream(fmri.device, [cur, aux])
+        msg = None
+        if self._dp_msg16 and self.scaler is None:
+            if getattr(self, "_dp_msgbuf", None) is None or self._dp_msgbuf.numel() != grads.numel() or self._dp_msgbuf.dtype != vit._dtype16():
+                self._dp_msgbuf = torch.empty(grads.numel(), dtype=vit._dtype16(), device=grads.device)
+            msg = self._dp_msgbuf
+        per_bucket = self.scaler is None and self.accumulation_steps == 1 and fmri.shape[0] * vit.pos_embedding.shape[1] <= self.FUSE_MAX_ROWS
+        if os.environ.get("NEUROVIT_DP_UPDATE_PER_BUCKET") is not None:
+            per_bucket = per_bucket and os.environ["NEUROVIT_DP_UPDATE_PER_BUCKET"] != "0"
+        self.last_dp = dict(buckets=self._dp_buckets, messages="16-bit" if msg is not None else "fp32", update_per_bucket=bool(per_bucket), world=self._dp_world)
+        self._dp_keep = DpPlan(ctypes.sizeof(DpPlan), int(self._dp_world), nc.handle, nc.stream.cuda_stream, int(self._dp_buckets), int(per_bucket),
+                               None if msg is None else msg.data_ptr())
+        return self._dp_keep
 
     def _step(self, fmri: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         if self._native_ok(fmri, labels):

@@ -220,9 +220,9 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     compiler makes of include/neurovit_hip.h: same size, same offset for every field (the header is plain C: gcc compiles it)."""
     import subprocess
     from neurovit_amd import ops
-    from neurovit_amd._cabi import HEADER, AdamwArena, TrainHparams, VitConfig, VitInput
+    from neurovit_amd._cabi import HEADER, AdamwArena, DpPlan, TrainHparams, VitConfig, VitInput
     structs = {"nv_vit_config": VitConfig, "nv_vit_input": VitInput, "nv_gemm_problem": ops.GemmProblem, "nv_reduce_job": ops.ReduceJob,
-               "nv_train_hparams": TrainHparams, "nv_adamw_arena": AdamwArena}
+               "nv_train_hparams": TrainHparams, "nv_adamw_arena": AdamwArena, "nv_dp_plan": DpPlan}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')

@@ -207,3 +207,52 @@ def test_rccl_process_group_runs_the_bucket_pipeline():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rccl rehearsal ok" in r.stdout
     assert "torch.float32" in r.stdout and "torch.bfloat16" in r.stdout
+
+
+def test_native_dp_step_on_a_one_rank_rccl_communicator_equals_the_single_process_step(monkeypatch):
+    """The data-parallel form of the NATIVE step (nv_vit_train_step + nv_dp_plan: backward in stage groups, RCCL all-reduce of every
+    gradient bucket issued from native code on its own stream, AdamW per bucket behind it or once at the end) on a communicator of
+    ONE rank - all this test box offers; the sum over one rank is the identity, so with fp32 messages the parameters after three steps
+    must equal the single-process native step BIT FOR BIT in both update placements.  16-bit messages round the gradients once: close.
+    (World sizes 2 and 8 of the Python-driven pipeline are covered over gloo, here and in tests/test_parallel_cpu.py; the native
+    path differs from it only in who enqueues the same launches and collectives.)"""
+    from neurovit_amd.parallel import NativeComm
+    from neurovit_amd.trainer import TrainStep
+    batches = [_data(7), _data(8), _data(9)]
+    single = _run_steps(_model(), batches, fuse_update=0)
+    start = _model().volume_encoder.vit3d.flat_parameters()[0].detach().cpu()
+    comm = NativeComm("cuda")
+    t = torch.arange(1000, dtype=torch.float32, device="cuda")
+    assert torch.equal(comm.all_reduce(t.clone()), t)
+    comm.close()
+    for per_bucket in ("1", "0"):
+        monkeypatch.setenv("NEUROVIT_DP_UPDATE_PER_BUCKET", per_bucket)
+        model = _model()
+        step = TrainStep(model, n_buckets=3, native_dp=True)
+        for x, y in batches:
+            step(x, y)
+        torch.cuda.synchronize()
+        assert step.last_path == "native-dp" and step.last_dp["update_per_bucket"] == (per_bucket == "1") and step.last_dp["messages"] == "fp32"
+        assert torch.equal(model.volume_encoder.vit3d.flat_parameters()[0].detach().cpu(), single), f"update_per_bucket = {per_bucket}"
+    model = _model()
+    step = TrainStep(model, n_buckets=4, native_dp=True, grad_comm_dtype=torch.bfloat16)
+    for x, y in batches:
+        step(x, y)
+    torch.cuda.synchronize()
+    assert step.last_dp["messages"] == "16-bit"
+    got = model.volume_encoder.vit3d.flat_parameters()[0].detach().cpu()
+    assert float(((got - start) - (single - start)).norm() / (single - start).norm()) < 0.05
+    # fp16 operands under the dynamic loss scale: fp32 messages, the overflow check on the reduced gradients, one update at the end
+    from neurovit_amd import _cabi
+    try:
+        ref_model = _model(); ref_model.set_operands("fp16")
+        ref = _run_steps(ref_model, batches)
+        model = _model(); model.set_operands("fp16")
+        step = TrainStep(model, n_buckets=3, native_dp=True)
+        for x, y in batches:
+            step(x, y)
+        torch.cuda.synchronize()
+        assert step.scaler is not None and step.last_path == "native-dp" and not step.last_dp["update_per_bucket"]
+        assert torch.equal(model.volume_encoder.vit3d.flat_parameters()[0].detach().cpu(), ref)
+    finally:
+        _cabi.set_operand_format("bf16")

@@ -61,6 +61,28 @@ def main():
               f"{step.sync.bytes_reduced / (4 + timed) / 1e6:.0f} MB reduced per step")
         tol = 0 if dtype == torch.float32 else 5e-2
         assert all(abs(a - b) <= tol * max(1.0, abs(b)) for a, b in zip(losses, losses_ref)), "loss curve differs from the single-process run"
+    # the NATIVE data-parallel step (nv_vit_train_step + nv_dp_plan): a one-rank communicator of the library's own, collectives issued from native code
+    for msgs, per_bucket in ((torch.float32, "1"), (torch.bfloat16, "1"), (torch.float32, "0")):
+        os.environ["NEUROVIT_DP_UPDATE_PER_BUCKET"] = per_bucket
+        model = build()
+        step = TrainStep(model, n_buckets=int(os.environ.get("REHEARSAL_BUCKETS", "7")), native_dp=True, grad_comm_dtype=msgs)
+        losses = [float(step(x, y)) for _ in range(4)]
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(timed):
+            step(x, y)
+        host_ms = (time.perf_counter() - t) / timed * 1e3
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) / timed * 1e3
+        print(f"native-dp {msgs} update_per_bucket={per_bucket}: path {step.last_path} {step.last_dp}; host enqueue {host_ms:.3f} ms/step; {ms:.3f} ms/step; losses {['%.5f' % v for v in losses]}")
+        tol = 0 if msgs == torch.float32 else 5e-2
+        assert all(abs(a - b) <= tol * max(1.0, abs(b)) for a, b in zip(losses, losses_ref)), "loss curve differs from the single-process run"
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(timed):
+        ref(x, y)
+    torch.cuda.synchronize()
+    print(f"single-process native step: {(time.perf_counter() - t) / timed * 1e3:.3f} ms/step (fuse_update {ref.last_fuse_update})")
     dist.destroy_process_group()
     print("rccl rehearsal ok")
 
