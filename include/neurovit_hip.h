@@ -470,7 +470,9 @@ int nv_vit_set_head_step(int on);   /* A/B aid: 0 = nv_vit_train_step runs the h
  * been enqueued, comm_stream waits for it and all-reduces the group's (contiguous) gradient range while the main stream continues -
  * fp32 in `grads` itself, or, with grads16 != NULL, as 16-bit messages in that arena (the Linear weight gradients are written there by
  * their GEMMs, the small ranges are converted on comm_stream).  update_per_bucket = 1 queues AdamW of that range (grad * grad_scale /
- * world) behind its all-reduce on comm_stream; 0 = one update over the arena when every bucket is in.  With grads16 the update reads
+ * world) behind its all-reduce on comm_stream; 2 = on aux_stream, one bucket late (in front of the next bucket's weight-gradient work,
+ * once the all-reduce has finished: the update then never runs beside the weight-gradient GEMMs; the last bucket's on `stream`);
+ * 0 = one update over the arena when every bucket is in.  With grads16 the update reads
  * the reduced messages and `grads` keeps the LOCAL gradients.  Micro-steps with update = 0 run no collective. */
 typedef struct nv_dp_plan {
   int struct_size;

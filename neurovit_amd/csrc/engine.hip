@@ -923,9 +923,23 @@ static int dp_backward_update(const nv_vit_config* cfg, int B, const float* vide
       mirrored.push_back({q.w1, q.w1 + (long)D.m * D.d}); mirrored.push_back({q.w2, q.w2 + (long)D.d * D.m});
     }
   }
+  // update_per_bucket: 1 = AdamW of a bucket on the communication stream right behind its all-reduce; 2 = on the AUXILIARY stream, one bucket late
+  // (queued in front of the next bucket's weight-gradient work once the all-reduce has finished: the HBM-bound update then shares the chip
+  // with the main stream's chain only, never with the weight-gradient GEMMs - the placement of the single-process step's fuse_update = 3)
+  const int upd = (dp->update_per_bucket == 2 && !forked) ? 1 : dp->update_per_bucket;
+  auto adamw_range = [&](long begin, long end, void* on) -> int {
+    return nv_adamw_step_scaled(params + begin, msg ? (const void*)(msg + begin) : (const void*)(grads + begin), msg ? 1 : 0, adam_m + begin, adam_v + begin,
+                                (r16*)params16 + begin, end - begin, hp->step, hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, gs, 0, nullptr, on);
+  };
+  long late_begin = -1, late_end = -1;
   int s0 = 0;
   for (int b = 0; b < nb; ++b) {
     const int cnt = n_stages / nb + (b < n_stages % nb ? 1 : 0), s1 = s0 + cnt - 1;       // stages [s0, s1]: parallel.py::bucket_stages
+    if (late_begin >= 0) {                                                                // [A] the previous bucket's update, behind its all-reduce
+      RUN(stream_sync((hipStream_t)C, (hipStream_t)aux_stream));
+      RUN(adamw_range(late_begin, late_end, aux_stream));
+      late_begin = -1;
+    }
     const int first = (head_fused && s0 == 0) ? 1 : s0;                                  // (the fused head step has run stage 0 already)
     const bool joined = (s1 == last_stage);
     if (first <= s1)
@@ -953,13 +967,13 @@ static int dp_backward_update(const nv_vit_config* cfg, int B, const float* vide
     } else {
       RUN(nv_comm_all_reduce(dp->comm, grads + begin, end - begin, 0, C));
     }
-    if (dp->update_per_bucket)
-      RUN(nv_adamw_step_scaled(params + begin, msg ? (const void*)(msg + begin) : (const void*)(grads + begin), msg ? 1 : 0, adam_m + begin, adam_v + begin,
-                               (r16*)params16 + begin, end - begin, hp->step, hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, gs, 0, nullptr, C));
+    if (upd == 1) RUN(adamw_range(begin, end, C));
+    else if (upd == 2) { late_begin = begin; late_end = end; }
     s0 = s1 + 1;
   }
   RUN(stream_sync((hipStream_t)C, (hipStream_t)stream));                                    // every bucket reduced (and updated) before what follows on the main stream
-  if (!dp->update_per_bucket) {
+  if (late_begin >= 0) RUN(adamw_range(late_begin, late_end, stream));                       // the last bucket (layer 0 + embedding): nothing left to overlap with
+  if (!upd) {
     if (hp->loss_scale_state) {
       RUN(nv_loss_scale_check(grads, T.total, hp->loss_scale_state, stream));
       RUN(nv_loss_scale_update(hp->loss_scale_state, hp->lr, hp->beta1, hp->beta2, stream));
@@ -992,6 +1006,7 @@ extern "C" int nv_vit_train_step(const nv_vit_config* cfg, int B, const float* v
     NV_CHECK_ARG(dp->struct_size == (int)sizeof(nv_dp_plan) && dp->comm && dp->comm_stream && dp->world >= 1 && dp->n_buckets >= 1,
                  "nv_vit_train_step: nv_dp_plan.struct_size = %d (expected %d), or null communicator / stream, world < 1, n_buckets < 1", dp->struct_size, (int)sizeof(nv_dp_plan));
     NV_CHECK_ARG(!fused, "nv_vit_train_step: with a data-parallel plan the optimizer update follows the all-reduce (nv_dp_plan.update_per_bucket): fuse_update must be 0");
+    NV_CHECK_ARG(dp->update_per_bucket >= 0 && dp->update_per_bucket <= 2, "nv_vit_train_step: nv_dp_plan.update_per_bucket = %d (0, 1, 2)", dp->update_per_bucket);
     NV_CHECK_ARG(!hp->loss_scale_state || (!dp->grads16 && !dp->update_per_bucket),
                  "nv_vit_train_step: a dynamic loss scale checks the REDUCED fp32 gradients before any update: fp32 messages, update_per_bucket = 0");
     NV_CHECK_ARG(dp->comm_stream != stream && dp->comm_stream != aux_stream, "nv_vit_train_step: nv_dp_plan.comm_stream must be a stream of its own");

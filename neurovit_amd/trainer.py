@@ -331,9 +331,10 @@ class TrainStep:
                 self._dp_msgbuf = torch.empty(grads.numel(), dtype=vit._dtype16(), device=grads.device)
             msg = self._dp_msgbuf
         per_bucket = self.scaler is None and self.accumulation_steps == 1 and fmri.shape[0] * vit.pos_embedding.shape[1] <= self.FUSE_MAX_ROWS
-        if os.environ.get("NEUROVIT_DP_UPDATE_PER_BUCKET") is not None:
-            per_bucket = per_bucket and os.environ["NEUROVIT_DP_UPDATE_PER_BUCKET"] != "0"
-        self.last_dp = dict(buckets=self._dp_buckets, messages="16-bit" if msg is not None else "fp32", update_per_bucket=bool(per_bucket), world=self._dp_world)
+        per_bucket = int(per_bucket)
+        if os.environ.get("NEUROVIT_DP_UPDATE_PER_BUCKET") is not None and per_bucket:      # A/B aid: 0 = once at the end, 1 = comm stream, 2 = auxiliary stream one bucket late
+            per_bucket = int(os.environ["NEUROVIT_DP_UPDATE_PER_BUCKET"])
+        self.last_dp = dict(buckets=self._dp_buckets, messages="16-bit" if msg is not None else "fp32", update_per_bucket=per_bucket, world=self._dp_world)
         self._dp_keep = DpPlan(ctypes.sizeof(DpPlan), int(self._dp_world), nc.handle, nc.stream.cuda_stream, int(self._dp_buckets), int(per_bucket),
                                None if msg is None else msg.data_ptr())
         return self._dp_keep

@@ -225,14 +225,14 @@ def test_native_dp_step_on_a_one_rank_rccl_communicator_equals_the_single_proces
     t = torch.arange(1000, dtype=torch.float32, device="cuda")
     assert torch.equal(comm.all_reduce(t.clone()), t)
     comm.close()
-    for per_bucket in ("1", "0"):
+    for per_bucket in ("1", "2", "0"):
         monkeypatch.setenv("NEUROVIT_DP_UPDATE_PER_BUCKET", per_bucket)
         model = _model()
         step = TrainStep(model, n_buckets=3, native_dp=True)
         for x, y in batches:
             step(x, y)
         torch.cuda.synchronize()
-        assert step.last_path == "native-dp" and step.last_dp["update_per_bucket"] == (per_bucket == "1") and step.last_dp["messages"] == "fp32"
+        assert step.last_path == "native-dp" and step.last_dp["update_per_bucket"] == int(per_bucket) and step.last_dp["messages"] == "fp32"
         assert torch.equal(model.volume_encoder.vit3d.flat_parameters()[0].detach().cpu(), single), f"update_per_bucket = {per_bucket}"
     model = _model()
     step = TrainStep(model, n_buckets=4, native_dp=True, grad_comm_dtype=torch.bfloat16)
