@@ -360,6 +360,8 @@ typedef struct nv_vit_config {
   int pool_mean;   /* 0: pool='cls' (NeuroEncoder.py:194), 1: pool='mean' (vit_3d.py:127) */
   int image_width, patch_width;   /* vit_3d.py:80-81 takes (height, width) pairs: image_size / image_patch_size are the HEIGHTS,
                                      these the widths; 0 = square (the NeuroEncoder path is cubic: NeuroEncoder.py:183-186) */
+  int no_proj_dropout;            /* (revision 6) 1: no nn.Dropout behind the output projection - the heads == 1 && dim_head == dim geometry, whose
+                                     to_out is nn.Identity() (vit_3d.py:32,43-46); the other three dropout sites of a block are unaffected */
 } nv_vit_config;
 
 /* heads == 1 && dim_head == dim: the reference has no output projection (vit_3d.py:32,43-46) but the table still carries every

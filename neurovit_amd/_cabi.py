@@ -24,7 +24,8 @@ class VitConfig(ctypes.Structure):
                 ("frame_patch_size", ctypes.c_int), ("channels", ctypes.c_int), ("num_classes", ctypes.c_int),
                 ("dim", ctypes.c_int), ("depth", ctypes.c_int), ("heads", ctypes.c_int), ("dim_head", ctypes.c_int),
                 ("mlp_dim", ctypes.c_int), ("ln_eps", ctypes.c_float), ("pool_mean", ctypes.c_int),
-                ("image_width", ctypes.c_int), ("patch_width", ctypes.c_int)]      # 0 = square
+                ("image_width", ctypes.c_int), ("patch_width", ctypes.c_int),      # 0 = square
+                ("no_proj_dropout", ctypes.c_int)]      # heads == 1 and dim_head == dim: to_out is nn.Identity(), no Dropout behind it (vit_3d.py:43-46)
 
 
 class VitInput(ctypes.Structure):

@@ -44,6 +44,10 @@ static bool cls_tail_wanted(const Dims& D, int training, float drop_p, int rows_
   return want && !D.pool_mean && (!training || D.B <= 4);
 }
 
+// nn.Dropout behind the output projection (vit_3d.py:45): absent - with the projection itself - when heads == 1 and dim_head == dim
+// (vit_3d.py:32,43-46: to_out = nn.Identity()); the engine still runs that geometry's projection slot (identity weight, zero bias)
+static inline float proj_drop_p(const nv_vit_config* c, float drop_p) { return c->no_proj_dropout ? 0.f : drop_p; }
+
 // image width / width of a patch: nv_vit_config.image_width / patch_width, 0 = square (vit_3d.py:80-81 takes pairs)
 static inline int img_w(const nv_vit_config* c) { return c->image_width > 0 ? c->image_width : c->image_size; }
 static inline int pat_w(const nv_vit_config* c) { return c->patch_width > 0 ? c->patch_width : c->image_patch_size; }
@@ -350,14 +354,14 @@ static int forward_in_impl(const nv_vit_config* cfg, int B, const float* video, 
     if (tail && l == D.L - 1) {
       // cls rows only (row b of the small problem = row b * n of the buffers); LN2 statistics land at st2[0 .. B) / st2[M .. M + B)
       const long rs = D.n;
-      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, site_seed(drop_seed, 4 * l + 1), drop_p, stream));
+      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, site_seed(drop_seed, 4 * l + 1), proj_drop_p(cfg, drop_p), stream));
       RUN(nv_ln_fwd(x1, d * rs, B, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d * rs, st2, st2 + M, stream));
       RUN(nv_skinny_nt(1, B, D.m, d, ws + w.xn2, d * rs, p16 + q.w1, d, p + q.b1, nullptr, 0, ws + w.h, D.m * rs, training ? ws + w.u : nullptr, D.m * rs, site_seed(drop_seed, 4 * l + 2), drop_p, stream));
       RUN(nv_skinny_nt(0, B, d, D.m, ws + w.h, D.m * rs, p16 + q.w2, D.m, p + q.b2, x1, d * rs, x2, d * rs, nullptr, 0, site_seed(drop_seed, 4 * l + 3), drop_p, stream));
       xin = x2;
       continue;
     }
-    RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 1), drop_p, stream));
+    RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 1), proj_drop_p(cfg, drop_p), stream));
     RUN(nv_ln_fwd(x1, d, M, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d, st2, st2 + M, stream));
     RUN(nv_gemm_bf16(0, 3, M, D.m, d, ws + w.xn2, d, p16 + q.w1, d, ws + w.h, D.m, p + q.b1, nullptr, 0, training ? ws + w.u : nullptr, D.m, 0, 1.f, site_seed(drop_seed, 4 * l + 2), drop_p, stream));
     RUN(nv_gemm_bf16(0, 4, M, d, D.m, ws + w.h, D.m, p16 + q.w2, D.m, x2, d, p + q.b2, x1, d, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 3), drop_p, stream));
@@ -622,14 +626,14 @@ extern "C" int nv_vit_forward_fp8_train(const nv_vit_config* cfg, int B, const f
     RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), site_seed(drop_seed, 4 * l + 0), drop_p, stream));
     if (tail && l == D.L - 1) {       // the last block on its B cls rows: the bf16 weight-streaming kernels, as in nv_vit_forward_in
       const long rs = D.n;
-      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, site_seed(drop_seed, 4 * l + 1), drop_p, stream));
+      RUN(nv_skinny_nt(0, B, d, D.inner, ws + w.ao, D.inner * rs, p16 + q.wo, D.inner, p + q.bo, xin, d * rs, x1, d * rs, nullptr, 0, site_seed(drop_seed, 4 * l + 1), proj_drop_p(cfg, drop_p), stream));
       RUN(nv_ln_fwd(x1, d * rs, B, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d * rs, st2, st2 + M, stream));
       RUN(nv_skinny_nt(1, B, D.m, d, ws + w.xn2, d * rs, p16 + q.w1, d, p + q.b1, nullptr, 0, ws + w.h, D.m * rs, ws + w.u, D.m * rs, site_seed(drop_seed, 4 * l + 2), drop_p, stream));
       RUN(nv_skinny_nt(0, B, d, D.m, ws + w.h, D.m * rs, p16 + q.w2, D.m, p + q.b2, x1, d * rs, x2, d * rs, nullptr, 0, site_seed(drop_seed, 4 * l + 3), drop_p, stream));
       xin = x2;
       continue;
     }
-    RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 1), drop_p, stream));
+    RUN(nv_gemm_bf16(0, 4, M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, x1, d, p + q.bo, xin, d, nullptr, 0, 0, 1.f, site_seed(drop_seed, 4 * l + 1), proj_drop_p(cfg, drop_p), stream));
     RUN(nv_ln_fwd_f8_train(x1, d, M, d, p + q.n2g, p + q.n2b, eps, s_xn2, x8, d, ws + w.xn2, d, st2, st2 + M, stream));
     RUN(nv_gemm_f8_gelu_train(M, D.m, d, x8, d, p8 + q.w1, d, cs + 3L * D.inner, p + q.b1, s_h, h8, D.m, ws + w.h, D.m, ws + w.u, D.m,
                               site_seed(drop_seed, 4 * l + 2), drop_p, stream));
@@ -775,7 +779,7 @@ static int backward_impl(const nv_vit_config* cfg, int B, const float* video, co
     RUN(nv_gemm_bf16(1, 1, M, d, D.m, du, D.m, p16 + q.w1, d, dxn, d, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));                        // dxn2 = dU W1
     }
     RUN(nv_ln_bwd(dxn, d * rs, (float*)(ws + w.x1), d * rs, st2, st2 + M, p + q.n2g, Mr, d, g, g, d * rs, g16b, d * rs, gr + q.n2g, gr + q.n2b, gr + q.bo, acc, RED(l),
-                  W.red_bytes, site_seed(drop_seed, 4 * l + 1), drop_p, stream, ln_reduce));                                   // g += dLN2 -> g16b
+                  W.red_bytes, site_seed(drop_seed, 4 * l + 1), proj_drop_p(cfg, drop_p), stream, ln_reduce));                                   // g += dLN2 -> g16b
     // ---- Attention backward (vit_3d.py:48-60)
     if (tail) {
       RUN(nv_skinny_nn_sparse(B, D.inner, d, g16b, d * rs, p16 + q.wo, D.inner, ws + W.dao, M, D.n, stream));                       // dAO = g Wo on the cls rows, zeros elsewhere

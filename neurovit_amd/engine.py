@@ -27,7 +27,7 @@ def make_config(*, image_size, image_patch_size, frames, frame_patch_size, num_c
         raise ValueError("pool type must be either cls (cls token) or mean (mean pooling)")
     return VitConfig(image_size, image_patch_size, frames, frame_patch_size, channels, num_classes, dim, depth, heads,
                      dim_head, mlp_dim, ln_eps, int(pool == 'mean'), 0 if image_width == image_size else image_width,
-                     0 if patch_width == image_patch_size else patch_width)
+                     0 if patch_width == image_patch_size else patch_width, int(heads == 1 and dim_head == dim))
 
 
 def image_hw(cfg: VitConfig):

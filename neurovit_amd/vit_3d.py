@@ -453,10 +453,6 @@ class ViT(nn.Module):
     # ------------------------------------------------------------------ execution
     def draw_dropout(self):
         """(p of the blocks, p of the embedding, seed) of the next forward: (0, 0, 0) in eval mode or without dropout."""
-        if self._no_proj and self.training and self._dropout_p[0] > 0:
-            raise NotImplementedError("neurovit_amd.ViT: heads == 1 with dim_head == dim has no Dropout behind the (absent) output "
-                                      "projection (vit_3d.py:43-46); the engine's block dropout would put one there - train this "
-                                      "geometry with dropout = 0")
         if self.training and (self._dropout_p[0] > 0 or self._dropout_p[1] > 0):
             # nn.Dropout semantics (vit_3d.py:21,23,39,45,100) with a counter-based mask: a fresh seed per forward from
             # torch's CPU generator (so torch.manual_seed reproduces runs); backward recomputes the same masks.

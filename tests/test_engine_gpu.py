@@ -32,6 +32,7 @@ RATIO, SLACK = 1.5, 2e-4   # G3a
 REL = 5e-3                 # G3b forward stages / logits, relative L2
 MAXREL = 5e-3              # base-size logits (two numbers) vs emulating oracle
 GRAD_REL = 1.5e-2          # G3b parameter gradients, relative L2
+FORM_TIGHT = 2e-4          # ... of the head and the last block's FeedForward / out-projection parameters alone (no re-rounding downstream; measured <= 6e-5)
 FORM_REL = 5e-3            # gradient arena of the cls-rows form against the every-row form (see run_case)
 OPERANDS = "bf16"          # 16-bit operand format of the runs below; tests/test_fp16_gpu.py re-runs the cases with "fp16" (and tighter G3b / G4 gates)
 DT16 = {"bf16": torch.bfloat16, "fp16": torch.float16}
@@ -92,6 +93,19 @@ def run_case(engine, tag, cfgdict, seeds, B=2, dropout=(0.0, 0.0, 0)):
         if not (e_h32 <= RATIO * e_e32 + SLACK and e_he <= GRAD_REL):
             fails.append((k, e_he, e_h32, e_e32))
     assert not fails, (tag, "cls-rows form: gradients against the oracles", fails)
+    # ... and TIGHTLY where no later bf16 re-rounding can have flipped: the head and the last block's own FeedForward / out-projection
+    # parameters are formed from the B cls rows before the attention backward mixes rows, so the two forms differ there by the summation
+    # order of one or two products (and the isolated bf16 flips of dU / h that follow from it) - a systematic 1e-3-level defect of the
+    # cls-row kernels' backward shows up here, three orders above what is measured (values in the report; gate = FORM_TIGHT)
+    last = f"transformer.layers.{cfg.depth - 1}."
+    tight = [k for k in names if k.startswith("mlp_head.") or k.startswith(last + "1.net.") or k.startswith(last + "0.to_out.")]
+    worst = ("", 0.0)
+    for k, o, nn in zip(names, off, num):
+        if k in tight:
+            d = rel_l2(g2[o:o + nn], gcpu[o:o + nn])
+            worst = max(worst, (k, d), key=lambda t: t[1])
+    report(f"{tag} cls-rows form vs all rows, tensors ahead of any re-rounding ({len(tight)}): worst {worst[0]} {worst[1]:.2e}")
+    assert worst[1] < FORM_TIGHT, (tag, "cls-rows form: head / last-block FeedForward / out-projection gradients", worst)
     e = rel_l2(g2, gcpu)
     report(f"{tag} cls-rows form of the last block vs all rows: logits {rel_l2(logits2, logits):.2e}, gradient arena {e:.2e} (every parameter inside the oracle gates)")
     assert e < FORM_REL, (tag, "cls-rows form: gradients", e)

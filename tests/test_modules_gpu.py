@@ -145,7 +145,7 @@ def test_noproj_vit_matches_reference_fixture(nv, golden):
     """heads == 1 with dim_head == dim (vit_3d.py:32,43-46: to_out is nn.Identity): same state_dict keys as the reference (no to_out),
     the engine's projection slots held as identity / zero constants outside the optimizer.  Logits, gradients and one fused AdamW
     step against the fixture made by the imported reference; the constants survive the step; the standalone Attention module agrees
-    with the oracle; block dropout in this geometry is refused."""
+    with the oracle; block dropout in this geometry leaves out the site behind the absent projection, as the reference does."""
     from neurovit_amd.optim import FusedAdamW
     from neurovit_amd.vit_3d import ViT
     g = golden("noproj_vit.npz")
@@ -192,10 +192,23 @@ def test_noproj_vit_matches_reference_fixture(nv, golden):
     want = ref_cpu.attention(bsd, pre, x.cpu(), 1, d)
     got = att(x)
     assert got.shape == x.shape and rel_l2(got, want) < 1e-2
+    # block dropout in this geometry: the reference has NO Dropout behind the (absent) projection (vit_3d.py:43-46) - nv_vit_config.no_proj_dropout
+    # switches that one site off in the engine; the oracle regenerates the other sites' masks bit for bit, so the train-mode logits must agree
+    # with it (a mask wrongly applied behind the identity projection would move them by ~10 %)
     m.train()
     m._dropout_p = (0.1, 0.0)
-    with pytest.raises(NotImplementedError):
-        m(video)
+    torch.manual_seed(5)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    torch.manual_seed(5)
+    got = m(video)
+    with torch.no_grad():
+        want = ref_cpu.vit_forward(sd2, ref_cpu.ViTCfg(**W.NOPROJ), video.cpu(), emulate_bf16=True, dropout=(0.1, 0.0, seed))
+        plain = ref_cpu.vit_forward(sd2, ref_cpu.ViTCfg(**W.NOPROJ), video.cpu(), emulate_bf16=True)
+    e_drop = rel_err(got, want)
+    report(f"no-projection ViT under block dropout 0.1 vs the oracle with the same masks: {e_drop:.2e} (the masks move the logits by {rel_err(plain, want):.2e})")
+    assert e_drop < 2e-2 and rel_err(plain, want) > 5 * e_drop
+    got.sum().backward()
+    assert all(torch.isfinite(q.grad).all() for q in m.parameters())
 
 
 def _micro_model(nv, lr=1e-3, wd=1e-2):
