@@ -2,8 +2,13 @@
 """Summarise a rocprofv3 --kernel-trace --stats CSV: per-kernel calls, total / average time per step.
 usage: tools/kstats.py <kernel_stats.csv> <steps>"""
 import csv
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import pretty_many      # noqa: E402
 rows = list(csv.DictReader(open(sys.argv[1])))
+for r, n in zip(rows, pretty_many([r["Name"] for r in rows])):
+    r["Name"] = n
 steps = float(sys.argv[2])
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"total kernel time per step: {tot / steps / 1e6:.3f} ms; launches per step: {sum(int(r['Calls']) for r in rows) / steps:.1f}")

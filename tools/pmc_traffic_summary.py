@@ -19,58 +19,10 @@ import os
 import re
 import sys
 
-
-def kernel_key(name: str) -> str:
-    """'void (anonymous namespace)::gemm_pp_kernel<256, 128, 4, 2, false, true, 6>(GemmArgs)' -> 'gemm_pp_kernel<256, 128, 4, 2, false, true, 6>'"""
-    s = name.strip()
-    if s.endswith(")"):                      # strip the final balanced argument list
-        depth, i = 0, len(s) - 1
-        while i >= 0:
-            if s[i] == ")":
-                depth += 1
-            elif s[i] == "(":
-                depth -= 1
-                if depth == 0:
-                    break
-            i -= 1
-        if i > 0:
-            s = s[:i]
-    if s.startswith("void "):
-        s = s[5:]
-    return s.replace("(anonymous namespace)::", "").strip()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-# kernel instantiation -> nv_prof kind (include/neurovit_hip.h, nv_prof_enable): the same classes bench.py's roofline leg times
-def kind_of(key: str):
-    def tn(m, base):
-        a_t, b_t = m.group(1) == "true", m.group(2) == "true"
-        return base + (2 if a_t else (1 if b_t else 0))
-    m = re.match(r"gemm_ws_kernel<\d+, \d+, \d+, \d+, (true|false), (true|false), \d+>", key)
-    if m:
-        return tn(m, 0)
-    if key.startswith("gemm_ws_grouped_kernel"):
-        return 2
-    m = re.match(r"gemm_pp_kernel<\d+, \d+, \d+, \d+, (true|false), (true|false), \d+(, (true|false))?>", key)
-    if m:
-        return 5 if m.group(4) == "true" else tn(m, 10)
-    if key.startswith("gemm_pp_f8_kernel"):
-        return 5
-    if key.startswith("gemm_pp_grouped_tn_adamw_kernel"):
-        return 14
-    if key.startswith("gemm_pp_grouped_tn_kernel"):
-        return 13
-    m = re.match(r"gemm_pq_kernel<(true|false), (true|false), \d+(, (true|false))?>", key)
-    if m:
-        return 5 if m.group(4) == "true" else tn(m, 20)
-    if key.startswith("attn_fwd"):
-        return 3
-    if key.startswith("attn_bwd"):
-        return 4
-    if key.startswith("gemm_f32_nt_kernel"):
-        return 30
-    if key.startswith("attn_f32_fwd_kernel"):
-        return 31
-    return None
+from kernel_names import kernel_key, kind_of      # noqa: E402  (tools/kernel_names.py: demangles the __bf16 / _Float16 template names)
 
 
 def load(path, counter):

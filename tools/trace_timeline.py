@@ -4,12 +4,17 @@ the gap to the previous dispatch's end on the same queue and the idle time of th
 usage: trace_timeline.py <kernel_trace.csv> [step-index-from-the-end = 2] [--summary]
 A step starts at its patch_ln_fwd_kernel dispatch and ends in front of the next one."""
 import csv
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import pretty_many      # noqa: E402
 
 path = sys.argv[1]
 back = int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 2
 summary = "--summary" in sys.argv
 rows = list(csv.DictReader(open(path)))
+for r, n in zip(rows, pretty_many([r["Kernel_Name"] for r in rows])):
+    r["Kernel_Name"] = n
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
