@@ -600,7 +600,7 @@ def main():
     # (tools/pmc_traffic_summary.py -> profiles/rNN_pmc_traffic.json, per nv_prof kind); the algorithmic bytes beside them are
     # counted live, per launch, by the launchers (operands read once + outputs written once).  traffic / algorithmic = the waste.
     pmc, traffic_src = {}, None
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         tfile = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
@@ -608,6 +608,15 @@ def main():
             if not pmc:                          # round-1/2 file: one family-wide figure only
                 pmc = {"family": {"fetch_MB_per_launch": tj["fetch_MB_per_launch"], "write_MB_per_launch": tj["write_MB_per_launch"]}}
             break
+
+    # matrix-pipe utilisation of the same launches, ALONE on the chip: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) from a rocprofv3 --pmc
+    # pass of this command (tools/r05_pmc.sh -> tools/pmc_sq_summary.py; the profiler serialises dispatches under --pmc)
+    sq, sq_src = {}, None
+    for tag in ("r05",):
+        sfile = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.json")
+        if os.path.exists(sfile):
+            sj = json.load(open(sfile))
+            sq, sq_src = sj.get("by_kind", {}), sj["source"]
 
     def kind_traffic_mb(k):
         d = pmc.get(str(k))
@@ -621,6 +630,7 @@ def main():
                                     "launches_per_step": v["launches"] // prof_steps,
                                     "algorithmic_MB": None if algo_mb is None else round(algo_mb, 2),
                                     "traffic_MB": None if t_mb is None else round(t_mb, 2),
+                                    "mfma_busy": sq.get(str(k), {}).get("mfma_busy"),
                                     "traffic_over_algorithmic": None if (algo_mb is None or t_mb is None) else round(t_mb / algo_mb, 2)}
     # family figure over exactly the launches `achieved` is computed from: per-kind PMC traffic weighted by this run's launch counts
     gk = [k for k in GEMM_KINDS if k in kinds]
@@ -633,6 +643,9 @@ def main():
     g_bytes = sum(kinds[k].get("bytes", 0.0) for k in gk)
     roofline = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family: gemm_pp_kernel / gemm_pp_grouped_tn_kernel (256x128 tiles) + gemm_ws_kernel (64x128 tiles), all fused epilogues",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                "mfma_busy_source": sq_src,
+                "in_step_stretch": "profiles/r05_step_timeline_*.txt: the N = 768 data-gradient GEMM takes 18.8 us alone, 19.5 us beside the weight-gradient GEMMs, 32.3 us beside "
+                                   "them AND the per-layer AdamW (HBM / fabric contention, not CU starvation); ln_bwd 9.8 us alone, 22.4 us beside the weight-gradient GEMMs (CU sharing)",
                 "traffic": traffic, "traffic_unit": "bytes/launch of FABRIC traffic (L2 memory-side read + write requests, rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE: Infinity-Cache hits are counted, so this is an upper bound of the HBM bytes, not the HBM bytes; none of the 688 counters `rocprofv3 -L` lists on the MI355X box is a memory-side-cache or memory-controller counter, so the split cannot be measured), mean over the launches of `achieved`", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(g_bytes / max(g_n, 1), 1),
                 "traffic_over_algorithmic": None if not (traffic and g_bytes) else round(traffic / (g_bytes / g_n), 2),

@@ -54,7 +54,7 @@ def main():
         for k, n, fm, wm in rows:
             kd = kind_of(k)
             f.write(f"\"{k}\",{'' if kd is None else kd},{n},{fm:.3f},{wm:.3f}\n")
-    steps = next((n for k, n, _, _ in rows if k.startswith("adamw_kernel")), None)          # one AdamW launch per train step
+    steps = next((n for k, n, _, _ in rows if k.startswith("patch_ln_fwd_kernel")), None)   # one patch gather per train step (AdamW is 1 or 13 launches by placement)
     by_kind = {}
     for k, n, fm, wm in rows:
         kd = kind_of(k)
