@@ -150,6 +150,22 @@ int nv_adamw_ranges(const nv_adamw_arena* opt, const long* begins, const long* l
  * tiles; 0 = one per tile; default 128), (13, n) = at most n workgroups per nv_adamw_ranges launch (0 = one per 2048-element chunk) */
 int nv_gemm_set_tile(int bm, int bn);
 
+/* ---- LayerNorm folded into the GEMMs around it - inference forwards ("fused LayerNorm" as GEMM prologue; vit_3d.py:18-19,37-41):
+ *   LN(x) W^T + b  =  rstd (x Wg^T) - rstd mu colsum(Wg) + (W beta + b),   Wg = W diag(gamma)
+ * so a block's two LayerNorm launches (and their normalised copies) disappear: the GEMM that PRODUCES the residual stream (out-projection, FC2:
+ * nv_gemm_resid_ln = nv_gemm_bf16 epilogue 4 without dropout) also writes the rows in the operand format and, per row and 128-column tile, (mean, sum of squared
+ * deviations); the GEMM that CONSUMES them (to_qkv, FC1: nv_gemm_lnfold) contracts the un-normalised rows with Wg and applies mu / rstd - merged from the tile
+ * partials by Chan's update, no E[x^2] - E[x]^2 - in its epilogue.  nv_ln_fold_weight prepares Wg (operand format), colsum (of the rounded Wg) and the folded bias.
+ * Kernels with an LDS epilogue only (nv_gemm_lnfold_supported: every ViT3D-base shape from batch 1 up); same MFMA mainloops as nv_gemm_bf16. */
+int nv_gemm_lnfold_supported(int M, int N, int K);
+long nv_ln_fold_stats_floats(int M, int d);
+int nv_ln_fold_weight(const float* W, long ldw, int N, int K, const float* gamma, const float* beta, const float* bias, void* Wg16, long ldg,
+                      float* colsum, float* fbias, void* stream);
+int nv_gemm_resid_ln(int M, int N, int K, const void* A, long lda, const void* W, long ldw, const float* bias, const float* resid, long ldr, float* out,
+                     long ldo, void* out16, long ldo16, float* stats, void* stream);
+int nv_gemm_lnfold(int gelu, int M, int N, int K, const void* X16, long ldx, const void* Wg16, long ldw, const float* stats, const float* colsum,
+                   const float* fbias, float eps, void* out16, long ldo, void* stream);
+
 /* ---- Linear layers on a few rows (the cls rows of the last block under pool='cls'): weight-streaming kernels, rows addressed through
  * leading dimensions (a [B, n, d] tensor's cls rows: ld = n * d).  bf16 operands, fp32 accumulation, cast points of nv_gemm_bf16.
  * nv_skinny_nt: W [N, K] row-major.  epi 0: out f32 [R, N] = resid + (bias + A W^T)   epi 1: u = bias + A W^T (bf16, optional), out bf16 = gelu(u)
@@ -396,6 +412,15 @@ int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* video, const
 int nv_vit_forward(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5,
                    const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
                    unsigned long drop_seed, float* logits, void* stream);
+/* Inference forward with the blocks' LayerNorms folded into the GEMMs around them (nv_gemm_resid_ln / nv_gemm_lnfold above): nv_vit_forward_in(training = 0)
+ * without 21 of ViT3D-base's 24 LayerNorm launches (not folded: LN1 of block 0, LN1 of the last block - the Grad-CAM hook tensor - and a last block on its cls
+ * rows).  fold16: 16-bit arena (operand format) with the parameter arena's element offsets; fold32: nv_vit_lnfold_floats floats; both filled by
+ * nv_vit_lnfold_prepare whenever the parameters have changed.  Falls back to the unfolded launches for shapes outside the LDS-epilogue kernels. */
+long nv_vit_lnfold_floats(const nv_vit_config* cfg);
+int nv_vit_lnfold_prepare(const nv_vit_config* cfg, const float* params, void* fold16, float* fold32, void* stream);
+int nv_vit_forward_lnfold(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
+                          const float* params, const void* params16, const void* fold16, const float* fold32, void* workspace, long ws_bytes,
+                          float* logits, void* stream);
 /* fp32 inference forward: ViT.forward (vit_3d.py:112-126) as the reference's fp32 validate computes it (Trainer.py:101-118) - every
  * operand fp32 (weights straight from `params`, no shadow arena), contractions on the fp32 MFMA, eval mode (no dropout).
  * Workspace: nv_vit_workspace_bytes(cfg, B, 2).  Input forms as nv_vit_forward_in. */

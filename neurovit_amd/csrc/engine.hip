@@ -104,6 +104,7 @@ void make_params(const Dims& D, ParamTab& T) {
 struct LayerW { long xn1, st1, qkv, lse, ao, x1, xn2, st2, u, h, x2; };
 struct WS {
   long xp, pst, t, est, x0, xh, hst, wpe16, xm;
+  long fst1, fst2; // partial row statistics of the LayerNorm-folded inference forward (nv_gemm_resid_ln -> nv_gemm_lnfold): of a block's input / of x1
   long f8x, f8h;   // training layout: transient e4m3 operands of an fp8 training forward (LayerNorm output [M, d], GELU output [M, m])
   std::vector<LayerW> layer;
   // backward scratch
@@ -120,6 +121,7 @@ void make_ws(const Dims& D, int training, WS& W) {
   W.xh = add((long)D.B * d * 4); W.hst = add((long)D.B * 2 * 4);
   W.xm = D.pool_mean ? add((long)D.B * d * 4) : -1;      // pool='mean': token mean of the last block's output
   W.wpe16 = (D.P != D.Ppad) ? add(d * D.Ppad * 2) : -1;
+  W.fst1 = add(nv_ln_fold_stats_floats((int)M, (int)d) * 4); W.fst2 = add(nv_ln_fold_stats_floats((int)M, (int)d) * 4);
   const int nl = training ? D.L : 1;     // inference: every layer reuses one set of buffers (x ping-pongs x1 <-> x2/x0)
   W.layer.resize(D.L);
   for (int l = 0; l < nl; ++l) {
@@ -290,7 +292,35 @@ extern "C" int nv_vit_forward(const nv_vit_config* cfg, int B, const float* vide
 
 static int forward_in_impl(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
                            const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
-                           unsigned long drop_seed, float* logits, void* stream, bool skip_head);
+                           unsigned long drop_seed, float* logits, void* stream, bool skip_head, const void* fold16 = nullptr, const float* fold32 = nullptr);
+
+// ---- LayerNorm folded into the GEMMs around it (inference forwards; gemm_common.h EPI_BIAS_RESID_LN / EPI_LNFOLD_*).
+// fold16: 16-bit arena with the parameter arena's element offsets holding W_qkv diag(gamma1) and W_1 diag(gamma2) of every block; fold32: per block
+// [colsum qkv (3 inner) | folded bias qkv (3 inner) | colsum FC1 (m) | folded bias FC1 (m)].  Prepared once per parameter state (nv_vit_lnfold_prepare).
+extern "C" long nv_vit_lnfold_floats(const nv_vit_config* cfg) {
+  Dims D; if (make_dims(cfg, 1, D)) return -1;
+  return (long)D.L * (6L * D.inner + 2L * D.m);
+}
+extern "C" int nv_vit_lnfold_prepare(const nv_vit_config* cfg, const float* params, void* fold16, float* fold32, void* stream) {
+  Dims D; RUN(make_dims(cfg, 1, D));
+  ParamTab T; make_params(D, T);
+  NV_CHECK_ARG(params && fold16 && fold32 && nv_aligned16(params) && nv_aligned16(fold16) && nv_aligned16(fold32), "nv_vit_lnfold_prepare: null / unaligned arena");
+  r16* f16 = (r16*)fold16;
+  const long per = 6L * D.inner + 2L * D.m;
+  for (int l = 0; l < D.L; ++l) {
+    const LayerP& q = T.layer[l];
+    float* f = fold32 + l * per;
+    RUN(nv_ln_fold_weight(params + q.wqkv, D.d, 3 * D.inner, D.d, params + q.n1g, params + q.n1b, nullptr, f16 + q.wqkv, D.d, f, f + 3L * D.inner, stream));
+    RUN(nv_ln_fold_weight(params + q.w1, D.d, D.m, D.d, params + q.n2g, params + q.n2b, params + q.b1, f16 + q.w1, D.d, f + 6L * D.inner, f + 6L * D.inner + D.m, stream));
+  }
+  return NV_OK;
+}
+extern "C" int nv_vit_forward_lnfold(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
+                                     const float* params, const void* params16, const void* fold16, const float* fold32, void* workspace, long ws_bytes,
+                                     float* logits, void* stream) {
+  NV_CHECK_ARG(fold16 && fold32 && nv_aligned16(fold16) && nv_aligned16(fold32), "nv_vit_forward_lnfold: null / unaligned fold arenas (nv_vit_lnfold_prepare)");
+  return forward_in_impl(cfg, B, video, shape5, strides5, in, params, params16, workspace, ws_bytes, 0, 0.f, 0.f, 0, logits, stream, false, fold16, fold32);
+}
 
 extern "C" int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
                                  const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
@@ -301,7 +331,7 @@ extern "C" int nv_vit_forward_in(const nv_vit_config* cfg, int B, const float* v
 // skip_head: everything up to the last block's output; the caller runs the head itself (nv_vit_train_step: nv_head_step)
 static int forward_in_impl(const nv_vit_config* cfg, int B, const float* video, const long* shape5, const long* strides5, const nv_vit_input* in,
                            const float* params, const void* params16, void* workspace, long ws_bytes, int training, float drop_p, float emb_drop_p,
-                           unsigned long drop_seed, float* logits, void* stream, bool skip_head) {
+                           unsigned long drop_seed, float* logits, void* stream, bool skip_head, const void* fold16, const float* fold32) {
   Dims D; RUN(make_dims(cfg, B, D));
   ParamTab T; make_params(D, T);
   WS W; make_ws(D, training, W);
@@ -340,16 +370,32 @@ static int forward_in_impl(const nv_vit_config* cfg, int B, const float* video, 
   const float scale = 1.0f / sqrtf((float)D.dh);
   const float* xin = (float*)(ws + W.x0);
   const bool tail = cls_tail_wanted(D, training, drop_p, in ? in->rows_form : 0);
+  // LayerNorm folded into the GEMMs (inference, no dropout, every one of a block's four shapes on an LDS-epilogue kernel).  Not folded: LN1 of block 0 (its
+  // input comes out of embed_finish, not out of a GEMM epilogue), LN1 of the LAST block (its output is the Grad-CAM hook tensor, NeuroEncoder.py:70-75: it
+  // must exist), and a last block that runs on its cls rows.  ViT3D-base: 21 of the 24 LayerNorm launches of a forward.
+  const bool fold = fold16 && fold32 && !training && drop_p == 0.f && nv_gemm_lnfold_supported(M, 3 * D.inner, d) && nv_gemm_lnfold_supported(M, D.m, d) &&
+                    nv_gemm_lnfold_supported(M, d, D.inner) && nv_gemm_lnfold_supported(M, d, D.m);
+  const r16* f16 = (const r16*)fold16;
+  const long fper = 6L * D.inner + 2L * D.m;
+  float* fst1 = (float*)(ws + W.fst1);
+  float* fst2 = (float*)(ws + W.fst2);
+  bool have_in16 = false;            // the previous block's FC2 left this block's input in the operand format (in xn1) with its statistics (fst1)
   for (int l = 0; l < D.L; ++l) {
     const LayerP& q = T.layer[l];
     const LayerW& w = W.layer[l];
+    const float* ff = fold ? fold32 + l * fper : nullptr;
     // inference ping-pong: layer output goes to x2, except that x2 would alias the next layer's output -> alternate x0/x2
     float* x1 = (float*)(ws + w.x1);
     float* x2 = (float*)(ws + ((!training && (l & 1)) ? W.x0 : w.x2));
     float* st1 = (float*)(ws + w.st1);
     float* st2 = (float*)(ws + w.st2);
-    RUN(nv_ln_fwd(xin, d, M, d, p + q.n1g, p + q.n1b, eps, ws + w.xn1, d, st1, st1 + M, stream));
-    RUN(nv_gemm_bf16(0, 0, M, 3 * D.inner, d, ws + w.xn1, d, p16 + q.wqkv, d, ws + w.qkv, 3 * D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+    if (have_in16) {
+      RUN(nv_gemm_lnfold(0, M, 3 * D.inner, d, ws + w.xn1, d, f16 + q.wqkv, d, fst1, ff, ff + 3L * D.inner, eps, ws + w.qkv, 3 * D.inner, stream));
+    } else {
+      RUN(nv_ln_fwd(xin, d, M, d, p + q.n1g, p + q.n1b, eps, ws + w.xn1, d, st1, st1 + M, stream));
+      RUN(nv_gemm_bf16(0, 0, M, 3 * D.inner, d, ws + w.xn1, d, p16 + q.wqkv, d, ws + w.qkv, 3 * D.inner, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+    }
+    have_in16 = false;
     RUN(nv_attn_fwd(ws + w.qkv, 3 * D.inner, B, D.n, D.heads, D.dh, scale, ws + w.ao, D.inner, (float*)(ws + w.lse), site_seed(drop_seed, 4 * l + 0), drop_p, stream));
     if (tail && l == D.L - 1) {
       // cls rows only (row b of the small problem = row b * n of the buffers); LN2 statistics land at st2[0 .. B) / st2[M .. M + B)
@@ -358,6 +404,20 @@ static int forward_in_impl(const nv_vit_config* cfg, int B, const float* video, 
       RUN(nv_ln_fwd(x1, d * rs, B, d, p + q.n2g, p + q.n2b, eps, ws + w.xn2, d * rs, st2, st2 + M, stream));
       RUN(nv_skinny_nt(1, B, D.m, d, ws + w.xn2, d * rs, p16 + q.w1, d, p + q.b1, nullptr, 0, ws + w.h, D.m * rs, training ? ws + w.u : nullptr, D.m * rs, site_seed(drop_seed, 4 * l + 2), drop_p, stream));
       RUN(nv_skinny_nt(0, B, d, D.m, ws + w.h, D.m * rs, p16 + q.w2, D.m, p + q.b2, x1, d * rs, x2, d * rs, nullptr, 0, site_seed(drop_seed, 4 * l + 3), drop_p, stream));
+      xin = x2;
+      continue;
+    }
+    if (fold) {
+      // out-projection writes x1 (f32), x1 in the operand format (into the xn2 buffer) and its row statistics; FC1 contracts those rows with W1 diag(gamma2)
+      RUN(nv_gemm_resid_ln(M, d, D.inner, ws + w.ao, D.inner, p16 + q.wo, D.inner, p + q.bo, xin, d, x1, d, ws + w.xn2, d, fst2, stream));
+      RUN(nv_gemm_lnfold(1, M, D.m, d, ws + w.xn2, d, f16 + q.w1, d, fst2, ff + 6L * D.inner, ff + 6L * D.inner + D.m, eps, ws + w.h, D.m, stream));
+      const bool next_folds = l + 1 <= D.L - 2;          // the next block's LN1 (blocks 1 .. L-2)
+      if (next_folds) {
+        RUN(nv_gemm_resid_ln(M, d, D.m, ws + w.h, D.m, p16 + q.w2, D.m, p + q.b2, x1, d, x2, d, ws + W.layer[l + 1].xn1, d, fst1, stream));
+        have_in16 = true;
+      } else {
+        RUN(nv_gemm_bf16(0, 4, M, d, D.m, ws + w.h, D.m, p16 + q.w2, D.m, x2, d, p + q.b2, x1, d, nullptr, 0, 0, 1.f, 0, 0.f, stream));
+      }
       xin = x2;
       continue;
     }

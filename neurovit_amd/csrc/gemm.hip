@@ -460,6 +460,60 @@ static int launch(const GemmArgs& a, hipStream_t s) {
   NV_DISPATCH_OPERAND(T, return launch_fmt<T, A_T, B_T, EPI>(a, s));
 }
 
+// ---- LayerNorm folded into the GEMMs around it (gemm_common.h EPI_BIAS_RESID_LN / EPI_LNFOLD_*): NT problems on the kernels with an LDS epilogue
+template <typename T, int EPI>
+static int launch_fold_fmt(const GemmArgs& a, hipStream_t s) {
+  const GemmPlan p = plan_gemm(false, false, EPI, a.M, a.N, a.K, a.lda, a.ldb);
+  if (p.family == 2) return launch_pp(0, EPI, a, s);
+  if (p.family == 1) {
+    if (p.ws == 1) return launch_ws<T, 128, 128, 3, 1, false, false, EPI>(a, s);
+    return p.ring == 3 ? launch_ws<T, 64, 128, 3, 2, false, false, EPI>(a, s) : launch_ws<T, 64, 128, 3, 1, false, false, EPI>(a, s);
+  }
+  nv_set_error("nv_gemm_lnfold: no LDS-epilogue kernel runs this shape (M=%d N=%d K=%d): ask nv_gemm_lnfold_supported first", a.M, a.N, a.K);
+  return NV_ERR_ARG;
+}
+extern "C" int nv_gemm_lnfold_supported(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || (N % 8) || (K % 8)) return 0;
+  const GemmPlan p = plan_gemm(false, false, EPI_LNFOLD_STORE, M, N, K, K, K);
+  return (p.family == 1 || p.family == 2) ? 1 : 0;
+}
+extern "C" long nv_ln_fold_stats_floats(int M, int d) { return 2L * M * ((d + 127) / 128); }
+
+static void fold_args(GemmArgs& a, int M, int N, int K, const void* A, long lda, const void* W, long ldw, const float* bias) {
+  a.A = (const r16*)A; a.B = (const r16*)W; a.bias = bias; a.aux_in = nullptr; a.aux_out = nullptr; a.aux_out2 = nullptr;
+  a.lda = lda; a.ldb = ldw; a.ld_aux_in = 0; a.ld_aux_out = 0; a.ld_aux_out2 = 0;
+  a.M = M; a.N = N; a.K = K; a.accumulate = 0; a.alpha = 1.f; a.drop = make_drop(0, 0.f); a.colscale = nullptr;
+  a.col_order = (N > M) ? 1 : 0;
+}
+
+// out f32 [M, N] = resid + (A W^T + bias)  (vit_3d.py:73-74)  +  out16 = the same rows in the operand format  +  stats [ceil(N / 128)][M][2]
+extern "C" int nv_gemm_resid_ln(int M, int N, int K, const void* A, long lda, const void* W, long ldw, const float* bias, const float* resid, long ldr, float* out,
+                                long ldo, void* out16, long ldo16, float* stats, void* stream) {
+  NV_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && W && bias && resid && out && out16 && stats, "nv_gemm_resid_ln: null pointer / empty problem");
+  NV_CHECK_ARG(nv_aligned16(A) && nv_aligned16(W) && nv_aligned16(bias) && nv_aligned16(resid) && nv_aligned16(out) && ((uintptr_t)out16 & 7) == 0 && nv_aligned16(stats) &&
+                   (lda % 8) == 0 && (ldw % 8) == 0 && (ldr % 4) == 0 && (ldo % 4) == 0 && (ldo16 % 4) == 0 && (N % 8) == 0 && (K % 8) == 0 && lda >= K && ldw >= K && ldo >= N && ldo16 >= N,
+               "nv_gemm_resid_ln: alignment / leading dimensions");
+  GemmArgs a;
+  fold_args(a, M, N, K, A, lda, W, ldw, bias);
+  a.C = out; a.ldc = ldo; a.aux_in = resid; a.ld_aux_in = ldr; a.aux_out = out16; a.ld_aux_out = ldo16; a.aux_out2 = stats;
+  NV_DISPATCH_OPERAND(T, return launch_fold_fmt<T, EPI_BIAS_RESID_LN>(a, (hipStream_t)stream));
+}
+
+// out16 [M, N] = (gelu)(LayerNorm_K(x) W^T + b) computed as rstd (X16 Wg16^T - mu colsum) + fbias: X16 the UN-normalised rows, Wg16 / colsum / fbias from
+// nv_ln_fold_weight, stats from the nv_gemm_resid_ln launch that produced X16 (K = the LayerNorm width)
+extern "C" int nv_gemm_lnfold(int gelu, int M, int N, int K, const void* X16, long ldx, const void* Wg16, long ldw, const float* stats, const float* colsum,
+                              const float* fbias, float eps, void* out16, long ldo, void* stream) {
+  NV_CHECK_ARG(M > 0 && N > 0 && K > 0 && X16 && Wg16 && stats && colsum && fbias && out16, "nv_gemm_lnfold: null pointer / empty problem");
+  NV_CHECK_ARG(nv_aligned16(X16) && nv_aligned16(Wg16) && nv_aligned16(colsum) && nv_aligned16(fbias) && nv_aligned16(out16) && (ldx % 8) == 0 && (ldw % 8) == 0 &&
+                   (ldo % 4) == 0 && (N % 8) == 0 && (K % 8) == 0 && ldx >= K && ldw >= K && ldo >= N,
+               "nv_gemm_lnfold: alignment / leading dimensions");
+  GemmArgs a;
+  fold_args(a, M, N, K, X16, ldx, Wg16, ldw, fbias);
+  a.C = out16; a.ldc = ldo; a.ln_stats = stats; a.ln_cs = colsum; a.ln_tiles = (K + 127) / 128; a.ln_eps = eps;
+  if (gelu) NV_DISPATCH_OPERAND(T, return launch_fold_fmt<T, EPI_LNFOLD_GELU>(a, (hipStream_t)stream));
+  NV_DISPATCH_OPERAND(T, return launch_fold_fmt<T, EPI_LNFOLD_STORE>(a, (hipStream_t)stream));
+}
+
 // Rows of the workgroup tile nv_gemm_bf16 will use for this problem when asked for the fused column-sum epilogue (6): the
 // epilogue writes ceil(M / rows) partial rows.  0 = that epilogue is not available for the shape (use epilogue 5 + nv_colsum_bf16).
 extern "C" int nv_gemm_tile_rows(int layout, int M, int N, int K, long lda, long ldb) {

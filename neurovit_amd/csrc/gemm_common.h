@@ -15,6 +15,13 @@ enum {
                         // pre-activation u, aux_out2(bf16) = gelu(u) - out of the same epilogue (one pass over the tile instead of a quantise pass)
   EPI_DGELU_COLSUM = 6, // EPI_DGELU + aux_out(f32)[tile_row, n] = column sums of the stored bf16 values over the tile's rows: the bias
                         // gradient of the Linear in front of the GELU, produced where the tile already is (large-tile kernels only)
+  // ---- LayerNorm folded into the GEMMs around it (inference forwards): LN(x) W^T = rstd (x W_g^T) - rstd mu colsum(W_g) + (W beta + b) with
+  // W_g = W diag(gamma).  The producer of the residual stream also writes x in the operand format and per-(row, 128-column tile) statistics; the consumer
+  // contracts the UN-normalised rows with W_g and applies the row statistics in its epilogue: no LayerNorm launch, no normalised copy.  LDS-epilogue kernels only.
+  EPI_BIAS_RESID_LN = 10,  // EPI_BIAS_RESID (no dropout) + aux_out(16-bit) = the stored row + aux_out2(f32)[tile column][M][2] = (mean, sum of squared deviations) of the
+                           // tile's <= 128 columns of each row (merged pairwise by the consumer: Chan's update - no E[x^2] - E[x]^2 cancellation)
+  EPI_LNFOLD_STORE = 11,   // C(16-bit) = rstd[m] (acc - mu[m] ln_cs[n]) + bias[n]; (mu, rstd) of row m from ln_stats (ln_tiles partials over K = the LayerNorm width)
+  EPI_LNFOLD_GELU = 12,    // C(16-bit) = gelu(the same)
   EPI_ADAMW = 9,        // weight-gradient GEMM that applies torch.optim.AdamW to the weight it differentiates: acc is the gradient of
                         // opt.p[m, n] (same leading dimension as C); p, m, v are updated in place, p16 = bf16(p); C is only written when
                         // opt.keep_grad.  Saves the 4-byte store and the 4-byte re-read of every gradient (8 of 34 B/param per step)
@@ -42,6 +49,10 @@ struct GemmArgs {
   float alpha;
   const float* colscale;   // fp8 operands: acc *= colscale[n] (1 / (activation scale * weight-row scale)) before the epilogue; null otherwise
   OptFuse opt;             // EPI_ADAMW only
+  const float* ln_stats = nullptr;   // EPI_LNFOLD_*: [ln_tiles][M][2] partial row statistics written by an EPI_BIAS_RESID_LN launch over the same rows
+  const float* ln_cs = nullptr;      //               colsum over k of W_g[n, k] (of the ROUNDED 16-bit values the MFMA reads)
+  int ln_tiles = 0;
+  float ln_eps = 0.f;
 };
 
 // algorithmic bytes of one GEMM launch: both operands read once, every output written once, epilogue inputs read once
@@ -58,6 +69,8 @@ static inline double gemm_algo_bytes(const GemmArgs& a, int epi, int operand_byt
     case EPI_BIAS_GELU_F8: b += mn; break;
     case EPI_BIAS_GELU_F8T: b += mn * 5; break;
     case EPI_ADAMW: b += mn * (26 + (a.opt.keep_grad ? 4 : 0)); break;      // p, m, v read and written, bf16 shadow written
+    case EPI_BIAS_RESID_LN: b += mn * 10; break;
+    case EPI_LNFOLD_STORE: case EPI_LNFOLD_GELU: b += mn * 2 + (double)a.M * a.ln_tiles * 8; break;
     default: break;
   }
   return b;
@@ -195,7 +208,8 @@ __device__ __forceinline__ r16x8 read_frag(const char* img, int rc0, int ks, int
 template <int EPI, typename T>
 __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, int n) {
   if (g.colscale) v *= *reinterpret_cast<const f32x4*>(g.colscale + n);
-  if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_GELU_F8 || EPI == EPI_BIAS_GELU_F8T) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+  if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_GELU_F8 || EPI == EPI_BIAS_GELU_F8T || EPI == EPI_BIAS_RESID_LN)
+    v += *reinterpret_cast<const f32x4*>(g.bias + n);
   f32x4 keep = f32x4{1.f, 1.f, 1.f, 1.f};
   if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_DGELU || EPI == EPI_DGELU_COLSUM || EPI == EPI_BIAS_GELU_F8T) {
     if (g.drop.thresh) {
@@ -242,6 +256,10 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& g, int m, in
   } else if constexpr (EPI == EPI_BIAS_RESID) {
     v = v * keep + *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
     *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
+  } else if constexpr (EPI == EPI_BIAS_RESID_LN) {
+    v += *reinterpret_cast<const f32x4*>((const float*)g.aux_in + (long)m * g.ld_aux_in + n);
+    *reinterpret_cast<f32x4*>((float*)g.C + (long)m * g.ldc + n) = v;
+    *reinterpret_cast<r16x4*>((r16*)g.aux_out + (long)m * g.ld_aux_out + n) = cvt4<T>(v[0], v[1], v[2], v[3]);      // (the row statistics: epilogue_lds)
   } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DGELU_COLSUM) {
     const f32x4 u = dec4<T>(*reinterpret_cast<const r16x4*>((const r16*)g.aux_in + (long)m * g.ld_aux_in + n));
     const r16x4 o = cvt4<T>(v[0] * keep[0] * gelu_grad_f(u[0]), v[1] * keep[1] * gelu_grad_f(u[1]),
@@ -322,19 +340,74 @@ __device__ __forceinline__ void epilogue_lds_adamw(const char* ctile, const Gemm
   }
 }
 
+// (mu, rstd) of row m from the partial statistics of its 128-column tiles: pairwise merge of (count, mean, M2) - Chan et al. - in tile order
+__device__ __forceinline__ void ln_row_stats(const GemmArgs& g, int m, float& mu, float& rstd) {
+  float mean = 0.f, m2 = 0.f, n = 0.f;
+  for (int t = 0; t < g.ln_tiles; ++t) {
+    const float nt = (float)min(128, g.K - 128 * t);
+    const float mt = g.ln_stats[((long)t * g.M + m) * 2], qt = g.ln_stats[((long)t * g.M + m) * 2 + 1];
+    const float tot = n + nt, delta = mt - mean;
+    mean += delta * (nt / tot);
+    m2 += qt + delta * delta * (n * nt / tot);
+    n = tot;
+  }
+  mu = mean;
+  rstd = 1.0f / sqrtf(m2 / (float)g.K + g.ln_eps);
+}
+
 template <int EPI, typename T, int BM, int BN, int NT>
 __device__ __forceinline__ void epilogue_lds(char* ctile, const GemmArgs& g, int m0, int n0, int tid) {
   if constexpr (EPI == EPI_ADAMW) { epilogue_lds_adamw<T, BM, BN, NT>(ctile, g, m0, n0, tid); return; }
   constexpr int CPR = BN / 4;                 // 16-byte chunks per row
   static_assert(NT % CPR == 0 && 64 % CPR == 0, "every thread keeps one column group");
+  constexpr bool FOLD = (EPI == EPI_LNFOLD_STORE || EPI == EPI_LNFOLD_GELU);
+  float* scr = reinterpret_cast<float*>(ctile + BM * cpitch<BN>());       // scratch behind the parked tile (column sums / row statistics)
+  if constexpr (FOLD) {
+    static_assert(BM * 8 <= colsum_scratch_bytes<BM, BN, NT>(), "row statistics fit in the scratch behind the tile");
+    for (int r = tid; r < BM; r += NT) {
+      float mu = 0.f, rstd = 0.f;
+      if (m0 + r < g.M) ln_row_stats(g, m0 + r, mu, rstd);
+      scr[2 * r] = mu; scr[2 * r + 1] = rstd;
+    }
+    __syncthreads();
+  }
   f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
   for (int c = tid; c < BM * CPR; c += NT) {
     const int row = c / CPR, col = (c % CPR) * 4;
     const int m = m0 + row, n = n0 + col;
     if (m < g.M && n < g.N) {
-      const f32x4 r = epilogue4<EPI, T>(*reinterpret_cast<const f32x4*>(ctile + row * cpitch<BN>() + col * 4), g, m, n);
-      if constexpr (EPI == EPI_DGELU_COLSUM) csum += r;
+      f32x4* cell = reinterpret_cast<f32x4*>(ctile + row * cpitch<BN>() + col * 4);
+      if constexpr (FOLD) {
+        const float mu = scr[2 * row], rstd = scr[2 * row + 1];
+        const f32x4 y = (*cell - mu * *reinterpret_cast<const f32x4*>(g.ln_cs + n)) * rstd + *reinterpret_cast<const f32x4*>(g.bias + n);
+        if constexpr (EPI == EPI_LNFOLD_GELU) *reinterpret_cast<r16x4*>((r16*)g.C + (long)m * g.ldc + n) = cvt4<T>(gelu_f(y[0]), gelu_f(y[1]), gelu_f(y[2]), gelu_f(y[3]));
+        else *reinterpret_cast<r16x4*>((r16*)g.C + (long)m * g.ldc + n) = cvt4<T>(y[0], y[1], y[2], y[3]);
+      } else {
+        const f32x4 r = epilogue4<EPI, T>(*cell, g, m, n);
+        if constexpr (EPI == EPI_DGELU_COLSUM) csum += r;
+        if constexpr (EPI == EPI_BIAS_RESID_LN) *cell = r;        // the finished row values, for the statistics below
+      }
+    }
+  }
+  if constexpr (EPI == EPI_BIAS_RESID_LN) {
+    // statistics of this tile's columns of every row: eight lanes per row (BN / 8 columns each), two passes over the LDS copy (mean, then squared deviations)
+    static_assert(BN == 128 && NT % 8 == 0, "the consumer merges 128-column partials");
+    __syncthreads();
+    const int ncols = min(BN, g.N - n0);                                   // N % 8 == 0: whole 8-column pieces
+    float* out = (float*)g.aux_out2 + ((long)(n0 / BN) * g.M) * 2;
+    for (int w = tid; w < BM * 8; w += NT) {
+      const int row = w >> 3, c0 = (w & 7) * (BN / 8);
+      const float* x = reinterpret_cast<const float*>(ctile + row * cpitch<BN>()) + c0;
+      const int nv = min(BN / 8, max(0, ncols - c0));
+      float sum = 0.f;
+      for (int j = 0; j < nv; ++j) sum += x[j];
+      sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+      const float mean = sum / (float)ncols;
+      float q = 0.f;
+      for (int j = 0; j < nv; ++j) { const float dlt = x[j] - mean; q = __builtin_fmaf(dlt, dlt, q); }
+      q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+      if ((w & 7) == 0 && m0 + row < g.M) { out[(long)(m0 + row) * 2] = mean; out[(long)(m0 + row) * 2 + 1] = q; }
     }
   }
   if constexpr (EPI == EPI_DGELU_COLSUM) {
@@ -345,7 +418,6 @@ __device__ __forceinline__ void epilogue_lds(char* ctile, const GemmArgs& g, int
       csum[0] += __shfl_xor(csum[0], o, 64); csum[1] += __shfl_xor(csum[1], o, 64);
       csum[2] += __shfl_xor(csum[2], o, 64); csum[3] += __shfl_xor(csum[3], o, 64);
     }
-    float* scr = reinterpret_cast<float*>(ctile + BM * cpitch<BN>());
     const int lane = tid & 63, wave = tid >> 6;
     if (lane < CPR) *reinterpret_cast<f32x4*>(scr + wave * BN + lane * 4) = csum;
     __syncthreads();

@@ -417,6 +417,9 @@ static int launch_pp_fmt(int layout, int epi, const GemmArgs& a, hipStream_t s) 
     case 0 * 16 + EPI_BIAS_F32: return launch_pp_t<T, false, false, EPI_BIAS_F32>(a, s);
     case 0 * 16 + EPI_BIAS_GELU: return launch_pp_t<T, false, false, EPI_BIAS_GELU>(a, s);
     case 0 * 16 + EPI_BIAS_RESID: return launch_pp_t<T, false, false, EPI_BIAS_RESID>(a, s);
+    case 0 * 16 + EPI_BIAS_RESID_LN: return launch_pp_t<T, false, false, EPI_BIAS_RESID_LN>(a, s);
+    case 0 * 16 + EPI_LNFOLD_STORE: return launch_pp_t<T, false, false, EPI_LNFOLD_STORE>(a, s);
+    case 0 * 16 + EPI_LNFOLD_GELU: return launch_pp_t<T, false, false, EPI_LNFOLD_GELU>(a, s);
     case 1 * 16 + EPI_STORE_BF16: return launch_pp_t<T, false, true, EPI_STORE_BF16>(a, s);
     case 1 * 16 + EPI_STORE_F32: return launch_pp_t<T, false, true, EPI_STORE_F32>(a, s);
     case 1 * 16 + EPI_DGELU: return launch_pp_t<T, false, true, EPI_DGELU>(a, s);

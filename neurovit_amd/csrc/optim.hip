@@ -299,6 +299,38 @@ extern "C" int nv_copy_2d_f32(const float* src, long ld_src, int rows, int cols,
   return NV_OK;
 }
 
+// ---- LayerNorm folded into the Linear behind it (inference forwards): Wg16[n, k] = T(W[n, k] gamma[k]); colsum[n] = sum_k of the ROUNDED Wg16[n, k] (what the MFMA
+// will really multiply the row mean with); fbias[n] = sum_k W[n, k] beta[k] (+ bias[n]).  One wave per output row.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fold_weight_kernel(const float* __restrict__ W, long ldw, int N, int K, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ bias, r16* __restrict__ Wg, long ldg,
+                                                             float* __restrict__ colsum, float* __restrict__ fbias) {
+  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float cs = 0.f, fb = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)n * ldw + k);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + k), b = *reinterpret_cast<const f32x4*>(beta + k);
+    const r16x4 q = cvt4<T>(w[0] * g[0], w[1] * g[1], w[2] * g[2], w[3] * g[3]);
+    *reinterpret_cast<r16x4*>(Wg + (long)n * ldg + k) = q;
+    const f32x4 qf = dec4<T>(q);
+    cs += (qf[0] + qf[1]) + (qf[2] + qf[3]);
+    fb += (w[0] * b[0] + w[1] * b[1]) + (w[2] * b[2] + w[3] * b[3]);
+  }
+  cs = wave_sum(cs); fb = wave_sum(fb);
+  if (lane == 0) { colsum[n] = cs; fbias[n] = fb + (bias ? bias[n] : 0.f); }
+}
+extern "C" int nv_ln_fold_weight(const float* W, long ldw, int N, int K, const float* gamma, const float* beta, const float* bias, void* Wg16, long ldg,
+                                 float* colsum, float* fbias, void* stream) {
+  NV_CHECK_ARG(W && gamma && beta && Wg16 && colsum && fbias && N > 0 && K > 0 && (K % 4) == 0 && (ldw % 4) == 0 && (ldg % 4) == 0 && ldw >= K && ldg >= K,
+               "nv_ln_fold_weight: K, ldw, ldg must be multiples of 4");
+  NV_CHECK_ARG(nv_aligned16(W) && nv_aligned16(gamma) && nv_aligned16(beta) && ((uintptr_t)Wg16 & 7) == 0, "nv_ln_fold_weight: alignment");
+  NV_DISPATCH_OPERAND(T, hipLaunchKernelGGL(ln_fold_weight_kernel<T>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, gamma, beta, bias, (r16*)Wg16, ldg,
+                                            colsum, fbias));
+  NV_CHECK_LAUNCH("nv_ln_fold_weight");
+  return NV_OK;
+}
+
 // ---- dynamic loss scale: torch.amp.GradScaler (src/Trainer.py:29,74-76: scaler.scale(loss).backward(); scaler.step(optimizer);
 // scaler.update()) for training on fp16 operands, kept ENTIRELY on the device - the reference's scaler.step() reads found_inf back
 // to the host every step.  State block: NV_LOSS_SCALE_FLOATS floats (indices LS_*, common.h).  Per optimizer step:

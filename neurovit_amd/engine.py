@@ -142,6 +142,44 @@ class VitRuntime:
         self._dropout = dropout
         return logits
 
+    # ------------------------------------------------------------------ inference forward with the LayerNorms folded into the GEMMs around them
+    def lnfold_prepare(self, params: torch.Tensor, reuse=None):
+        """W_qkv diag(gamma1) / W_1 diag(gamma2) of every block in the operand format (an arena with the parameter arena's element offsets), their
+        column sums and the folded biases (nv_vit_lnfold_prepare).  reuse: a dict this function returned earlier - overwritten in place."""
+        _cabi.set_operand_format(self.operands)
+        n32 = lib.nv_vit_lnfold_floats(ctypes.byref(self.cfg))
+        if n32 < 0:
+            check(-1, "nv_vit_lnfold_floats")
+        dt = torch.float16 if self.operands == "fp16" else torch.bfloat16
+        if reuse is not None and reuse["fold16"].numel() == params.numel() and reuse["fold16"].dtype == dt and reuse["fold16"].device == params.device:
+            f16, f32 = reuse["fold16"], reuse["fold32"]
+        else:
+            f16 = torch.zeros(params.numel(), dtype=dt, device=params.device)
+            f32 = torch.empty(n32, dtype=torch.float32, device=params.device)
+        check(lib.nv_vit_lnfold_prepare(ctypes.byref(self.cfg), params.data_ptr(), f16.data_ptr(), f32.data_ptr(), torch.cuda.current_stream().cuda_stream),
+              "nv_vit_lnfold_prepare")
+        return dict(fold16=f16, fold32=f32)
+
+    def forward_lnfold(self, video: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, fold, vol_sigma=None, time_points: int = 0,
+                       rows_form: Optional[int] = None) -> torch.Tensor:
+        """Inference forward (no dropout) whose blocks run without LayerNorm launches: nv_vit_forward_lnfold."""
+        rows_form = self.rows_form if rows_form is None else int(rows_form)
+        _cabi.set_operand_format(self.operands)
+        B, inp = self._input_form(video, vol_sigma, time_points, rows_form)
+        ws = self.workspace(B, False, video.device)
+        logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
+        check(lib.nv_vit_forward_lnfold(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
+                                        None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p), params.data_ptr(), params16.data_ptr(),
+                                        fold["fold16"].data_ptr(), fold["fold32"].data_ptr(), ws.data_ptr(), ws.numel(), logits.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "nv_vit_forward_lnfold")
+        self._keep = (vol_sigma, inp)
+        self._rows_form = rows_form
+        self._last = (B, False, ws, video)
+        self.generation += 1
+        self.backward_done = False
+        self._dropout = (0.0, 0.0, 0)
+        return logits
+
     # ------------------------------------------------------------------ fp32 inference (the reference's fp32 validate, Trainer.py:101-118)
     def forward_f32(self, video: torch.Tensor, params: torch.Tensor, vol_sigma=None, time_points: int = 0) -> torch.Tensor:
         """Inference forward with every operand in fp32 (weights straight from the fp32 arena, contractions on the fp32 MFMA):

@@ -537,3 +537,38 @@ def temporal_head_bwd(x: torch.Tensor, params: torch.Tensor, ff: int, dout: torc
     check(lib.nv_temporal_head_bwd(_p(x), B, T, int(ff), _p(params), eps, int(drop_seed), float(drop_p), _p(dout), _p(grads), int(bool(accumulate)),
                                    _p(dx), _stream()), "nv_temporal_head_bwd")
     return dx
+
+
+def ln_fold_weight(W: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """(Wg16 = op16(W diag(gamma)), colsum of the rounded Wg16 rows, folded bias W beta (+ bias)): the Linear behind a LayerNorm, folded (nv_ln_fold_weight)."""
+    _need_cuda(W)
+    N, K = W.shape
+    Wg = torch.empty((N, K), dtype=op16(), device=W.device)
+    cs = torch.empty(N, dtype=torch.float32, device=W.device)
+    fb = torch.empty(N, dtype=torch.float32, device=W.device)
+    check(lib.nv_ln_fold_weight(_p(W), W.stride(0), N, K, _p(gamma), _p(beta), _p(bias), _p(Wg), Wg.stride(0), _p(cs), _p(fb), _stream()), "nv_ln_fold_weight")
+    return Wg, cs, fb
+
+
+def gemm_resid_ln(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, resid: torch.Tensor):
+    """x = resid + (A W^T + bias) as f32, the same rows in the operand format, and the per-tile row statistics (nv_gemm_resid_ln)."""
+    _need_cuda(A, W)
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    out16 = torch.empty((M, N), dtype=op16(), device=A.device)
+    stats = torch.empty(lib.nv_ln_fold_stats_floats(M, N), dtype=torch.float32, device=A.device)
+    check(lib.nv_gemm_resid_ln(M, N, K, _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(resid), resid.stride(0), _p(out), out.stride(0), _p(out16), out16.stride(0),
+                               _p(stats), _stream()), "nv_gemm_resid_ln")
+    return out, out16, stats
+
+
+def gemm_lnfold(X16: torch.Tensor, Wg16: torch.Tensor, stats: torch.Tensor, colsum: torch.Tensor, fbias: torch.Tensor, gelu: bool = False, eps: float = 1e-5):
+    """(gelu)(LayerNorm(x) W^T + b) from the un-normalised rows X16, their statistics and the folded weight (nv_gemm_lnfold)."""
+    _need_cuda(X16, Wg16)
+    M, K = X16.shape
+    N = Wg16.shape[0]
+    out = torch.empty((M, N), dtype=op16(), device=X16.device)
+    check(lib.nv_gemm_lnfold(int(gelu), M, N, K, _p(X16), X16.stride(0), _p(Wg16), Wg16.stride(0), _p(stats), _p(colsum), _p(fbias), float(eps), _p(out), out.stride(0),
+                             _stream()), "nv_gemm_lnfold")
+    return out

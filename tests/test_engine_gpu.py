@@ -619,3 +619,44 @@ def test_fp8_train_step_large_geometry_depth2_vs_fp8_emulating_oracle(eng):
         assert abs(losses[i] - lemu) <= 2e-2, (i, losses[i], lemu)          # measured 3.3e-3 ... 9.6e-3
     assert cos > 0.95
     assert all(np.isfinite(losses)) and losses[2] < losses[0]           # it trains
+
+
+@pytest.mark.parametrize("tag,cfgname,seeds,B", [("tiny", "TINY", (3, 4), 8), ("base", "BASE", (5, 6), 1), ("base", "BASE", (1, 2), 2), ("micro", "MICRO", (1, 2), 2)])
+def test_inference_forward_with_folded_layernorms(eng, tag, cfgname, seeds, B):
+    """nv_vit_forward_lnfold: the blocks' LayerNorms folded into the GEMMs around them - 21 of ViT3D-base's 24 LayerNorm launches gone.
+    Same logits as the plain inference forward up to 16-bit rounding points that moved (bf16(x) W_g instead of bf16(LN(x)) W), as close to the fp32 oracle as
+    the plain forward is; the Grad-CAM hook tensor (the last block's attention-LayerNorm output, never folded) still exists; shapes outside the LDS-epilogue
+    kernels (micro) fall back to the plain launches bit for bit."""
+    from neurovit_amd._cabi import lib
+    cfgdict = dict(getattr(W, cfgname))
+    sd = W.make_tensors(W.vit_param_spec(**cfgdict), seeds[0])
+    cfg, off, num, arena = load_arena(eng, cfgdict, sd)
+    params = arena.cuda()
+    p16 = params.to(DT16[OPERANDS])
+    rt = eng.VitRuntime(cfg)
+    rt.operands = OPERANDS
+    S = cfgdict["image_size"]
+    fmri = W.make_volume((B, S, S, S), seeds[1])
+    video = ref_cpu.fmri_to_video(fmri.cuda())
+    ocfg = ref_cpu.ViTCfg(**cfgdict)
+    n, d, L = ocfg.num_patches + 1, ocfg.dim, ocfg.depth
+    plain = rt.forward(video, params, p16, training=False).clone()
+    xn_plain = rt.tap("xn1", L - 1, (B, n, d), DT16[OPERANDS]).float().clone()
+    fold = rt.lnfold_prepare(params)
+    folded = rt.forward_lnfold(video, params, p16, fold).clone()
+    xn_fold = rt.tap("xn1", L - 1, (B, n, d), DT16[OPERANDS]).float().clone()
+    M, inner, m = B * n, ocfg.heads * ocfg.dim_head, ocfg.mlp_dim
+    supported = all(lib.nv_gemm_lnfold_supported(*s) for s in ((M, 3 * inner, d), (M, m, d), (M, d, inner), (M, d, m)))
+    if not supported:
+        assert torch.equal(folded, plain) and torch.equal(xn_fold, xn_plain)
+        return
+    with torch.no_grad():
+        ref32 = ref_cpu.vit_forward(sd, ocfg, ref_cpu.fmri_to_video(fmri[:1]))
+    e_p, e_f, e_pf = rel_err(plain[:1], ref32), rel_err(folded[:1], ref32), rel_err(folded, plain)
+    report(f"{tag} B={B} seeds {seeds} ({OPERANDS}) folded-LayerNorm inference forward: logits vs fp32 oracle {e_f:.3e} (plain launches {e_p:.3e}); folded vs plain {e_pf:.3e}; "
+           f"hook tensor rel-L2 {rel_l2(xn_fold, xn_plain):.2e}")
+    assert not torch.equal(folded, plain)                                  # (it did take the other kernels)
+    assert e_f <= 1.5 * e_p + (2e-3 if OPERANDS == "bf16" else 3e-4), (e_f, e_p)
+    assert e_pf <= (6e-3 if OPERANDS == "bf16" else 1e-3), e_pf
+    assert rel_l2(xn_fold, xn_plain) <= (5e-3 if OPERANDS == "bf16" else 1e-3)
+    assert torch.equal(rt.forward_lnfold(video, params, p16, fold), folded)     # run-to-run deterministic

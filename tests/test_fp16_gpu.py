@@ -468,3 +468,9 @@ def test_static_loss_scale_keeps_the_fused_update_and_changes_no_bit():
         losses[mode] = [float(step(x, y)) for _ in range(3)]
         assert step.last_fuse_update == (3 if mode != "dynamic" else 0) and np.isfinite(losses[mode]).all()
     assert max(abs(a - b) for a, b in zip(losses[1024.0], losses["dynamic"])) < 2e-3, losses
+
+
+def test_folded_layernorm_inference_forward_fp16(eng):
+    """the LayerNorm-folded inference forward on fp16 operands: the un-normalised residual keeps three more bits than in bf16 - inside 1e-3 of the fp32 oracle"""
+    teg.test_inference_forward_with_folded_layernorms(eng, "base", "BASE", (5, 6), 1)
+    teg.test_inference_forward_with_folded_layernorms(eng, "tiny", "TINY", (3, 4), 8)

@@ -956,3 +956,79 @@ def test_zscore_crop_matches_dataset_preprocessing(dtype, four_d):
     # constant volume: std = 0 -> (x - mean) / 1e-8 = 0, no NaN (DatasetADNI.py:213 adds 1e-8 for exactly this)
     const = torch.full((1, 91, 109, 91), 7.0, device="cuda")
     assert torch.count_nonzero(zscore_crop(const)) == 0
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm folded into the GEMMs around it
+def _fold_reference(x, gamma, beta, W, b, gelu):
+    y = F.layer_norm(x.double(), (x.shape[1],), gamma.double(), beta.double(), 1e-5) @ W.double().T
+    if b is not None:
+        y = y + b.double()
+    return F.gelu(y) if gelu else y
+
+
+@pytest.mark.parametrize("M,d,inner,N", [(2052, 768, 768, 2304), (2052, 768, 3072, 3072), (520, 192, 192, 384), (2052, 1024, 512, 2048)])
+def test_layernorm_folded_into_the_gemms_around_it(ops, M, d, inner, N):
+    """the producer of the residual stream (nv_gemm_resid_ln) also writes the rows in bf16 and per-(row, 128-column tile) statistics; the consumer
+    (nv_gemm_lnfold) contracts the UN-normalised rows with W diag(gamma) and applies mu / rstd in its epilogue.  Against float64: the producer's three outputs,
+    the merged statistics, and the consumer's output at the tolerance of the unfolded pair (LayerNorm -> bf16 -> GEMM); d = 192 has a ragged last tile."""
+    from neurovit_amd._cabi import lib
+    if not (lib.nv_gemm_lnfold_supported(M, N, d) and lib.nv_gemm_lnfold_supported(M, d, inner)):
+        pytest.skip("shape outside the LDS-epilogue kernels")
+    A, Wp, bp = bf(rnd(M, inner, seed=1)), bf(rnd(d, inner, seed=2, scale=inner ** -0.5)), rnd(d, seed=3)
+    resid = rnd(M, d, seed=4) * 2 + 0.5 * rnd(M, 1, seed=5)              # a residual stream whose rows have their own offsets
+    out, out16, stats = ops.gemm_resid_ln(dev(A), dev(Wp), dev(bp), dev(resid))
+    x = resid.double() + A.double() @ Wp.double().T + bp.double()
+    assert_close_f32(out, x, "resid_ln.out", 1e-5)
+    assert torch.equal(out16.cpu(), out.cpu().to(torch.bfloat16))
+    # merged statistics (Chan's update, as the consumer's epilogue does it) against float64
+    tiles = (d + 127) // 128
+    st = stats.cpu().double().reshape(tiles, M, 2)
+    mean, m2, n = torch.zeros(M, dtype=torch.float64), torch.zeros(M, dtype=torch.float64), 0.0
+    for t in range(tiles):
+        nt = float(min(128, d - 128 * t))
+        delta = st[t, :, 0] - mean
+        mean = mean + delta * nt / (n + nt)
+        m2 = m2 + st[t, :, 1] + delta * delta * n * nt / (n + nt)
+        n += nt
+    assert_close_f32(mean, x.mean(1), "merged mean", 2e-5)
+    assert_close_f32(m2 / d, x.var(1, unbiased=False), "merged variance", 2e-5)
+    gamma, beta = 1 + 0.1 * rnd(d, seed=6), 0.1 * rnd(d, seed=7)
+    Wc, bc = rnd(N, d, seed=8, scale=d ** -0.5), 0.1 * rnd(N, seed=9)
+    for gelu, bias in ((False, None), (True, bc)):
+        Wg, cs, fb = ops.ln_fold_weight(dev(Wc), dev(gamma), dev(beta), None if bias is None else dev(bias))
+        assert torch.equal(Wg.cpu(), (Wc * gamma).to(torch.bfloat16))
+        assert_close_f32(cs, (Wc * gamma).to(torch.bfloat16).double().sum(1), "colsum", 1e-5)
+        assert_close_f32(fb, Wc.double() @ beta.double() + (0 if bias is None else bias.double()), "folded bias", 1e-5)
+        y = ops.gemm_lnfold(out16, Wg, stats, cs, fb, gelu=gelu)
+        ref = _fold_reference(out.cpu(), gamma, beta, Wc, bias, gelu)
+        assert_close_stat(y, ref, f"lnfold gelu={gelu}")
+        # ... and it is as close to float64 as the launches it replaces
+        xn, _ = ops.ln_fwd(out, dev(gamma), dev(beta))
+        plain = ops.gemm(ops.NT, ops.EPI_BIAS_GELU if gelu else ops.EPI_STORE_BF16, xn, dev(bf(Wc)), bias=None if bias is None else dev(bias)) if (gelu or bias is None) else None
+        if plain is not None:
+            e_fold, e_plain = rel_l2(y.float(), ref), rel_l2(plain.float(), ref)
+            assert e_fold <= 1.5 * e_plain + 1e-4, (e_fold, e_plain)
+
+
+def test_layernorm_fold_error_grows_with_the_row_offset_and_stays_inside_its_bound(ops):
+    """The fold is exact algebra; in 16-bit operands its rounding error relative to the unfolded pair grows with |mean| / std of a residual row (x is rounded BEFORE
+    the mean is taken out: SURVEY 7.3 item 3's cancellation).  Rows of the transformer's residual stream sit at |mean| / std < 1; the bound
+    2^-8 sqrt(1 + (mean / std)^2) is asserted up to 16, and a constant row (std = 0: rstd = 1 / sqrt(eps)) stays finite and matches the reference's beta-only output."""
+    M, d, N = 520, 768, 768
+    gamma, beta = 1 + 0.1 * rnd(d, seed=6), 0.1 * rnd(d, seed=7)
+    Wc = rnd(N, d, seed=8, scale=d ** -0.5)
+    Wg, cs, fb = ops.ln_fold_weight(dev(Wc), dev(gamma), dev(beta))
+    zero_a, eye = torch.zeros(M, 64, dtype=torch.bfloat16), torch.zeros(d, 64, dtype=torch.bfloat16)
+    for ratio in (0.0, 1.0, 4.0, 16.0):
+        x = rnd(M, d, seed=11) + ratio
+        out, out16, stats = ops.gemm_resid_ln(dev(zero_a), dev(eye), dev(torch.zeros(d)), dev(x))      # x = resid + 0
+        y = ops.gemm_lnfold(out16, Wg, stats, cs, fb)
+        ref = _fold_reference(x, gamma, beta, Wc, None, False)
+        e = rel_l2(y.float(), ref)
+        report(f"LayerNorm fold, row offset / std = {ratio:g}: rel-L2 {e:.2e} (bound {2.0 ** -8 * (1 + ratio * ratio) ** 0.5:.2e})")
+        assert e <= 2.0 ** -8 * (1 + ratio * ratio) ** 0.5
+    const = torch.full((M, d), 3.0)
+    out, out16, stats = ops.gemm_resid_ln(dev(zero_a), dev(eye), dev(torch.zeros(d)), dev(const))
+    y = ops.gemm_lnfold(out16, Wg, stats, cs, fb).float().cpu()
+    ref = _fold_reference(const, gamma, beta, Wc, None, False)
+    assert torch.isfinite(y).all() and rel_l2(y, ref) < 2e-2
