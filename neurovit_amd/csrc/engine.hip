@@ -373,7 +373,9 @@ static int forward_in_impl(const nv_vit_config* cfg, int B, const float* video, 
   // LayerNorm folded into the GEMMs (inference, no dropout, every one of a block's four shapes on an LDS-epilogue kernel).  Not folded: LN1 of block 0 (its
   // input comes out of embed_finish, not out of a GEMM epilogue), LN1 of the LAST block (its output is the Grad-CAM hook tensor, NeuroEncoder.py:70-75: it
   // must exist), and a last block that runs on its cls rows.  ViT3D-base: 21 of the 24 LayerNorm launches of a forward.
-  const bool fold = fold16 && fold32 && !training && drop_p == 0.f && nv_gemm_lnfold_supported(M, 3 * D.inner, d) && nv_gemm_lnfold_supported(M, D.m, d) &&
+  // (measured, ViT3D-base forward-only, same box, folded / plain: batch 4 +6.5 %, 8 +2.9 %, 20 +1.9 %, 64 +0.6 %; ViT3D-large (16 388 rows: its qkv would leave the
+  //  256 x 256 kernel) -0.6 %: beyond 12 288 rows the plain launches stay)
+  const bool fold = fold16 && fold32 && !training && drop_p == 0.f && M <= 12288 && nv_gemm_lnfold_supported(M, 3 * D.inner, d) && nv_gemm_lnfold_supported(M, D.m, d) &&
                     nv_gemm_lnfold_supported(M, d, D.inner) && nv_gemm_lnfold_supported(M, d, D.m);
   const r16* f16 = (const r16*)fold16;
   const long fper = 6L * D.inner + 2L * D.m;

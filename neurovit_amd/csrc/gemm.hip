@@ -213,7 +213,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, const int bid) {
       fs = (fs + 1 == S) ? 0 : fs + 1;
     }
     __builtin_amdgcn_s_barrier();                       // barrier E: the consumers have parked the C tile in LDS
-    epilogue_lds<EPI, T, BM, BN, WS_THREADS>(smem, g, m0, n0, tid);
+    epilogue_lds<EPI, T, BM, BN, WS_THREADS>(smem, g, m0, n0, tid, reinterpret_cast<const float*>(smem + S * STAGE));
     return;
   }
 
@@ -240,6 +240,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, const int bid) {
 #define SB __builtin_amdgcn_sched_barrier(0);   // pin the phase order: [reads of a later half step][MFMAs of this one]
 #define WS_ADVANCE ci = (ci + 1 == S) ? 0 : ci + 1; cur = nxt; nxt = smem + ((ci + 1 == S) ? 0 : ci + 1) * STAGE;
 
+  if constexpr (epi_is_fold<EPI>()) {                  // row statistics of the folded LayerNorm, while the first stage is on its way (gemm_common.h)
+    ln_rows_to_lds(g, m0, BM, reinterpret_cast<float*>(smem + S * STAGE), tid, 256);
+    ln_cols_to_lds<BM, BN>(g, n0, reinterpret_cast<float*>(smem + S * STAGE), 255 - tid);      // (from the far end: the rows are 64 or 128 threads' work)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();                         // barrier -1
   if constexpr (KS == 1) {
     WS_READ(fa0, fb0, cur, 0)
@@ -299,7 +304,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, const int bid) {
   park_acc<MI, NI, BN>(acc, smem, wm * TM, wn * TN, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw barrier carries no wait: the parked tile must be written first
   __builtin_amdgcn_s_barrier();                         // barrier E
-  epilogue_lds<EPI, T, BM, BN, WS_THREADS>(smem, g, m0, n0, tid);
+  epilogue_lds<EPI, T, BM, BN, WS_THREADS>(smem, g, m0, n0, tid, reinterpret_cast<const float*>(smem + S * STAGE));
 }
 
 template <typename T, int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>
@@ -359,7 +364,7 @@ static int launch_tile(const GemmArgs& a, hipStream_t s) {
 
 template <typename T, int BM, int BN, int S, int KS, bool A_T, bool B_T, int EPI>
 static int launch_ws(const GemmArgs& a, hipStream_t s) {
-  constexpr int LDS = S * KS * (BM + BN) * BK * 2;
+  constexpr int LDS = S * KS * (BM + BN) * BK * 2 + ln_rows_bytes<EPI, BM, BN>();
   static_assert(LDS <= 160 * 1024, "LDS ring too large");
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   auto kern = gemm_ws_kernel<T, BM, BN, S, KS, A_T, B_T, EPI>;

@@ -18,8 +18,8 @@ enum {
   // ---- LayerNorm folded into the GEMMs around it (inference forwards): LN(x) W^T = rstd (x W_g^T) - rstd mu colsum(W_g) + (W beta + b) with
   // W_g = W diag(gamma).  The producer of the residual stream also writes x in the operand format and per-(row, 128-column tile) statistics; the consumer
   // contracts the UN-normalised rows with W_g and applies the row statistics in its epilogue: no LayerNorm launch, no normalised copy.  LDS-epilogue kernels only.
-  EPI_BIAS_RESID_LN = 10,  // EPI_BIAS_RESID (no dropout) + aux_out(16-bit) = the stored row + aux_out2(f32)[tile column][M][2] = (mean, sum of squared deviations) of the
-                           // tile's <= 128 columns of each row (merged pairwise by the consumer: Chan's update - no E[x^2] - E[x]^2 cancellation)
+  EPI_BIAS_RESID_LN = 10,  // EPI_BIAS_RESID (no dropout) + aux_out(16-bit) = the stored row + aux_out2(f32)[tile column][M][2] = partial statistics of the
+                           // tile's <= 128 columns of each row, as (sum, sum of squares) - converted per tile and merged pairwise by the consumer (Chan's update)
   EPI_LNFOLD_STORE = 11,   // C(16-bit) = rstd[m] (acc - mu[m] ln_cs[n]) + bias[n]; (mu, rstd) of row m from ln_stats (ln_tiles partials over K = the LayerNorm width)
   EPI_LNFOLD_GELU = 12,    // C(16-bit) = gelu(the same)
   EPI_ADAMW = 9,        // weight-gradient GEMM that applies torch.optim.AdamW to the weight it differentiates: acc is the gradient of
@@ -340,12 +340,15 @@ __device__ __forceinline__ void epilogue_lds_adamw(const char* ctile, const Gemm
   }
 }
 
-// (mu, rstd) of row m from the partial statistics of its 128-column tiles: pairwise merge of (count, mean, M2) - Chan et al. - in tile order
+// (mu, rstd) of row m from the partial sums (sum, sum of squares) of its 128-column tiles: per tile (count, mean, M2 = ss - s^2 / count), merged pairwise in
+// tile order (Chan et al.).  fp32 single-pass sums over <= 128 values lose ~1e-7 (mean / std)^2 of the variance: nothing at the ratios (< 16) at which
+// rounding x to 16 bits ahead of the subtraction - the fold itself - still works.
 __device__ __forceinline__ void ln_row_stats(const GemmArgs& g, int m, float& mu, float& rstd) {
   float mean = 0.f, m2 = 0.f, n = 0.f;
   for (int t = 0; t < g.ln_tiles; ++t) {
     const float nt = (float)min(128, g.K - 128 * t);
-    const float mt = g.ln_stats[((long)t * g.M + m) * 2], qt = g.ln_stats[((long)t * g.M + m) * 2 + 1];
+    const float st = g.ln_stats[((long)t * g.M + m) * 2], sst = g.ln_stats[((long)t * g.M + m) * 2 + 1];
+    const float mt = st / nt, qt = fmaxf(sst - st * mt, 0.f);
     const float tot = n + nt, delta = mt - mean;
     mean += delta * (nt / tot);
     m2 += qt + delta * delta * (n * nt / tot);
@@ -354,60 +357,80 @@ __device__ __forceinline__ void ln_row_stats(const GemmArgs& g, int m, float& mu
   mu = mean;
   rstd = 1.0f / sqrtf(m2 / (float)g.K + g.ln_eps);
 }
+// EPI_LNFOLD_*: the (mu, rstd) pairs of the workgroup's BM rows, computed by `nthreads` threads (t = 0 .. nthreads-1) into LDS at the START of the kernel, while
+// the first operand tiles are still on their way - at the tail, in front of the epilogue, the dependent global loads were 2-3 us of exposed latency per launch
+__device__ __forceinline__ void ln_rows_to_lds(const GemmArgs& g, int m0, int BM, float* dst, int t, int nthreads) {
+  for (int r = t; r < BM; r += nthreads) {
+    float mu = 0.f, rstd = 0.f;
+    if (m0 + r < g.M) ln_row_stats(g, m0 + r, mu, rstd);
+    dst[2 * r] = mu; dst[2 * r + 1] = rstd;
+  }
+}
+// sum over the 32 lanes of a half-wave on the VALU: DPP inside a row of 16 (quad xor 1, quad xor 2, row_half_mirror, row_mirror), then the two rows of the
+// half-wave with v_permlane16_swap (gfx950) - five ds_bpermute round trips per value through __shfl_xor otherwise
+__device__ __forceinline__ float dpp_fold(float v, const int ctrl_sel) {
+  int o;
+  if (ctrl_sel == 0) o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true);         // quad_perm [1, 0, 3, 2]
+  else if (ctrl_sel == 1) o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true);    // quad_perm [2, 3, 0, 1]
+  else if (ctrl_sel == 2) o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true);   // row_half_mirror
+  else o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true);                      // row_mirror
+  return v + __builtin_bit_cast(float, o);
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v = dpp_fold(v, 0); v = dpp_fold(v, 1); v = dpp_fold(v, 2); v = dpp_fold(v, 3);
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));      // (wait states on both sides: the asm is outside the compiler's hazard bookkeeping) (a, b) = the values of lanes l & ~16 and l | 16 (attention.hip::lane_pair16)
+  return a + b;
+}
+
+template <int EPI> constexpr bool epi_is_fold() { return EPI == EPI_LNFOLD_STORE || EPI == EPI_LNFOLD_GELU; }
+// LDS behind the ring, alive for the whole kernel: (mu, rstd) of the BM rows, then colsum and folded bias of the tile's BN columns
+template <int EPI, int BM, int BN = 128> constexpr int ln_rows_bytes() { return epi_is_fold<EPI>() ? BM * 8 + BN * 8 : 0; }
+// the tile's BN entries of ln_cs and of the folded bias into LDS behind the row statistics (threads t = 0 .. BN / 2 - 1 of the caller: one f32x4 each)
+template <int BM, int BN>
+__device__ __forceinline__ void ln_cols_to_lds(const GemmArgs& g, int n0, float* lnrow, int t) {
+  if (t < BN / 2) {
+    const int which = t / (BN / 4), n = n0 + (t % (BN / 4)) * 4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n < g.N) v = *reinterpret_cast<const f32x4*>((which ? g.bias : g.ln_cs) + n);
+    *reinterpret_cast<f32x4*>(lnrow + 2 * BM + which * BN + (t % (BN / 4)) * 4) = v;
+  }
+}
 
 template <int EPI, typename T, int BM, int BN, int NT>
-__device__ __forceinline__ void epilogue_lds(char* ctile, const GemmArgs& g, int m0, int n0, int tid) {
+__device__ __forceinline__ void epilogue_lds(char* ctile, const GemmArgs& g, int m0, int n0, int tid, const float* lnrow = nullptr) {
   if constexpr (EPI == EPI_ADAMW) { epilogue_lds_adamw<T, BM, BN, NT>(ctile, g, m0, n0, tid); return; }
   constexpr int CPR = BN / 4;                 // 16-byte chunks per row
   static_assert(NT % CPR == 0 && 64 % CPR == 0, "every thread keeps one column group");
-  constexpr bool FOLD = (EPI == EPI_LNFOLD_STORE || EPI == EPI_LNFOLD_GELU);
-  float* scr = reinterpret_cast<float*>(ctile + BM * cpitch<BN>());       // scratch behind the parked tile (column sums / row statistics)
-  if constexpr (FOLD) {
-    static_assert(BM * 8 <= colsum_scratch_bytes<BM, BN, NT>(), "row statistics fit in the scratch behind the tile");
-    for (int r = tid; r < BM; r += NT) {
-      float mu = 0.f, rstd = 0.f;
-      if (m0 + r < g.M) ln_row_stats(g, m0 + r, mu, rstd);
-      scr[2 * r] = mu; scr[2 * r + 1] = rstd;
-    }
-    __syncthreads();
-  }
+  constexpr bool FOLD = epi_is_fold<EPI>();
+  float* scr = reinterpret_cast<float*>(ctile + BM * cpitch<BN>());       // scratch behind the parked tile (column sums)
   f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};
+  static_assert(EPI != EPI_BIAS_RESID_LN || ((BM * CPR) % 64 == 0 && NT % 64 == 0 && CPR == 32 && BN == 128), "whole waves leave the loop together; 32 lanes share a row");
 #pragma unroll 4
   for (int c = tid; c < BM * CPR; c += NT) {
     const int row = c / CPR, col = (c % CPR) * 4;
     const int m = m0 + row, n = n0 + col;
+    f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
     if (m < g.M && n < g.N) {
-      f32x4* cell = reinterpret_cast<f32x4*>(ctile + row * cpitch<BN>() + col * 4);
+      const f32x4 cell = *reinterpret_cast<const f32x4*>(ctile + row * cpitch<BN>() + col * 4);
       if constexpr (FOLD) {
-        const float mu = scr[2 * row], rstd = scr[2 * row + 1];
-        const f32x4 y = (*cell - mu * *reinterpret_cast<const f32x4*>(g.ln_cs + n)) * rstd + *reinterpret_cast<const f32x4*>(g.bias + n);
+        const float mu = lnrow[2 * row], rstd = lnrow[2 * row + 1];
+        const f32x4 y = (cell - mu * *reinterpret_cast<const f32x4*>(lnrow + 2 * BM + col)) * rstd + *reinterpret_cast<const f32x4*>(lnrow + 2 * BM + BN + col);
         if constexpr (EPI == EPI_LNFOLD_GELU) *reinterpret_cast<r16x4*>((r16*)g.C + (long)m * g.ldc + n) = cvt4<T>(gelu_f(y[0]), gelu_f(y[1]), gelu_f(y[2]), gelu_f(y[3]));
         else *reinterpret_cast<r16x4*>((r16*)g.C + (long)m * g.ldc + n) = cvt4<T>(y[0], y[1], y[2], y[3]);
       } else {
-        const f32x4 r = epilogue4<EPI, T>(*cell, g, m, n);
+        r = epilogue4<EPI, T>(cell, g, m, n);
         if constexpr (EPI == EPI_DGELU_COLSUM) csum += r;
-        if constexpr (EPI == EPI_BIAS_RESID_LN) *cell = r;        // the finished row values, for the statistics below
       }
     }
-  }
-  if constexpr (EPI == EPI_BIAS_RESID_LN) {
-    // statistics of this tile's columns of every row: eight lanes per row (BN / 8 columns each), two passes over the LDS copy (mean, then squared deviations)
-    static_assert(BN == 128 && NT % 8 == 0, "the consumer merges 128-column partials");
-    __syncthreads();
-    const int ncols = min(BN, g.N - n0);                                   // N % 8 == 0: whole 8-column pieces
-    float* out = (float*)g.aux_out2 + ((long)(n0 / BN) * g.M) * 2;
-    for (int w = tid; w < BM * 8; w += NT) {
-      const int row = w >> 3, c0 = (w & 7) * (BN / 8);
-      const float* x = reinterpret_cast<const float*>(ctile + row * cpitch<BN>()) + c0;
-      const int nv = min(BN / 8, max(0, ncols - c0));
-      float sum = 0.f;
-      for (int j = 0; j < nv; ++j) sum += x[j];
-      sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
-      const float mean = sum / (float)ncols;
-      float q = 0.f;
-      for (int j = 0; j < nv; ++j) { const float dlt = x[j] - mean; q = __builtin_fmaf(dlt, dlt, q); }
-      q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
-      if ((w & 7) == 0 && m0 + row < g.M) { out[(long)(m0 + row) * 2] = mean; out[(long)(m0 + row) * 2 + 1] = q; }
+    if constexpr (EPI == EPI_BIAS_RESID_LN) {
+      // sum and sum of squares of this tile's columns of the row: the 32 lanes of a half-wave hold one row (4 finished values each; zeros beyond N / M)
+      float s1 = (r[0] + r[1]) + (r[2] + r[3]), s2 = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+      s1 = half_wave_sum(s1); s2 = half_wave_sum(s2);
+      if ((tid & 31) == 0 && m < g.M) {
+        float* out = (float*)g.aux_out2 + ((long)(n0 / BN) * g.M + m) * 2;
+        out[0] = s1; out[1] = s2;
+      }
     }
   }
   if constexpr (EPI == EPI_DGELU_COLSUM) {

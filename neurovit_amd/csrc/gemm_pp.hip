@@ -107,7 +107,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
   constexpr int MH = MI / 2;                  // m-tiles per half
   constexpr int NP = 4 * NSUB;                // DMA pieces per loader wave per K tile
   static_assert(2 * NP <= 63, "vmcnt range");
-  static_assert(PP_S * STAGE <= 160 * 1024 && BM * cpitch<BN>() + colsum_scratch_bytes<BM, BN, PP_THREADS>() <= PP_S * STAGE, "LDS budget");
+  static_assert(PP_S * STAGE + ln_rows_bytes<EPI, BM, BN>() <= 160 * 1024 && BM * cpitch<BN>() + colsum_scratch_bytes<BM, BN, PP_THREADS>() <= PP_S * STAGE, "LDS budget");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Tile order: each XCD (private 4 MiB L2) owns a contiguous run of logical ids (xcd_remap) and its 32 CUs hold 32 consecutive
@@ -167,7 +167,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
     }
     __builtin_amdgcn_s_barrier();                                  // B_nk: every fragment read has returned
     __builtin_amdgcn_s_barrier();                                  // accumulators parked
-    epilogue_lds<EPI, T, BM, BN, PP_THREADS>(smem, g, m0, n0, tid);
+    epilogue_lds<EPI, T, BM, BN, PP_THREADS>(smem, g, m0, n0, tid, reinterpret_cast<const float*>(smem + PP_S * STAGE));
     return;
   }
 
@@ -228,6 +228,11 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
                                                                      0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);                         \
   }
 
+  if constexpr (epi_is_fold<EPI>()) {                  // row statistics of the folded LayerNorm, while the first K tile is on its way (gemm_common.h)
+    ln_rows_to_lds(g, m0, BM, reinterpret_cast<float*>(smem + PP_S * STAGE), tid, 64 * PP_CWAVES);
+    ln_cols_to_lds<BM, BN>(g, n0, reinterpret_cast<float*>(smem + PP_S * STAGE), 64 * PP_CWAVES - 1 - tid);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   int slot = 0;
   if (grp == 0) {
     for (int kt = 0; kt < nk; ++kt) {
@@ -289,7 +294,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, const int bid) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  epilogue_lds<EPI, T, BM, BN, PP_THREADS>(smem, g, m0, n0, tid);
+  epilogue_lds<EPI, T, BM, BN, PP_THREADS>(smem, g, m0, n0, tid, reinterpret_cast<const float*>(smem + PP_S * STAGE));
 #endif
 }
 
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_grouped_tn_adamw_kernel
 template <typename T, bool A_T, bool B_T, int EPI>
 int launch_pp_t(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = PP_BM, BN = PP_BN;
-  constexpr int LDS = PP_S * (BM / 128 + BN / 128) * PP_SUB;
+  constexpr int LDS = PP_S * (BM / 128 + BN / 128) * PP_SUB + ln_rows_bytes<EPI, BM, BN>();
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   auto kern = gemm_pp_kernel<T, BM, BN, 4, 2, A_T, B_T, EPI>;
   static bool attr_set = false;

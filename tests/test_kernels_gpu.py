@@ -980,18 +980,19 @@ def test_layernorm_folded_into_the_gemms_around_it(ops, M, d, inner, N):
     x = resid.double() + A.double() @ Wp.double().T + bp.double()
     assert_close_f32(out, x, "resid_ln.out", 1e-5)
     assert torch.equal(out16.cpu(), out.cpu().to(torch.bfloat16))
-    # merged statistics (Chan's update, as the consumer's epilogue does it) against float64
+    # the tile partials (sum, sum of squares), merged as the consumer's prologue does it (per tile -> (mean, M2), then Chan's update), against float64
     tiles = (d + 127) // 128
     st = stats.cpu().double().reshape(tiles, M, 2)
     mean, m2, n = torch.zeros(M, dtype=torch.float64), torch.zeros(M, dtype=torch.float64), 0.0
     for t in range(tiles):
         nt = float(min(128, d - 128 * t))
-        delta = st[t, :, 0] - mean
+        mt = st[t, :, 0] / nt
+        delta = mt - mean
         mean = mean + delta * nt / (n + nt)
-        m2 = m2 + st[t, :, 1] + delta * delta * n * nt / (n + nt)
+        m2 = m2 + (st[t, :, 1] - st[t, :, 0] * mt).clamp_min(0) + delta * delta * n * nt / (n + nt)
         n += nt
     assert_close_f32(mean, x.mean(1), "merged mean", 2e-5)
-    assert_close_f32(m2 / d, x.var(1, unbiased=False), "merged variance", 2e-5)
+    assert_close_f32(m2 / d, x.var(1, unbiased=False), "merged variance", 1e-4)
     gamma, beta = 1 + 0.1 * rnd(d, seed=6), 0.1 * rnd(d, seed=7)
     Wc, bc = rnd(N, d, seed=8, scale=d ** -0.5), 0.1 * rnd(N, seed=9)
     for gelu, bias in ((False, None), (True, bc)):
@@ -1001,7 +1002,7 @@ def test_layernorm_folded_into_the_gemms_around_it(ops, M, d, inner, N):
         assert_close_f32(fb, Wc.double() @ beta.double() + (0 if bias is None else bias.double()), "folded bias", 1e-5)
         y = ops.gemm_lnfold(out16, Wg, stats, cs, fb, gelu=gelu)
         ref = _fold_reference(out.cpu(), gamma, beta, Wc, bias, gelu)
-        assert_close_stat(y, ref, f"lnfold gelu={gelu}")
+        assert rel_l2(y.float(), ref) <= 4e-3 and rel_err(y.float(), ref) <= 2.0 ** -6      # three bf16 roundings (rows, weight, output) against exact float64 inputs
         # ... and it is as close to float64 as the launches it replaces
         xn, _ = ops.ln_fwd(out, dev(gamma), dev(beta))
         plain = ops.gemm(ops.NT, ops.EPI_BIAS_GELU if gelu else ops.EPI_STORE_BF16, xn, dev(bf(Wc)), bias=None if bias is None else dev(bias)) if (gelu or bias is None) else None
@@ -1014,7 +1015,7 @@ def test_layernorm_fold_error_grows_with_the_row_offset_and_stays_inside_its_bou
     """The fold is exact algebra; in 16-bit operands its rounding error relative to the unfolded pair grows with |mean| / std of a residual row (x is rounded BEFORE
     the mean is taken out: SURVEY 7.3 item 3's cancellation).  Rows of the transformer's residual stream sit at |mean| / std < 1; the bound
     2^-8 sqrt(1 + (mean / std)^2) is asserted up to 16, and a constant row (std = 0: rstd = 1 / sqrt(eps)) stays finite and matches the reference's beta-only output."""
-    M, d, N = 520, 768, 768
+    M, d, N = 2052, 768, 768
     gamma, beta = 1 + 0.1 * rnd(d, seed=6), 0.1 * rnd(d, seed=7)
     Wc = rnd(N, d, seed=8, scale=d ** -0.5)
     Wg, cs, fb = ops.ln_fold_weight(dev(Wc), dev(gamma), dev(beta))
