@@ -105,6 +105,8 @@ class _Lib:
                 dll.nv_gemm_set_tile(12, int(os.environ["NEUROVIT_ADAMW_WGS"]))
             if os.environ.get("NEUROVIT_HEAD_STEP"):           # A/B aid: 0 = the native step runs the head as three calls
                 dll.nv_vit_set_head_step(int(os.environ["NEUROVIT_HEAD_STEP"]))
+            if os.environ.get("NEUROVIT_WGRAD_WGS"):           # A/B aid: workgroups of the grouped weight-gradient launch
+                dll.nv_gemm_set_tile(14, int(os.environ["NEUROVIT_WGRAD_WGS"]))
             if os.environ.get("NEUROVIT_ADAMW_CAP"):
                 dll.nv_gemm_set_tile(13, int(os.environ["NEUROVIT_ADAMW_CAP"]))
             self._dll = dll

@@ -335,6 +335,7 @@ extern "C" int nv_gemm_set_tile(int bm, int bn) {   // tuning aid (tools/gemm_be
   if (bm == 10) { g_pq_min_tiles = bn; return 0; }
   if (bm == 11) { g_pp_w32 = bn ? 1 : 0; return 0; }     // NT problems of the 256 x 128 kernel on 32 x 32 x 16 MFMAs
   if (bm == 12) { g_pp_adamw_wgs = bn > 0 ? bn : 0; return 0; }     // workgroups of nv_gemm_bf16_grouped_adamw (0 = one per tile)
+  if (bm == 14) { g_pp_wgrad_wgs = bn > 0 ? bn : 0; return 0; }      // workgroups of the grouped weight-gradient launch (0 = one per tile)
   if (bm == 13) { extern int g_adamw_ranges_cap; g_adamw_ranges_cap = bn > 0 ? bn : 0; return 0; }
   const bool small = (bm == 64 && (bn == 64 || bn == 128)) || (bm == 128 && bn == 128);
   NV_CHECK_ARG(bm == 0 || bm == 1 || (bm >= 3 && bm <= 5) || bm == 9 || small, "nv_gemm_set_tile: (%d, %d) is not a compiled tile", bm, bn);

@@ -12,3 +12,4 @@ int launch_pp_grouped_tn(const GemmGroup& G, int tiles, double flops, hipStream_
 extern int g_pp_dbg;
 extern int g_pp_w32;
 extern int g_pp_adamw_wgs;
+extern int g_pp_wgrad_wgs;

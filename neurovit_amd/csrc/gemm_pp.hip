@@ -318,10 +318,15 @@ __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_dbg_kernel(const GemmAr
 // grouped weight gradients (TN, fp32 store / accumulate)
 template <typename T>
 __global__ __launch_bounds__(PP_THREADS, 3) void gemm_pp_grouped_tn_kernel(const GemmGroup G) {
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  int p = 0;
-  while (p + 1 < G.count && bid >= G.tile_end[p]) ++p;      // workgroup-uniform
-  gemm_pp_body<T, PP_BM, PP_BN, 4, 2, true, true, EPI_STORE_F32>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
+  // a workgroup walks tiles bid, bid + grid, ...: one tile each by default; with fewer workgroups than tiles (g_pp_wgrad_wgs) the launch holds that many
+  // CUs - each of them completely: 12 waves x <= 168 VGPRs fill a CU's register file - and leaves the rest to the other stream's kernels
+  const int total = G.tile_end[GROUP_MAX - 1];
+  for (int bid = xcd_remap(blockIdx.x, gridDim.x); bid < total; bid += gridDim.x) {
+    int p = 0;
+    while (p + 1 < G.count && bid >= G.tile_end[p]) ++p;      // workgroup-uniform
+    gemm_pp_body<T, PP_BM, PP_BN, 4, 2, true, true, EPI_STORE_F32>(G.p[p], bid - (p ? G.tile_end[p - 1] : 0));
+    if (bid + (int)gridDim.x < total) __syncthreads();          // the parked tile has been consumed before the next tile's first DMA lands on it
+  }
 }
 
 // the same with the AdamW update of the differentiated weights in the epilogue (EPI_ADAMW)
@@ -364,6 +369,7 @@ int launch_pp_t(const GemmArgs& a, hipStream_t s) {
 // batch 4, same box, volumes/s of the train step - one per tile (216) 1107, 144: 1082, 136: 1108, 128: 1122, 120: 1123, 112: 1124,
 // 108: 1133 against 1140 for 128 on another box, 96: 1055, 72: 1078; update unfused 1094 (profiles/r04_adamw_in_wgrad_epilogue.log)
 int g_pp_adamw_wgs = 128;
+int g_pp_wgrad_wgs = 0;      // workgroups of the plain grouped weight-gradient launch (0 = one per tile); nv_gemm_set_tile(14, n)
 int g_pp_w32 = 0;   // NT problems on the 32 x 32 x 16 MFMA form of the kernel (nv_gemm_set_tile(11, 0 | 1))
 template <typename T, int EPI>
 static int launch_pp_w32_t(const GemmArgs& a, hipStream_t s) {
@@ -488,7 +494,8 @@ static int launch_pp_grouped_tn_fmt(const GemmGroup& G, int tiles, double flops,
     for (int i = 0; i < G.count; ++i) bytes += gemm_algo_bytes(G.p[i], adamw ? EPI_ADAMW : EPI_STORE_F32, 2);
     nv_prof_bytes(slot, bytes);
   }
-  const int wgs = (adamw && g_pp_adamw_wgs > 0 && g_pp_adamw_wgs < tiles) ? g_pp_adamw_wgs : tiles;
+  const int cap = adamw ? g_pp_adamw_wgs : g_pp_wgrad_wgs;
+  const int wgs = (cap > 0 && cap < tiles) ? cap : tiles;
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(PP_THREADS), LDS, s, G);
   nv_prof_end(slot, s);
   NV_CHECK_LAUNCH("nv_gemm_bf16_grouped/pp");

@@ -966,7 +966,7 @@ def _fold_reference(x, gamma, beta, W, b, gelu):
     return F.gelu(y) if gelu else y
 
 
-@pytest.mark.parametrize("M,d,inner,N", [(2052, 768, 768, 2304), (2052, 768, 3072, 3072), (520, 192, 192, 384), (2052, 1024, 512, 2048)])
+@pytest.mark.parametrize("M,d,inner,N", [(2052, 768, 768, 2304), (2052, 768, 3072, 3072), (2052, 192, 192, 384), (2052, 1024, 512, 2048)])
 def test_layernorm_folded_into_the_gemms_around_it(ops, M, d, inner, N):
     """the producer of the residual stream (nv_gemm_resid_ln) also writes the rows in bf16 and per-(row, 128-column tile) statistics; the consumer
     (nv_gemm_lnfold) contracts the UN-normalised rows with W diag(gamma) and applies mu / rstd in its epilogue.  Against float64: the producer's three outputs,
