@@ -116,6 +116,42 @@ def _q8(x: torch.Tensor, scale) -> torch.Tensor:
     return _Q8.apply(x, scale.detach())
 
 
+class _LinearF8(torch.autograd.Function):
+    """A Linear of the fp8 TRAINING forward as the HIP path computes it (csrc/engine.hip::nv_vit_forward_fp8_train + the unchanged bf16 backward):
+    forward  y = q8(x * sx) / sx . q8_rows(w)^T   (e4m3 operands, fp32 accumulate);
+    backward on the 16-bit copies the same forward kernels wrote, exactly as the bf16 path: dx = r(dy) r(w), dw = r(dy)^T r(x) - no straight-through
+    estimator at all (the quantiser never sits in the backward graph), hence no saturation mask either."""
+
+    @staticmethod
+    def forward(ctx, x, w, sx):
+        ctx.save_for_backward(x, w)
+        with torch.no_grad():
+            return F.linear(_q8(x, sx), _q8_rows(w))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _r(dy)
+        dx = torch.matmul(dy, _r(w))
+        dw = torch.matmul(dy.reshape(-1, dy.shape[-1]).t(), _r(x).reshape(-1, x.shape[-1]))
+        return dx, dw, None
+
+
+class _GeluF8(torch.autograd.Function):
+    """gelu(u) * mask of the fp8 training forward (the FC1 epilogue writes it as e4m3 for FC2 and as bf16 for the backward pass); backward as the bf16 path:
+    dU = r(dH * mask * gelu'(r(u)))."""
+
+    @staticmethod
+    def forward(ctx, u, mask):
+        ctx.save_for_backward(_r(u), mask)
+        return F.gelu(u) * mask
+
+    @staticmethod
+    def backward(ctx, dh):
+        u16, mask = ctx.saved_tensors
+        return _r(dh * mask * _gelu_grad(u16)), None
+
+
 def _q8_rows(w: torch.Tensor) -> torch.Tensor:
     """Per-output-row weight quantisation of csrc/quant.hip::quant_rows_f8_kernel (the row scales are constants for autograd)."""
     amax = w.detach().abs().amax(dim=1, keepdim=True)
@@ -357,7 +393,7 @@ def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None, drop=None, 
         taps[pre + "norm.out"] = xn
     if f8 is not None:          # fp8 path: LN output and to_qkv weight in e4m3, fp32 accumulate, bf16 qkv (f8 = scale of the LN output, or
                                 # (that, scale of the attention output or None): the out-projection in e4m3 too)
-        qkv = _r(F.linear(_q8(xn, f8[0] if isinstance(f8, tuple) else f8), _q8_rows(sd[pre + "to_qkv.weight"])), "qkv")
+        qkv = _r(_LinearF8.apply(xn, sd[pre + "to_qkv.weight"], f8[0] if isinstance(f8, tuple) else f8), "qkv")
     elif emulate:
         xn = _r(xn, "xn1")
         qkv = _r(_linear(xn, sd[pre + "to_qkv.weight"], None, True, "xn1"), "qkv")
@@ -383,7 +419,7 @@ def attention(sd, pre, x, heads, dim_head, emulate=False, taps=None, drop=None, 
         taps[pre + "attn.out"] = out
     if (pre + "to_out.0.weight") in sd:            # project_out (vit_3d.py:32,43-46)
         if f8 is not None and isinstance(f8, tuple) and f8[1]:    # fp8 path: attention output and to_out weight in e4m3 (f8[1] = its scale)
-            return F.linear(_q8(out, f8[1]), _q8_rows(sd[pre + "to_out.0.weight"])) + sd[pre + "to_out.0.bias"]
+            return _LinearF8.apply(out, sd[pre + "to_out.0.weight"], f8[1]) + sd[pre + "to_out.0.bias"]
         out = _linear(out, sd[pre + "to_out.0.weight"], sd[pre + "to_out.0.bias"], emulate, "ao")
         if drop:
             out = out * drop_mask(drop[2], drop[0], (B * n, out.shape[-1])).reshape(out.shape)
@@ -398,10 +434,9 @@ def feed_forward(sd, pre, x, emulate=False, drop=None, f8=None):
     omask = drop_mask(drop[2], drop[0], (rows, d)).reshape(x.shape) if drop else None
     xn = F.layer_norm(x, (d,), sd[pre + "net.0.weight"], sd[pre + "net.0.bias"], LN_EPS)
     if f8 is not None:          # fp8 path: f8 = (scale of the LN output, scale of the GELU output); train mode: the two dropout masks as below
-        u = F.linear(_q8(xn, f8[0]), _q8_rows(sd[pre + "net.1.weight"])) + sd[pre + "net.1.bias"]
-        gl = F.gelu(u)
-        h = _q8(gl if hmask is None else gl * hmask, f8[1])
-        y = F.linear(h, _q8_rows(sd[pre + "net.4.weight"])) + sd[pre + "net.4.bias"]
+        u = _LinearF8.apply(xn, sd[pre + "net.1.weight"], f8[0]) + sd[pre + "net.1.bias"]
+        h = _GeluF8.apply(u, torch.ones(()) if hmask is None else hmask)
+        y = _RoundGrad.apply(_LinearF8.apply(h, sd[pre + "net.4.weight"], f8[1])) + sd[pre + "net.4.bias"]
         return y if omask is None else y * omask
     if emulate:
         u = _linear(_r(xn, "xn2"), sd[pre + "net.1.weight"], sd[pre + "net.1.bias"], True, "xn2")

@@ -32,6 +32,7 @@ RATIO, SLACK = 1.5, 2e-4   # G3a
 REL = 5e-3                 # G3b forward stages / logits, relative L2
 MAXREL = 5e-3              # base-size logits (two numbers) vs emulating oracle
 GRAD_REL = 1.5e-2          # G3b parameter gradients, relative L2
+FP8_GRAD_REL = 6e-2        # fp8 training forward: first-step gradient arena against the emulating oracle, relative L2 (e4m3 forward noise feeds every gradient)
 FORM_TIGHT = 2e-4          # ... of the head and the last block's FeedForward / out-projection parameters alone (no re-rounding downstream; measured <= 6e-5)
 FORM_REL = 5e-3            # gradient arena of the cls-rows form against the every-row form (see run_case)
 OPERANDS = "bf16"          # 16-bit operand format of the runs below; tests/test_fp16_gpu.py re-runs the cases with "fp16" (and tighter G3b / G4 gates)
@@ -608,8 +609,9 @@ def test_fp8_train_step_large_geometry_depth2_vs_fp8_emulating_oracle(eng):
                         g_emu[o:o + n] = grads[k].reshape(-1)
         curves[tag] = cur
     cos = torch.nn.functional.cosine_similarity(g_hip.flatten(), g_emu.flatten(), dim=0).item()
+    g_l2 = rel_l2(g_hip, g_emu)
     report(f"fp8 train step (large geometry, depth 2, 3 steps): losses HIP {losses}, fp8 emulation {curves['fp8 emulation']}, fp32 {curves['fp32']}; "
-           f"first-step gradient arena vs emulation: cosine {cos:.4f}")
+           f"first-step gradient arena vs emulation: cosine {cos:.4f}, rel-L2 {g_l2:.3e}")
     # the emulation's own distance from fp32 over the three steps is the yardstick (a scalar loss read from two small logits of ONE
     # volume: step by step the emulation may happen to land closer to fp32 than the kernels do, so the spread is taken over the curve)
     spread = max(abs(e - r) for e, r in zip(curves["fp8 emulation"], curves["fp32"]))
@@ -617,7 +619,9 @@ def test_fp8_train_step_large_geometry_depth2_vs_fp8_emulating_oracle(eng):
         l32, lemu = curves["fp32"][i], curves["fp8 emulation"][i]
         assert abs(losses[i] - l32) <= RATIO * spread + 5e-3 * max(1.0, abs(l32)), (i, losses[i], lemu, l32, spread)
         assert abs(losses[i] - lemu) <= 2e-2, (i, losses[i], lemu)          # measured 3.3e-3 ... 9.6e-3
-    assert cos > 0.95
+    # round 5: the oracle's fp8 linears restate the HIP backward itself (bf16 operands the forward kernels wrote, no straight-through estimator, no
+    # saturation mask: ref_cpu._LinearF8), so the gradient arena is gated in relative L2 like any other emulation - not only in direction
+    assert cos > 0.99 and g_l2 < FP8_GRAD_REL, (cos, g_l2)
     assert all(np.isfinite(losses)) and losses[2] < losses[0]           # it trains
 
 

@@ -1,8 +1,9 @@
 # Round artefacts on the GPU box: parity report, bench line (+cpu baseline, secondary lines), rocprofv3 kernel stats, PMC traffic.
-# Usage (from the repo root, through gpurun): bash tools/final_artifacts.sh [skip-tests]
+# Usage (from the repo root, through gpurun): bash tools/final_artifacts.sh [skip-tests | secondary]   (secondary: only the secondary lines + kernel stats - a second call)
 set -e
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/final
+if [ "$1" != "secondary" ]; then
 rm -rf $OUT; mkdir -p $OUT
 rm -f $R/gpurun_out/parity_report.txt
 if [ "$1" != "skip-tests" ]; then
@@ -13,8 +14,13 @@ fi
 python bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
 cut -c1-300 $OUT/bench.json
 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1 || { tail $OUT/smoke.log; exit 1; }
+tail -1 $OUT/smoke.log
+exit 0
+fi
+mkdir -p $OUT
 # secondary lines: inference forwards (bf16 / fp8 / fp32), batch 20 / 64, the large preset (bf16 and fp8-forward train step), dropout
-( python bench.py --forward-only --steps 30 --warmup 5; python bench.py --forward-only --precise --steps 20 --warmup 3;
+( python bench.py --forward-only --steps 100 --warmup 10; NEUROVIT_LN_FOLD=0 python bench.py --forward-only --steps 100 --warmup 10; python bench.py --forward-only --operands fp16 --steps 100 --warmup 10;
+  python bench.py --operands fp16 --steps 30 --warmup 5 --no-cpu-baseline --no-extras; python bench.py --forward-only --precise --steps 20 --warmup 3;
   python bench.py --forward-only --batch 20 --steps 20 --warmup 3; python bench.py --forward-only --batch 20 --fp8 --steps 20 --warmup 3;
   python bench.py --forward-only --batch 20 --precise --steps 10 --warmup 3;
   python bench.py --forward-only --batch 64 --steps 10 --warmup 3; python bench.py --forward-only --batch 64 --fp8 --steps 10 --warmup 3;
@@ -25,8 +31,7 @@ python tools/neuro4d_train_bench.py 2> /dev/null | tail -1 > $OUT/neuro4d_train.
 cat $OUT/neuro4d_train.log
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/stats_run.log 2>&1
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1
+# (PMC passes: tools/r05_pmc.sh)
 T=$(find $OUT/stats -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/trace_timeline.py $T 18 --summary > $OUT/timeline_summary.txt || true
 echo done
