@@ -33,7 +33,7 @@ REL = 5e-3                 # G3b forward stages / logits, relative L2
 MAXREL = 5e-3              # base-size logits (two numbers) vs emulating oracle
 GRAD_REL = 1.5e-2          # G3b parameter gradients, relative L2
 FP8_GRAD_REL = 6e-2        # fp8 training forward: first-step gradient arena against the emulating oracle, relative L2 (e4m3 forward noise feeds every gradient)
-FORM_TIGHT = 2e-4          # ... of the head and the last block's FeedForward / out-projection parameters alone (no re-rounding downstream; measured <= 6e-5)
+FORM_TIGHT = 2e-5          # ... of the head and the last block's FeedForward / out-projection parameters alone (no re-rounding downstream): measured <= 4e-7 over all bf16 cases
 FORM_REL = 5e-3            # gradient arena of the cls-rows form against the every-row form (see run_case)
 OPERANDS = "bf16"          # 16-bit operand format of the runs below; tests/test_fp16_gpu.py re-runs the cases with "fp16" (and tighter G3b / G4 gates)
 DT16 = {"bf16": torch.bfloat16, "fp16": torch.float16}
