@@ -475,3 +475,37 @@ def test_folded_layernorm_inference_forward_fp16(eng):
     """the LayerNorm-folded inference forward on fp16 operands: the un-normalised residual keeps three more bits than in bf16 - inside 1e-3 of the fp32 oracle"""
     teg.test_inference_forward_with_folded_layernorms(eng, "base", "BASE", (5, 6), 1)
     teg.test_inference_forward_with_folded_layernorms(eng, "tiny", "TINY", (3, 4), 8)
+
+
+def test_neuro4d_fp16_encoder_vs_reference_fixture(golden):
+    """BASELINE.json configs[3] shape on fp16 operands: the 4D NeuroEncoder (frozen ViT3D over the T timepoints - fused 4D gather when T % 4 == 0, the regroup copy
+    otherwise -, native temporal head) against the fixture of the imported reference: the per-volume logits of the encoder within 1e-3 (bf16: 5.7e-3 on this
+    d1024 / L6 model), the model output as before; a frozen fp16 encoder needs no loss scale (the temporal head is fp32)."""
+    import os
+    import tempfile
+    from neurovit_amd.NeuroEncoder import NeuroEncoder
+    from neurovit_amd.trainer import TrainStep
+    g = golden("neuro4d.npz")
+    S, p, T = 16, 8, 5
+    vc = dict(image_size=S, image_patch_size=p, frames=S, frame_patch_size=p, num_classes=2, dim=1024, depth=6, heads=8, mlp_dim=2048, channels=1, dim_head=64)
+    sd3 = W.make_tensors(W.vit_param_spec(**vc), 21, prefix="volume_encoder.vit3d.")
+    with tempfile.TemporaryDirectory() as td:
+        torch.save(dict(sd3), os.path.join(td, "ckpt3d.pth"))
+        model = NeuroEncoder(W.neuro_config(S, p, dim=4, DEVICE="cuda", GLOBAL_BASE_PATH=td, BEST_MODEL_PATH="ckpt3d.pth", TRAINING_VIT_OPERANDS="fp16"))
+    model.load_state_dict(W.make_tensors(W.temporal_param_spec(), 22), strict=False)
+    model.eval()
+    assert model.volume_encoder.vit3d.operands == "fp16"
+    x = W.make_volume((2, S, S, S, T), 23).cuda()
+    logits = model(x)
+    assert rel_err(logits, g["logits"]) < 1e-5
+    with torch.no_grad():
+        vols = x.permute(0, 4, 1, 2, 3).reshape(2 * T, S, S, S)
+        e = rel_err(model.volume_encoder(vols), g["volume_logits"])
+    report(f"neuro4d fp16 per-volume logits vs reference fixture (d1024 / L6 encoder): rel {e:.3e}")
+    assert e <= 1e-3, e
+    assert model.volume_encoder.vit3d._shadow.dtype == torch.float16
+    model.train(); model.volume_encoder.eval()
+    step = TrainStep(model)
+    assert step.scaler is None
+    loss = step(x, torch.from_numpy(g["labels"]).long().cuda())
+    assert torch.isfinite(loss).item()
