@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -62,13 +63,28 @@ def flops_forward(cfg: VitConfig) -> float:
     return 2.0 * N * P * d + cfg.depth * per_layer + 2 * d * cfg.num_classes
 
 
+class _Pass:
+    """One training-layout forward whose activations a backward may still read: its workspace, its input (the backward re-gathers
+    the patches), the form of the last block, the dropout draw.  `done`: a whole backward has run - the workspace may be refilled."""
+    __slots__ = ("B", "ws", "video", "keep", "rows_form", "dropout", "dlogits", "done", "__weakref__")
+
+    def __init__(self, B, ws, video, keep, rows_form, dropout, done=False):
+        self.B, self.ws, self.video, self.keep, self.rows_form, self.dropout, self.dlogits, self.done = B, ws, video, keep, rows_form, dropout, None, done
+
+
 class VitRuntime:
-    """Executes ViT forward / backward through the native engine on caller-provided arenas."""
+    """Executes ViT forward / backward through the native engine on caller-provided arenas.
+    Training-layout workspaces are handed out per forward pass: a pass whose backward has not run yet (and whose autograd node is still
+    alive) keeps its workspace, and the next training forward takes another one - as many live sets of activations as the caller's graph
+    holds, the reference's autograd semantics (siamese / two-forward losses); the usual forward-backward loop never needs a second."""
 
     def __init__(self, cfg: VitConfig):
         self.cfg = cfg
         self._ws: Dict[Tuple[int, int, str], torch.Tensor] = {}
         self._last = None   # (B, training, workspace, video) of the most recent forward
+        self._pool: Dict[Tuple[int, int, str], list] = {}   # further training workspaces (beyond self._ws[key]) for overlapping passes
+        self._holder = {}   # workspace address -> weakref of the _Pass that filled it last
+        self._cur: Optional[_Pass] = None     # the pass backward() runs against (the most recent training forward unless autograd names another)
         self.generation = 0          # counts forwards: a backward may only run against the forward that filled the workspace
         self.backward_done = False   # a backward of the most recent forward has run (gates the Grad-CAM gradient tap)
         self._aux = {}      # device -> auxiliary stream for the weight-gradient GEMMs
@@ -91,6 +107,34 @@ class VitRuntime:
             ws = ws[pad:pad + nbytes]
             self._ws[key] = ws
         return ws
+
+    def _training_workspace(self, B: int, device) -> torch.Tensor:
+        """A training-layout workspace no pending pass still needs: the first one whose last pass has had its backward or is gone."""
+        key = (B, 1, str(device))
+        first = self.workspace(B, True, device)
+        more = self._pool.setdefault(key, [])
+        for ws in [first] + more:
+            ref = self._holder.get(ws.data_ptr())
+            rec = ref() if ref is not None else None
+            if rec is None or rec.done:
+                return ws
+        nbytes = first.numel()
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        pad = (-ws.data_ptr()) % 256
+        ws = ws[pad:pad + nbytes]
+        more.append(ws)
+        return ws
+
+    def _open_pass(self, B, ws, video, keep, rows_form, dropout, done=False) -> _Pass:
+        rec = _Pass(B, ws, video, keep, rows_form, dropout, done)
+        self._holder[ws.data_ptr()] = weakref.ref(rec)
+        self._cur = rec
+        return rec
+
+    def pass_is_live(self, rec: _Pass) -> bool:
+        """the workspace still holds THIS pass's activations (no later forward or train step has refilled it)"""
+        ref = self._holder.get(rec.ws.data_ptr())
+        return ref is not None and ref() is rec
 
     def _input_form(self, video: torch.Tensor, vol_sigma, time_points: int, rows_form: int = 0):
         """(B, nv_vit_input or None) after checking the extents: plain [B, C, F, H, W] view, or (time_points > 0) a contiguous
@@ -127,7 +171,7 @@ class VitRuntime:
         rows_form = self.rows_form if rows_form is None else int(rows_form)
         _cabi.set_operand_format(self.operands)
         B, inp = self._input_form(video, vol_sigma, time_points, rows_form)
-        ws = self.workspace(B, training, video.device)
+        ws = self._training_workspace(B, video.device) if training else self.workspace(B, training, video.device)
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
         check(lib.nv_vit_forward_in(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
                                     None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p),
@@ -137,6 +181,8 @@ class VitRuntime:
         self._keep = (vol_sigma, inp)                    # the backward re-gathers the same (raw) input
         self._rows_form = rows_form                      # ... and takes the same form of the last block
         self._last = (B, training, ws, video)
+        if training:
+            self._open_pass(B, ws, video, self._keep, rows_form, dropout)
         self.generation += 1
         self.backward_done = False
         self._dropout = dropout
@@ -240,7 +286,7 @@ class VitRuntime:
         rows_form = self.rows_form if rows_form is None else int(rows_form)
         _cabi.set_operand_format(self.operands)
         B, inp = self._input_form(video, vol_sigma, 0, rows_form)
-        ws = self.workspace(B, True, video.device)
+        ws = self._training_workspace(B, video.device)
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=video.device)
         check(lib.nv_vit_forward_fp8_train(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
                                            None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p), params.data_ptr(),
@@ -250,6 +296,7 @@ class VitRuntime:
         self._keep = (vol_sigma, inp)
         self._rows_form = rows_form
         self._last = (B, True, ws, video)
+        self._open_pass(B, ws, video, self._keep, rows_form, dropout)
         self.generation += 1
         self.backward_done = False
         self._dropout = dropout
@@ -276,22 +323,28 @@ class VitRuntime:
         """Whole backward, or only stages [first, last] (0 = head, 1+k = layer depth-1-k, depth+1 = embedding).
         join_aux=False (only for ranges before the last stage): the current stream is not made to wait for the auxiliary
         stream - order the consumer of the range's gradients after `aux_stream_object()` as well."""
-        assert self._last is not None and self._last[1] == 1, "backward needs a preceding forward(training=True)"
-        B, _, ws, video = self._last
-        if getattr(self, "_keep", (None, None))[1] is not None and self._keep[1].time_points:
+        rec = self._cur
+        assert rec is not None, "backward needs a preceding forward(training=True)"
+        if not self.pass_is_live(rec):
+            raise RuntimeError("neurovit_amd: backward() of a forward pass whose activations have been overwritten - a later forward or train step "
+                               "has refilled its workspace (a pass keeps its workspace only until a whole backward of it has run)")
+        B, ws, video = rec.B, rec.ws, rec.video
+        if rec.keep[1] is not None and rec.keep[1].time_points:
             raise NotImplementedError("neurovit_amd: the fused 4D input form is forward-only (the 4D model's encoder is frozen, NeuroEncoder.py:34-36)")
         first, last = (0, self.cfg.depth + 1) if stages is None else stages
         _cabi.set_operand_format(self.operands)
         if first == 0:
-            self._dlogits = dlogits.contiguous().float()
+            rec.dlogits = dlogits.contiguous().float()
         # grads16: bf16 arena (element offsets of `grads`) that also receives the Linear weight gradients, rounded, straight from
         # their GEMMs - the data-parallel message buffer (mirrored_ranges() lists what lands there)
         check(lib.nv_vit_backward_stages16(ctypes.byref(self.cfg), B, video.data_ptr(), ops.strides5(video), params.data_ptr(),
-                                           params16.data_ptr(), ws.data_ptr(), ws.numel(), self._dlogits.data_ptr(),
+                                           params16.data_ptr(), ws.data_ptr(), ws.numel(), rec.dlogits.data_ptr(),
                                            grads.data_ptr(), None if grads16 is None else grads16.data_ptr(), int(accumulate), first, last,
-                                           float(self._dropout[0]), float(self._dropout[1]), int(self._dropout[2]),
-                                           torch.cuda.current_stream().cuda_stream, self._aux_stream(video.device), int(join_aux), int(self._rows_form)),
+                                           float(rec.dropout[0]), float(rec.dropout[1]), int(rec.dropout[2]),
+                                           torch.cuda.current_stream().cuda_stream, self._aux_stream(video.device), int(join_aux), int(rec.rows_form)),
               "nv_vit_backward_stages16")
+        if last == self.cfg.depth + 1:
+            rec.done = True              # the workspace may be refilled by the next training forward
 
     def train_step(self, video: torch.Tensor, labels: torch.Tensor, params: torch.Tensor, params16: torch.Tensor, grads: torch.Tensor,
                    adam_m: torch.Tensor, adam_v: torch.Tensor, *, step: int, lr: float, betas, eps: float, weight_decay: float,
@@ -312,7 +365,7 @@ class VitRuntime:
         dev = video.device
         logits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        self._dlogits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=dev)
+        dlogits = torch.empty((B, self.cfg.num_classes), dtype=torch.float32, device=dev)
         assert labels.is_cuda and labels.dtype == torch.int64 and labels.numel() == B and labels.is_contiguous()
         hp = TrainHparams(ctypes.sizeof(TrainHparams), int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
                           float(grad_scale), int(bool(accumulate)), int(bool(update)), int(fuse_update), float(loss_scale),
@@ -321,16 +374,26 @@ class VitRuntime:
         check(lib.nv_vit_train_step(ctypes.byref(self.cfg), B, video.data_ptr(), ops.shape5(video), ops.strides5(video),
                                     None if inp is None else ctypes.cast(ctypes.pointer(inp), ctypes.c_void_p),
                                     params.data_ptr(), params16.data_ptr(), grads.data_ptr(), adam_m.data_ptr(), adam_v.data_ptr(),
-                                    ws.data_ptr(), ws.numel(), labels.data_ptr(), logits.data_ptr(), loss.data_ptr(), self._dlogits.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), labels.data_ptr(), logits.data_ptr(), loss.data_ptr(), dlogits.data_ptr(),
                                     ctypes.byref(hp), float(dropout[0]), float(dropout[1]), int(dropout[2]),
                                     torch.cuda.current_stream().cuda_stream, self._aux_stream(dev)), "nv_vit_train_step")
         self._keep = (vol_sigma, inp)
         self._rows_form = rows_form
         self._last = (B, True, ws, video)
+        self._open_pass(B, ws, video, self._keep, rows_form, dropout, done=True).dlogits = dlogits     # (a pending pass in this workspace is now stale)
         self.generation += 1
         self.backward_done = True                        # the Grad-CAM gradient tap holds this step's gradient
         self._dropout = dropout
         return loss, logits
+
+    def note_step_replayed(self, B: int, video: torch.Tensor) -> None:
+        """A captured train step (trainer.py) has been replayed: the primary training workspace holds ITS activations and gradient taps."""
+        ws = self.workspace(B, True, video.device)
+        self._last = (B, True, ws, video)
+        self._open_pass(B, ws, video, getattr(self, "_keep", (None, None)), self._rows_form, (0.0, 0.0, 0), done=True)
+        self.generation += 1
+        self.backward_done = True
+        self._dropout = (0.0, 0.0, 0)
 
     def aux_stream_object(self, device) -> Optional[torch.cuda.Stream]:
         """The torch stream object behind the engine's auxiliary stream (None when the engine runs single-stream)."""

@@ -243,11 +243,7 @@ class TrainStep:
         graph, loss, logits = ent[0], ent[1], ent[2]
         vit._refresh_shadow()
         graph.replay()
-        rt = vit._rt
-        rt._last = (fmri.shape[0], True, rt.workspace(fmri.shape[0], True, fmri.device), fmri.permute(0, 3, 1, 2).unsqueeze(1))
-        rt.generation += 1
-        rt.backward_done = True
-        rt._dropout = (0.0, 0.0, 0)
+        vit._rt.note_step_replayed(fmri.shape[0], fmri.permute(0, 3, 1, 2).unsqueeze(1))
         opt._steps += 1
         opt._step_arena(vit, 1.0 / self.static_scale if self.static_scale > 0 else 1.0)      # AdamW over the arena + 16-bit shadow (mark_shadow_fresh inside)
         vit._last_logits = logits

@@ -217,19 +217,21 @@ class _ViTFunction(torch.autograd.Function):
         # reflects requires_grad alone (it stays True under torch.no_grad()), so neither tells whether a graph is being built
         ctx.module = module
         out = module._run_forward(video, need_grad, extra)
-        ctx.generation = module._rt.generation     # the workspace holds THIS forward's activations until the next forward
+        ctx.rec = module._rt._cur if need_grad else None      # THIS pass's workspace and input: kept until its backward has run
         return out
 
     @staticmethod
     def backward(ctx, dlogits):
-        rt = ctx.module._rt
-        if ctx.generation != rt.generation:
+        rt, rec = ctx.module._rt, ctx.rec
+        if rec is None or not rt.pass_is_live(rec):
             raise RuntimeError(
-                "neurovit_amd.ViT: backward() of a forward pass whose activations have been overwritten - the engine keeps ONE "
-                f"workspace per module and forward #{rt.generation} has run since forward #{ctx.generation}. Call backward() "
-                "before the next forward of the same module (siamese / two-forward losses need one module instance per branch).")
+                "neurovit_amd.ViT: backward() of a forward pass whose activations have been overwritten - a pass keeps its workspace "
+                "until one whole backward of it has run; a second backward (retain_graph) after another training forward or a train "
+                "step of the same module finds it refilled.")
+        rt._cur = rec                 # several passes may be pending (siamese / two-forward losses): each runs against its own workspace
         ctx.module._run_backward(dlogits)
-        rt.backward_done = True
+        if rt._last is not None and rt._last[2] is rec.ws:
+            rt.backward_done = True   # the Grad-CAM taps read the MOST RECENT forward's workspace
         return (None, None, None, None) + (None,) * len(ctx.module._plist)
 
 

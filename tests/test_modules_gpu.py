@@ -938,21 +938,76 @@ def test_wrong_volume_shape_raises_instead_of_reading_out_of_bounds(nv):
     assert rc == -1 and "the model was built for" in last_error()
 
 
+def test_two_forward_passes_before_one_backward(nv):
+    """The reference's autograd keeps every pending pass's activations (siamese / two-forward losses).  Here a training forward whose
+    backward has not run keeps its workspace and the next one takes another: the joint backward equals the two passes run one after the
+    other (gradients accumulate), the usual loop still needs ONE workspace, and an inference forward between a forward and its
+    backward disturbs nothing."""
+    S, p = 32, 8
+    size = dict(TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
+    model = nv.NeuroEncoder(W.neuro_config(S, p, DEVICE="cuda", **size))
+    model.train()
+    vit = model.volume_encoder.vit3d
+    rt = vit._rt
+    x1, x2 = W.make_volume((2, S, S, S), 1).cuda(), W.make_volume((2, S, S, S), 2).cuda()
+    assert model.gradients == {}                                             # nothing ran yet
+    y1 = model(x1)
+    assert model.gradients == {}                                             # forward only: the hook gradient does not exist yet
+    y2 = model(x2)                                                           # y1's pass is pending: this one takes a second workspace
+    more = rt._pool[(2, 1, str(x1.device))]
+    assert len(more) == 1
+    (y1.square().sum() + y2.sum()).backward()
+    joint = vit.flat_gradients().clone()
+    assert model.gradients.shape == (2, (S // p) ** 3 + 1, 128)              # the most recent forward's (x2's) hook gradient
+    hook2 = model.gradients.clone()
+    for q in model.parameters():
+        q.grad = None
+    del y1, y2
+    for _ in range(3):                                                       # forward, backward, forward, ...: one workspace
+        model(x1).square().sum().backward()
+        for q in model.parameters():
+            q.grad = None
+    assert len(more) == 1 and rt._cur.ws is rt.workspace(2, True, x1.device)
+    model(x1).square().sum().backward()
+    model(x2).sum().backward()                                               # accumulates into the same arena
+    assert rel_err(joint, vit.flat_gradients()) < 1e-6
+    assert torch.equal(hook2, model.gradients)
+    # an inference forward between a training forward and its backward
+    for q in model.parameters():
+        q.grad = None
+    y = model(x1)
+    with torch.no_grad():
+        model.eval(); model(x2); model.train()
+    y.square().sum().backward()
+    a = vit.flat_gradients().clone()
+    for q in model.parameters():
+        q.grad = None
+    model(x1).square().sum().backward()
+    assert torch.equal(a, vit.flat_gradients())
+
+
 def test_backward_of_a_stale_forward_raises(nv):
+    """A pass keeps its workspace until one whole backward of it has run.  A second backward of the same graph (retain_graph) after
+    another training forward of the module finds the workspace refilled: that raises instead of computing from the wrong activations."""
     S, p = 32, 8
     size = dict(TRAINING_VIT_DIM=128, TRAINING_VIT_DEPTH=2, TRAINING_VIT_HEADS=2, TRAINING_VIT_MLP_DIM=256)
     model = nv.NeuroEncoder(W.neuro_config(S, p, DEVICE="cuda", **size))
     model.train()
     x1, x2 = W.make_volume((2, S, S, S), 1).cuda(), W.make_volume((2, S, S, S), 2).cuda()
-    assert model.gradients == {}                                             # nothing ran yet
     y1 = model(x1)
-    assert model.gradients == {}                                             # forward only: the hook gradient does not exist yet
-    y2 = model(x2)                                                           # overwrites the workspace y1's graph points at
+    y1.sum().backward(retain_graph=True)
+    g1 = model.volume_encoder.vit3d.flat_gradients().clone()
+    y1.sum().backward(retain_graph=True)                                     # twice in a row is fine (and accumulates)
+    assert rel_err(2 * g1, model.volume_encoder.vit3d.flat_gradients()) < 1e-6
+    y2 = model(x2)                                                           # y1's pass has had its backward: its workspace is refilled
     with pytest.raises(RuntimeError, match="activations have been overwritten"):
-        (y1.sum() + y2.sum()).backward()
-    y3 = model(x1)
-    y3.sum().backward()                                                      # the normal order keeps working
-    assert model.gradients.shape == (2, (S // p) ** 3 + 1, 128)
+        y1.sum().backward()
+    y2.sum().backward()                                                      # the normal order keeps working
+    from neurovit_amd.trainer import TrainStep
+    y3 = model(x1)                                                           # pending ...
+    TrainStep(model)(x2, torch.tensor([0, 1], device="cuda"))                # ... and the one-call step refills the primary workspace
+    with pytest.raises(RuntimeError, match="activations have been overwritten"):
+        y3.sum().backward()
 
 
 def test_ce_loss_out_of_range_label_poisons_loss_without_oob_read(nv):
