@@ -412,7 +412,10 @@ static GemmPlan plan_gemm(bool A_T, bool B_T, int epi, int M, int N, int K, long
     int ws = (g_tile_override >= 4) ? 0 : g_tile_override;                 // 1: 128x128, 2: 128x64, 3: 64x128 (forced); 0: heuristic
     // measured on the ViT3D-base shapes (M = 2052): the 64x128 tile wins or ties everywhere (two workgroups per CU, so
     // one block's epilogue overlaps the other's MFMA phase); very large problems prefer 128x128 (less LDS / L2 traffic)
-    if (ws == 0 && t128 >= 32) ws = (t128 >= 1024) ? 1 : 3;
+    // (round 5: the gate was t128 >= 32 and left the N = 768 problems of ONE volume - M = 513: 5 x 6 tiles of 128 x 128 - on the small-tile kernel:
+    //  FC2 25.6 us against 16.5 on 54 tiles of 64 x 128 with the 128-deep ring, dxn2 31.2 against 15.5, dxn1 22.5 against 12.0)
+    const long t64x128w = (long)((M + 63) / 64) * ((N + 127) / 128);
+    if (ws == 0 && (t128 >= 32 || t64x128w >= 48)) ws = (t128 >= 1024) ? 1 : 3;
     // ring geometry: 1 = 3 stages x 64-deep, 2 = deep ring (6 / 4 stages x 64), 3 = 3 stages x 128-deep (one barrier per 128 of K;
     // needs whole 128-deep steps unless both operands are K-strided, where the buffer bounds zero-fill)
     int ring = g_ring_override;
