@@ -704,9 +704,15 @@ def test_neuro4d_full_size_config(nv):
     assert out.shape == (4, 2) and torch.isfinite(out).all()
     with torch.no_grad():
         # (.contiguous(): a T-strided view would take the scalar gather path, whose LayerNorm sums are ordered differently)
+        # ((2) the 40-volume batch is beyond the LayerNorm fold's row limit and takes the plain launches; one volume takes the folded ones unless told not to)
+        vit = model.volume_encoder.vit3d
+        folded_one = torch.stack([model.volume_encoder(x[0, ..., t].contiguous()[None]) for t in (0, 7, 19)])[:, 0]
+        vit.fold_layernorm = False
         per_volume = torch.stack([model.volume_encoder(x[0, ..., t].contiguous()[None]) for t in (0, 7, 19)])[:, 0]
+        vit.fold_layernorm = True
         batched = model.volume_encoder(x[:2].permute(0, 4, 1, 2, 3).reshape(2 * T, S, S, S))
-        assert torch.equal(per_volume, batched[[0, 7, 19]])       # batch independence at M = 20 * 513 rows
+        assert torch.equal(per_volume, batched[[0, 7, 19]])       # batch independence at M = 20 * 513 rows (the same launches: bit for bit)
+        assert rel_err(folded_one, per_volume) < 6e-3              # ... and across the two forms of the LayerNorms: bf16 rounding points that moved
     y = torch.tensor([0, 1, 1, 0], device="cuda")
     crit = torch.nn.CrossEntropyLoss()
     model.zero_grad()
