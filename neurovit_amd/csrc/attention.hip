@@ -57,7 +57,6 @@ __device__ __forceinline__ r16x8 frag_tr(const char* img, int t, int ks, int r, 
   const r16x4 hi = lds_read_tr(img + img128_off(32 * ks + 16 + 4 * g + q, ch) + sub);
   return cat4(lo, hi);
 }
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 // bare v_exp_f32: arguments here are <= 0 and results in [0, 1]; results below 2^-126 flush to zero (they vanish in the sums)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // Exchange with the lanes l ^ 16 and l ^ 32 (the four lane groups that share a score row) on the VALU: v_permlane16_swap /

@@ -17,6 +17,7 @@ typedef short r16x2 __attribute__((ext_vector_type(2)));
 typedef short r16x4 __attribute__((ext_vector_type(4)));
 typedef short r16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) r16x4 lds_r16x4;
 template <typename T> struct vec16 {
