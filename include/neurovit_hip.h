@@ -230,6 +230,11 @@ int nv_zscore_crop(const void* raw, int dtype, const long* strides5, int B, cons
 int nv_patch_ln_fwd(const float* video, const long* strides5, int B, int C, int F, int H, int W, int p1, int p2, int pf,
                     const float* gamma, const float* beta, float eps, void* out, long ldo, float* mean, float* rstd,
                     const float* vol_sigma, void* stream);
+/* Two forms of the same arithmetic (bit-identical rows): a wave per token gathering its 64-byte runs itself (default: measured 14.5 us at
+ * ViT3D-base batch 4), or a workgroup per patch COLUMN that stages its p1 * p2 rows of F contiguous floats through LDS with fully
+ * coalesced reads and serves its F / pf tokens from there (frame stride 1, channels 1, the slab within 156 KiB of LDS - what a [B, H, W, D]
+ * volume gives; 21 us: load, then compute, one workgroup per CU).  nv_patch_set_mode: 0 = the first, 2 = the second where it applies. */
+int nv_patch_set_mode(int mode);
 /* vol_sigma (may be NULL): [B] = std + 1e-8 of each RAW volume (nv_volume_sigma).  `video` is then the un-normalised (cropped
  * view of the) scanner volume: LayerNorm over a patch of (x - mu) / sigma equals LayerNorm over the patch of x with eps * sigma^2,
  * so the dataset's z-score (src/data/DatasetADNI.py:213) is folded into this kernel's epsilon - no normalised copy is written.

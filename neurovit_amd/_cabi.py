@@ -107,6 +107,8 @@ class _Lib:
                 dll.nv_vit_set_head_step(int(os.environ["NEUROVIT_HEAD_STEP"]))
             if os.environ.get("NEUROVIT_WGRAD_WGS"):           # A/B aid: workgroups of the grouped weight-gradient launch
                 dll.nv_gemm_set_tile(14, int(os.environ["NEUROVIT_WGRAD_WGS"]))
+            if os.environ.get("NEUROVIT_PATCH_MODE"):          # A/B aid: 2 = the LDS-staged slab form of the patch gather instead of the per-token one
+                dll.nv_patch_set_mode(int(os.environ["NEUROVIT_PATCH_MODE"]))
             if os.environ.get("NEUROVIT_ADAMW_CAP"):
                 dll.nv_gemm_set_tile(13, int(os.environ["NEUROVIT_ADAMW_CAP"]))
             self._dll = dll

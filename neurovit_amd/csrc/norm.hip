@@ -399,6 +399,14 @@ __device__ __forceinline__ long patch_elem_offset(const PatchGeom& g, int b, int
   return patch_tok_offset(g, b, n) + patch_feat_offset(g, k);
 }
 
+#ifndef NV_PATCH_NT
+#define NV_PATCH_NT 1
+#endif
+#if NV_PATCH_NT
+#define NV_PATCH_LOAD(p) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p))
+#else
+#define NV_PATCH_LOAD(p) (*reinterpret_cast<const f32x4*>(p))
+#endif
 // VEC: C == 1, sf == 1, pf % 4 == 0, 16-byte aligned runs, P <= 4096: float4 gathers, row cached in registers.
 template <bool VEC, typename OT>
 __global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const float* __restrict__ video, PatchGeom g, const float* __restrict__ gamma,
@@ -426,12 +434,12 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const float* __restri
       const long vstep = (long)(256 / inner) * g.sh;
 #pragma unroll
       for (int v = 0; v < NV; ++v)
-        xv[v] = ((lane + 64 * v) * 4 < g.P) ? *reinterpret_cast<const f32x4*>(lp + v * vstep) : f32x4{0.f, 0.f, 0.f, 0.f};
+        xv[v] = ((lane + 64 * v) * 4 < g.P) ? NV_PATCH_LOAD(lp + v * vstep) : f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int k = (lane + 64 * v) * 4;
-        xv[v] = (k < g.P) ? *reinterpret_cast<const f32x4*>(tokp + patch_feat_offset(g, k)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        xv[v] = (k < g.P) ? NV_PATCH_LOAD(tokp + patch_feat_offset(g, k)) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
     row_stats<NV>(xv, g.P, lane, eps, mean, rstd);
@@ -463,6 +471,84 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const float* __restri
   }
 }
 
+// LDS-staged (F, H, W) slabs (north_star: "LDS-staged (D,H,W) tiles and coalesced HBM reads") - the SELECTABLE form, see the measurement below.  One workgroup owns a patch COLUMN - the gf tokens that share
+// (b, ht, wt) - and streams its p1 * p2 rows of F contiguous floats into LDS with full-line, fully coalesced 16-byte loads (for [B, H, W, D] volumes the rows of one
+// i1 are one contiguous run of p2 * F floats); the per-token gather of patch_ln_fwd_kernel reads 64-byte half lines, every line twice (two tokens share it).  Each
+// wave then takes tokens ft = wave, wave + 4, ...: its lanes pick the SAME features as in the per-token kernel (k = 4 lane + 256 v) out of the slab and run the same
+// row_stats / normalise / store code - bit-identical output.  Row pitch F + 16 floats: the four rows a 16-lane phase of a ds_read_b128 touches sit on disjoint banks.
+template <typename OT>
+__global__ __launch_bounds__(256) void patch_ln_fwd_slab_kernel(const float* __restrict__ video, PatchGeom g, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, OT* __restrict__ out, long ldo,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                const float* __restrict__ vol_sigma) {
+  extern __shared__ __attribute__((aligned(16))) float slab[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cols = g.gh * g.gw;
+  const int b = blockIdx.x / cols, hw = blockIdx.x - b * cols;
+  const int ht = hw / g.gw, wt = hw - ht * g.gw;
+  const int pitch = g.F + 16, rows = g.p1 * g.p2, f4 = g.F >> 2, items = rows * f4;
+  const float* base = video + (long)b * g.sb + (long)(ht * g.p1) * g.sh + (long)(wt * g.p2) * g.sw;
+  constexpr int U = 8;                                     // loads in flight per thread
+  for (int q0 = tid; q0 < items; q0 += 256 * U) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + 256 * u;
+      if (q < items) {
+        const int r = q / f4, c4 = q - r * f4, i1 = r / g.p2, i2 = r - i1 * g.p2;
+        v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (long)i1 * g.sh + (long)i2 * g.sw + 4 * c4));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + 256 * u;
+      if (q < items) {
+        const int r = q / f4, c4 = q - r * f4;
+        *reinterpret_cast<f32x4*>(slab + r * pitch + 4 * c4) = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  if (vol_sigma) { const float sg = vol_sigma[b]; eps *= sg * sg; }      // (see patch_ln_fwd_kernel)
+  constexpr int NV = 16;
+  for (int ft = wave; ft < g.gf; ft += WAVES_PER_BLOCK) {
+    const int tok = b * g.N + (ft * g.gh + ht) * g.gw + wt;
+    OT* orow = out + (long)tok * ldo;
+    f32x4 xv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int k = (lane + 64 * v) * 4;                   // feature ((i1 p2 + i2) pf + ifr): slab row k / pf, column ft pf + k % pf
+      const int run = k / g.pf, ifr = k - run * g.pf;
+      xv[v] = (k < g.P) ? *reinterpret_cast<const f32x4*>(slab + run * pitch + ft * g.pf + ifr) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float mean, rstd;
+    row_stats<NV>(xv, g.P, lane, eps, mean, rstd);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int k = (lane + 64 * v) * 4;
+      if (k < g.P) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + k), bt = *reinterpret_cast<const f32x4*>(beta + k);
+        const f32x4 o = (xv[v] - mean) * rstd * gm + bt;
+        store4<OT>(orow + k, o);
+      }
+    }
+    if (lane == 0) {
+      mean_out[tok] = mean;
+      rstd_out[tok] = rstd;
+    }
+  }
+}
+// MEASURED (round 5, ViT3D-base batch 4, same box): 21.2 - 22.7 us against 14.4 - 14.9 for the per-token gather - a workgroup loads its 128 KiB, THEN computes, one
+// workgroup per CU, so HBM idles during the arithmetic; the gather's thousands of independent waves overlap the two.  The gather therefore stays the default and the
+// slabs are the selectable form (nv_patch_set_mode(2); tests hold the two bit-identical).  What the comparison did find: the gather's loads were missing the
+// non-temporal hint - the 33.5 MB volume batch displaced that much of the weights from the Infinity Cache on every forward (NV_PATCH_LOAD: forward 0.998 -> 0.982 ms).
+static int g_patch_mode = 0;      // 0 = per-token gather (default), 2 = LDS-staged slabs where they apply
+extern "C" int nv_patch_set_mode(int mode) { g_patch_mode = mode == 2 ? 2 : 0; return 0; }
+static long patch_slab_lds(const PatchGeom& g) { return (long)g.p1 * g.p2 * (g.F + 16) * sizeof(float); }
+static bool patch_slab_ok(const PatchGeom& g) {
+  return g_patch_mode == 2 && (g.F % 4) == 0 && g.gf >= 2 && patch_slab_lds(g) <= 156 * 1024;
+}
+
 static bool patch_vec_ok(const float* video, const PatchGeom& g, long ldo) {
   return g.C == 1 && g.sf == 1 && (g.pf % 4) == 0 && g.P <= 4096 && nv_aligned16(video) && (g.sb % 4) == 0 && (g.sh % 4) == 0 &&
          (g.sw % 4) == 0 && ldo == g.P;
@@ -490,7 +576,16 @@ static int patch_ln_fwd_launch(const float* video, const long* strides5, int B, 
   else NV_CHECK_ARG(ldo >= g.P && (ldo % 8) == 0, "nv_patch_ln_fwd: ldo=%ld must be >= patch_dim=%d and a multiple of 8", ldo, g.P);
   const dim3 grid((g.B * g.N + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (patch_vec_ok(video, g, ldo) && nv_aligned16(gamma) && nv_aligned16(beta) && nv_aligned16(out))
+  const bool vec = patch_vec_ok(video, g, ldo) && nv_aligned16(gamma) && nv_aligned16(beta) && nv_aligned16(out);
+  if (vec && patch_slab_ok(g)) {
+    const int lds = (int)patch_slab_lds(g);
+    static int lds_set = 0;
+    if (lds > lds_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(patch_ln_fwd_slab_kernel<OT>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+      lds_set = 156 * 1024;
+    }
+    hipLaunchKernelGGL((patch_ln_fwd_slab_kernel<OT>), dim3(g.B * g.gh * g.gw), block, lds, s, video, g, gamma, beta, eps, out, ldo, mean, rstd, vol_sigma);
+  } else if (vec)
     hipLaunchKernelGGL((patch_ln_fwd_kernel<true, OT>), grid, block, 0, s, video, g, gamma, beta, eps, out, ldo, mean, rstd, vol_sigma);
   else
     hipLaunchKernelGGL((patch_ln_fwd_kernel<false, OT>), grid, block, 0, s, video, g, gamma, beta, eps, out, ldo, mean, rstd, vol_sigma);
@@ -592,7 +687,7 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_t_kernel(const float* __rest
   for (int k0 = 0; k0 < g.P; k0 += KR) {
     const int k = k0 + kk;
     if (act && k < g.P) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(item_ptr(k));
+      const f32x4 v = NV_PATCH_LOAD(item_ptr(k));            // second and last sweep over the sample: non-temporal
       const float gm = gamma[k], bt = beta[k];
       const f32x4 y = (v - mu) * rs * gm + bt;
 #pragma unroll
@@ -662,8 +757,9 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(const float* __restri
       const float* fp = video + patch_feat_offset(g, k);   // the feature part once per thread, the token part is wave-uniform
       for (int tok = t0; tok < t1; ++tok) {
         const int b = tok / g.N, n = tok - b * g.N;
-        const f32x4 xh = (*reinterpret_cast<const f32x4*>(fp + patch_tok_offset(g, b, n)) - mean_in[tok]) * rstd_in[tok];
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(dxp + (long)tok * ldd + k);
+        // (both streams are read for the last time in this step: non-temporal, so that they do not displace the weights from the Infinity Cache)
+        const f32x4 xh = (NV_PATCH_LOAD(fp + patch_tok_offset(g, b, n)) - mean_in[tok]) * rstd_in[tok];
+        const f32x4 dv = NV_PATCH_LOAD(dxp + (long)tok * ldd + k);
         ag += dv * xh;
         ab += dv;
       }

@@ -552,6 +552,34 @@ def test_patch_gather_bit_exact(ops, S, p):
     assert torch.equal(st[0].cpu(), torch.zeros_like(st[0].cpu())) and torch.equal(st[1].cpu(), torch.ones_like(st[1].cpu()))
 
 
+@pytest.mark.parametrize("S,p,B", [(128, 16, 2), (128, 8, 1), (64, 16, 3), (32, 8, 2), (96, 12, 1)])
+def test_patch_slabs_equal_the_per_token_gather_bitwise(ops, S, p, B):
+    """K1's two forms (nv_patch_set_mode): a wave per token gathering its 64-byte runs (the default: faster) against a workgroup per patch column staging
+    (F, H, W) slabs through LDS with coalesced reads (mode 2): the same rows, statistics included, bit for bit, for 16-bit and fp32 tokens and for raw volumes
+    (vol_sigma)."""
+    from neurovit_amd._cabi import lib
+    g = torch.Generator().manual_seed(S + p)
+    vol = torch.randn(B, S, S, S, generator=g) * 3.0 + 1.5
+    P = p ** 3
+    gamma, beta = dev(torch.randn(P, generator=g)), dev(torch.randn(P, generator=g))
+    sig = dev(torch.rand(B, generator=g) + 0.5)
+    video = ref_cpu.fmri_to_video(dev(vol))
+    res = {}
+    for mode in (0, 2):
+        lib.nv_patch_set_mode(mode)
+        try:
+            res[mode] = (ops.patch_ln_fwd(video, p, p, p, gamma, beta), ops.patch_ln_fwd_f32(video, p, p, p, gamma, beta),
+                         ops.patch_ln_fwd(video, p, p, p, gamma, beta, vol_sigma=sig))
+        finally:
+            lib.nv_patch_set_mode(0)
+    for (o0, s0), (o1, s1) in zip(res[0], res[2]):
+        assert torch.equal(o0, o1) and torch.equal(s0, s1)
+    # ... and against the oracle's patchify + LayerNorm (fp32 tokens)
+    tok = ref_cpu.patchify(ref_cpu.fmri_to_video(vol), p, p, p).reshape(-1, P)
+    want = torch.nn.functional.layer_norm(tok, (P,), gamma.cpu(), beta.cpu(), 1e-5)
+    assert rel_err(res[0][1][0].cpu(), want) < 1e-5
+
+
 def test_patch_gather_matches_golden_index_map(ops, golden):
     """Same check against the fixture produced by the reference's own Rearrange (S=32, p=8)."""
     S, p = 32, 8
