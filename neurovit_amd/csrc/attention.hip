@@ -515,24 +515,28 @@ __global__ __launch_bounds__(256, NV_WIDE_FWD_BLOCKS) void attn_fwd_wide_kernel(
   // the Q fragments' loads retire HERE as far as the compiler's wait bookkeeping goes: left to their first use inside the loop it
   // would wait for them there, on every pass, with counts that ignore the DMA issued in between (vmcnt(3..0): a full drain)
   asm volatile("" ::"v"(qf[0][0]), "v"(qf[0][1]), "v"(qf[1][0]), "v"(qf[1][1]));
+  // wave-uniform: does the wave's first / second 16-row group hold any query row?  (Rows beyond n are computed on clamped loads and never stored: skipping them
+  // changes no result; at n = 513 the fifth workgroup of every (batch, head) holds ONE row in 128.)
+  const bool act0 = q0 < n, act1 = q0 + 16 < n;
   auto tile = [&](int kt) {
     char* cur = wsmem + (kt & 1) * 2 * IMG;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
     __builtin_amdgcn_s_barrier();                         // ... everybody's; and every read of the other stage (tile kt-1) is done
     if (kt + 1 < nkt) issue(kt + 1, wsmem + ((kt + 1) & 1) * 2 * IMG);
+    if (!act0) return;                                    // no query row of this wave exists (the last workgroup of n = 512 + 1: three of its four waves)
     RowFrags F;
     f32x4 s[2][4];
     load_row_frags(cur, r, g, F);
     mfma_rows<T>(F, qf[0], s[0], true);
-    mfma_rows<T>(F, qf[1], s[1], true);
+    if (act1) mfma_rows<T>(F, qf[1], s[1], true);
     __builtin_amdgcn_sched_barrier(0);
     load_tr_frags(cur + IMG, r, g, F);                    // V fragments requested before the softmax arithmetic
     __builtin_amdgcn_sched_barrier(0);
     fwd_softmax<DROP>(s[0], kt, kt == nkt - 1, n, o[0], m[0], l[0], scale_log2e, drop, gb.by, q0 + r, g);
-    fwd_softmax<DROP>(s[1], kt, kt == nkt - 1, n, o[1], m[1], l[1], scale_log2e, drop, gb.by, q0 + 16 + r, g);
+    if (act1) fwd_softmax<DROP>(s[1], kt, kt == nkt - 1, n, o[1], m[1], l[1], scale_log2e, drop, gb.by, q0 + 16 + r, g);
     __builtin_amdgcn_sched_barrier(0);
     fwd_pv<T>(F, s[0], o[0]);
-    fwd_pv<T>(F, s[1], o[1]);
+    if (act1) fwd_pv<T>(F, s[1], o[1]);
   };
   // two loops, one per half of the key range (the split point every forward kernel uses), the first state parked in between:
   // as ONE loop with the parking under `if (kt == nh)` the compiler copied all 34 state registers on every pass
