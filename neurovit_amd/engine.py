@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 import weakref
 from typing import Dict, List, Optional, Tuple
 
@@ -117,6 +118,11 @@ class VitRuntime:
             ref = self._holder.get(ws.data_ptr())
             rec = ref() if ref is not None else None
             if rec is None or rec.done:
+                return ws
+            # a pass only THIS runtime still refers to (self._cur, + `rec` here + the call's argument = 3): no autograd node holds it, and a direct
+            # rt.backward() always means the most recent forward - which the caller is about to replace: its workspace is free (forward-only loops in
+            # training layout, fp8 calibration: one workspace, not two)
+            if rec is self._cur and sys.getrefcount(rec) <= 3:
                 return ws
         nbytes = first.numel()
         ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)

@@ -974,6 +974,9 @@ def test_two_forward_passes_before_one_backward(nv):
         for q in model.parameters():
             q.grad = None
     assert len(more) == 1 and rt._cur.ws is rt.workspace(2, True, x1.device)
+    for _ in range(3):                                                       # training forwards whose outputs are dropped unused: still one workspace
+        model(x1)
+    assert len(more) == 1 and rt._cur.ws is rt.workspace(2, True, x1.device)
     model(x1).square().sum().backward()
     model(x2).sum().backward()                                               # accumulates into the same arena
     assert rel_err(joint, vit.flat_gradients()) < 1e-6
