@@ -4,8 +4,8 @@
 What is gated here:
   * kernels against float64 references of fp16-rounded operands (16-bit outputs: 1e-3 + half an fp16 ulp; fp32 outputs: 1e-5) and against the
     oracle's emulation with float16 cast points (`ref_cpu.operand_format("fp16")`);
-  * the whole encoder three-way (tests/test_engine_gpu.py's cases re-run on fp16 operands, with tighter decorrelation bounds: the
-    format has 11 significand bits instead of 8);
+  * the whole encoder three-way (tests/test_engine_gpu.py's cases re-run on fp16 operands) with the stage / logits bound against the emulating
+    oracle at SURVEY G3's 1e-3 as written (bf16 needs 5e-3: the format has 8 significand bits, this one 11) and gradients at 1.5e-3;
   * G4 - THE NORTH-STAR TOLERANCE: logits of the fp16 path within 1e-3 (max-norm relative) of the fp32 logits the imported reference
     produced (fixtures micro / tiny / neuro3d) and of the fp32 oracle on ViT3D-base 128^3;
   * the train step: dynamic loss scale on the device (optim.LossScaler = GradScaler: skip on inf / NaN, backoff, growth, AdamW's
@@ -33,8 +33,9 @@ def fp16_operands(monkeypatch):
     require_gpu()
     _cabi.set_operand_format("fp16")
     monkeypatch.setattr(teg, "OPERANDS", "fp16")
-    monkeypatch.setattr(teg, "REL", 1.5e-3)          # G3b: bf16 5e-3 - decorrelation at the quantisation-noise level, 8 x finer here
-    monkeypatch.setattr(teg, "GRAD_REL", 4e-3)       # bf16 1.5e-2
+    monkeypatch.setattr(teg, "REL", 1e-3)            # G3b = SURVEY's G3 AS WRITTEN (<= 1e-3 per stage and on logits against the emulating oracle): bf16 needs 5e-3
+                                                     # (decorrelation at its quantisation-noise level), fp16's is 8 x finer: measured <= 3.3e-4 over every case
+    monkeypatch.setattr(teg, "GRAD_REL", 1.5e-3)     # bf16 1.5e-2; measured <= 9.3e-4 (tiny, patch-LayerNorm weight)
     monkeypatch.setattr(teg, "FORM_REL", 1e-3)       # bf16 5e-3
     monkeypatch.setattr(teg, "FORM_TIGHT", 2e-4)     # the last block's own gradients, form against form: measured <= 3.5e-5 (an fp16 flip of dU under the 1024 x loss scale)
     monkeypatch.setattr(teg, "LOSS_SCALE", 1024.0)   # gradients are formed under a power-of-two loss scale, as fp16 training does
