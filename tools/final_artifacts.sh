@@ -18,7 +18,7 @@ tail -1 $OUT/smoke.log
 exit 0
 fi
 mkdir -p $OUT
-# secondary lines: inference forwards (bf16 / fp8 / fp32), batch 20 / 64, the large preset (bf16 and fp8-forward train step), dropout
+# secondary lines: inference forwards (bf16 / fp8 / fp32), batch 20 / 64, the large preset (bf16 and fp8-forward train step), dropout, the reference's shipped config (90^3, patch 9, batch 128)
 ( python bench.py --forward-only --steps 100 --warmup 10; NEUROVIT_LN_FOLD=0 python bench.py --forward-only --steps 100 --warmup 10; python bench.py --forward-only --operands fp16 --steps 100 --warmup 10;
   python bench.py --operands fp16 --steps 30 --warmup 5 --no-cpu-baseline --no-extras; python bench.py --forward-only --precise --steps 20 --warmup 3;
   python bench.py --forward-only --batch 20 --steps 20 --warmup 3; python bench.py --forward-only --batch 20 --fp8 --steps 20 --warmup 3;
@@ -26,7 +26,8 @@ mkdir -p $OUT
   python bench.py --forward-only --batch 64 --steps 10 --warmup 3; python bench.py --forward-only --batch 64 --fp8 --steps 10 --warmup 3;
   python bench.py --preset large --steps 8 --warmup 2 --no-cpu-baseline --no-extras; python bench.py --preset large --fp8 --steps 8 --warmup 2 --no-cpu-baseline --no-extras;
   python bench.py --preset large --forward-only --steps 8 --warmup 2;
-  python bench.py --preset large --forward-only --fp8 --steps 8 --warmup 2; python bench.py --dropout 0.1 --steps 30 --warmup 5 --no-cpu-baseline --no-extras ) > $OUT/bench_secondary.jsonl 2> $OUT/bench_secondary.err || true
+  python bench.py --preset large --forward-only --fp8 --steps 8 --warmup 2; python bench.py --dropout 0.1 --steps 30 --warmup 5 --no-cpu-baseline --no-extras;
+  python bench.py --preset reference --batch 128 --steps 6 --warmup 2 --no-cpu-baseline --no-extras; python bench.py --preset reference --batch 128 --forward-only --steps 6 --warmup 2 --no-cpu-baseline ) > $OUT/bench_secondary.jsonl 2> $OUT/bench_secondary.err || true
 python tools/neuro4d_train_bench.py 2> /dev/null | tail -1 > $OUT/neuro4d_train.log || true
 cat $OUT/neuro4d_train.log
 cd /tmp && export TMPDIR=/tmp
