@@ -452,6 +452,32 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const float* __restri
         store4<OT>(orow + k, o);
       }
     }
+  } else if (g.P <= 64 * 16) {
+    // any geometry whose patch fits sixteen elements per lane (the reference's shipped config: 9^3 = 729 features, not a multiple of four): ONE gather
+    // into registers instead of three sweeps over the volume (mean, variance, normalise) - the same sums in the same order as the loop form below
+    float xr[16];
+    const long tbase = patch_tok_offset(g, b, n);
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int k = lane + 64 * v;
+      xr[v] = (k < g.P) ? __builtin_nontemporal_load(video + tbase + patch_feat_offset(g, k)) : 0.f;
+      s += xr[v];
+    }
+    mean = wave_sum(s) / (float)g.P;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const float t = xr[v] - mean;
+      if (lane + 64 * v < g.P) q += t * t;
+    }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)g.P + eps);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int k = lane + 64 * v;
+      if (k < ldo) orow[k] = (k < g.P) ? (OT)((xr[v] - mean) * rstd * gamma[k] + beta[k]) : (OT)0.f;
+    }
+    for (int k = lane + 1024; k < ldo; k += 64) orow[k] = (OT)0.f;
   } else {
     float s = 0.f;
     for (int k = lane; k < g.P; k += 64) s += video[patch_elem_offset(g, b, n, k)];
